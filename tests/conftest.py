@@ -1,0 +1,49 @@
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PKG_NAME = "video-based-gait-analysis-for-dementia_amd"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return importlib.import_module(PKG_NAME)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    return importlib.import_module("oracle.grnet_oracle")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    d = os.path.join(ROOT, "tests", "golden")
+    return {name: np.load(os.path.join(d, name + ".npz")) for name in ("grnet_n4", "geometry", "gru")}
+
+
+@pytest.fixture(scope="session")
+def synth_weights(pkg):
+    return pkg.synth.make_state_dict()
+
+
+@pytest.fixture(scope="session")
+def synth_smpl(pkg):
+    return pkg.synth.make_smpl_tables()
+
+
+def rel_err(a, b):
+    """max |a-b| / max|b| -- the 'relative' of the 1e-3 bar (scale of the tensor, not per element)."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
