@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s of the MAX-GRNet per-frame path (224x224, fp32) on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one pass of the hot path over one clip of 16 synthetic frames per GPU (BASELINE.json
+configs[1]: 1 clip x 16 x 224 x 224, fp32), frames already resident in HBM.  With N > 1 (one process
+per GPU, launched by torch.distributed.run) every rank owns the 16-frame shard [16r, 16r+16) of a
+16N-frame clip -- frames are independent (grnet.py:136-152), so the shards need no collective -- and
+the step ends with the one exchange the north star names: an RCCL all-gather of the per-frame pose
+results (theta, kp_3d, kp_2d, point_local_feat = the GRU input).  Weak scaling.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel family (conv_mfma_f32, the fp32
+MFMA implicit-GEMM convolution): algorithmic FLOPs of all conv launches of a step / their summed
+duration, measured live with HIP events on the launch stream.  `cpu_baseline` times the oracle (a
+port of the reference's CPU path; the reference itself cannot travel to the GPU box) on the host cores.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "video-based-gait-analysis-for-dementia_amd"
+FRAMES_PER_GPU = 16
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA = vector peak
+
+
+def cpu_baseline(pkg, frames_np, budget_s=20.0):
+    oracle = importlib.import_module("oracle.grnet_oracle")
+    sd, smpl = pkg.synth.make_state_dict(), pkg.synth.make_smpl_tables()
+    oracle.grnet_forward(frames_np[:2], sd, smpl)           # warm-up (oneDNN primitive caches)
+    t_all, passes = 0.0, 0
+    while t_all < budget_s and passes < 12:
+        t0 = time.perf_counter()
+        oracle.grnet_forward(frames_np, sd, smpl)
+        t_all += time.perf_counter() - t0
+        passes += 1
+    n = frames_np.shape[0] * passes
+    return {"value": round(n / t_all, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{passes} passes of the oracle (torch-CPU convs + numpy tail) over the same {frames_np.shape[0]} frames, fp32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step (default: configs[1])")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    pkg = importlib.import_module(PKG)
+    harness = pkg.harness
+    n = args.frames
+    model = pkg.build_synthetic_model(max_frames=n, device_id=local_rank, with_gru=False)
+    frames_np = pkg.synth.make_frames(n, start=rank * n)
+    frames = torch.from_numpy(frames_np).cuda()
+    runner = harness.ClipRunner(model, frames, use_graph=not args.no_graph, world=world, rank=rank, dist=dist)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        runner.step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant-kernel roofline: all conv launches of one step, HIP events on the launch stream
+    conv_ms = min(model.time_convs(n) for _ in range(5))
+    conv_flops = model.conv_flops_per_frame() * n
+    achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        total_frames = n * world * args.steps
+        line = {
+            "metric": "frames/sec (224x224, seq=16)", "value": round(total_frames / elapsed, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"1 clip x {n} frames x 3x224x224 per GPU, fp32, MAX-GRNet per-frame path "
+                                   "(HRNet-W32 + PARE head + SMPL LBS), seed-defined synthetic weights",
+                       "frames_per_gpu": n, "launch": "eager" if args.no_graph else "hipGraph replay",
+                       "kernel_launches_per_step": model.num_kernel_launches(),
+                       "exchange": "none (1 GPU)" if world == 1 else "RCCL all-gather of per-frame pose results"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "kernel": "conv_mfma_f32 (all instantiations)", "conv_ms_per_step": round(conv_ms, 4),
+                         "conv_gflop_per_step": round(conv_flops / 1e9, 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(pkg, frames_np)
+        print(json.dumps(line), flush=True)
+    model.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,116 @@
+/*
+ * libgrnet_hip.so -- C ABI of the MI355X-native MAX-GRNet per-frame inference path.
+ *
+ * The reference has no FFI for this path: it sits behind a plain torch.nn.Module.  Each entry
+ * point below names the reference interface it replaces (file:line under the reference repo);
+ * INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions: every function returns 0 on success or a negative GRNET_E* code and never throws
+ * across the ABI; grnet_last_error() returns a static-lifetime (per handle) message.  One handle
+ * per GPU per process; a handle is not thread-safe (one caller thread + its stream); different
+ * handles are independent.  All device work is enqueued on the stream passed in (a hipStream_t,
+ * passed as void*); grnet_forward performs no allocation and no host synchronisation, so it can
+ * be captured into a hipGraph by the caller (or by the library: GRNET_OPT_USE_GRAPH).
+ * All tensors are fp32, dense, row-major ("C order"); device pointers are plain HIP device
+ * pointers (e.g. torch.Tensor.data_ptr()), owned by the caller and never freed by the library.
+ */
+#ifndef GRNET_HIP_H
+#define GRNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct grnet grnet_t;
+
+#define GRNET_OK 0
+#define GRNET_EINVAL (-22)   /* bad argument / shape */
+#define GRNET_ENOENT (-2)    /* missing weight tensor at finalize */
+#define GRNET_ENOMEM (-12)
+#define GRNET_EHIP (-5)      /* a HIP runtime call failed; see grnet_last_error */
+#define GRNET_ESTATE (-1)    /* call order violated (e.g. forward before finalize) */
+
+#define GRNET_DTYPE_F32 0
+#define GRNET_DTYPE_I64 1    /* accepted for num_batches_tracked, ignored */
+
+/* GRNet(...).to(device) -- lib/models/grnet.py:27-91, demo.py:106-111.  Allocates every
+ * activation buffer for up to max_frames frames per call (the reference's batch axis N = B*T,
+ * grnet.py:136-138).  dtype: 0 = fp32 (the only compute type in this round). */
+int grnet_create(grnet_t** out_handle, int device_id, int dtype, int max_frames);
+
+/* model.load_state_dict(...) -- demo.py:116-122, batch_generation.py:214-218, and
+ * GRNet.load_pare_dict / load_ckpt_w_prefix -- grnet.py:93-109, lib/utils/utils.py:185-196.
+ * Called once per checkpoint tensor under its REFERENCE key name ("backbone.conv1.weight",
+ * "head.pose_mlp.weight", ...; GRU keys "pfeat_corrector.featnet.*" or "gru.*").  host_ptr is
+ * read during the call only. */
+int grnet_load_tensor(grnet_t* h, const char* state_dict_key, const void* host_ptr, const int64_t* shape, int ndim,
+                      int dtype);
+
+/* SMPL(...) buffers -- lib/models/smpl.py:97-106,144 (smplx.SMPL tables + J_regressor_extra).
+ * v_template (6890,3), shapedirs (6890,3,10), posedirs (207,20670), J_regressor (24,6890),
+ * lbs_weights (6890,24), parents (24), J_regressor_extra (9,6890); host pointers. */
+int grnet_load_smpl(grnet_t* h, const float* v_template, const float* shapedirs, const float* posedirs,
+                    const float* J_regressor, const float* lbs_weights, const int32_t* parents,
+                    const float* J_regressor_extra);
+
+/* model.eval() + first use: folds every BatchNorm2d (eval, eps 1e-5) into its convolution in
+ * fp64, repacks weights to the kernel layout and uploads them.  Fails with GRNET_ENOENT naming
+ * the first missing tensor. */
+int grnet_finalize_weights(grnet_t* h);
+
+/* Caller-allocated device buffers for one call of n frames; any pointer may be NULL (that output
+ * is then computed into an internal buffer and not returned).  Shapes follow VPRegressor.forward,
+ * lib/models/pare.py:78-84, flattened over (B,T) -> n. */
+typedef struct grnet_outputs {
+    float* theta;             /* (n,85)  [cam(3), axis-angle pose(72), betas(10)]   pare.py:79 */
+    float* verts;             /* (n,6890,3)                                         pare.py:80 */
+    float* kp_2d;             /* (n,29,2)                                           pare.py:81 */
+    float* kp_3d;             /* (n,29,3)                                           pare.py:82 */
+    float* rotmat;            /* (n,24,3,3)                                         pare.py:83 */
+    float* point_local_feat;  /* (n,128,24)  GRU input, grnet.py:148,163             */
+    float* cam_shape_feats;   /* (n,64,24)                                          */
+    float* pred_rot6d;        /* (n,24,6)   pare.py:299 */
+    float* features;          /* (n,480,56,56) backbone output, hrnet.py:524 (debug / parity) */
+    float* part_attn;         /* (n,25,56,56) heat-maps incl. background channel 0, pare.py:312 */
+    float* smpl_feats;        /* (n,128,56,56) pare.py:323 */
+} grnet_outputs_t;
+
+/* model(batch)[-1] -- GRNet.forward, lib/models/grnet.py:129-175 (use_gait_feat=False path),
+ * callers demo.py:164 and batch_generation.py:315.  frames_dev: (n,3,224,224) NCHW fp32 already
+ * normalised; 1 <= n_frames <= max_frames. */
+int grnet_forward(grnet_t* h, const float* frames_dev, int n_frames, const grnet_outputs_t* out, void* stream);
+
+/* BidirectionalModel.forward -- lib/models/layers/gait_feat_encoder.py:79-104 (use_pareFeat=True,
+ * eval).  x (b,T,3072) laid out c*24+j, cparams (b,T,3) -> y (b,3), phase (b,T,4), xc (b,T,3072);
+ * device pointers; xc may be NULL. */
+int grnet_gru_forward(grnet_t* h, const float* x_dev, const float* cparams_dev, int b, int T, float* y_dev,
+                      float* phase_dev, float* xc_dev, void* stream);
+
+#define GRNET_OPT_USE_GRAPH 1     /* 1: capture each distinct (n, pointers) forward into a hipGraph and replay it */
+#define GRNET_OPT_CONV_TILE 2     /* 0 auto, 7 or 14: force the conv pixel tile (tuning / tests) */
+int grnet_set_option(grnet_t* h, int option, int value);
+
+/* Introspection used by bench.py / tests. */
+int grnet_num_kernel_launches(grnet_t* h);      /* launches enqueued by one grnet_forward */
+double grnet_conv_flops_per_frame(grnet_t* h);  /* 2 * MACs of all convolutions on the path */
+/* Re-enqueue ONLY the convolution launches of the last forward, bracketed by HIP events on
+ * `stream`; returns elapsed ms in *ms_out (synchronises the stream). */
+int grnet_time_convs(grnet_t* h, int n_frames, void* stream, float* ms_out);
+
+/* Single-op entry points (parity tests of each kernel against the oracle; not used by the path).
+ * w_host: (Cout,Cin,ks,ks) already folded, bias_host (Cout) or NULL, add_dev: same shape as out or NULL. */
+int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, int wid, const float* w_host,
+                    const float* bias_host, int cout, int ks, int stride, int relu, const float* add_dev,
+                    float* out_dev, int tile_hint, void* stream);
+int grnet_op_bilinear2x(grnet_t* h, const float* in_dev, int n, int c, int hgt, int wid, float* out_dev, void* stream);
+
+const char* grnet_last_error(grnet_t* h);
+const char* grnet_version(void);
+void grnet_destroy(grnet_t* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRNET_HIP_H */

@@ -1,0 +1,200 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the committed goldens.
+
+Tolerance: BASELINE.json's north_star asks for 1e-3 relative on fp32 outputs; the kernels are exact
+fp32 fma chains, so the tests hold them to 1e-4 (max abs error / max abs value of the tensor).
+"""
+import numpy as np
+import pytest
+import torch
+
+from .conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4          # well inside the 1e-3 bar
+
+
+@pytest.fixture(scope="module")
+def model(pkg):
+    m = pkg.build_synthetic_model(max_frames=16)
+    yield m
+    m.close()
+
+
+def _rand(shape, seed):
+    g = np.random.Generator(np.random.Philox(key=[99, seed]))
+    return g.standard_normal(shape).astype(np.float32)
+
+
+# (Cin, Cout, k, stride, H) -- every family of SURVEY Appendix B, incl. the edge cases: Cin=3 (padded
+# to the 8-channel chunk), Cout=25 (masked stores), 7x7 and 14x14 maps (multi-image tiles, scalar stores)
+CONV_CASES = [
+    (3, 64, 3, 2, 224), (64, 64, 3, 2, 112), (64, 64, 1, 1, 56), (64, 256, 1, 1, 56), (256, 64, 1, 1, 56),
+    (64, 64, 3, 1, 56), (256, 32, 3, 1, 56), (256, 64, 3, 2, 56), (32, 32, 3, 1, 56), (64, 64, 3, 1, 28),
+    (128, 128, 3, 1, 14), (256, 256, 3, 1, 7), (32, 64, 3, 2, 56), (64, 128, 3, 2, 28), (128, 256, 3, 2, 14),
+    (32, 32, 3, 2, 56), (64, 32, 1, 1, 28), (128, 32, 1, 1, 14), (256, 32, 1, 1, 7), (256, 128, 1, 1, 7),
+    (128, 128, 3, 1, 28), (256, 256, 3, 1, 14), (128, 128, 3, 1, 56), (480, 256, 3, 1, 56), (128, 25, 1, 1, 56),
+    (128, 64, 1, 1, 56), (32, 256, 3, 2, 14), (64, 256, 3, 2, 14),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("tile", [7, 14])
+def test_conv_kernel(model, oracle, case, tile):
+    cin, cout, k, stride, h = case
+    n = 3 if h <= 28 else 2          # odd image count: partial multi-image tiles on the 7x7 / 14x14 maps
+    x = _rand((n, cin, h, h), 1)
+    w = _rand((cout, cin, k, k), 2) * np.float32(np.sqrt(2.0 / (cin * k * k)))
+    b = _rand((cout,), 3) * np.float32(0.1)
+    ho = (h + 2 * (k // 2) - k) // stride + 1
+    add = _rand((n, cout, ho, ho), 4)
+    ref = torch.relu(oracle.conv2d(x, w, stride=stride, bias=b) + torch.from_numpy(add)).numpy()
+    got = model.op_conv2d(torch.from_numpy(x).cuda(), w, b, stride=stride, relu=True, add=torch.from_numpy(add).cuda(),
+                          tile_hint=tile).cpu().numpy()
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < 1e-5, (case, tile, rel_err(got, ref))
+
+
+def test_conv_plain_no_epilogue(model, oracle):
+    x = _rand((1, 32, 56, 56), 5)
+    w = _rand((32, 32, 3, 3), 6) * np.float32(0.06)
+    ref = oracle.conv2d(x, w).numpy()
+    got = model.op_conv2d(torch.from_numpy(x).cuda(), w).cpu().numpy()
+    assert rel_err(got, ref) < 1e-5
+
+
+def test_conv_identity_asymmetric(model):
+    """1x1 identity weights on an asymmetric input: catches a transposed C/D register map."""
+    x = np.arange(2 * 32 * 56 * 56, dtype=np.float32).reshape(2, 32, 56, 56) % 1013
+    w = np.zeros((32, 32, 1, 1), np.float32)
+    w[np.arange(32), (np.arange(32) * 7 + 3) % 32, 0, 0] = 1.0       # a permutation, not symmetric
+    got = model.op_conv2d(torch.from_numpy(x).cuda(), w).cpu().numpy()
+    assert np.array_equal(got, x[:, (np.arange(32) * 7 + 3) % 32])
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 28, 28), (3, 128, 14, 14), (2, 256, 7, 7), (1, 128, 28, 28)])
+def test_bilinear2x(model, oracle, shape):
+    x = _rand(shape, 7)
+    ref = oracle.upsample_bilinear2x(x).numpy()
+    got = model.op_bilinear2x(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert rel_err(got, ref) < 1e-5
+
+
+@pytest.fixture(scope="module")
+def run4(model, pkg):
+    frames = pkg.synth.make_frames(4)
+    x = torch.from_numpy(frames).cuda().reshape(2, 2, 3, 224, 224)
+    out = model(x, extras=("features", "part_attn", "smpl_feats", "point_local_feat", "cam_shape_feats", "pred_rot6d"))[-1]
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def test_forward_matches_golden(run4, golden):
+    g = golden["grnet_n4"]
+    o = run4
+    report = {}
+    checks = [
+        ("features_s4", o["features"][..., ::4, ::4]), ("part_attn_s2", o["part_attn"][:, 1:, ::2, ::2]),
+        ("smpl_feats_s4", o["smpl_feats"][..., ::4, ::4]), ("point_local_feat", o["point_local_feat"]),
+        ("cam_shape_feats", o["cam_shape_feats"]), ("pred_rot6d", o["pred_rot6d"]),
+        ("rotmat", o["rotmat"]), ("theta", o["theta"]), ("kp_3d", o["kp_3d"]), ("kp_2d", o["kp_2d"]),
+        ("verts_s5", o["verts"][:, :, ::5]),
+    ]
+    for name, mine in checks:
+        report[name] = rel_err(mine, g[name])
+    print(report)
+    bad = {k: v for k, v in report.items() if not v < TOL}
+    assert not bad, bad
+    assert o["theta"].shape == (2, 2, 85) and o["verts"].shape == (2, 2, 6890, 3)
+    assert o["kp_2d"].shape == (2, 2, 29, 2) and o["kp_3d"].shape == (2, 2, 29, 3) and o["rotmat"].shape == (2, 2, 24, 3, 3)
+    mpjpe = np.linalg.norm(o["kp_3d"] - g["kp_3d"], axis=-1).mean()
+    assert mpjpe < 1e-4
+
+
+def test_forward_matches_oracle_full(run4, pkg, oracle, synth_weights, synth_smpl):
+    """Whole tensors (not strided samples) against the oracle on the same frames."""
+    frames = pkg.synth.make_frames(4).reshape(2, 2, 3, 224, 224)
+    ref = oracle.grnet_forward(frames, synth_weights, synth_smpl, return_intermediates=True)
+    for k in ("features", "smpl_feats", "point_local_feat", "cam_shape_feats", "theta", "verts", "kp_3d", "kp_2d", "rotmat"):
+        assert rel_err(run4[k], ref[k]) < TOL, (k, rel_err(run4[k], ref[k]))
+    assert rel_err(run4["part_attn"][:, 1:], ref["part_attn"]) < TOL
+    # pose as rotations: geodesic distance between predicted and reference rotation matrices
+    R1, R2 = run4["rotmat"].reshape(-1, 3, 3), ref["rotmat"].reshape(-1, 3, 3)
+    cos = (np.einsum("nij,nij->n", R1, R2) - 1) / 2
+    assert np.arccos(np.clip(cos, -1, 1)).max() < 2e-3
+
+
+def test_batch_invariance_full_size(model, pkg):
+    """BASELINE config 2 size (16 frames): every frame is independent (grnet.py:136-152), so the
+    16-frame call must reproduce single-frame and chunked calls bit for bit."""
+    frames = torch.from_numpy(pkg.synth.make_frames(16)).cuda()
+    full = model(frames)[-1]
+    one = model(frames[5:6])[-1]
+    part = model(frames[8:11])[-1]
+    torch.cuda.synchronize()
+    for k in ("theta", "kp_3d", "kp_2d", "verts", "rotmat"):
+        assert torch.equal(full[k][0, 5], one[k][0, 0]), k
+        assert torch.equal(full[k][0, 8:11], part[k][0]), k
+    R = full["rotmat"].reshape(-1, 3, 3)
+    eye = torch.eye(3, device=R.device).expand_as(R)
+    assert (R @ R.transpose(1, 2) - eye).abs().max() < 1e-4        # rot6d -> rotmat is orthonormal
+    assert torch.isfinite(full["verts"]).all()
+
+
+def test_chunked_above_max_frames(pkg):
+    m = pkg.build_synthetic_model(max_frames=3, with_gru=False)
+    frames = torch.from_numpy(pkg.synth.make_frames(5)).cuda()
+    a = m(frames)[-1]
+    m2 = pkg.build_synthetic_model(max_frames=8, with_gru=False)
+    b = m2(frames)[-1]
+    torch.cuda.synchronize()
+    for k in ("theta", "kp_3d", "verts"):
+        assert torch.equal(a[k], b[k]), k
+    m.close(); m2.close()
+
+
+def test_graph_replay_equals_eager(model, pkg):
+    frames = torch.from_numpy(pkg.synth.make_frames(4)).cuda()
+    eager = {k: v.clone() for k, v in model(frames)[-1].items()}
+    model.set_option(pkg._lib.OPT_USE_GRAPH, 1)
+    try:
+        lib, h = model._lib, model._h
+        import ctypes as C
+        outs = {k: torch.empty_like(v.reshape(4, *v.shape[2:])) for k, v in eager.items()}
+        o = pkg._lib.Outputs()
+        for k, t in outs.items():
+            setattr(o, k, t.data_ptr())
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for _ in range(3):      # capture, then two replays
+            rc = lib.grnet_forward(h, C.c_void_p(frames.data_ptr()), 4, C.byref(o), stream)
+            assert rc == 0, lib.grnet_last_error(h)
+        torch.cuda.synchronize()
+        for k in eager:
+            assert torch.equal(outs[k], eager[k].reshape(outs[k].shape)), k
+    finally:
+        model.set_option(pkg._lib.OPT_USE_GRAPH, 0)
+
+
+def test_gru_matches_golden_and_oracle(model, pkg, oracle, golden):
+    g = golden["gru"]
+    sd = pkg.synth.make_gru_state_dict()
+    for (b, t) in ((2, 6), (1, 16), (3, 40)):
+        x, cp = pkg.synth.make_gru_inputs(b, t)
+        y, ph, xc = model.gru_forward(torch.from_numpy(x).cuda(), torch.from_numpy(cp).cuda())
+        torch.cuda.synchronize()
+        ry, rph, rxc = oracle.gru_forward(x, cp, sd)
+        assert rel_err(y.cpu().numpy(), ry) < TOL and rel_err(ph.cpu().numpy(), rph) < TOL
+        assert rel_err(xc.cpu().numpy(), rxc) < 1e-5
+        if f"y_{b}_{t}" in g:
+            assert rel_err(y.cpu().numpy(), g[f"y_{b}_{t}"]) < TOL
+            assert rel_err(ph.cpu().numpy(), g[f"phase_{b}_{t}"]) < TOL
+
+
+def test_errors_are_loud(model, pkg):
+    with pytest.raises(ValueError):
+        model(torch.zeros(3, 224, 224, device="cuda"))
+    with pytest.raises(ValueError):
+        model(torch.zeros(1, 3, 128, 128, device="cuda"))
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(1, 3, 224, 224))          # host tensor: no CPU fallback
+    with pytest.raises(RuntimeError):
+        pkg.GRNet(max_frames=1).load_state_dict({"backbone.conv1.weight": np.zeros((64, 3, 3, 3), np.float32)}, strict=True)

@@ -1,0 +1,72 @@
+"""ctypes binding of libgrnet_hip.so (the C ABI declared in include/grnet_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or fails to load, importing the
+model raises.  Nothing here touches ``oracle/``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgrnet_hip.so")
+
+OK, EINVAL, ENOENT, ENOMEM, EHIP, ESTATE = 0, -22, -2, -12, -5, -1
+DTYPE_F32, DTYPE_I64 = 0, 1
+OPT_USE_GRAPH, OPT_CONV_TILE = 1, 2
+
+
+class Outputs(C.Structure):
+    """grnet_outputs_t"""
+    _fields_ = [(n, C.c_void_p) for n in (
+        "theta", "verts", "kp_2d", "kp_3d", "rotmat", "point_local_feat", "cam_shape_feats", "pred_rot6d",
+        "features", "part_attn", "smpl_feats")]
+
+
+EXPORTS = {
+    "grnet_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
+    "grnet_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_int]),
+    "grnet_load_smpl": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7),
+    "grnet_finalize_weights": (C.c_int, [C.c_void_p]),
+    "grnet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Outputs), C.c_void_p]),
+    "grnet_gru_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
+    "grnet_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "grnet_num_kernel_launches": (C.c_int, [C.c_void_p]),
+    "grnet_conv_flops_per_frame": (C.c_double, [C.c_void_p]),
+    "grnet_time_convs": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
+    "grnet_op_conv2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "grnet_op_bilinear2x": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "grnet_last_error": (C.c_char_p, [C.c_void_p]),
+    "grnet_version": (C.c_char_p, []),
+    "grnet_destroy": (None, [C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raise loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C video-based-gait-analysis-for-dementia_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class GrnetError(RuntimeError):
+    pass
+
+
+def check(lib, handle, rc, what):
+    if rc != 0:
+        msg = lib.grnet_last_error(handle).decode() if handle else ""
+        raise GrnetError(f"{what} failed with code {rc}: {msg}")

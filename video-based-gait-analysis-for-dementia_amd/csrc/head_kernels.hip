@@ -1,0 +1,444 @@
+// Everything on the per-frame path that is not a convolution: HR-module fuse sums, bilinear
+// upsampling, PARE part-attention pooling, the regressor tail, SMPL linear blend skinning and
+// the camera projection.  All of it is HBM/L2-bound byte work (< 0.1 % of the FLOPs):
+// wavefront reductions, coalesced 16-byte accesses, one pass over each tensor.
+#include "kernels.h"
+
+namespace grk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// HR-module fuse output 0: y = relu(x_0 + up2(t_1) + up4(t_2) + up8(t_3)), nearest upsampling
+// (reference: HighResolutionModule.forward, hrnet.py:258-265; nn.Upsample(nearest), hrnet.py:208).
+__global__ __launch_bounds__(256) void fuse_sum_kernel(const SumArgs a) {
+    const int HW = a.H * a.W;
+    const long total4 = (long)a.N * a.C * HW / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const long e = i * 4;
+        const int pix = (int)(e % HW);
+        const long nc = e / HW;
+        const int c = (int)(nc % a.C), n = (int)(nc / a.C);
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < a.n_add; ++k) {
+            const int sh = a.add_shift[k];
+            if (sh == 0) {
+                v += *reinterpret_cast<const f32x4*>(a.add[k] + ((size_t)n * a.add_ctot[k] + a.add_coff[k] + c) * HW + pix);
+            } else {
+                const int hs = a.H >> sh, ws = a.W >> sh;
+                const float* ap = a.add[k] + ((size_t)n * a.add_ctot[k] + a.add_coff[k] + c) * (hs * ws);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int y = (pix + r) / a.W, x = (pix + r) - y * a.W;
+                    v[r] += ap[(y >> sh) * ws + (x >> sh)];
+                }
+            }
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(a.out + ((size_t)n * a.out_ctot + a.out_coff + c) * HW + pix) = v;
+    }
+}
+
+hipError_t launch_fuse_sum(const SumArgs& a, hipStream_t s) {
+    if ((a.H * a.W) % 4 != 0 || a.n_add < 1 || a.n_add > 4) return hipErrorInvalidValue;
+    const long total4 = (long)a.N * a.C * a.H * a.W / 4;
+    int blocks = (int)((total4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fuse_sum_kernel, dim3(blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (hrnet.py:443):
+// src = dst * (in-1)/(out-1); taps floor(src), min(floor+1, in-1).
+__global__ __launch_bounds__(256) void bilinear2x_kernel(const float* __restrict__ in, float* __restrict__ out, int NC,
+                                                           int H, int W) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const float sy = (float)(H - 1) / (float)(Ho - 1), sx = (float)(W - 1) / (float)(Wo - 1);
+    const long total = (long)NC * Ho * Wo;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wo);
+        const long t = i / Wo;
+        const int y = (int)(t % Ho);
+        const long nc = t / Ho;
+        const float fy = sy * y, fx = sx * x;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+        const float ly = fy - y0, lx = fx - x0;
+        const float* p = in + nc * H * W;
+        const float top = p[y0 * W + x0] * (1.f - lx) + p[y0 * W + x1] * lx;
+        const float bot = p[y1 * W + x0] * (1.f - lx) + p[y1 * W + x1] * lx;
+        out[i] = top * (1.f - ly) + bot * ly;
+    }
+}
+
+hipError_t launch_bilinear2x(const float* in, float* out, int N, int C, int H, int W, hipStream_t s) {
+    const long total = (long)N * C * 4 * H * W;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bilinear2x_kernel, dim3(blocks), dim3(256), 0, s, in, out, N * C, H, W);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Part attention (KeypointAttention.forward, keypoint_attention.py:42-48; called twice with the
+// same heat-maps, pare.py:331-332): softmax over the 3136 positions of each (frame, joint), then
+// out[n,c,j] = sum_p prob[n,j,p] * feat[n,c,p].  Pass 1: per-row max and 1/sum.  Pass 2: both
+// feature maps (128 + 64 channels) pooled with the probabilities rebuilt on the fly.
+__global__ __launch_bounds__(256) void softmax_stats_kernel(const float* __restrict__ heat, int heat_ctot, float* __restrict__ stats,
+                                                              int P) {
+    const int n = blockIdx.x / 24, j = blockIdx.x % 24;
+    const float* h = heat + ((size_t)n * heat_ctot + 1 + j) * P;      // channel 0 = background (pare.py:316)
+    __shared__ float red[4];
+    float m = -INFINITY;
+    for (int p = threadIdx.x; p < P; p += 256) m = fmaxf(m, h[p]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int p = threadIdx.x; p < P; p += 256) s += expf(h[p] - m);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        stats[2 * blockIdx.x] = m;
+        stats[2 * blockIdx.x + 1] = 1.f / (red[0] + red[1] + red[2] + red[3]);
+    }
+}
+
+// block = (frame n, 32 channels of the stacked [featA | featB] map); 256 threads =
+// 16 channel pairs x 4 joint groups of 6 x 4 pixel phases; pixel tiles of 64 staged in LDS.
+constexpr int kPoolPT = 64;
+__global__ __launch_bounds__(256) void attn_pool_kernel(const float* __restrict__ heat, int heat_ctot, const float* __restrict__ stats,
+                                                          const float* __restrict__ featA, int CA, const float* __restrict__ featB,
+                                                          int CB, float* __restrict__ outA, float* __restrict__ outB, int P) {
+    __shared__ float prob[24][kPoolPT + 1];
+    __shared__ float feat[32][kPoolPT + 1];
+    __shared__ float red[4][32][24];
+    const int n = blockIdx.x, cb = blockIdx.y * 32;
+    const int tid = threadIdx.x;
+    const int cp = tid & 15, jg = (tid >> 4) & 3, ph = tid >> 6;
+    const bool isA = cb < CA;
+    const float* fbase = isA ? featA + ((size_t)n * CA + cb) * P : featB + ((size_t)n * CB + (cb - CA)) * P;
+    const float* hbase = heat + ((size_t)n * heat_ctot + 1) * P;
+    float acc[2][6];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) acc[a][b] = 0.f;
+
+    for (int p0 = 0; p0 < P; p0 += kPoolPT) {
+        for (int e = tid; e < 24 * kPoolPT; e += 256) {
+            const int j = e / kPoolPT, pp = e % kPoolPT;
+            const float m = stats[2 * (n * 24 + j)], inv = stats[2 * (n * 24 + j) + 1];
+            prob[j][pp] = (p0 + pp < P) ? expf(hbase[(size_t)j * P + p0 + pp] - m) * inv : 0.f;
+        }
+        for (int e = tid; e < 32 * kPoolPT; e += 256) {
+            const int c = e / kPoolPT, pp = e % kPoolPT;
+            feat[c][pp] = (p0 + pp < P) ? fbase[(size_t)c * P + p0 + pp] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int pp = ph; pp < kPoolPT; pp += 4) {
+            const float f0 = feat[2 * cp][pp], f1 = feat[2 * cp + 1][pp];
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const float pr = prob[jg * 6 + b][pp];
+                acc[0][b] += f0 * pr;
+                acc[1][b] += f1 * pr;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) red[ph][2 * cp + a][jg * 6 + b] = acc[a][b];
+    __syncthreads();
+    for (int e = tid; e < 32 * 24; e += 256) {
+        const int c = e / 24, j = e % 24;
+        const float v = red[0][c][j] + red[1][c][j] + red[2][c][j] + red[3][c][j];
+        if (isA) outA[((size_t)n * CA + cb + c) * 24 + j] = v;
+        else outB[((size_t)n * CB + (cb - CA) + c) * 24 + j] = v;
+    }
+}
+
+hipError_t launch_softmax_pool(const float* heat, int heat_ctot, const float* featA, int CA, const float* featB, int CB,
+                               float* outA, float* outB, float* stats_ws, int N, int P, hipStream_t s) {
+    if (CA % 32 != 0 || CB % 32 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(softmax_stats_kernel, dim3(N * 24), dim3(256), 0, s, heat, heat_ctot, stats_ws, P);
+    hipLaunchKernelGGL(attn_pool_kernel, dim3(N, (CA + CB) / 32), dim3(256), 0, s, heat, heat_ctot, stats_ws, featA, CA, featB,
+                       CB, outA, outB, P);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Regressor tail, one workgroup per frame:
+//   pose[j][o] = sum_c plf[c][j] * Wp[o][c][j]                     (LocallyConnected2d, locallyconnected2d.py:43-46)
+//   shape / cam = Linear(flatten(csf)), flat index c*24+j          (pare.py:342,365-366)
+//   rot6d -> rotmat (Gram-Schmidt, geometry.py:395-410), rotmat -> quaternion -> axis-angle with
+//   NaN -> 0 (geometry.py:68-97,159-293), theta = [cam, aa, shape] (pare.py:79).
+__device__ __forceinline__ void rot6d_to_rotmat_dev(const float* x, float* R) {
+    // x viewed as (3,2): a1 = x[0],x[2],x[4]; a2 = x[1],x[3],x[5]; R columns = b1 b2 b3
+    const float a1x = x[0], a1y = x[2], a1z = x[4], a2x = x[1], a2y = x[3], a2z = x[5];
+    const float n1 = fmaxf(sqrtf(a1x * a1x + a1y * a1y + a1z * a1z), 1e-6f);
+    const float b1x = a1x / n1, b1y = a1y / n1, b1z = a1z / n1;
+    const float d = b1x * a2x + b1y * a2y + b1z * a2z;
+    const float ux = a2x - d * b1x, uy = a2y - d * b1y, uz = a2z - d * b1z;
+    const float n2 = fmaxf(sqrtf(ux * ux + uy * uy + uz * uz), 1e-6f);
+    const float b2x = ux / n2, b2y = uy / n2, b2z = uz / n2;
+    const float b3x = b1y * b2z - b1z * b2y, b3y = b1z * b2x - b1x * b2z, b3z = b1x * b2y - b1y * b2x;
+    R[0] = b1x; R[1] = b2x; R[2] = b3x;
+    R[3] = b1y; R[4] = b2y; R[5] = b3y;
+    R[6] = b1z; R[7] = b2z; R[8] = b3z;
+}
+
+__device__ __forceinline__ void rotmat_to_aa_dev(const float* R, float* aa) {
+    // m = R^T (geometry.py:243): m[i][j] = R[j][i]
+    const float m00 = R[0], m01 = R[3], m02 = R[6];
+    const float m10 = R[1], m11 = R[4], m12 = R[7];
+    const float m20 = R[2], m21 = R[5], m22 = R[8];
+    float q0, q1, q2, q3, t;
+    if (m22 < 1e-6f) {
+        if (m00 > m11) { t = 1.f + m00 - m11 - m22; q0 = m12 - m21; q1 = t; q2 = m01 + m10; q3 = m20 + m02; }
+        else           { t = 1.f - m00 + m11 - m22; q0 = m20 - m02; q1 = m01 + m10; q2 = t; q3 = m12 + m21; }
+    } else {
+        if (m00 < -m11) { t = 1.f - m00 - m11 + m22; q0 = m01 - m10; q1 = m20 + m02; q2 = m12 + m21; q3 = t; }
+        else            { t = 1.f + m00 + m11 + m22; q0 = t; q1 = m12 - m21; q2 = m20 - m02; q3 = m01 - m10; }
+    }
+    const float sc = 0.5f / sqrtf(t);
+    q0 *= sc; q1 *= sc; q2 *= sc; q3 *= sc;
+    const float s2 = q1 * q1 + q2 * q2 + q3 * q3;
+    const float sn = sqrtf(s2);
+    const float two_theta = 2.f * (q0 < 0.f ? atan2f(-sn, -q0) : atan2f(sn, q0));
+    const float k = s2 > 0.f ? two_theta / sn : 2.f;
+    float a0 = q1 * k, a1 = q2 * k, a2 = q3 * k;
+    aa[0] = isnan(a0) ? 0.f : a0;
+    aa[1] = isnan(a1) ? 0.f : a1;
+    aa[2] = isnan(a2) ? 0.f : a2;
+}
+
+__global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict__ plf, const float* __restrict__ csf, TailWeights w,
+                                                          float* __restrict__ rot6d, float* __restrict__ shape,
+                                                          float* __restrict__ cam, float* __restrict__ rotmat,
+                                                          float* __restrict__ theta) {
+    __shared__ float s_plf[128 * 24];
+    __shared__ float s_csf[64 * 24];
+    __shared__ float s_pose[24 * 6];
+    __shared__ float s_sc[13];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < 128 * 24; e += 256) s_plf[e] = plf[(size_t)n * 128 * 24 + e];
+    for (int e = tid; e < 64 * 24; e += 256) s_csf[e] = csf[(size_t)n * 64 * 24 + e];
+    __syncthreads();
+    if (tid < 144) {
+        const int j = tid / 6, o = tid % 6;
+        float acc = 0.f;
+        for (int c = 0; c < 128; ++c) acc += s_plf[c * 24 + j] * w.pose_w[(o * 128 + c) * 24 + j];
+        s_pose[j * 6 + o] = acc;
+        rot6d[(size_t)n * 144 + j * 6 + o] = acc;
+    }
+    for (int o = wave; o < 13; o += 4) {
+        const float* wr = o < 10 ? w.shape_w + (size_t)o * 1536 : w.cam_w + (size_t)(o - 10) * 1536;
+        float acc = 0.f;
+        for (int k = lane; k < 1536; k += 64) acc += s_csf[k] * wr[k];
+        acc = wave_sum(acc);
+        if (lane == 0) s_sc[o] = acc + (o < 10 ? w.shape_b[o] : w.cam_b[o - 10]);
+    }
+    __syncthreads();
+    if (tid < 24) {
+        float R[9], aa[3];
+        rot6d_to_rotmat_dev(&s_pose[tid * 6], R);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) rotmat[(size_t)n * 216 + tid * 9 + k] = R[k];
+        rotmat_to_aa_dev(R, aa);
+        theta[(size_t)n * 85 + 3 + tid * 3 + 0] = aa[0];
+        theta[(size_t)n * 85 + 3 + tid * 3 + 1] = aa[1];
+        theta[(size_t)n * 85 + 3 + tid * 3 + 2] = aa[2];
+    }
+    if (tid >= 64 && tid < 74) {
+        const int o = tid - 64;
+        shape[(size_t)n * 10 + o] = s_sc[o];
+        theta[(size_t)n * 85 + 75 + o] = s_sc[o];
+    }
+    if (tid >= 128 && tid < 131) {
+        const int o = tid - 128;
+        cam[(size_t)n * 3 + o] = s_sc[10 + o];
+        theta[(size_t)n * 85 + o] = s_sc[10 + o];
+    }
+}
+
+hipError_t launch_head_tail(const float* plf, const float* csf, TailWeights w, float* rot6d, float* shape, float* cam,
+                            float* rotmat, float* theta, int N, hipStream_t s) {
+    hipLaunchKernelGGL(head_tail_kernel, dim3(N), dim3(256), 0, s, plf, csf, w, rot6d, shape, cam, rotmat, theta);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// SMPL linear blend skinning (published algorithm as implemented by smplx 0.1.26, SURVEY A.7;
+// reference call sites lib/models/smpl.py:108-130,157-162).
+//   kernel 1 (one wave per frame): rest joints J = J_template + J_shapedirs.betas (the joint
+//     regressor is linear, so it is applied to the tables once at load), the 24-joint kinematic
+//     chain, skinning matrices A_j = G_j - [0 | G_j.J_j] as 3x4 rows, posed joints.
+//   kernel 2 (vertices): v_shaped, pose blend shapes, T_v = sum_j w_vj A_j, verts.
+//   kernel 3 (one block per frame): the 29 "spin2" joints (smpl.py:113-118) incl. the thorax row
+//     of J_regressor_extra, weak-perspective -> perspective camera, projection / 112
+//     (geometry.py:427-479, smpl.py:172-186).
+__global__ __launch_bounds__(64) void smpl_chain_kernel(const float* __restrict__ betas, const float* __restrict__ rotmat, SmplTables t,
+                                                          float* __restrict__ A_ws, float* __restrict__ kp3d) {
+    __shared__ float J[24][3];
+    __shared__ float G[24][12];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    for (int e = tid; e < 72; e += 64) {
+        float v = t.J_template[e];
+#pragma unroll
+        for (int l = 0; l < 10; ++l) v += t.J_shapedirs[e * 10 + l] * betas[(size_t)n * 10 + l];
+        J[e / 3][e % 3] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float* R = rotmat + (size_t)n * 216;
+        for (int i = 0; i < 24; ++i) {
+            const int p = t.parents[i];
+            float tl[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) tl[k] = J[i][k] - (i > 0 ? J[p][k] : 0.f);
+            if (i == 0) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) G[0][r * 4 + c] = R[r * 3 + c];
+                    G[0][r * 4 + 3] = tl[r];
+                }
+            } else {
+                const float* Ri = R + i * 9;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const float g0 = G[p][r * 4 + 0], g1 = G[p][r * 4 + 1], g2 = G[p][r * 4 + 2];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) G[i][r * 4 + c] = g0 * Ri[c] + g1 * Ri[3 + c] + g2 * Ri[6 + c];
+                    G[i][r * 4 + 3] = g0 * tl[0] + g1 * tl[1] + g2 * tl[2] + G[p][r * 4 + 3];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < 24 * 12; e += 64) {
+        const int i = e / 12, rc = e % 12, r = rc / 4, c = rc % 4;
+        float v = G[i][rc];
+        if (c == 3) {
+            kp3d[((size_t)n * 29 + i) * 3 + r] = v;                  // posed joint = translation of G_i
+            v -= G[i][r * 4 + 0] * J[i][0] + G[i][r * 4 + 1] * J[i][1] + G[i][r * 4 + 2] * J[i][2];
+        }
+        A_ws[(size_t)n * 288 + e] = v;
+    }
+}
+
+constexpr int kNumVerts = 6890;
+__global__ __launch_bounds__(256) void smpl_verts_kernel(const float* __restrict__ betas, const float* __restrict__ rotmat, SmplTables t,
+                                                           const float* __restrict__ A_ws, float* __restrict__ verts) {
+    __shared__ float sA[288];
+    __shared__ float pf[208];
+    __shared__ float sb[10];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    for (int e = tid; e < 288; e += 256) sA[e] = A_ws[(size_t)n * 288 + e];
+    if (tid < 207) {
+        const int k = tid % 9;
+        pf[tid] = rotmat[(size_t)n * 216 + 9 + tid] - ((k == 0 || k == 4 || k == 8) ? 1.f : 0.f);   // (R[1:] - I).flatten
+    }
+    if (tid < 10) sb[tid] = betas[(size_t)n * 10 + tid];
+    __syncthreads();
+    const int v = blockIdx.x * 256 + tid;
+    if (v >= kNumVerts) return;
+    float p[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float acc = t.v_template[v * 3 + d];
+#pragma unroll
+        for (int l = 0; l < 10; ++l) acc += t.shapedirs[(v * 3 + d) * 10 + l] * sb[l];
+        p[d] = acc;
+    }
+    const float* pd = t.posedirs + (size_t)v * 3;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll 9
+    for (int k = 0; k < 207; ++k) {
+        const float f = pf[k];
+        o0 += f * pd[(size_t)k * (kNumVerts * 3) + 0];
+        o1 += f * pd[(size_t)k * (kNumVerts * 3) + 1];
+        o2 += f * pd[(size_t)k * (kNumVerts * 3) + 2];
+    }
+    p[0] += o0; p[1] += o1; p[2] += o2;
+    float T[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) T[e] = 0.f;
+    const float* wv = t.lbs_weights + (size_t)v * 24;
+    for (int j = 0; j < 24; ++j) {
+        const float wj = wv[j];
+        if (wj != 0.f) {
+#pragma unroll
+            for (int e = 0; e < 12; ++e) T[e] += wj * sA[j * 12 + e];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+        verts[((size_t)n * kNumVerts + v) * 3 + r] = T[r * 4 + 0] * p[0] + T[r * 4 + 1] * p[1] + T[r * 4 + 2] * p[2] + T[r * 4 + 3];
+}
+
+__global__ __launch_bounds__(256) void smpl_joints_kernel(const float* __restrict__ verts, const float* __restrict__ cam, SmplTables t,
+                                                            float* __restrict__ kp3d, float* __restrict__ kp2d) {
+    __shared__ float red[4][3];
+    __shared__ float sj[29][3];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* vn = verts + (size_t)n * kNumVerts * 3;
+    const float* je = t.J_extra + (size_t)5 * kNumVerts;          // 'Thorax (MPII)' = row 50-45 (smpl.py:117)
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int v = tid; v < kNumVerts; v += 256) {
+        const float w = je[v];
+        if (w != 0.f) { a0 += w * vn[v * 3]; a1 += w * vn[v * 3 + 1]; a2 += w * vn[v * 3 + 2]; }
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+    if (lane == 0) { red[wave][0] = a0; red[wave][1] = a1; red[wave][2] = a2; }
+    if (tid < 72) sj[tid / 3][tid % 3] = kp3d[(size_t)n * 87 + tid];          // 24 posed joints (kernel 1)
+    // joints45[35,37,40,42] = vertices lthumb 2746, lmiddle 2445, rthumb 6191, rmiddle 5905
+    if (tid >= 96 && tid < 108) {
+        const int e = tid - 96, jj = e / 3, d = e % 3;
+        const int vid = jj == 0 ? 2746 : jj == 1 ? 2445 : jj == 2 ? 6191 : 5905;
+        sj[24 + jj][d] = vn[vid * 3 + d];
+    }
+    __syncthreads();
+    if (tid < 3) sj[28][tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    __syncthreads();
+    if (tid < 87) kp3d[(size_t)n * 87 + tid] = sj[tid / 3][tid % 3];
+    if (tid < 29) {
+        const float s = cam[(size_t)n * 3], tx = cam[(size_t)n * 3 + 1], ty = cam[(size_t)n * 3 + 2];
+        const float tz = 2.f * 5000.f / (224.f * s + 1e-9f);
+        const float X = sj[tid][0] + tx, Y = sj[tid][1] + ty, Z = sj[tid][2] + tz;
+        kp2d[((size_t)n * 29 + tid) * 2 + 0] = 5000.f * (X / Z) / 112.f;
+        kp2d[((size_t)n * 29 + tid) * 2 + 1] = 5000.f * (Y / Z) / 112.f;
+    }
+}
+
+hipError_t launch_smpl(const float* betas, const float* rotmat, const float* cam, SmplTables t, float* A_ws, float* verts,
+                       float* kp3d, float* kp2d, int N, hipStream_t s) {
+    hipLaunchKernelGGL(smpl_chain_kernel, dim3(N), dim3(64), 0, s, betas, rotmat, t, A_ws, kp3d);
+    hipLaunchKernelGGL(smpl_verts_kernel, dim3((kNumVerts + 255) / 256, N), dim3(256), 0, s, betas, rotmat, t, A_ws, verts);
+    hipLaunchKernelGGL(smpl_joints_kernel, dim3(N), dim3(256), 0, s, verts, cam, t, kp3d, kp2d);
+    return hipGetLastError();
+}
+
+}  // namespace grk

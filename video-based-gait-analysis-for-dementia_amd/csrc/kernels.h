@@ -1,0 +1,106 @@
+// Internal launch interface between the network plan (grnet.cpp) and the HIP kernels.
+// All tensors are fp32 NCHW in HBM; a View addresses a channel slice [coff, coff+c) of a
+// buffer that holds ctot channels per image, so producers write straight into their slice of
+// the 480-channel concat buffer (reference: torch.cat, hrnet.py:524) with no copy kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace grk {
+
+struct View {
+    float* p = nullptr;   // base of the whole buffer (image 0, channel 0)
+    int ctot = 0;         // channels per image in the underlying buffer
+    int coff = 0;         // first channel of this view
+    int c = 0, h = 0, w = 0;
+};
+
+constexpr int kMaxAdd = 3;
+constexpr int kConvCK = 8;      // input channels staged per K-chunk
+
+// One fused convolution: out = act( conv(in, w) + bias + sum_k nearest_up(add_k, 2^shift_k) ).
+// BatchNorm (eval) is folded into w / bias on the host in fp64 (reference: conv -> BN,
+// hrnet.py:46-52; folding is exact up to fp32 rounding of the folded weights).
+struct ConvArgs {
+    const float* in; int in_ctot, in_coff;
+    int N, Cin, H, W;
+    float* out; int out_ctot, out_coff;
+    int Cout, Ho, Wo;
+    const float* w;            // packed [KS*KS][CinPad][CoutPad], BN scale folded in
+    const float* bias;         // [CoutPad], BN shift (+ conv bias) folded in
+    int CinPad, CoutPad;
+    int ks, stride, relu;
+    int n_add;
+    const float* add[kMaxAdd]; int add_ctot[kMaxAdd], add_coff[kMaxAdd], add_shift[kMaxAdd];
+    const float* zeros;        // >= 64 B of zeros in HBM: source for halo / padded-channel loads
+    // filled by the launcher
+    int R, G, Rin, Wp, PSTR, tiles_y, groups, TC;
+};
+
+// Returns hipSuccess or the launch error.  `tile_hint`: 0 = auto, 7 / 14 = force pixel sub-tiles.
+hipError_t launch_conv(ConvArgs a, hipStream_t s, int tile_hint = 0);
+int conv_pick_tc(int Cout);                 // cout tile (32 or 64) -> defines CoutPad at pack time
+hipError_t conv_init();                     // sets max dynamic LDS on every instantiation
+const char* conv_dominant_kernel_name();
+
+// out = relu?( sum_k nearest_up(add_k) ), 1..4 addends, out and every addend are Views.
+struct SumArgs {
+    float* out; int out_ctot, out_coff;
+    int N, C, H, W, relu, n_add;
+    const float* add[4]; int add_ctot[4], add_coff[4], add_shift[4];
+};
+hipError_t launch_fuse_sum(const SumArgs& a, hipStream_t s);
+
+// nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (hrnet.py:443)
+hipError_t launch_bilinear2x(const float* in, float* out, int N, int C, int H, int W, hipStream_t s);
+
+// PARE head tail ---------------------------------------------------------------------------
+// softmax over H*W of heat[:,1+j] and attention pooling of feat channels (keypoint_attention.py:42-48)
+// heat: (N,25,P) with channel 0 = background; featA (N,CA,P) -> outA (N,CA,24); featB (N,CB,P) -> outB (N,CB,24)
+hipError_t launch_softmax_pool(const float* heat, int heat_ctot, const float* featA, int CA, const float* featB, int CB,
+                               float* outA, float* outB, float* prob_ws, int N, int P, hipStream_t s);
+
+struct TailWeights {
+    const float* pose_w;    // (6,128,24)
+    const float* shape_w;   // (10,1536)
+    const float* shape_b;
+    const float* cam_w;     // (3,1536)
+    const float* cam_b;
+};
+// plf (N,128,24), csf (N,64,24) -> rot6d (N,24,6), shape (N,10), cam (N,3), rotmat (N,24,9), theta (N,85)
+hipError_t launch_head_tail(const float* plf, const float* csf, TailWeights w, float* rot6d, float* shape, float* cam,
+                            float* rotmat, float* theta, int N, hipStream_t s);
+
+struct SmplTables {
+    const float* v_template;   // (6890,3)
+    const float* shapedirs;    // (6890*3,10)
+    const float* posedirs;     // (207,20670)
+    const float* J_template;   // (24,3)   = J_regressor . v_template           (precomputed at load)
+    const float* J_shapedirs;  // (24*3,10) = J_regressor . shapedirs             (precomputed at load)
+    const float* lbs_weights;  // (6890,24)
+    const float* J_extra;      // (9,6890)
+    const int* parents;        // (24)
+};
+// betas (N,10), rotmat (N,24,9), cam (N,3) -> verts (N,6890,3), kp3d (N,29,3), kp2d (N,29,2)
+hipError_t launch_smpl(const float* betas, const float* rotmat, const float* cam, SmplTables t, float* A_ws,
+                       float* verts, float* kp3d, float* kp2d, int N, hipStream_t s);
+
+// GRU gait encoder (gait_feat_encoder.py:79-104) ------------------------------------------------
+struct GruWeights {
+    const float* cparam_w;                 // (128,3,24)
+    const float* w_ih[2][2]; const float* w_hh[2][2]; const float* b_ih[2][2]; const float* b_hh[2][2];  // [layer][dir]
+    const float* speed_w0; const float* speed_b0; const float* speed_w2; const float* speed_b2;
+    const float* step_w0;  const float* step_b0;  const float* step_w2;  const float* step_b2;
+    const float* phase_w0; const float* phase_b0; const float* phase_w2; const float* phase_b2;
+};
+struct GruWorkspace {
+    float* xin;      // (b*T, 3072)   x + xc
+    float* gi;       // (2, b*T, 900) input projections per direction
+    float* l0;       // (b*T, 600)
+    float* l1;       // (b*T, 600)
+    float* hfin;     // (b, 1200)
+};
+hipError_t launch_gru(const float* x, const float* cparams, GruWeights w, GruWorkspace ws, float* y, float* phase,
+                      float* xc, int b, int T, hipStream_t s);
+
+}  // namespace grk

@@ -1,0 +1,275 @@
+"""Host-side mirror of the reference's model interface for the per-frame path.
+
+``GRNet`` keeps the constructor signature, ``load_state_dict`` / ``eval`` / ``to`` surface and the
+``forward(features, bbox=None, cimg=None, J_regressor=None) -> [dict]`` contract of
+``lib/models/grnet.py:25-175`` (output keys per ``lib/models/pare.py:78-84``), but every FLOP runs
+in libgrnet_hip.so on the MI355X.  PyTorch is used only as the tensor container (``data_ptr()``),
+for the current HIP stream and for reading checkpoints.
+
+Differences from the reference that are deliberate: no ``sys.exit`` on a missing PARE
+checkpoint (weights arrive through ``load_state_dict`` / ``load_pare_dict``), ``torch.load`` uses
+``map_location='cpu'``, and ``use_gait_feat=True`` raises (the reference's FeatCorrector cannot be
+constructed as shipped, feature_correction.py:40-62).
+"""
+import ctypes as C
+import logging
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+from . import _lib, netspec
+
+logger = logging.getLogger(__name__)
+_IncompatibleKeys = namedtuple("_IncompatibleKeys", ["missing_keys", "unexpected_keys"])
+
+SMPL_PREFIX = "regressor.smpl.smpl."
+_SMPL_KEYS = ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights", "parents", "J_regressor_extra")
+_TOLERATED_SMPL_KEYS = ("faces_tensor", "vertex_joint_selector.extra_joints_idxs", "betas", "global_orient",
+                        "body_pose", "transl")
+
+
+def _np32(t):
+    if torch.is_tensor(t):
+        t = t.detach().cpu().numpy()
+    return np.ascontiguousarray(np.asarray(t), dtype=np.float32)
+
+
+class GRNet:
+    is_demo = False
+
+    def __init__(self, num_joints=24, num_input_features=480, num_features_pare=128, num_features_smpl=64,
+                 backbone='hrnet_w32', focal_length=5000., img_res=224, pretrained_pare=None, writer=None, seqlen=50,
+                 pretrained_hrnet=None, use_gait_feat=False, featcorr=None, use_pose_encoder=False,
+                 use_shpcam_encoder=False, max_frames=64, device_id=0):
+        if (num_joints, num_input_features, num_features_pare, num_features_smpl) != (24, 480, 128, 64) \
+                or backbone != 'hrnet_w32' or focal_length != 5000. or img_res != 224:
+            raise ValueError("the HIP path implements the reference's fixed configuration "
+                             "(24 joints, hrnet_w32 -> 480 features, PARE 128/64, f=5000, 224 px)")
+        if use_gait_feat:
+            raise NotImplementedError("use_gait_feat=True: the reference's FeatCorrector is not constructible "
+                                      "(feature_correction.py:40-62); use BidirectionalModel for the GRU")
+        self._lib = _lib.load()
+        self.max_frames = int(max_frames)
+        self.device = torch.device("cuda", device_id)
+        h = C.c_void_p()
+        rc = self._lib.grnet_create(C.byref(h), device_id, 0, self.max_frames)
+        if rc != 0:
+            raise _lib.GrnetError(f"grnet_create failed with code {rc} (is a GPU visible?)")
+        self._h = h
+        self._finalized = False
+        self._smpl_loaded = False
+        self._loaded = set()
+        self.seqlen = seqlen
+        self.training = False
+        self.focal_length = focal_length
+        if pretrained_pare:
+            self.load_pare_dict(pretrained_pare)
+
+    # ------------------------------------------------------------------ weights
+    def _load_tensor(self, key, value):
+        if torch.is_tensor(value):
+            value = value.detach().cpu().numpy()
+        value = np.asarray(value)
+        if value.dtype.kind in "iu":
+            dtype, arr = _lib.DTYPE_I64, np.ascontiguousarray(value, dtype=np.int64)
+        else:
+            dtype, arr = _lib.DTYPE_F32, np.ascontiguousarray(value, dtype=np.float32)
+        shape = (C.c_int64 * max(arr.ndim, 1))(*arr.shape)
+        rc = self._lib.grnet_load_tensor(self._h, key.encode(), arr.ctypes.data_as(C.c_void_p), shape, arr.ndim, dtype)
+        _lib.check(self._lib, self._h, rc, f"grnet_load_tensor({key})")
+        self._loaded.add(key)
+
+    def load_smpl(self, tables):
+        """SMPL buffers (smplx.SMPL tables + J_regressor_extra, lib/models/smpl.py:97-106)."""
+        arrs = [_np32(tables[k]) for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights")]
+        parents = np.ascontiguousarray(np.asarray(tables["parents"]).astype(np.int32))
+        parents[0] = -1
+        extra = _np32(tables["J_regressor_extra"])
+        want = [netspec.SMPL_TABLE_SHAPES[k] for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights")]
+        for a, w, k in zip(arrs, want, _SMPL_KEYS):
+            if int(np.prod(a.shape)) != int(np.prod(w)):
+                raise ValueError(f"SMPL table {k} has shape {a.shape}, expected {w}")
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        rc = self._lib.grnet_load_smpl(self._h, ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]), ptr(arrs[3]), ptr(arrs[4]),
+                                       ptr(parents), ptr(extra))
+        _lib.check(self._lib, self._h, rc, "grnet_load_smpl")
+        self._smpl_loaded = True
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Reference key names (demo.py:116-122; batch_generation.py:214-218)."""
+        if self._finalized:
+            raise RuntimeError("weights are already finalized on the device")
+        spec = netspec.grnet_spec()
+        unexpected, smpl = [], {}
+        for k, v in state_dict.items():
+            if k.startswith(SMPL_PREFIX):
+                name = k[len(SMPL_PREFIX):]
+                if name in _SMPL_KEYS:
+                    smpl[name] = v
+                elif name not in _TOLERATED_SMPL_KEYS:
+                    unexpected.append(k)
+            elif k in spec or k.startswith("pfeat_corrector.featnet.") or k.startswith("gru."):
+                want = spec.get(k)
+                if want is not None and tuple(np.shape(v)) != tuple(want[0]):
+                    raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(np.shape(v))} vs model {tuple(want[0])}")
+                self._load_tensor(k, v)
+            else:
+                unexpected.append(k)
+        if len(smpl) == len(_SMPL_KEYS):
+            self.load_smpl(smpl)
+        missing = [k for k in spec if k not in self._loaded]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for GRNet: missing {missing[:5]}{'...' if len(missing) > 5 else ''}"
+                               f" unexpected {unexpected[:5]}{'...' if len(unexpected) > 5 else ''}")
+        return _IncompatibleKeys(missing, unexpected)
+
+    def load_pare_dict(self, pretrained_pare):
+        """PARE head weights re-keyed from 'model.head.*' (grnet.py:93-109; utils.py:185-196)."""
+        ckpt = torch.load(pretrained_pare, map_location="cpu")["state_dict"]
+        if "model.head.init_pose" not in ckpt or "model.head.init_shape" not in ckpt:
+            raise KeyError(f"Checkpoint at {pretrained_pare} does not match VPARE implementation.")
+        sd = {"head." + k[len("model.head."):]: v for k, v in ckpt.items() if k.startswith("model.head.")}
+        return self.load_state_dict(sd, strict=False)
+
+    def finalize(self):
+        if not self._finalized:
+            if not self._smpl_loaded:
+                raise RuntimeError("SMPL tables were not loaded (regressor.smpl.smpl.* keys or load_smpl())")
+            _lib.check(self._lib, self._h, self._lib.grnet_finalize_weights(self._h), "grnet_finalize_weights")
+            self._finalized = True
+        return self
+
+    # torch.nn.Module surface used by the entry points
+    def to(self, device=None):
+        return self
+
+    def eval(self):
+        return self
+
+    def set_option(self, option, value):
+        _lib.check(self._lib, self._h, self._lib.grnet_set_option(self._h, option, value), "grnet_set_option")
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, features, bbox=None, cimg=None, J_regressor=None, extras=()):
+        if features.dim() == 5:
+            batch_size, seqlen, nc, h, w = features.shape
+            features = features.reshape(-1, nc, h, w)
+        elif features.dim() == 4:
+            batch_size = 1
+            seqlen, nc, h, w = features.shape
+        else:
+            raise ValueError(f"Wrong feature dimension: {features.dim()}.")
+        if (nc, h, w) != (3, 224, 224):
+            raise ValueError(f"expected frames of shape (3,224,224), got {(nc, h, w)}")
+        if J_regressor is not None:
+            raise NotImplementedError("J_regressor override (evaluation-only, pare.py:70-76) is outside the inference path")
+        if not features.is_cuda:
+            raise RuntimeError("frames must live in HBM (features.to('cuda')); the HIP path has no CPU fallback")
+        self.finalize()
+        x = features.to(torch.float32).contiguous()
+        n = x.shape[0]
+        dev = x.device
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        out = {"theta": new(n, 85), "verts": new(n, 6890, 3), "kp_2d": new(n, 29, 2), "kp_3d": new(n, 29, 3),
+               "rotmat": new(n, 24, 3, 3)}
+        shapes = {"point_local_feat": (128, 24), "cam_shape_feats": (64, 24), "pred_rot6d": (24, 6),
+                  "features": (480, 56, 56), "part_attn": (25, 56, 56), "smpl_feats": (128, 56, 56)}
+        for k in extras:
+            out[k] = new(n, *shapes[k])
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        for s in range(0, n, self.max_frames):
+            m = min(self.max_frames, n - s)
+            o = _lib.Outputs()
+            for k, t in out.items():
+                setattr(o, k, t[s:s + m].data_ptr())
+            rc = self._lib.grnet_forward(self._h, C.c_void_p(x[s:s + m].data_ptr()), m, C.byref(o), stream)
+            _lib.check(self._lib, self._h, rc, "grnet_forward")
+        res = {"theta": out["theta"].reshape(batch_size, seqlen, 85),
+               "verts": out["verts"].reshape(batch_size, seqlen, 6890, 3),
+               "kp_2d": out["kp_2d"].reshape(batch_size, seqlen, 29, 2),
+               "kp_3d": out["kp_3d"].reshape(batch_size, seqlen, 29, 3),
+               "rotmat": out["rotmat"].reshape(batch_size, seqlen, 24, 3, 3)}
+        for k in extras:
+            res[k] = out[k]
+        return [res]
+
+    __call__ = forward
+
+    # ------------------------------------------------------------------ introspection (bench / tests)
+    def num_kernel_launches(self):
+        return self._lib.grnet_num_kernel_launches(self._h)
+
+    def conv_flops_per_frame(self):
+        return self._lib.grnet_conv_flops_per_frame(self._h)
+
+    def time_convs(self, n_frames):
+        ms = C.c_float()
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self._lib, self._h, self._lib.grnet_time_convs(self._h, n_frames, stream, C.byref(ms)), "grnet_time_convs")
+        return ms.value
+
+    def gru_forward(self, x, cparams):
+        """BidirectionalModel.forward on this handle's GRU weights (keys gru.* / pfeat_corrector.featnet.*)."""
+        self.finalize()
+        b, t, f = x.shape
+        if f != 3072 or tuple(cparams.shape) != (b, t, 3):
+            raise ValueError("x must be (b,T,3072) and cparams (b,T,3)")
+        x = x.to(torch.float32).contiguous()
+        cp = cparams.to(torch.float32).contiguous()
+        y = torch.empty(b, 3, dtype=torch.float32, device=x.device)
+        ph = torch.empty(b, t, 4, dtype=torch.float32, device=x.device)
+        xc = torch.empty(b, t, 3072, dtype=torch.float32, device=x.device)
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        rc = self._lib.grnet_gru_forward(self._h, x.data_ptr(), cp.data_ptr(), b, t, y.data_ptr(), ph.data_ptr(),
+                                         xc.data_ptr(), stream)
+        _lib.check(self._lib, self._h, rc, "grnet_gru_forward")
+        return y, ph, xc
+
+    # single-op hooks for kernel parity tests
+    def op_conv2d(self, x, w, bias=None, stride=1, relu=False, add=None, tile_hint=0):
+        n, cin, h, wd = x.shape
+        cout, _, ks, _ = w.shape
+        pad = ks // 2
+        ho, wo = (h + 2 * pad - ks) // stride + 1, (wd + 2 * pad - ks) // stride + 1
+        out = torch.empty(n, cout, ho, wo, dtype=torch.float32, device=x.device)
+        wn = _np32(w)
+        bn = _np32(bias) if bias is not None else None
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        rc = self._lib.grnet_op_conv2d(self._h, x.data_ptr(), n, cin, h, wd, wn.ctypes.data_as(C.c_void_p),
+                                       bn.ctypes.data_as(C.c_void_p) if bn is not None else None, cout, ks, stride,
+                                       int(relu), add.data_ptr() if add is not None else None, out.data_ptr(),
+                                       tile_hint, stream)
+        _lib.check(self._lib, self._h, rc, "grnet_op_conv2d")
+        return out
+
+    def op_bilinear2x(self, x):
+        n, c, h, w = x.shape
+        out = torch.empty(n, c, 2 * h, 2 * w, dtype=torch.float32, device=x.device)
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        rc = self._lib.grnet_op_bilinear2x(self._h, x.data_ptr(), n, c, h, w, out.data_ptr(), stream)
+        _lib.check(self._lib, self._h, rc, "grnet_op_bilinear2x")
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.grnet_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def build_synthetic_model(max_frames=64, device_id=0, with_gru=True):
+    """GRNet with the seed-defined weights / SMPL tables of synth.py (no checkpoint exists offline)."""
+    from . import synth
+    m = GRNet(max_frames=max_frames, device_id=device_id)
+    sd = synth.make_state_dict()
+    if with_gru:
+        sd.update({"gru." + k: v for k, v in synth.make_gru_state_dict().items()})
+    m.load_state_dict(sd, strict=True)
+    m.load_smpl(synth.make_smpl_tables())
+    return m.finalize()

@@ -1,0 +1,105 @@
+"""Host harness of the per-frame path: frame sharding across the GPUs of one node, the one
+all-gather that reassembles the pose sequence, and the fixed-buffer clip runner the bench uses.
+
+Reference counterparts: the model loops of ``demo.py:126-188`` and
+``batch_generation.py:289-329`` (single process, single device there).  Frames are independent in
+the reference's runnable configuration (``grnet.py:136-152``), so a clip shards into contiguous
+frame ranges with no data-path collective; the only exchange is the all-gather of the per-frame
+results before anything temporal (the GRU gait encoder) runs on the whole sequence.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+# per-frame pose record gathered across ranks: name -> floats per frame
+POSE_RECORD = (("theta", 85), ("kp_3d", 87), ("kp_2d", 58), ("point_local_feat", 3072))
+POSE_RECORD_FLOATS = sum(s for _, s in POSE_RECORD)
+
+
+def shard_range(n_total, world, rank):
+    """Contiguous frame range [lo, hi) of ``rank``: ceil(n/world) frames each, last ranks may be short/empty."""
+    per = -(-n_total // world)
+    lo = min(rank * per, n_total)
+    return lo, min(lo + per, n_total)
+
+
+def pack_layout(n_local):
+    """Offsets (in floats) of each field inside one rank's packed block: field-major, frame-minor."""
+    off, layout = 0, {}
+    for name, sz in POSE_RECORD:
+        layout[name] = (off, sz)
+        off += sz * n_local
+    return layout, off
+
+
+def gather_pose_records(packed_local, n_local, world, dist, out=None):
+    """One all-gather of every rank's packed block (RCCL over xGMI on GPUs, gloo in CPU tests).
+
+    ``packed_local``: 1-D tensor of ``n_local * POSE_RECORD_FLOATS`` floats laid out by ``pack_layout``;
+    every rank must pass the same ``n_local`` (pad the last shard).  Returns the (world, block) tensor.
+    """
+    block = packed_local.numel()
+    if out is None:
+        out = torch.empty(world * block, dtype=packed_local.dtype, device=packed_local.device)
+    if world == 1:
+        out.copy_(packed_local)
+    else:
+        dist.all_gather_into_tensor(out, packed_local)
+    return out.view(world, block)
+
+
+def unpack_sequence(gathered, n_local, n_total):
+    """(world, block) -> dict of whole-sequence tensors (n_total, ...) in frame order."""
+    layout, _ = pack_layout(n_local)
+    world = gathered.shape[0]
+    seq = {}
+    for name, (off, sz) in layout.items():
+        seq[name] = gathered[:, off:off + sz * n_local].reshape(world * n_local, sz)[:n_total]
+    seq["theta"] = seq["theta"].reshape(-1, 85)
+    seq["kp_3d"] = seq["kp_3d"].reshape(-1, 29, 3)
+    seq["kp_2d"] = seq["kp_2d"].reshape(-1, 29, 2)
+    seq["point_local_feat"] = seq["point_local_feat"].reshape(-1, 128, 24)
+    return seq
+
+
+class ClipRunner:
+    """Runs the hot path over one resident shard of frames with fixed device buffers.
+
+    Fixed pointers let the library replay ONE captured hipGraph per step (GRNET_OPT_USE_GRAPH); the
+    small per-frame results are written straight into the packed block that the all-gather sends, so
+    the exchange needs no packing kernel.  ``verts`` / ``rotmat`` stay sharded (rank-local).
+    """
+
+    def __init__(self, model, frames, use_graph=True, world=1, rank=0, dist=None):
+        self.model, self.frames, self.world, self.rank, self.dist = model, frames.contiguous(), world, rank, dist
+        self.n = n = frames.shape[0]
+        dev = frames.device
+        layout, block = pack_layout(n)
+        self.packed = torch.zeros(block, dtype=torch.float32, device=dev)
+        self.verts = torch.empty(n, 6890, 3, dtype=torch.float32, device=dev)
+        self.rotmat = torch.empty(n, 24, 3, 3, dtype=torch.float32, device=dev)
+        self.gathered = torch.empty(world * block, dtype=torch.float32, device=dev)
+        self.out = _lib.Outputs()
+        for name, (off, sz) in layout.items():
+            setattr(self.out, name, self.packed[off:off + sz * n].data_ptr())
+        self.out.verts = self.verts.data_ptr()
+        self.out.rotmat = self.rotmat.data_ptr()
+        model.finalize()
+        if use_graph:
+            model.set_option(_lib.OPT_USE_GRAPH, 1)
+        self._lib, self._h = model._lib, model._h
+        self._stream = torch.cuda.current_stream(dev)
+
+    def step(self):
+        rc = self._lib.grnet_forward(self._h, C.c_void_p(self.frames.data_ptr()), self.n, C.byref(self.out),
+                                     C.c_void_p(self._stream.cuda_stream))
+        _lib.check(self._lib, self._h, rc, "grnet_forward")
+        if self.world > 1:
+            gather_pose_records(self.packed, self.n, self.world, self.dist, out=self.gathered)
+
+    def sequence(self, n_total=None):
+        """Whole-clip results in frame order (after step())."""
+        g = self.gathered.view(self.world, -1) if self.world > 1 else self.packed.view(1, -1)
+        return unpack_sequence(g, self.n, n_total if n_total is not None else self.n * self.world)
