@@ -106,6 +106,12 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
                     float* out_dev, int tile_hint, void* stream);
 int grnet_op_bilinear2x(grnet_t* h, const float* in_dev, int n, int c, int hgt, int wid, float* out_dev, void* stream);
 
+/* Copy a named intermediate of the LAST forward (first n_frames images) into out_dev as a dense
+ * (n,C,H,W) tensor; shape_out[3] receives C,H,W (out_dev may be NULL to query the shape).  Names:
+ * stem_conv1, stem_conv2, layer1, stage{2,3,4}.{branch}, up{2,3,4}.{layer}.{bilinear,conv}.
+ * Parity tests compare these with the oracle's taps of hrnet.py:469-536. */
+int grnet_debug_tensor(grnet_t* h, const char* name, int n_frames, float* out_dev, int64_t* shape_out, void* stream);
+
 const char* grnet_last_error(grnet_t* h);
 const char* grnet_version(void);
 void grnet_destroy(grnet_t* h);

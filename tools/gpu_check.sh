@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 rocminfo 2>/dev/null | grep -E "Marketing Name|gfx|Compute Unit" | head -8 > gpurun_out/rocminfo.txt
-timeout 1500 python -m pytest tests -m gpu -q -x --timeout 600 2>&1 | tail -60 > gpurun_out/pytest_gpu.log
+timeout 1500 python -m pytest tests -m gpu -q --timeout 600 2>&1 | tail -120 > gpurun_out/pytest_gpu.log
 echo "pytest exit: ${PIPESTATUS[0]}" >> gpurun_out/pytest_gpu.log
 timeout 600 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1
 echo "smoke exit: $?" >> gpurun_out/smoke.log

@@ -36,6 +36,7 @@ EXPORTS = {
     "grnet_op_conv2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "grnet_op_bilinear2x": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "grnet_debug_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
     "grnet_last_error": (C.c_char_p, [C.c_void_p]),
     "grnet_version": (C.c_char_p, []),
     "grnet_destroy": (None, [C.c_void_p]),
@@ -49,6 +50,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime under the same SONAMEs as /opt/rocm's: import it FIRST so that
+    # this library binds to the runtime torch allocates tensors with (one runtime per process).
+    import torch  # noqa: F401
     if not os.path.isfile(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

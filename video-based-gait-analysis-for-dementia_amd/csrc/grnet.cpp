@@ -106,6 +106,7 @@ struct grnet {
         }
     };
     std::map<GraphKey, hipGraphExec_t> graphs;
+    hipStream_t capture_stream = nullptr;   // the caller's stream may be the (uncapturable) null stream
     int launches_last = 0;
 
     int fail(int code, const std::string& msg) {
@@ -223,6 +224,8 @@ struct grnet {
         return outs;
     }
     std::vector<std::pair<View, std::vector<AddRef>>> sum_views;
+    std::vector<std::pair<std::string, View>> named;   // intermediate tensors exposed to grnet_debug_tensor
+    void name_view(const std::string& n, const View& v) { named.emplace_back(n, v); }
 
     void build_plan() {
         const std::string b = "backbone.";
@@ -230,7 +233,9 @@ struct grnet {
         View in = v_input;
         in.p = reinterpret_cast<float*>(~(uintptr_t)0);   // tag: caller's frames pointer
         View x = conv_bn(in, b + "conv1.weight", b + "bn1", 64, 3, 2, true);
+        name_view("stem_conv1", x);
         x = conv_bn(x, b + "conv2.weight", b + "bn2", 64, 3, 2, true);
+        name_view("stem_conv2", x);
         for (int k = 0; k < 4; ++k) {                       // layer1: 4 Bottlenecks (hrnet.py:80-100)
             const std::string q = b + "layer1." + std::to_string(k) + ".";
             View res = k == 0 ? conv_bn(x, q + "downsample.0.weight", q + "downsample.1", 256, 1, 1, false) : x;
@@ -238,18 +243,22 @@ struct grnet {
             y = conv_bn(y, q + "conv2.weight", q + "bn2", 64, 3, 1, true);
             x = conv_bn(y, q + "conv3.weight", q + "bn3", 256, 1, 1, true, {AddRef{res, 0}});
         }
+        name_view("layer1", x);
         std::vector<View> xs;
         xs.push_back(conv_bn(x, b + "transition1.0.0.weight", b + "transition1.0.1", 32, 3, 1, true));
         xs.push_back(conv_bn(x, b + "transition1.1.0.0.weight", b + "transition1.1.0.1", 64, 3, 2, true));
         xs = hr_module(xs, b + "stage2.0.", nullptr);
+        for (size_t i = 0; i < xs.size(); ++i) name_view("stage2." + std::to_string(i), xs[i]);
         xs.push_back(conv_bn(xs.back(), b + "transition2.2.0.0.weight", b + "transition2.2.0.1", 128, 3, 2, true));
         for (int m = 0; m < 4; ++m) xs = hr_module(xs, b + "stage3." + std::to_string(m) + ".", nullptr);
+        for (size_t i = 0; i < xs.size(); ++i) name_view("stage3." + std::to_string(i), xs[i]);
         xs.push_back(conv_bn(xs.back(), b + "transition3.3.0.0.weight", b + "transition3.3.0.1", 256, 3, 2, true));
         v_cat = new_buffer(480, 56, 56);                    // torch.cat([x0, x1, x2, x3], 1) (hrnet.py:524)
         for (int m = 0; m < 3; ++m) {
             View o0 = slice(v_cat, 0, 32);
             xs = hr_module(xs, b + "stage4." + std::to_string(m) + ".", m == 2 ? &o0 : nullptr);
         }
+        for (size_t i = 0; i < xs.size(); ++i) name_view("stage4." + std::to_string(i), xs[i]);
         int coff = 32;
         for (int idx = 2; idx <= 4; ++idx) {                // upsample heads (hrnet.py:440-453,521-523)
             const int br = idx - 1, c = kBranchCh[br], n_layers = idx - 1;
@@ -257,9 +266,11 @@ struct grnet {
             for (int l = 0; l < n_layers; ++l) {
                 const std::string q = b + "upsample_stage_" + std::to_string(idx) + ".";
                 View up = add_bilinear(t);
+                name_view("up" + std::to_string(idx) + "." + std::to_string(l) + ".bilinear", up);
                 View dst = slice(v_cat, coff, c);
                 t = conv_bn(up, q + std::to_string(4 * l + 1) + ".weight", q + std::to_string(4 * l + 2), c, 3, 1, true, {},
                             l == n_layers - 1 ? &dst : nullptr);
+                name_view("up" + std::to_string(idx) + "." + std::to_string(l) + ".conv", t);
             }
             coff += c;
         }
@@ -318,6 +329,7 @@ struct grnet {
         }
         for (auto& op : ops) { resolve(op.bin); resolve(op.bout); }
         for (auto& sv : sum_views) { resolve(sv.first); for (auto& a : sv.second) resolve(a.v); }
+        for (auto& nv : named) resolve(nv.second);
         resolve(v_cat); resolve(v_heat); resolve(v_smpl_feats); resolve(v_csmap);
         const size_t n = max_frames;
         int rc;
@@ -552,9 +564,10 @@ struct grnet {
         auto it = graphs.find(key);
         if (it == graphs.end()) {
             hipGraph_t g = nullptr;
-            HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            int rc = enqueue(frames, n, o, s);
-            hipError_t e = hipStreamEndCapture(s, &g);
+            if (!capture_stream) HIP_TRY(hipStreamCreateWithFlags(&capture_stream, hipStreamNonBlocking));
+            HIP_TRY(hipStreamBeginCapture(capture_stream, hipStreamCaptureModeThreadLocal));
+            int rc = enqueue(frames, n, o, capture_stream);
+            hipError_t e = hipStreamEndCapture(capture_stream, &g);
             if (rc) { if (g) hipGraphDestroy(g); return rc; }
             if (e != hipSuccess) return fail(GRNET_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
             hipGraphExec_t ge = nullptr;
@@ -759,11 +772,28 @@ int grnet_op_bilinear2x(grnet_t* h, const float* in_dev, int n, int c, int hgt, 
     return 0;
 }
 
+int grnet_debug_tensor(grnet_t* h, const char* name, int n_frames, float* out_dev, int64_t* shape_out, void* stream) {
+    if (!h || !name) return GRNET_EINVAL;
+    for (auto& nv : h->named) {
+        if (nv.first != name) continue;
+        const View& v = nv.second;
+        if (shape_out) { shape_out[0] = v.c; shape_out[1] = v.h; shape_out[2] = v.w; }
+        if (!out_dev) return 0;
+        const size_t plane = (size_t)v.h * v.w;
+        hipError_t e = hipMemcpy2DAsync(out_dev, (size_t)v.c * plane * 4, v.p + (size_t)v.coff * plane, (size_t)v.ctot * plane * 4,
+                                        (size_t)v.c * plane * 4, n_frames, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("debug copy: ") + hipGetErrorString(e));
+        return 0;
+    }
+    return h->fail(GRNET_EINVAL, std::string("unknown debug tensor ") + name);
+}
+
 const char* grnet_last_error(grnet_t* h) { return h ? h->err.c_str() : "null handle"; }
 
 void grnet_destroy(grnet_t* h) {
     if (!h) return;
     for (auto& g : h->graphs) hipGraphExecDestroy(g.second);
+    if (h->capture_stream) hipStreamDestroy(h->capture_stream);
     for (void* p : h->dev_allocs) hipFree(p);
     if (h->arena) hipFree(h->arena);
     delete h;

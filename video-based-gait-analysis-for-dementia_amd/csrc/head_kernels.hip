@@ -80,9 +80,12 @@ __global__ __launch_bounds__(256) void bilinear2x_kernel(const float* __restrict
         const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
         const float ly = fy - y0, lx = fx - x0;
         const float* p = in + nc * H * W;
-        const float top = p[y0 * W + x0] * (1.f - lx) + p[y0 * W + x1] * lx;
-        const float bot = p[y1 * W + x0] * (1.f - lx) + p[y1 * W + x1] * lx;
-        out[i] = top * (1.f - ly) + bot * ly;
+        // explicit roundings: the grid-stride loop is unrolled differently for different sizes, and
+        // compiler-chosen fma contraction would make a frame's result depend on the batch it is in
+        const float wx0 = 1.f - lx, wy0 = 1.f - ly;
+        const float top = __fmaf_rn(p[y0 * W + x1], lx, __fmul_rn(p[y0 * W + x0], wx0));
+        const float bot = __fmaf_rn(p[y1 * W + x1], lx, __fmul_rn(p[y1 * W + x0], wx0));
+        out[i] = __fmaf_rn(bot, ly, __fmul_rn(top, wy0));
     }
 }
 

@@ -209,6 +209,17 @@ class GRNet:
         _lib.check(self._lib, self._h, self._lib.grnet_time_convs(self._h, n_frames, stream, C.byref(ms)), "grnet_time_convs")
         return ms.value
 
+    def debug_tensor(self, name, n_frames):
+        """Named intermediate of the last forward as an (n,C,H,W) tensor (see grnet_debug_tensor)."""
+        shp = (C.c_int64 * 3)()
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self._lib, self._h, self._lib.grnet_debug_tensor(self._h, name.encode(), n_frames, None, shp, stream),
+                   "grnet_debug_tensor")
+        out = torch.empty(n_frames, shp[0], shp[1], shp[2], dtype=torch.float32, device=self.device)
+        _lib.check(self._lib, self._h, self._lib.grnet_debug_tensor(self._h, name.encode(), n_frames, out.data_ptr(), shp,
+                                                                     stream), "grnet_debug_tensor")
+        return out
+
     def gru_forward(self, x, cparams):
         """BidirectionalModel.forward on this handle's GRU weights (keys gru.* / pfeat_corrector.featnet.*)."""
         self.finalize()
