@@ -38,9 +38,12 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
-@pytest.mark.parametrize("tile", [7, 14])
+@pytest.mark.parametrize("tile", [7, 14, 1071, 1072, 1041, 1042])   # whole-K tiles and split-K (psw, csw) variants
 def test_conv_kernel(model, oracle, case, tile):
     cin, cout, k, stride, h = case
+    wo = (h + 2 * (k // 2) - k) // stride + 1
+    if tile in (1041, 1042) and wo > 64:
+        pytest.skip("a 64-pixel tile cannot hold one output row")
     n = 3 if h <= 28 else 2          # odd image count: partial multi-image tiles on the 7x7 / 14x14 maps
     x = _rand((n, cin, h, h), 1)
     w = _rand((cout, cin, k, k), 2) * np.float32(np.sqrt(2.0 / (cin * k * k)))
@@ -125,15 +128,25 @@ def test_forward_matches_oracle_full(run4, pkg, oracle, synth_weights, synth_smp
 
 def test_batch_invariance_full_size(model, pkg):
     """BASELINE config 2 size (16 frames): every frame is independent (grnet.py:136-152), so the
-    16-frame call must reproduce single-frame and chunked calls bit for bit."""
+    16-frame call must reproduce single-frame and chunked calls -- bit for bit when the same kernel
+    configuration is forced, and to fp32 re-association noise when the cost model picks per-size tiles."""
     frames = torch.from_numpy(pkg.synth.make_frames(16)).cuda()
     full = model(frames)[-1]
     one = model(frames[5:6])[-1]
     part = model(frames[8:11])[-1]
     torch.cuda.synchronize()
     for k in ("theta", "kp_3d", "kp_2d", "verts", "rotmat"):
-        assert torch.equal(full[k][0, 5], one[k][0, 0]), k
-        assert torch.equal(full[k][0, 8:11], part[k][0]), k
+        assert rel_err(full[k][0, 5].cpu().numpy(), one[k][0, 0].cpu().numpy()) < 2e-5, k
+        assert rel_err(full[k][0, 8:11].cpu().numpy(), part[k][0].cpu().numpy()) < 2e-5, k
+    model.set_option(pkg._lib.OPT_CONV_TILE, 7)
+    try:
+        full7 = model(frames)[-1]
+        one7 = model(frames[5:6])[-1]
+        torch.cuda.synchronize()
+        for k in ("theta", "kp_3d", "kp_2d", "verts", "rotmat"):
+            assert torch.equal(full7[k][0, 5], one7[k][0, 0]), k
+    finally:
+        model.set_option(pkg._lib.OPT_CONV_TILE, 0)
     R = full["rotmat"].reshape(-1, 3, 3)
     eye = torch.eye(3, device=R.device).expand_as(R)
     assert (R @ R.transpose(1, 2) - eye).abs().max() < 1e-4        # rot6d -> rotmat is orthonormal
@@ -148,7 +161,7 @@ def test_chunked_above_max_frames(pkg):
     b = m2(frames)[-1]
     torch.cuda.synchronize()
     for k in ("theta", "kp_3d", "verts"):
-        assert torch.equal(a[k], b[k]), k
+        assert rel_err(a[k].cpu().numpy(), b[k].cpu().numpy()) < 2e-5, k
     m.close(); m2.close()
 
 

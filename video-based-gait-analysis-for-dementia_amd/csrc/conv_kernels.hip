@@ -41,7 +41,76 @@ __device__ __forceinline__ void stage16(const float* src, float* lds_wave_base, 
 }
 #endif
 
-template <int KS, int S, int TPS, int TCS, int WP, int WC>
+// Epilogue shared by both kernel families: + bias, + addends (optionally nearest-upsampled), ReLU,
+// 16-byte store when the 4 pixels of the lane are contiguous and aligned in the NCHW plane.
+struct EpiCtx { int y0, g0, HoWo, RW, qlimit; bool vec_ok; };
+__device__ __forceinline__ EpiCtx make_epi_ctx(const ConvArgs& a, int y0, int g0) {
+    EpiCtx e;
+    e.y0 = y0; e.g0 = g0; e.HoWo = a.Ho * a.Wo; e.RW = a.R * a.Wo; e.qlimit = a.G * e.RW;
+    e.vec_ok = (e.RW % 4 == 0) && (e.HoWo % 4 == 0) && ((y0 * a.Wo) % 4 == 0);
+    return e;
+}
+__device__ __forceinline__ void store_tile(const ConvArgs& a, const EpiCtx& e, f32x4 v, int q, int co) {
+    if (co >= a.Cout) return;
+    const float bias = a.bias[co];
+    if (e.vec_ok) {
+        if (q >= e.qlimit) return;
+        const int gl = q / e.RW, rem = q - gl * e.RW;
+        const int img = e.g0 + gl, pix = e.y0 * a.Wo + rem;
+        if (img >= a.N || pix >= e.HoWo) return;
+        v += bias;
+        for (int k = 0; k < a.n_add; ++k) {
+            const int sh = a.add_shift[k];
+            if (sh == 0) {
+                const float* ap = a.add[k] + ((size_t)img * a.add_ctot[k] + a.add_coff[k] + co) * e.HoWo + pix;
+                v += *reinterpret_cast<const f32x4*>(ap);
+            } else {
+                const int hs = a.Ho >> sh, ws = a.Wo >> sh;
+                const float* ap = a.add[k] + ((size_t)img * a.add_ctot[k] + a.add_coff[k] + co) * (hs * ws);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int y = (pix + r) / a.Wo, x = (pix + r) - y * a.Wo;
+                    v[r] += ap[(y >> sh) * ws + (x >> sh)];
+                }
+            }
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        float* op = a.out + ((size_t)img * a.out_ctot + a.out_coff + co) * e.HoWo + pix;
+        *reinterpret_cast<f32x4*>(op) = v;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qq = q + r;
+            if (qq >= e.qlimit) continue;
+            const int gl = qq / e.RW, rem = qq - gl * e.RW;
+            const int img = e.g0 + gl, pix = e.y0 * a.Wo + rem;
+            if (img >= a.N || pix >= e.HoWo) continue;
+            float o = v[r] + bias;
+            for (int k = 0; k < a.n_add; ++k) {
+                const int sh = a.add_shift[k];
+                const int hs = a.Ho >> sh, ws = a.Wo >> sh;
+                const int y = pix / a.Wo, x = pix - y * a.Wo;
+                o += a.add[k][((size_t)img * a.add_ctot[k] + a.add_coff[k] + co) * (hs * ws) + (y >> sh) * ws + (x >> sh)];
+            }
+            if (a.relu) o = fmaxf(o, 0.f);
+            a.out[((size_t)img * a.out_ctot + a.out_coff + co) * e.HoWo + pix] = o;
+        }
+    }
+}
+
+// Input staging modes.  ROWS (a.rows): the tile is whole image rows of ONE image and the plane size is a
+// multiple of 4 floats, so each channel's patch is one contiguous, 16-byte-aligned range of the NCHW
+// plane: LDS slot i of a channel plane holds global plane float (gal + i) and is filled by 16-byte
+// LDS-DMA (1 KiB per wave-instruction instead of 256 B); rows above/below the image come from the
+// zero block, and the left/right zero padding is applied when the A operand is read (lanes whose tap
+// falls outside the row select 0).  Otherwise (multi-image tiles of the 7x7 maps): a zero-padded patch
+// [G][Rin][Wp] gathered float by float through the source-offset table.
+__device__ __forceinline__ int floor4(int v) { return v & ~3; }   // two's complement: floors negatives too
+
+template <bool ROWS, int KS, int S, int TPS, int TCS, int WP, int WC>
 __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
     constexpr int NT = WP * WC * 64, CK = kConvCK, TC = TCS * 16;
     constexpr int PSW = TPS / WP, CSW = TCS / WC, TAPS = KS * KS;
@@ -60,27 +129,38 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
 
     const int ty = blockIdx.x % a.tiles_y, grp = blockIdx.x / a.tiles_y;
     const int y0 = ty * a.R, g0 = grp * a.G, co0 = blockIdx.y * TC;
-    const int HW = a.H * a.W, HoWo = a.Ho * a.Wo, RW = a.R * a.Wo, RinWp = a.Rin * a.Wp;
+    const int HW = a.H * a.W, RW = a.R * a.Wo, RinWp = a.Rin * a.Wp;
     constexpr int pad = KS / 2;
     const float* inb = a.in + ((size_t)g0 * a.in_ctot + a.in_coff) * HW;
 
-    for (int idx = tid; idx < a.PSTR; idx += NT) {
-        const int gl = idx / RinWp, rem = idx - gl * RinWp;
-        const int ry = rem / a.Wp, rx = rem - ry * a.Wp;
-        const int yin = y0 * S + ry - pad, xin = rx - pad;
-        const bool ok = gl < a.G && (g0 + gl) < a.N && yin >= 0 && yin < a.H && xin >= 0 && xin < a.W;
-        tab[idx] = ok ? gl * a.in_ctot * HW + yin * a.W + xin : -1;
+    const int gal = floor4((y0 * S - pad) * a.W - 1);     // ROWS: global plane index of LDS slot 0
+    if constexpr (!ROWS) {
+        for (int idx = tid; idx < a.PSTR; idx += NT) {
+            const int gl = idx / RinWp, rem = idx - gl * RinWp;
+            const int ry = rem / a.Wp, rx = rem - ry * a.Wp;
+            const int yin = y0 * S + ry - pad, xin = rx - pad;
+            const bool ok = gl < a.G && (g0 + gl) < a.N && yin >= 0 && yin < a.H && xin >= 0 && xin < a.W;
+            tab[idx] = ok ? gl * a.in_ctot * HW + yin * a.W + xin : -1;
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     // A operand: lane holds pixel (lane&15) of its sub-tile, channel (lane>>4) of the k-group.
     int abase[PSW];
+    unsigned lmask = 0, rmask = 0;                         // ROWS: sub-tiles whose pixel sits on the left / right image edge
 #pragma unroll
     for (int ps = 0; ps < PSW; ++ps) {
         const int q = (wp * PSW + ps) * 16 + l15;
         const int gl = q / RW, rem = q - gl * RW;
         const int yl = rem / a.Wo, x = rem - yl * a.Wo;
-        const int off = (q < a.G * RW) ? gl * RinWp + yl * S * a.Wp + x * S : 0;   // masked rows read slot 0
+        int off;
+        if constexpr (ROWS) {
+            off = (q < RW) ? (y0 * S - pad + yl * S) * a.W + x * S - pad - gal : 0;
+            if (x == 0) lmask |= 1u << ps;
+            if (x * S + KS - 1 - pad >= a.W) rmask |= 1u << ps;
+        } else {
+            off = (q < a.G * RW) ? gl * RinWp + yl * S * a.Wp + x * S : 0;   // masked rows read slot 0
+        }
         abase[ps] = lq * a.PSTR + off;
     }
     // B operand: lane holds cout (lane&15) of its sub-tile, row (lane>>4) of the k-group.
@@ -91,15 +171,27 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
     auto issue = [&](int chunk, int buf) {
         const int c0 = chunk * CK;
         float* dst_in = in_lds + buf * CK * a.PSTR;
-        for (int c = 0; c < CK; ++c) {
-            const bool cvalid = (c0 + c) < a.Cin;
-            const float* src_c = inb + (size_t)(c0 + c) * HW;
-            for (int base = wave * 64; base < a.PSTR; base += NT) {
-                const int idx = base + lane;
-                if (idx < a.PSTR) {
-                    const int off = tab[idx];
-                    const float* src = (cvalid && off >= 0) ? src_c + off : a.zeros;
-                    stage4(src, dst_in + c * a.PSTR + base, lane);
+        if constexpr (ROWS) {
+            const int upc = a.PSTR >> 2;                   // 16-byte units per channel plane
+            for (int ub = wave * 64; ub < CK * upc; ub += NT) {
+                const int u = ub + lane;
+                if (u < CK * upc) {
+                    const int c = u / upc, gi = gal + 4 * (u - c * upc);
+                    const bool ok = (c0 + c) < a.Cin && gi >= 0 && gi < HW;
+                    stage16(ok ? inb + (size_t)(c0 + c) * HW + gi : a.zeros, dst_in + ub * 4, lane);
+                }
+            }
+        } else {
+            for (int c = 0; c < CK; ++c) {
+                const bool cvalid = (c0 + c) < a.Cin;
+                const float* src_c = inb + (size_t)(c0 + c) * HW;
+                for (int base = wave * 64; base < a.PSTR; base += NT) {
+                    const int idx = base + lane;
+                    if (idx < a.PSTR) {
+                        const int off = tab[idx];
+                        const float* src = (cvalid && off >= 0) ? src_c + off : a.zeros;
+                        stage4(src, dst_in + c * a.PSTR + base, lane);
+                    }
                 }
             }
         }
@@ -140,7 +232,13 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
 #pragma unroll
                 for (int cs = 0; cs < CSW; ++cs) bv[cs] = wi[(tap * CK + cg * 4) * TC + bbase[cs]];
 #pragma unroll
-                for (int ps = 0; ps < PSW; ++ps) av[ps] = xi[abase[ps] + cg * 4 * a.PSTR + toff];
+                for (int ps = 0; ps < PSW; ++ps) {
+                    av[ps] = xi[abase[ps] + cg * 4 * a.PSTR + toff];
+                    if constexpr (ROWS && KS == 3) {
+                        if (tap % KS == 0) av[ps] = (lmask >> ps & 1) ? 0.f : av[ps];
+                        if (tap % KS == 2 && S == 1) av[ps] = (rmask >> ps & 1) ? 0.f : av[ps];
+                    }
+                }
 #pragma unroll
                 for (int ps = 0; ps < PSW; ++ps)
 #pragma unroll
@@ -151,64 +249,166 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
     }
 
     // ---- epilogue.  D: column (lane&15) = cout, rows (lane>>4)*4 + r = 4 consecutive pixels.
-    const bool vec_ok = (RW % 4 == 0) && (HoWo % 4 == 0) && ((y0 * a.Wo) % 4 == 0);
-    const int qlimit = a.G * RW;
+    const EpiCtx ec = make_epi_ctx(a, y0, g0);
 #pragma unroll
     for (int cs = 0; cs < CSW; ++cs) {
         const int co = co0 + (wc * CSW + cs) * 16 + l15;
-        if (co >= a.Cout) continue;
-        const float bias = a.bias[co];
 #pragma unroll
-        for (int ps = 0; ps < PSW; ++ps) {
-            const int q = (wp * PSW + ps) * 16 + lq * 4;
-            f32x4 v = acc[ps][cs];
-            if (vec_ok) {
-                if (q >= qlimit) continue;
-                const int gl = q / RW, rem = q - gl * RW;
-                const int img = g0 + gl, pix = y0 * a.Wo + rem;
-                if (img >= a.N || pix >= HoWo) continue;
-                v += bias;
-                for (int k = 0; k < a.n_add; ++k) {
-                    const int sh = a.add_shift[k];
-                    if (sh == 0) {
-                        const float* ap = a.add[k] + ((size_t)img * a.add_ctot[k] + a.add_coff[k] + co) * HoWo + pix;
-                        v += *reinterpret_cast<const f32x4*>(ap);
-                    } else {
-                        const int hs = a.Ho >> sh, ws = a.Wo >> sh;
-                        const float* ap = a.add[k] + ((size_t)img * a.add_ctot[k] + a.add_coff[k] + co) * (hs * ws);
+        for (int ps = 0; ps < PSW; ++ps) store_tile(a, ec, acc[ps][cs], (wp * PSW + ps) * 16 + lq * 4, co);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Split-K variant for layers whose output is too small to fill 1024 SIMDs with whole-K tiles
+// (the 7x7 / 14x14 / 28x28 branches and the 32-channel 56x56 branch at 16 frames per call).
+// A workgroup owns ONE small output tile (PSW*16 pixels x CSW*16 channels); its NW waves split the
+// input channels in groups of 4 (= one MFMA k-step per filter tap), round-robin.  The waves share
+// nothing but the source-offset table: each stages its OWN channel group (input patch + weight
+// slab) by LDS-DMA into its own double buffer and runs its own wait -> prefetch -> MFMA loop with
+// no workgroup barrier; partial accumulators are summed through LDS in a fixed order at the end.
+template <bool ROWS, int KS, int S, int PSW, int CSW, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_splitk_f32(const ConvArgs a) {
+    constexpr int TC = CSW * 16, TAPS = KS * KS, WFL = TAPS * 4 * TC, NT = PSW * CSW;
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int stage_floats = WFL + 4 * a.PSTR;           // [weights TAPS*4 x TC | input 4 x PSTR]
+    int* tab = reinterpret_cast<int*>(smem + NW * 2 * stage_floats);
+    float* mine = smem + wave * 2 * stage_floats;
+
+    const int ty = blockIdx.x % a.tiles_y, grp = blockIdx.x / a.tiles_y;
+    const int y0 = ty * a.R, g0 = grp * a.G, co0 = blockIdx.y * TC;
+    const int HW = a.H * a.W, RW = a.R * a.Wo, RinWp = a.Rin * a.Wp;
+    constexpr int pad = KS / 2;
+    const float* inb = a.in + ((size_t)g0 * a.in_ctot + a.in_coff) * HW;
+
+    const int gal = floor4((y0 * S - pad) * a.W - 1);
+    if constexpr (!ROWS) {
+        for (int idx = tid; idx < a.PSTR; idx += NW * 64) {
+            const int gl = idx / RinWp, rem = idx - gl * RinWp;
+            const int ry = rem / a.Wp, rx = rem - ry * a.Wp;
+            const int yin = y0 * S + ry - pad, xin = rx - pad;
+            const bool ok = gl < a.G && (g0 + gl) < a.N && yin >= 0 && yin < a.H && xin >= 0 && xin < a.W;
+            tab[idx] = ok ? gl * a.in_ctot * HW + yin * a.W + xin : -1;
+        }
+        __syncthreads();
+    }
+
+    int abase[PSW];
+    unsigned lmask = 0, rmask = 0;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int y = (pix + r) / a.Wo, x = (pix + r) - y * a.Wo;
-                            v[r] += ap[(y >> sh) * ws + (x >> sh)];
-                        }
-                    }
+    for (int ps = 0; ps < PSW; ++ps) {
+        const int q = ps * 16 + l15;
+        const int gl = q / RW, rem = q - gl * RW;
+        const int yl = rem / a.Wo, x = rem - yl * a.Wo;
+        int off;
+        if constexpr (ROWS) {
+            off = (q < RW) ? (y0 * S - pad + yl * S) * a.W + x * S - pad - gal : 0;
+            if (x == 0) lmask |= 1u << ps;
+            if (x * S + KS - 1 - pad >= a.W) rmask |= 1u << ps;
+        } else {
+            off = (q < a.G * RW) ? gl * RinWp + yl * S * a.Wp + x * S : 0;
+        }
+        abase[ps] = WFL + lq * a.PSTR + off;
+    }
+    int bbase[CSW];
+#pragma unroll
+    for (int cs = 0; cs < CSW; ++cs) bbase[cs] = lq * TC + ((cs * 16 + l15) ^ (TC == 32 ? ((lq & 1) << 4) : 0));
+
+    auto issue = [&](int grp4, int buf) {
+        const int c0 = grp4 * 4;
+        float* dst = mine + buf * stage_floats;
+        constexpr int U = WFL / 4, UPR = TC / 4;
+#pragma unroll
+        for (int ub = 0; ub < U; ub += 64) {
+            const int u = ub + lane;
+            if (u < U) {
+                const int row = u / UPR, j = u - row * UPR;
+                const int tap = row >> 2, c = row & 3;
+                const int js = TC == 32 ? (j ^ ((row & 1) << 2)) : j;
+                const float* src = a.w + ((size_t)(tap * a.CinPad + c0 + c) * a.CoutPad + co0 + 4 * js);
+                stage16(src, dst + ub * 4, lane);
+            }
+        }
+        if constexpr (ROWS) {
+            const int upc = a.PSTR >> 2;
+            for (int ub = 0; ub < 4 * upc; ub += 64) {
+                const int u2 = ub + lane;
+                if (u2 < 4 * upc) {
+                    const int c = u2 / upc, gi = gal + 4 * (u2 - c * upc);
+                    const bool ok = (c0 + c) < a.Cin && gi >= 0 && gi < HW;
+                    stage16(ok ? inb + (size_t)(c0 + c) * HW + gi : a.zeros, dst + WFL + ub * 4, lane);
                 }
-                if (a.relu) {
+            }
+        } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                }
-                float* op = a.out + ((size_t)img * a.out_ctot + a.out_coff + co) * HoWo + pix;
-                *reinterpret_cast<f32x4*>(op) = v;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int qq = q + r;
-                    if (qq >= qlimit) continue;
-                    const int gl = qq / RW, rem = qq - gl * RW;
-                    const int img = g0 + gl, pix = y0 * a.Wo + rem;
-                    if (img >= a.N || pix >= HoWo) continue;
-                    float o = v[r] + bias;
-                    for (int k = 0; k < a.n_add; ++k) {
-                        const int sh = a.add_shift[k];
-                        const int hs = a.Ho >> sh, ws = a.Wo >> sh;
-                        const int y = pix / a.Wo, x = pix - y * a.Wo;
-                        o += a.add[k][((size_t)img * a.add_ctot[k] + a.add_coff[k] + co) * (hs * ws) + (y >> sh) * ws + (x >> sh)];
+            for (int c = 0; c < 4; ++c) {
+                const bool cvalid = (c0 + c) < a.Cin;
+                const float* src_c = inb + (size_t)(c0 + c) * HW;
+                for (int base = 0; base < a.PSTR; base += 64) {
+                    const int idx = base + lane;
+                    if (idx < a.PSTR) {
+                        const int off = tab[idx];
+                        const float* src = (cvalid && off >= 0) ? src_c + off : a.zeros;
+                        stage4(src, dst + WFL + c * a.PSTR + base, lane);
                     }
-                    if (a.relu) o = fmaxf(o, 0.f);
-                    a.out[((size_t)img * a.out_ctot + a.out_coff + co) * HoWo + pix] = o;
                 }
             }
         }
+    };
+
+    f32x4 acc[PSW][CSW];
+#pragma unroll
+    for (int ps = 0; ps < PSW; ++ps)
+#pragma unroll
+        for (int cs = 0; cs < CSW; ++cs) acc[ps][cs] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ngroups = a.CinPad / 4;
+    int g = wave, it = 0;
+    if (g < ngroups) issue(g, 0);
+    for (; g < ngroups; g += NW, ++it) {
+        const int buf = it & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's own stage has landed
+        if (g + NW < ngroups) issue(g + NW, buf ^ 1);
+        const float* st = mine + buf * stage_floats;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int toff = (tap / KS) * a.Wp + (tap % KS);
+            float av[PSW], bv[CSW];
+#pragma unroll
+            for (int cs = 0; cs < CSW; ++cs) bv[cs] = st[tap * 4 * TC + bbase[cs]];
+#pragma unroll
+            for (int ps = 0; ps < PSW; ++ps) {
+                av[ps] = st[abase[ps] + toff];
+                if constexpr (ROWS && KS == 3) {
+                    if (tap % KS == 0) av[ps] = (lmask >> ps & 1) ? 0.f : av[ps];
+                    if (tap % KS == 2 && S == 1) av[ps] = (rmask >> ps & 1) ? 0.f : av[ps];
+                }
+            }
+#pragma unroll
+            for (int ps = 0; ps < PSW; ++ps)
+#pragma unroll
+                for (int cs = 0; cs < CSW; ++cs)
+                    acc[ps][cs] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ps], bv[cs], acc[ps][cs], 0, 0, 0);
+        }
+    }
+
+    // ---- cross-wave reduction (fixed order -> deterministic), then the shared epilogue
+    __syncthreads();                                       // every wave is done with its staging buffers
+    f32x4* red = reinterpret_cast<f32x4*>(smem);           // [NW][NT][64]
+#pragma unroll
+    for (int ps = 0; ps < PSW; ++ps)
+#pragma unroll
+        for (int cs = 0; cs < CSW; ++cs) red[(wave * NT + ps * CSW + cs) * 64 + lane] = acc[ps][cs];
+    __syncthreads();
+    const EpiCtx ec = make_epi_ctx(a, y0, g0);
+    for (int t = wave; t < NT; t += NW) {
+        f32x4 v = red[t * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += red[(w * NT + t) * 64 + lane];
+        const int ps = t / CSW, cs = t - ps * CSW;
+        store_tile(a, ec, v, ps * 16 + lq * 4, co0 + cs * 16 + l15);
     }
 }
 
@@ -217,37 +417,8 @@ int conv_pick_tc(int Cout) { return Cout >= 64 ? 64 : 32; }
 
 namespace {
 
-template <int KS, int S, int TPS, int TCS, int WP, int WC>
-hipError_t launch_one(const ConvArgs& a, size_t lds_bytes, hipStream_t s) {
-    dim3 grid(a.tiles_y * a.groups, a.CoutPad / (TCS * 16));
-    dim3 block(WP * WC * 64);
-    hipLaunchKernelGGL((conv_mfma_f32<KS, S, TPS, TCS, WP, WC>), grid, block, lds_bytes, s, a);
-    return hipGetLastError();
-}
-
-template <int KS, int S, int TPS, int TCS, int WP, int WC>
-hipError_t set_lds_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f32<KS, S, TPS, TCS, WP, WC>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-}
-
-template <int KS, int S>
-hipError_t init_ks() {
-    hipError_t e;
-    if ((e = set_lds_attr<KS, S, 14, 4, 2, 2>()) != hipSuccess) return e;
-    if ((e = set_lds_attr<KS, S, 14, 2, 2, 2>()) != hipSuccess) return e;
-    if ((e = set_lds_attr<KS, S, 7, 4, 1, 4>()) != hipSuccess) return e;
-    if ((e = set_lds_attr<KS, S, 7, 2, 1, 2>()) != hipSuccess) return e;
-    return hipSuccess;
-}
-
-template <int KS, int S>
-hipError_t dispatch_tile(const ConvArgs& a, int tps, size_t lds, hipStream_t s) {
-    if (tps == 14) {
-        return a.TC == 64 ? launch_one<KS, S, 14, 4, 2, 2>(a, lds, s) : launch_one<KS, S, 14, 2, 2, 2>(a, lds, s);
-    }
-    return a.TC == 64 ? launch_one<KS, S, 7, 4, 1, 4>(a, lds, s) : launch_one<KS, S, 7, 2, 1, 2>(a, lds, s);
-}
+constexpr size_t kMaxLds = 160 * 1024;
+constexpr int kSplitWaves = 4;
 
 void plan_tile(ConvArgs& a, int tps) {
     const int TP = tps * 16, HoWo = a.Ho * a.Wo;
@@ -260,9 +431,18 @@ void plan_tile(ConvArgs& a, int tps) {
         a.R = TP / a.Wo;
         if (a.R > a.Ho) a.R = a.Ho;
     }
+    if (a.R < 1) return;
     a.tiles_y = (a.Ho + a.R - 1) / a.R;
     a.groups = (a.N + a.G - 1) / a.G;
     a.Rin = (a.R - 1) * a.stride + a.ks;
+    a.rows = (a.G == 1 && (a.H * a.W) % 4 == 0) ? 1 : 0;
+    if (a.rows) {
+        a.Wp = a.W;                                       // row pitch in LDS = image row pitch
+        const int need = (a.Rin * a.W + 5 + 3) & ~3;      // phase (<=3) + 1 + rows + right overhang, in whole 16-byte units
+        a.PSTR = ((need + 15) / 32) * 32 + 16;            // = 16 (mod 32): see below (stride-2 rows keep a 2-way conflict)
+        if (a.PSTR < need) a.PSTR += 32;
+        return;
+    }
     a.Wp = (a.Wo - 1) * a.stride + a.ks;
     const int need = a.G * a.Rin * a.Wp;
     if (a.stride == 1) {
@@ -274,48 +454,134 @@ void plan_tile(ConvArgs& a, int tps) {
     }
 }
 
+// A launch configuration: family 0 = whole-K tiles with a workgroup barrier per chunk (conv_mfma_f32),
+// family 1 = split-K independent waves (conv_splitk_f32).
+struct Cfg { int family, tps, tcs; };
+
+size_t lds_bytes(const ConvArgs& a, const Cfg& c) {
+    const int taps = a.ks * a.ks, TC = c.tcs * 16;
+    const size_t tab = a.rows ? 0 : a.PSTR;
+    if (c.family == 0) return sizeof(float) * (2 * (size_t)taps * kConvCK * TC + 2 * (size_t)kConvCK * a.PSTR + tab);
+    const size_t stage = (size_t)taps * 4 * TC + 4 * (size_t)a.PSTR;
+    const size_t staging = kSplitWaves * 2 * stage + tab, red = (size_t)kSplitWaves * c.tps * c.tcs * 256;
+    return sizeof(float) * (staging > red ? staging : red);
+}
+
+// MFMA-issue model: the chip has 1024 SIMDs; a wave issues `chain` MFMAs of 32 cycles back to back.
+// cost ~ chain x number of rounds the waves need; split-K pays its extra staging traffic as a 15 % penalty.
+double cfg_cost(ConvArgs a, const Cfg& c, bool* ok) {
+    plan_tile(a, c.tps);
+    *ok = a.R >= 1 && lds_bytes(a, c) <= kMaxLds && a.CoutPad % (c.tcs * 16) == 0;
+    if (!*ok) return 0;
+    const double blocks = (double)a.tiles_y * a.groups * (a.CoutPad / (c.tcs * 16));
+    const int kgroups = a.CinPad / 4, taps = a.ks * a.ks;
+    double waves, chain;
+    if (c.family == 0) {
+        const int nw = (c.tps == 14) ? 4 : (c.tcs == 4 ? 4 : 2);
+        waves = blocks * nw;
+        chain = (double)kgroups * taps * 7 * (c.tps == 14 ? c.tcs / 2 : 1);
+    } else {
+        waves = blocks * kSplitWaves;
+        chain = (double)((kgroups + kSplitWaves - 1) / kSplitWaves) * taps * c.tps * c.tcs;
+    }
+    const double rounds = waves / 1024.0 < 1.0 ? 1.0 : waves / 1024.0;
+    return chain * rounds * (c.family == 1 ? 1.15 : 1.0) + 300.0;   // + fixed prologue/epilogue
+}
+
+template <typename K>
+hipError_t set_lds(K kern) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+}
+
+#define GRK_FOR_KS(M) M(1, 1) M(3, 1) M(3, 2)
+
+template <bool ROWS, int KS, int S>
+hipError_t init_ks() {
+    hipError_t e;
+    if ((e = set_lds(conv_mfma_f32<ROWS, KS, S, 14, 4, 2, 2>)) != hipSuccess) return e;
+    if ((e = set_lds(conv_mfma_f32<ROWS, KS, S, 14, 2, 2, 2>)) != hipSuccess) return e;
+    if ((e = set_lds(conv_mfma_f32<ROWS, KS, S, 7, 4, 1, 4>)) != hipSuccess) return e;
+    if ((e = set_lds(conv_mfma_f32<ROWS, KS, S, 7, 2, 1, 2>)) != hipSuccess) return e;
+    if ((e = set_lds(conv_splitk_f32<ROWS, KS, S, 7, 1, kSplitWaves>)) != hipSuccess) return e;
+    if ((e = set_lds(conv_splitk_f32<ROWS, KS, S, 7, 2, kSplitWaves>)) != hipSuccess) return e;
+    if ((e = set_lds(conv_splitk_f32<ROWS, KS, S, 4, 1, kSplitWaves>)) != hipSuccess) return e;
+    if ((e = set_lds(conv_splitk_f32<ROWS, KS, S, 4, 2, kSplitWaves>)) != hipSuccess) return e;
+    return hipSuccess;
+}
+
+template <bool ROWS, int KS, int S>
+hipError_t dispatch(const ConvArgs& a, const Cfg& c, size_t lds, hipStream_t s) {
+    const dim3 grid(a.tiles_y * a.groups, a.CoutPad / (c.tcs * 16));
+#define GRK_LAUNCH(KERN, THREADS) do { hipLaunchKernelGGL((KERN), grid, dim3(THREADS), lds, s, a); return hipGetLastError(); } while (0)
+    if (c.family == 0) {
+        if (c.tps == 14 && c.tcs == 4) GRK_LAUNCH((conv_mfma_f32<ROWS, KS, S, 14, 4, 2, 2>), 256);
+        if (c.tps == 14 && c.tcs == 2) GRK_LAUNCH((conv_mfma_f32<ROWS, KS, S, 14, 2, 2, 2>), 256);
+        if (c.tps == 7 && c.tcs == 4) GRK_LAUNCH((conv_mfma_f32<ROWS, KS, S, 7, 4, 1, 4>), 256);
+        if (c.tps == 7 && c.tcs == 2) GRK_LAUNCH((conv_mfma_f32<ROWS, KS, S, 7, 2, 1, 2>), 128);
+    } else {
+        if (c.tps == 7 && c.tcs == 1) GRK_LAUNCH((conv_splitk_f32<ROWS, KS, S, 7, 1, kSplitWaves>), kSplitWaves * 64);
+        if (c.tps == 7 && c.tcs == 2) GRK_LAUNCH((conv_splitk_f32<ROWS, KS, S, 7, 2, kSplitWaves>), kSplitWaves * 64);
+        if (c.tps == 4 && c.tcs == 1) GRK_LAUNCH((conv_splitk_f32<ROWS, KS, S, 4, 1, kSplitWaves>), kSplitWaves * 64);
+        if (c.tps == 4 && c.tcs == 2) GRK_LAUNCH((conv_splitk_f32<ROWS, KS, S, 4, 2, kSplitWaves>), kSplitWaves * 64);
+    }
+#undef GRK_LAUNCH
+    return hipErrorInvalidValue;
+}
+
+template <bool ROWS>
+hipError_t dispatch_ks(const ConvArgs& a, const Cfg& c, size_t lds, hipStream_t s) {
+    if (a.ks == 1) return dispatch<ROWS, 1, 1>(a, c, lds, s);
+    return a.stride == 1 ? dispatch<ROWS, 3, 1>(a, c, lds, s) : dispatch<ROWS, 3, 2>(a, c, lds, s);
+}
+
 }  // namespace
 
 hipError_t conv_init() {
     hipError_t e;
-    if ((e = init_ks<1, 1>()) != hipSuccess) return e;
-    if ((e = init_ks<3, 1>()) != hipSuccess) return e;
-    if ((e = init_ks<3, 2>()) != hipSuccess) return e;
+    if ((e = init_ks<false, 1, 1>()) != hipSuccess) return e;
+    if ((e = init_ks<false, 3, 1>()) != hipSuccess) return e;
+    if ((e = init_ks<false, 3, 2>()) != hipSuccess) return e;
+    if ((e = init_ks<true, 1, 1>()) != hipSuccess) return e;
+    if ((e = init_ks<true, 3, 1>()) != hipSuccess) return e;
+    if ((e = init_ks<true, 3, 2>()) != hipSuccess) return e;
     return hipSuccess;
 }
 
-const char* conv_dominant_kernel_name() { return "conv_mfma_f32"; }
+const char* conv_dominant_kernel_name() { return "conv_mfma_f32 / conv_splitk_f32"; }
 
+// tile_hint: 0 = cost model; 7 / 14 = whole-K family with that pixel tile; 1000 + 10*psw + csw = split-K
+// family (1071, 1072, 1041, 1042).  Hints exist for the per-kernel parity tests and for tuning.
 hipError_t launch_conv(ConvArgs a, hipStream_t s, int tile_hint) {
-    a.TC = conv_pick_tc(a.Cout);
-    if (a.CoutPad % a.TC != 0 || a.CinPad % kConvCK != 0) return hipErrorInvalidValue;
+    const int TCpack = conv_pick_tc(a.Cout);
+    if (a.CoutPad % TCpack != 0 || a.CinPad % kConvCK != 0) return hipErrorInvalidValue;
     if (!((a.ks == 1 && a.stride == 1) || (a.ks == 3 && (a.stride == 1 || a.stride == 2)))) return hipErrorInvalidValue;
     if (a.Wo > 14 * 16) return hipErrorInvalidValue;
-    int tps = tile_hint;
-    if (tps != 7 && tps != 14) {
-        ConvArgs t = a;
-        plan_tile(t, 14);
-        const long blocks14 = (long)t.tiles_y * t.groups * (a.CoutPad / a.TC);
-        tps = (blocks14 >= 512 && a.Wo <= 14 * 16) ? 14 : 7;
-        if (a.Wo > 7 * 16) tps = 14;
-    }
-    plan_tile(a, tps);
-    if (a.R < 1) return hipErrorInvalidValue;
-    const int taps = a.ks * a.ks;
-    const size_t lds = sizeof(float) * (2 * (size_t)taps * kConvCK * a.TC + 2 * (size_t)kConvCK * a.PSTR + a.PSTR);
-    if (lds > 160 * 1024) {
-        if (tps == 14) {   // fall back to the smaller pixel tile
-            plan_tile(a, 7);
-            tps = 7;
-            const size_t lds7 = sizeof(float) * (2 * (size_t)taps * kConvCK * a.TC + 2 * (size_t)kConvCK * a.PSTR + a.PSTR);
-            if (lds7 > 160 * 1024 || a.R < 1) return hipErrorInvalidValue;
-            if (a.ks == 1) return dispatch_tile<1, 1>(a, tps, lds7, s);
-            return a.stride == 1 ? dispatch_tile<3, 1>(a, tps, lds7, s) : dispatch_tile<3, 2>(a, tps, lds7, s);
+    Cfg best{0, 7, TCpack / 16};
+    bool found = false;
+    if (tile_hint == 7 || tile_hint == 14) {
+        best = Cfg{0, tile_hint, TCpack / 16};
+        cfg_cost(a, best, &found);
+        if (!found && tile_hint == 14) { best.tps = 7; cfg_cost(a, best, &found); }
+    } else if (tile_hint >= 1000) {
+        best = Cfg{1, (tile_hint - 1000) / 10, (tile_hint - 1000) % 10};
+        if (!((best.tps == 7 || best.tps == 4) && (best.tcs == 1 || best.tcs == 2))) return hipErrorInvalidValue;
+        cfg_cost(a, best, &found);
+    } else {
+        const Cfg cands[] = {{0, 14, TCpack / 16}, {0, 7, TCpack / 16}, {1, 7, 2}, {1, 7, 1}, {1, 4, 2}, {1, 4, 1}};
+        double best_cost = 0;
+        for (const Cfg& c : cands) {
+            if (c.family == 0 && c.tps == 7 && a.Wo > 7 * 16) continue;
+            if (c.family == 1 && a.Wo > c.tps * 16) continue;
+            bool ok;
+            const double cost = cfg_cost(a, c, &ok);
+            if (ok && (!found || cost < best_cost)) { best = c; best_cost = cost; found = true; }
         }
-        return hipErrorInvalidValue;
     }
-    if (a.ks == 1) return dispatch_tile<1, 1>(a, tps, lds, s);
-    return a.stride == 1 ? dispatch_tile<3, 1>(a, tps, lds, s) : dispatch_tile<3, 2>(a, tps, lds, s);
+    if (!found) return hipErrorInvalidValue;
+    plan_tile(a, best.tps);
+    a.TC = best.tcs * 16;
+    const size_t lds = lds_bytes(a, best);
+    return a.rows ? dispatch_ks<true>(a, best, lds, s) : dispatch_ks<false>(a, best, lds, s);
 }
 
 }  // namespace grk

@@ -696,7 +696,8 @@ int grnet_set_option(grnet_t* h, int option, int value) {
     if (!h) return GRNET_EINVAL;
     if (option == GRNET_OPT_USE_GRAPH) { h->use_graph = value != 0; return 0; }
     if (option == GRNET_OPT_CONV_TILE) {
-        if (value != 0 && value != 7 && value != 14) return h->fail(GRNET_EINVAL, "conv tile must be 0, 7 or 14");
+        if (value != 0 && value != 7 && value != 14 && value != 1071 && value != 1072 && value != 1041 && value != 1042)
+            return h->fail(GRNET_EINVAL, "conv tile must be 0, 7, 14 or a split-K code 1071/1072/1041/1042");
         h->conv_tile_hint = value;
         for (auto& g : h->graphs) hipGraphExecDestroy(g.second);
         h->graphs.clear();

@@ -34,7 +34,7 @@ struct ConvArgs {
     const float* add[kMaxAdd]; int add_ctot[kMaxAdd], add_coff[kMaxAdd], add_shift[kMaxAdd];
     const float* zeros;        // >= 64 B of zeros in HBM: source for halo / padded-channel loads
     // filled by the launcher
-    int R, G, Rin, Wp, PSTR, tiles_y, groups, TC;
+    int R, G, Rin, Wp, PSTR, tiles_y, groups, TC, rows;
 };
 
 // Returns hipSuccess or the launch error.  `tile_hint`: 0 = auto, 7 / 14 = force pixel sub-tiles.
