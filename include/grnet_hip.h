@@ -90,6 +90,7 @@ int grnet_gru_forward(grnet_t* h, const float* x_dev, const float* cparams_dev, 
 
 #define GRNET_OPT_USE_GRAPH 1     /* 1: capture each distinct (n, pointers) forward into a hipGraph and replay it */
 #define GRNET_OPT_CONV_TILE 2     /* 0 = cost model; 7 / 14 = whole-K tiles; 1071/1072/1041/1042 = split-K (psw,csw) (tests / tuning) */
+#define GRNET_OPT_MULTI_LANE 3    /* 1 (default): independent HR-module branches run on parallel streams / graph branches */
 int grnet_set_option(grnet_t* h, int option, int value);
 
 /* Introspection used by bench.py / tests. */

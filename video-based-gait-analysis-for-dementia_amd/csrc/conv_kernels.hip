@@ -512,7 +512,7 @@ hipError_t init_ks() {
 template <bool ROWS, int KS, int S>
 hipError_t dispatch(const ConvArgs& a, const Cfg& c, size_t lds, hipStream_t s) {
     const dim3 grid(a.tiles_y * a.groups, a.CoutPad / (c.tcs * 16));
-#define GRK_LAUNCH(KERN, THREADS) do { hipLaunchKernelGGL((KERN), grid, dim3(THREADS), lds, s, a); return hipGetLastError(); } while (0)
+#define GRK_LAUNCH(KERN, THREADS) return launch_k(KERN, grid, dim3(THREADS), lds, s, a)
     if (c.family == 0) {
         if (c.tps == 14 && c.tcs == 4) GRK_LAUNCH((conv_mfma_f32<ROWS, KS, S, 14, 4, 2, 2>), 256);
         if (c.tps == 14 && c.tcs == 2) GRK_LAUNCH((conv_mfma_f32<ROWS, KS, S, 14, 2, 2, 2>), 256);

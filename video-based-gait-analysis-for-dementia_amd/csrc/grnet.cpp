@@ -15,6 +15,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -26,6 +27,8 @@
 #include "kernels.h"
 
 using namespace grk;
+
+namespace grk { thread_local GraphRecorder* g_recorder = nullptr; }
 
 namespace {
 
@@ -58,7 +61,14 @@ struct Op {
     int conv_idx = -1;
     SumArgs sum{};
     View bin, bout;   // bilinear
+    // multi-lane execution: independent branches of the HR modules run on parallel HIP streams
+    // (captured as parallel branches of the hipGraph); cross-lane read-after-write edges are events
+    int lane = 0;
+    std::vector<int> waits;   // ops (on other lanes) whose completion event this op waits for
+    bool record = false;      // some op on another lane consumes this op's output
 };
+
+constexpr int kLanes = 4;
 
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
@@ -107,6 +117,11 @@ struct grnet {
     };
     std::map<GraphKey, hipGraphExec_t> graphs;
     hipStream_t capture_stream = nullptr;   // the caller's stream may be the (uncapturable) null stream
+    hipStream_t side[kLanes] = {nullptr, nullptr, nullptr, nullptr};   // lanes 1..3 (lane 0 = the caller's stream)
+    hipEvent_t ev_fork = nullptr, ev_join[kLanes] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> op_events;
+    int cur_lane = 0;
+    bool multi_lane = true;
     int launches_last = 0;
 
     int fail(int code, const std::string& msg) {
@@ -152,6 +167,7 @@ struct grnet {
         Op op;
         op.kind = Op::CONV;
         op.conv_idx = (int)convs.size() - 1;
+        op.lane = cur_lane;
         ops.push_back(op);
         return convs.back().out;
     }
@@ -165,6 +181,7 @@ struct grnet {
         Op op;
         op.kind = Op::BILINEAR;
         op.bin = in; op.bout = out;
+        op.lane = cur_lane;
         ops.push_back(op);
         return out;
     }
@@ -174,6 +191,7 @@ struct grnet {
         const int nb = (int)xs.size();
         for (int b = 0; b < nb; ++b) {
             const int c = kBranchCh[b];
+            cur_lane = b;                                   // the branches are independent chains
             for (int k = 0; k < 4; ++k) {
                 const std::string q = p + "branches." + std::to_string(b) + "." + std::to_string(k) + ".";
                 View y = conv_bn(xs[b], q + "conv1.weight", q + "bn1", c, 3, 1, true);
@@ -186,14 +204,17 @@ struct grnet {
         for (int i = 0; i < nb; ++i)
             for (int j = i + 1; j < nb; ++j) {
                 const std::string q = p + "fuse_layers." + std::to_string(i) + "." + std::to_string(j) + ".";
+                cur_lane = j;                               // computed where its input lives
                 t[i][j] = conv_bn(xs[j], q + "0.weight", q + "1", kBranchCh[i], 1, 1, false);
             }
         std::vector<View> outs(nb);
         for (int i = 0; i < nb; ++i) {
+            cur_lane = i;
             if (i == 0) {
                 View o = out0 ? *out0 : new_buffer(kBranchCh[0], xs[0].h, xs[0].w);
                 Op op;
                 op.kind = Op::SUM;
+                op.lane = 0;
                 SumArgs& s = op.sum;
                 s.C = kBranchCh[0]; s.H = xs[0].h; s.W = xs[0].w; s.relu = 1;
                 s.n_add = nb;
@@ -208,6 +229,7 @@ struct grnet {
             std::vector<AddRef> adds;
             adds.push_back(AddRef{xs[i], 0});
             for (int j = 0; j < i - 1; ++j) {          // down chains of length >= 2, into temporaries
+                cur_lane = j;
                 View d = xs[j];
                 for (int k = 0; k < i - j; ++k) {
                     const bool last = k == i - j - 1;
@@ -218,9 +240,11 @@ struct grnet {
             }
             for (int j = i + 1; j < nb; ++j) adds.push_back(AddRef{t[i][j], j - i});
             // the single stride-2 conv from branch i-1 finishes the sum and applies the ReLU
+            cur_lane = i;
             const std::string q = p + "fuse_layers." + std::to_string(i) + "." + std::to_string(i - 1) + ".0.";
             outs[i] = conv_bn(xs[i - 1], q + "0.weight", q + "1", kBranchCh[i], 3, 2, true, adds);
         }
+        cur_lane = 0;
         return outs;
     }
     std::vector<std::pair<View, std::vector<AddRef>>> sum_views;
@@ -246,13 +270,19 @@ struct grnet {
         name_view("layer1", x);
         std::vector<View> xs;
         xs.push_back(conv_bn(x, b + "transition1.0.0.weight", b + "transition1.0.1", 32, 3, 1, true));
+        cur_lane = 1;
         xs.push_back(conv_bn(x, b + "transition1.1.0.0.weight", b + "transition1.1.0.1", 64, 3, 2, true));
+        cur_lane = 0;
         xs = hr_module(xs, b + "stage2.0.", nullptr);
         for (size_t i = 0; i < xs.size(); ++i) name_view("stage2." + std::to_string(i), xs[i]);
+        cur_lane = 2;
         xs.push_back(conv_bn(xs.back(), b + "transition2.2.0.0.weight", b + "transition2.2.0.1", 128, 3, 2, true));
+        cur_lane = 0;
         for (int m = 0; m < 4; ++m) xs = hr_module(xs, b + "stage3." + std::to_string(m) + ".", nullptr);
         for (size_t i = 0; i < xs.size(); ++i) name_view("stage3." + std::to_string(i), xs[i]);
+        cur_lane = 3;
         xs.push_back(conv_bn(xs.back(), b + "transition3.3.0.0.weight", b + "transition3.3.0.1", 256, 3, 2, true));
+        cur_lane = 0;
         v_cat = new_buffer(480, 56, 56);                    // torch.cat([x0, x1, x2, x3], 1) (hrnet.py:524)
         for (int m = 0; m < 3; ++m) {
             View o0 = slice(v_cat, 0, 32);
@@ -262,6 +292,7 @@ struct grnet {
         int coff = 32;
         for (int idx = 2; idx <= 4; ++idx) {                // upsample heads (hrnet.py:440-453,521-523)
             const int br = idx - 1, c = kBranchCh[br], n_layers = idx - 1;
+            cur_lane = br;                                  // the three upsample heads are independent
             View t = xs[br];
             for (int l = 0; l < n_layers; ++l) {
                 const std::string q = b + "upsample_stage_" + std::to_string(idx) + ".";
@@ -274,6 +305,7 @@ struct grnet {
             }
             coff += c;
         }
+        cur_lane = 0;
         // PARE head (pare.py:305-336).  The two 480->128 first convolutions read the same input and are
         // issued as one 480->256 convolution writing both halves of one buffer.
         const std::string hd = "head.";
@@ -283,8 +315,10 @@ struct grnet {
                               3, 1, true);
         View part_feats = conv_bn(slice(first, 0, 128), hd + "keypoint_deconv_layers.3.weight", hd + "keypoint_deconv_layers.4", 128, 3, 1, true);
         v_heat = add_conv(part_feats, {ConvSeg{hd + "keypoint_final_layer.weight", "", hd + "keypoint_final_layer.bias", 25}}, 1, 1, false);
+        cur_lane = 1;                                       // the 3D branch runs beside the 2D branch
         v_smpl_feats = conv_bn(slice(first, 128, 128), hd + "smpl_deconv_layers.3.weight", hd + "smpl_deconv_layers.4", 128, 3, 1, true);
         v_csmap = add_conv(v_smpl_feats, {ConvSeg{hd + "smpl_final_layer.weight", "", hd + "smpl_final_layer.bias", 64}}, 1, 1, false);
+        cur_lane = 0;
         Op op;
         op.kind = Op::POOL; ops.push_back(op);
         op.kind = Op::TAIL; ops.push_back(op);
@@ -331,6 +365,17 @@ struct grnet {
         for (auto& sv : sum_views) { resolve(sv.first); for (auto& a : sv.second) resolve(a.v); }
         for (auto& nv : named) resolve(nv.second);
         resolve(v_cat); resolve(v_heat); resolve(v_smpl_feats); resolve(v_csmap);
+        analyze_dependencies();
+        // streams / events of the parallel lanes are created here, never inside a stream capture
+        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return fail(GRNET_EHIP, "hipEventCreate failed");
+        for (int l = 1; l < kLanes; ++l) {
+            if (hipStreamCreateWithFlags(&side[l], hipStreamNonBlocking) != hipSuccess) return fail(GRNET_EHIP, "hipStreamCreate failed");
+            if (hipEventCreateWithFlags(&ev_join[l], hipEventDisableTiming) != hipSuccess) return fail(GRNET_EHIP, "hipEventCreate failed");
+        }
+        for (size_t i = 0; i < ops.size(); ++i)
+            if (ops[i].record && hipEventCreateWithFlags(&op_events[i], hipEventDisableTiming) != hipSuccess)
+                return fail(GRNET_EHIP, "hipEventCreate failed");
+        if (hipStreamCreateWithFlags(&capture_stream, hipStreamNonBlocking) != hipSuccess) return fail(GRNET_EHIP, "hipStreamCreate failed");
         const size_t n = max_frames;
         int rc;
         if ((rc = dev_alloc(&d_plf, n * 128 * 24))) return rc;
@@ -346,6 +391,52 @@ struct grnet {
         if ((rc = dev_alloc(&d_kp3d, n * 87))) return rc;
         if ((rc = dev_alloc(&d_kp2d, n * 58))) return rc;
         return 0;
+    }
+
+    // Read-after-write edges between lanes.  Every op writes a buffer nobody has written before (no
+    // buffer reuse; the writers of the concat buffer own disjoint channel slices), so RAW edges are the
+    // only hazards inside one forward; forwards are separated by the join at the end of enqueue().
+    void analyze_dependencies() {
+        std::map<const float*, std::vector<int>> writers;      // buffer base -> ops that wrote (part of) it
+        auto reads_of = [&](const Op& op, std::vector<const float*>& r) {
+            r.clear();
+            switch (op.kind) {
+                case Op::CONV: {
+                    const ConvLayer& L = convs[op.conv_idx];
+                    r.push_back(L.in.p);
+                    for (auto& a : L.adds) r.push_back(a.v.p);
+                    break;
+                }
+                case Op::SUM:
+                    for (auto& a : sum_views[op.conv_idx].second) r.push_back(a.v.p);
+                    break;
+                case Op::BILINEAR: r.push_back(op.bin.p); break;
+                case Op::POOL: r.push_back(v_heat.p); r.push_back(v_smpl_feats.p); r.push_back(v_csmap.p); break;
+                default: break;                                 // TAIL / SMPL follow POOL on lane 0
+            }
+        };
+        std::vector<const float*> r;
+        for (int i = 0; i < (int)ops.size(); ++i) {
+            Op& op = ops[i];
+            reads_of(op, r);
+            for (const float* buf : r) {
+                auto it = writers.find(buf);
+                if (it == writers.end()) continue;              // the caller's frames
+                for (int w : it->second)
+                    if (ops[w].lane != op.lane) {
+                        bool dup = false;
+                        for (int x : op.waits) dup |= x == w;
+                        if (!dup) op.waits.push_back(w);
+                        ops[w].record = true;
+                    }
+            }
+            const float* out = nullptr;
+            if (op.kind == Op::CONV) out = convs[op.conv_idx].out.p;
+            else if (op.kind == Op::SUM) out = sum_views[op.conv_idx].first.p;
+            else if (op.kind == Op::BILINEAR) out = op.bout.p;
+            if (out) writers[out].push_back(i);
+        }
+        op_events.assign(ops.size(), nullptr);
     }
 
     // ------------------------------------------------------------------ weights
@@ -505,8 +596,32 @@ struct grnet {
         float* verts = o.verts ? o.verts : d_verts;
         float* kp3d = o.kp_3d ? o.kp_3d : d_kp3d;
         float* kp2d = o.kp_2d ? o.kp_2d : d_kp2d;
-        for (const Op& op : ops) {
+        GraphRecorder* rec = g_recorder;                          // non-null: build graph nodes instead of launching
+        const bool lanes = multi_lane && !rec;
+        std::vector<hipGraphNode_t> lane_last(kLanes, nullptr), op_node(rec ? ops.size() : 0, nullptr);
+        hipStream_t lane_stream[kLanes] = {s, s, s, s};
+        if (lanes) {
+            HIP_TRY(hipEventRecord(ev_fork, s));                 // fork: side lanes start after everything before this forward
+            for (int l = 1; l < kLanes; ++l) {
+                lane_stream[l] = side[l];
+                HIP_TRY(hipStreamWaitEvent(side[l], ev_fork, 0));
+            }
+        }
+        hipStream_t caller = s;
+        for (size_t oi = 0; oi < ops.size(); ++oi) {
+            const Op& op = ops[oi];
             if (convs_only && op.kind != Op::CONV) continue;
+            s = lane_stream[op.lane];
+            const int lane = multi_lane ? op.lane : 0;
+            if (lanes)
+                for (int w : op.waits) HIP_TRY(hipStreamWaitEvent(s, op_events[w], 0));
+            if (rec) {                                            // dependencies: previous node of the lane + cross-lane producers
+                rec->deps.clear();
+                if (lane_last[lane]) rec->deps.push_back(lane_last[lane]);
+                if (multi_lane)
+                    for (int w : op.waits)
+                        if (op_node[w]) rec->deps.push_back(op_node[w]);
+            }
             switch (op.kind) {
                 case Op::CONV: {
                     HIP_TRY(launch_conv(conv_args(convs[op.conv_idx], frames, n), s, conv_tile_hint));
@@ -543,11 +658,29 @@ struct grnet {
                     launches += 3;
                     break;
             }
+            if (lanes && op.record) HIP_TRY(hipEventRecord(op_events[oi], s));
+            if (rec && !rec->deps.empty()) lane_last[lane] = op_node[oi] = rec->deps[0];
         }
+        s = caller;
+        if (lanes)
+            for (int l = 1; l < kLanes; ++l) {                   // join: the caller's stream continues after every lane
+                HIP_TRY(hipEventRecord(ev_join[l], side[l]));
+                HIP_TRY(hipStreamWaitEvent(s, ev_join[l], 0));
+            }
         if (!convs_only) {
-            if (o.features) { HIP_TRY(hipMemcpyAsync(o.features, v_cat.p, (size_t)n * 480 * 3136 * 4, hipMemcpyDeviceToDevice, s)); }
-            if (o.part_attn) { HIP_TRY(hipMemcpyAsync(o.part_attn, v_heat.p, (size_t)n * 25 * 3136 * 4, hipMemcpyDeviceToDevice, s)); }
-            if (o.smpl_feats) { HIP_TRY(hipMemcpyAsync(o.smpl_feats, v_smpl_feats.p, (size_t)n * 128 * 3136 * 4, hipMemcpyDeviceToDevice, s)); }
+            auto copy_out = [&](float* dst, const float* src, size_t bytes) -> int {
+                if (!dst) return 0;
+                if (!rec) { HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s)); return 0; }
+                std::vector<hipGraphNode_t> deps;
+                for (hipGraphNode_t nd : lane_last) if (nd) deps.push_back(nd);
+                hipGraphNode_t node = nullptr;
+                HIP_TRY(hipGraphAddMemcpyNode1D(&node, rec->graph, deps.data(), deps.size(), dst, src, bytes, hipMemcpyDeviceToDevice));
+                return 0;
+            };
+            int rc;
+            if ((rc = copy_out(o.features, v_cat.p, (size_t)n * 480 * 3136 * 4))) return rc;
+            if ((rc = copy_out(o.part_attn, v_heat.p, (size_t)n * 25 * 3136 * 4))) return rc;
+            if ((rc = copy_out(o.smpl_feats, v_smpl_feats.p, (size_t)n * 128 * 3136 * 4))) return rc;
             launches_last = launches;
         }
         return 0;
@@ -564,12 +697,14 @@ struct grnet {
         auto it = graphs.find(key);
         if (it == graphs.end()) {
             hipGraph_t g = nullptr;
-            if (!capture_stream) HIP_TRY(hipStreamCreateWithFlags(&capture_stream, hipStreamNonBlocking));
-            HIP_TRY(hipStreamBeginCapture(capture_stream, hipStreamCaptureModeThreadLocal));
-            int rc = enqueue(frames, n, o, capture_stream);
-            hipError_t e = hipStreamEndCapture(capture_stream, &g);
-            if (rc) { if (g) hipGraphDestroy(g); return rc; }
-            if (e != hipSuccess) return fail(GRNET_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+            HIP_TRY(hipGraphCreate(&g, 0));
+            GraphRecorder recorder;
+            recorder.graph = g;
+            g_recorder = &recorder;
+            int rc = enqueue(frames, n, o, s);
+            g_recorder = nullptr;
+            if (rc) { hipGraphDestroy(g); return rc; }
+            hipError_t e;
             hipGraphExec_t ge = nullptr;
             e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
             hipGraphDestroy(g);
@@ -703,6 +838,12 @@ int grnet_set_option(grnet_t* h, int option, int value) {
         h->graphs.clear();
         return 0;
     }
+    if (option == GRNET_OPT_MULTI_LANE) {
+        h->multi_lane = value != 0;
+        for (auto& g : h->graphs) hipGraphExecDestroy(g.second);
+        h->graphs.clear();
+        return 0;
+    }
     return h->fail(GRNET_EINVAL, "unknown option");
 }
 
@@ -795,6 +936,12 @@ void grnet_destroy(grnet_t* h) {
     if (!h) return;
     for (auto& g : h->graphs) hipGraphExecDestroy(g.second);
     if (h->capture_stream) hipStreamDestroy(h->capture_stream);
+    for (int l = 1; l < kLanes; ++l) {
+        if (h->side[l]) hipStreamDestroy(h->side[l]);
+        if (h->ev_join[l]) hipEventDestroy(h->ev_join[l]);
+    }
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    for (hipEvent_t e : h->op_events) if (e) hipEventDestroy(e);
     for (void* p : h->dev_allocs) hipFree(p);
     if (h->arena) hipFree(h->arena);
     delete h;

@@ -6,6 +6,8 @@
 
 namespace grk {
 
+#define GRK_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return _e; } while (0)
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -58,7 +60,7 @@ hipError_t launch_fuse_sum(const SumArgs& a, hipStream_t s) {
     const long total4 = (long)a.N * a.C * a.H * a.W / 4;
     int blocks = (int)((total4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(fuse_sum_kernel, dim3(blocks), dim3(256), 0, s, a);
+    GRK_TRY(launch_k(fuse_sum_kernel, dim3(blocks), dim3(256), 0, s, a));
     return hipGetLastError();
 }
 
@@ -93,7 +95,7 @@ hipError_t launch_bilinear2x(const float* in, float* out, int N, int C, int H, i
     const long total = (long)N * C * 4 * H * W;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(bilinear2x_kernel, dim3(blocks), dim3(256), 0, s, in, out, N * C, H, W);
+    GRK_TRY(launch_k(bilinear2x_kernel, dim3(blocks), dim3(256), 0, s, in, out, N * C, H, W));
     return hipGetLastError();
 }
 
@@ -185,9 +187,9 @@ __global__ __launch_bounds__(256) void attn_pool_kernel(const float* __restrict_
 hipError_t launch_softmax_pool(const float* heat, int heat_ctot, const float* featA, int CA, const float* featB, int CB,
                                float* outA, float* outB, float* stats_ws, int N, int P, hipStream_t s) {
     if (CA % 32 != 0 || CB % 32 != 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(softmax_stats_kernel, dim3(N * 24), dim3(256), 0, s, heat, heat_ctot, stats_ws, P);
-    hipLaunchKernelGGL(attn_pool_kernel, dim3(N, (CA + CB) / 32), dim3(256), 0, s, heat, heat_ctot, stats_ws, featA, CA, featB,
-                       CB, outA, outB, P);
+    GRK_TRY(launch_k(softmax_stats_kernel, dim3(N * 24), dim3(256), 0, s, heat, heat_ctot, stats_ws, P));
+    GRK_TRY(launch_k(attn_pool_kernel, dim3(N, (CA + CB) / 32), dim3(256), 0, s, heat, heat_ctot, stats_ws, featA, CA, featB,
+                       CB, outA, outB, P));
     return hipGetLastError();
 }
 
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
 
 hipError_t launch_head_tail(const float* plf, const float* csf, TailWeights w, float* rot6d, float* shape, float* cam,
                             float* rotmat, float* theta, int N, hipStream_t s) {
-    hipLaunchKernelGGL(head_tail_kernel, dim3(N), dim3(256), 0, s, plf, csf, w, rot6d, shape, cam, rotmat, theta);
+    GRK_TRY(launch_k(head_tail_kernel, dim3(N), dim3(256), 0, s, plf, csf, w, rot6d, shape, cam, rotmat, theta));
     return hipGetLastError();
 }
 
@@ -438,9 +440,9 @@ __global__ __launch_bounds__(256) void smpl_joints_kernel(const float* __restric
 
 hipError_t launch_smpl(const float* betas, const float* rotmat, const float* cam, SmplTables t, float* A_ws, float* verts,
                        float* kp3d, float* kp2d, int N, hipStream_t s) {
-    hipLaunchKernelGGL(smpl_chain_kernel, dim3(N), dim3(64), 0, s, betas, rotmat, t, A_ws, kp3d);
-    hipLaunchKernelGGL(smpl_verts_kernel, dim3((kNumVerts + 255) / 256, N), dim3(256), 0, s, betas, rotmat, t, A_ws, verts);
-    hipLaunchKernelGGL(smpl_joints_kernel, dim3(N), dim3(256), 0, s, verts, cam, t, kp3d, kp2d);
+    GRK_TRY(launch_k(smpl_chain_kernel, dim3(N), dim3(64), 0, s, betas, rotmat, t, A_ws, kp3d));
+    GRK_TRY(launch_k(smpl_verts_kernel, dim3((kNumVerts + 255) / 256, N), dim3(256), 0, s, betas, rotmat, t, A_ws, verts));
+    GRK_TRY(launch_k(smpl_joints_kernel, dim3(N), dim3(256), 0, s, verts, cam, t, kp3d, kp2d));
     return hipGetLastError();
 }
 

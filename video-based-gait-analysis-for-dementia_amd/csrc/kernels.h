@@ -6,7 +6,51 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <tuple>
+#include <utility>
+#include <vector>
+
 namespace grk {
+
+// Every kernel launch of the library goes through launch_k().  Normally it is a plain launch on the
+// given stream; while a GraphRecorder is installed (grnet.cpp builds the per-forward hipGraph with the
+// explicit node API, one parallel branch per lane) it appends a kernel node that depends on
+// `rec->deps` instead, and leaves {that node} as the dependency of the next launch of the same op.
+struct GraphRecorder {
+    hipGraph_t graph = nullptr;
+    std::vector<hipGraphNode_t> deps;
+    int nodes = 0;
+};
+extern thread_local GraphRecorder* g_recorder;
+
+template <typename... KArgs, typename... Args, size_t... I>
+hipError_t launch_k_impl(void (*kern)(KArgs...), dim3 grid, dim3 block, size_t shmem, hipStream_t s,
+                         std::index_sequence<I...>, Args&&... args) {
+    if (!g_recorder) {
+        hipLaunchKernelGGL(kern, grid, block, shmem, s, std::forward<Args>(args)...);
+        return hipGetLastError();
+    }
+    std::tuple<KArgs...> vals{static_cast<KArgs>(args)...};     // exact parameter types, copied by AddKernelNode
+    void* ptrs[] = {static_cast<void*>(&std::get<I>(vals))...};
+    hipKernelNodeParams p{};
+    p.func = reinterpret_cast<void*>(kern);
+    p.gridDim = grid;
+    p.blockDim = block;
+    p.sharedMemBytes = (unsigned)shmem;
+    p.kernelParams = ptrs;
+    p.extra = nullptr;
+    hipGraphNode_t node = nullptr;
+    hipError_t e = hipGraphAddKernelNode(&node, g_recorder->graph, g_recorder->deps.data(), g_recorder->deps.size(), &p);
+    if (e != hipSuccess) return e;
+    g_recorder->deps.assign(1, node);
+    ++g_recorder->nodes;
+    return hipSuccess;
+}
+template <typename... KArgs, typename... Args>
+hipError_t launch_k(void (*kern)(KArgs...), dim3 grid, dim3 block, size_t shmem, hipStream_t s, Args&&... args) {
+    static_assert(sizeof...(KArgs) == sizeof...(Args), "kernel argument count mismatch");
+    return launch_k_impl(kern, grid, block, shmem, s, std::index_sequence_for<KArgs...>{}, std::forward<Args>(args)...);
+}
 
 struct View {
     float* p = nullptr;   // base of the whole buffer (image 0, channel 0)
