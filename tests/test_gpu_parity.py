@@ -44,6 +44,8 @@ def test_conv_kernel(model, oracle, case, tile):
     wo = (h + 2 * (k // 2) - k) // stride + 1
     if tile in (1041, 1042) and wo > 64:
         pytest.skip("a 64-pixel tile cannot hold one output row")
+    if tile == 1072 and stride == 2 and h >= 112:
+        pytest.skip("split-K staging ring of this tile exceeds the 160 KB LDS")
     n = 3 if h <= 28 else 2          # odd image count: partial multi-image tiles on the 7x7 / 14x14 maps
     x = _rand((n, cin, h, h), 1)
     w = _rand((cout, cin, k, k), 2) * np.float32(np.sqrt(2.0 / (cin * k * k)))

@@ -1,0 +1,21 @@
+"""Per-layer timing of the conv kernels with phase ablation (timing only, outputs are wrong when dbg != 0).
+usage: python tools/conv_micro.py [cin,cout,k,s,h,hint ...]"""
+import importlib, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("video-based-gait-analysis-for-dementia_amd")
+m = pkg.GRNet(max_frames=1)
+N = int(os.environ.get("MICRO_N", "16"))
+cases = [(64, 64, 3, 1, 28, 1071), (64, 64, 3, 1, 28, 1072), (32, 32, 3, 1, 56, 14), (32, 32, 3, 1, 56, 1071), (32, 32, 3, 1, 56, 1072),
+         (128, 128, 3, 1, 14, 1071), (256, 256, 3, 1, 7, 1041), (256, 256, 3, 1, 7, 1071), (256, 256, 3, 1, 56, 14), (480, 256, 3, 1, 56, 14)]
+if len(sys.argv) > 1:
+    cases = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
+os.environ["GRNET_CONV_REPS"] = "50"
+for (cin, cout, k, s, h, hint) in cases:
+    x = torch.randn(N, cin, h, h, device="cuda")
+    w = (np.random.randn(cout, cin, k, k) * 0.05).astype(np.float32)
+    ideal = N * (h // s) ** 2 * cout * cin * k * k * 2 / 157.3e12 * 1e6
+    print(f"--- {cin}->{cout} k{k} s{s} @{h} hint {hint}: MFMA floor {ideal:.1f} us", file=sys.stderr)
+    for dbg in (0, 1, 2, 3, 4, 7):
+        os.environ["GRNET_CONV_DBG"] = str(dbg)
+        m.op_conv2d(x, w, None, stride=s, relu=True, tile_hint=hint)

@@ -223,28 +223,44 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
         if (ch + 1 < nchunks) issue(ch + 1, buf ^ 1);
         const float* wi = w_lds + buf * WFLOATS;
         const float* xi = in_lds + buf * CK * a.PSTR;
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
+        // k-steps of the chunk = (tap, channel group of 4); software pipeline: the LDS reads of step s+1
+        // are in flight under the MFMAs of step s, and a step's operands are taken out of the LDS queue
+        // while they are the only pending reads (lgkmcnt is a 4-bit counter).
+        constexpr int STEPS = TAPS * (CK / 4);
+        float av[2][PSW], bv[2][CSW];
+        auto load_step = [&](int st, float* ar, float* br) {
+            const int tap = st / (CK / 4), cg = st % (CK / 4);
             const int toff = (tap / KS) * a.Wp + (tap % KS);
 #pragma unroll
-            for (int cg = 0; cg < CK / 4; ++cg) {
-                float av[PSW], bv[CSW];
+            for (int cs = 0; cs < CSW; ++cs) br[cs] = wi[(tap * CK + cg * 4) * TC + bbase[cs]];
 #pragma unroll
-                for (int cs = 0; cs < CSW; ++cs) bv[cs] = wi[(tap * CK + cg * 4) * TC + bbase[cs]];
+            for (int ps = 0; ps < PSW; ++ps) ar[ps] = xi[abase[ps] + cg * 4 * a.PSTR + toff];
+        };
+        load_step(0, av[0], bv[0]);
 #pragma unroll
-                for (int ps = 0; ps < PSW; ++ps) {
-                    av[ps] = xi[abase[ps] + cg * 4 * a.PSTR + toff];
-                    if constexpr (ROWS && KS == 3) {
-                        if (tap % KS == 0) av[ps] = (lmask >> ps & 1) ? 0.f : av[ps];
-                        if (tap % KS == 2 && S == 1) av[ps] = (rmask >> ps & 1) ? 0.f : av[ps];
-                    }
+        for (int st = 0; st < STEPS; ++st) {
+            const int cur = st & 1, tap = st / (CK / 4);
+            float v[PSW], b[CSW];
+#pragma unroll
+            for (int ps = 0; ps < PSW; ++ps) {
+                v[ps] = av[cur][ps];
+                if constexpr (ROWS && KS == 3) {
+                    if (tap % KS == 0) v[ps] = (lmask >> ps & 1) ? 0.f : v[ps];
+                    if (tap % KS == 2 && S == 1) v[ps] = (rmask >> ps & 1) ? 0.f : v[ps];
                 }
-#pragma unroll
-                for (int ps = 0; ps < PSW; ++ps)
-#pragma unroll
-                    for (int cs = 0; cs < CSW; ++cs)
-                        acc[ps][cs] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ps], bv[cs], acc[ps][cs], 0, 0, 0);
+                asm volatile("" : "+v"(v[ps]));
             }
+#pragma unroll
+            for (int cs = 0; cs < CSW; ++cs) { b[cs] = bv[cur][cs]; asm volatile("" : "+v"(b[cs])); }
+            __builtin_amdgcn_sched_barrier(0);
+            if (st + 1 < STEPS) load_step(st + 1, av[cur ^ 1], bv[cur ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ps = 0; ps < PSW; ++ps)
+#pragma unroll
+                for (int cs = 0; cs < CSW; ++cs)
+                    acc[ps][cs] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[ps], b[cs], acc[ps][cs], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -267,6 +283,20 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
 // nothing but the source-offset table: each stages its OWN channel group (input patch + weight
 // slab) by LDS-DMA into its own double buffer and runs its own wait -> prefetch -> MFMA loop with
 // no workgroup barrier; partial accumulators are summed through LDS in a fixed order at the end.
+// s_waitcnt vmcnt(N) takes an immediate; the number of LDS-DMA instructions per stage is wave-uniform
+// but only known at run time, so pick the immediate with a scalar switch.  Waiting for FEWER outstanding
+// operations than allowed is always safe, so counts above 24 wait at 24.
+__device__ __forceinline__ void wait_vmcnt_le(int n) {
+#define GRK_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    switch (n < 24 ? n : 24) {
+        GRK_W(0) GRK_W(1) GRK_W(2) GRK_W(3) GRK_W(4) GRK_W(5) GRK_W(6) GRK_W(7) GRK_W(8) GRK_W(9) GRK_W(10) GRK_W(11) GRK_W(12)
+        GRK_W(13) GRK_W(14) GRK_W(15) GRK_W(16) GRK_W(17) GRK_W(18) GRK_W(19) GRK_W(20) GRK_W(21) GRK_W(22) GRK_W(23) GRK_W(24)
+    }
+#undef GRK_W
+}
+
+constexpr int kRing = 3;   // LDS-DMA stages per wave in the split-K kernel (stage i+1, i+2 in flight under the MFMAs of stage i)
+
 template <bool ROWS, int KS, int S, int PSW, int CSW, int NW>
 __global__ __launch_bounds__(NW * 64) void conv_splitk_f32(const ConvArgs a) {
     constexpr int TC = CSW * 16, TAPS = KS * KS, WFL = TAPS * 4 * TC, NT = PSW * CSW;
@@ -274,8 +304,8 @@ __global__ __launch_bounds__(NW * 64) void conv_splitk_f32(const ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     const int stage_floats = WFL + 4 * a.PSTR;           // [weights TAPS*4 x TC | input 4 x PSTR]
-    int* tab = reinterpret_cast<int*>(smem + NW * 2 * stage_floats);
-    float* mine = smem + wave * 2 * stage_floats;
+    int* tab = reinterpret_cast<int*>(smem + NW * kRing * stage_floats);
+    float* mine = smem + wave * kRing * stage_floats;
 
     const int ty = blockIdx.x % a.tiles_y, grp = blockIdx.x / a.tiles_y;
     const int y0 = ty * a.R, g0 = grp * a.G, co0 = blockIdx.y * TC;
@@ -364,34 +394,65 @@ __global__ __launch_bounds__(NW * 64) void conv_splitk_f32(const ConvArgs a) {
 #pragma unroll
         for (int cs = 0; cs < CSW; ++cs) acc[ps][cs] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Per-wave ring of kRing stages.  Every stage is exactly `ni` vector-memory instructions of this wave
+    // (each loop below runs its last iteration with at least one active lane), so "all but the newest
+    // `ahead` stages have landed" is s_waitcnt vmcnt(ahead * ni).
     const int ngroups = a.CinPad / 4;
-    int g = wave, it = 0;
-    if (g < ngroups) issue(g, 0);
-    for (; g < ngroups; g += NW, ++it) {
-        const int buf = it & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's own stage has landed
-        if (g + NW < ngroups) issue(g + NW, buf ^ 1);
+    const int my_stages = ngroups > wave ? (ngroups - wave + NW - 1) / NW : 0;
+    constexpr int NWI = (WFL / 4 + 63) / 64;
+    const int ni = NWI + (ROWS ? (a.PSTR + 63) / 64 : 4 * ((a.PSTR + 63) / 64));
+#pragma unroll
+    for (int d = 0; d < kRing; ++d)
+        if (d < my_stages) issue(wave + d * NW, d);
+    int buf = 0;
+    for (int i = 0; i < my_stages; ++i) {
+        const int left = my_stages - 1 - i;
+        if (a.dbg & 2) wait_vmcnt_le(0); else
+        wait_vmcnt_le((left < kRing - 1 ? left : kRing - 1) * ni);
         const float* st = mine + buf * stage_floats;
+        if (!(a.dbg & 1)) {
+            // software pipeline over the filter taps: the LDS reads of tap t+1 are in flight under the
+            // MFMAs of tap t (one exposed LDS latency per stage instead of one per tap)
+            float av[2][PSW], bv[2][CSW];
+            auto load_tap = [&](int tap, float* ar, float* br) {
+                const int toff = (tap / KS) * a.Wp + (tap % KS);
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int toff = (tap / KS) * a.Wp + (tap % KS);
-            float av[PSW], bv[CSW];
+                for (int cs = 0; cs < CSW; ++cs) br[cs] = st[tap * 4 * TC + bbase[cs]];
 #pragma unroll
-            for (int cs = 0; cs < CSW; ++cs) bv[cs] = st[tap * 4 * TC + bbase[cs]];
+                for (int ps = 0; ps < PSW; ++ps) ar[ps] = st[abase[ps] + toff];
+            };
+            load_tap(0, av[0], bv[0]);
 #pragma unroll
-            for (int ps = 0; ps < PSW; ++ps) {
-                av[ps] = st[abase[ps] + toff];
-                if constexpr (ROWS && KS == 3) {
-                    if (tap % KS == 0) av[ps] = (lmask >> ps & 1) ? 0.f : av[ps];
-                    if (tap % KS == 2 && S == 1) av[ps] = (rmask >> ps & 1) ? 0.f : av[ps];
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int cur = tap & 1;
+                // (1) take this tap's operands out of the LDS queue while they are the ONLY pending reads
+                //     (lgkmcnt is a 4-bit counter: two taps of 8 reads in flight would force a full drain)
+                float v[PSW], b[CSW];
+#pragma unroll
+                for (int ps = 0; ps < PSW; ++ps) {
+                    v[ps] = av[cur][ps];
+                    if constexpr (ROWS && KS == 3) {
+                        if (tap % KS == 0) v[ps] = (lmask >> ps & 1) ? 0.f : v[ps];
+                        if (tap % KS == 2 && S == 1) v[ps] = (rmask >> ps & 1) ? 0.f : v[ps];
+                    }
+                    asm volatile("" : "+v"(v[ps]));
                 }
+#pragma unroll
+                for (int cs = 0; cs < CSW; ++cs) { b[cs] = bv[cur][cs]; asm volatile("" : "+v"(b[cs])); }
+                __builtin_amdgcn_sched_barrier(0);
+                // (2) prefetch the next tap, (3) this tap's MFMAs cover its LDS latency
+                if (tap + 1 < TAPS) load_tap(tap + 1, av[cur ^ 1], bv[cur ^ 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ps = 0; ps < PSW; ++ps)
+#pragma unroll
+                    for (int cs = 0; cs < CSW; ++cs)
+                        acc[ps][cs] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[ps], b[cs], acc[ps][cs], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int ps = 0; ps < PSW; ++ps)
-#pragma unroll
-                for (int cs = 0; cs < CSW; ++cs)
-                    acc[ps][cs] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ps], bv[cs], acc[ps][cs], 0, 0, 0);
         }
+        if (i + kRing < my_stages && !(a.dbg & 2)) issue(wave + (i + kRing) * NW, buf);   // refill the buffer just consumed
+        buf = buf + 1 == kRing ? 0 : buf + 1;
     }
 
     // ---- cross-wave reduction (fixed order -> deterministic), then the shared epilogue
@@ -403,6 +464,7 @@ __global__ __launch_bounds__(NW * 64) void conv_splitk_f32(const ConvArgs a) {
         for (int cs = 0; cs < CSW; ++cs) red[(wave * NT + ps * CSW + cs) * 64 + lane] = acc[ps][cs];
     __syncthreads();
     const EpiCtx ec = make_epi_ctx(a, y0, g0);
+    if (a.dbg & 4) return;
     for (int t = wave; t < NT; t += NW) {
         f32x4 v = red[t * 64 + lane];
 #pragma unroll
@@ -463,7 +525,7 @@ size_t lds_bytes(const ConvArgs& a, const Cfg& c) {
     const size_t tab = a.rows ? 0 : a.PSTR;
     if (c.family == 0) return sizeof(float) * (2 * (size_t)taps * kConvCK * TC + 2 * (size_t)kConvCK * a.PSTR + tab);
     const size_t stage = (size_t)taps * 4 * TC + 4 * (size_t)a.PSTR;
-    const size_t staging = kSplitWaves * 2 * stage + tab, red = (size_t)kSplitWaves * c.tps * c.tcs * 256;
+    const size_t staging = kSplitWaves * 3 * stage + tab, red = (size_t)kSplitWaves * c.tps * c.tcs * 256;   // 3 = kRing
     return sizeof(float) * (staging > red ? staging : red);
 }
 

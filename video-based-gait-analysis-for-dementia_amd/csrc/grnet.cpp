@@ -897,8 +897,23 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
     a.w = wd; a.bias = bd; a.CinPad = cin_pad; a.CoutPad = cout_pad; a.ks = ks; a.stride = stride; a.relu = relu;
     if (add_dev) { a.n_add = 1; a.add[0] = add_dev; a.add_ctot[0] = cout; a.add_coff[0] = 0; a.add_shift[0] = 0; }
     a.zeros = h->zeros;
+    if (const char* d = getenv("GRNET_CONV_DBG")) a.dbg = atoi(d);
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t e = launch_conv(a, s, tile_hint);
+    if (const char* r = getenv("GRNET_CONV_REPS")) {           // timing loop for tools/conv_micro.py
+        const int reps = atoi(r);
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0, s);
+        for (int i = 0; i < reps; ++i) e = launch_conv(a, s, tile_hint);
+        hipEventRecord(e1, s);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        fprintf(stderr, "[conv_micro] cin %d cout %d k %d s %d hw %d n %d hint %d dbg %d: %.2f us/launch\n", cin, cout, ks, stride, hgt, n,
+                tile_hint, a.dbg, ms * 1e3f / reps);
+        hipEventDestroy(e0); hipEventDestroy(e1);
+    }
     hipError_t e2 = hipStreamSynchronize(s);
     hipFree(wd);
     hipFree(bd);

@@ -79,6 +79,7 @@ struct ConvArgs {
     const float* zeros;        // >= 64 B of zeros in HBM: source for halo / padded-channel loads
     // filled by the launcher
     int R, G, Rin, Wp, PSTR, tiles_y, groups, TC, rows;
+    int dbg;                   // timing-only ablation bits (tools/conv_micro.py); 0 in the product path
 };
 
 // Returns hipSuccess or the launch error.  `tile_hint`: 0 = auto, 7 / 14 = force pixel sub-tiles.
