@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""demo.py of the MI355X-native path: same flags, model loop and .pkl schema as the reference's
+demo.py (argparse :391-456, loop :126-231, pickle :254-267), with the model running in libgrnet_hip.so.
+
+Out of scope here (rows 12, 17, 19): ffmpeg video decoding, the YOLOv3+SORT tracker and the
+matplotlib / pyrender output video.  So this entry point takes what the reference takes once those
+steps are done: --img_folder (extracted frames) and --tracking_path (joblib {id: {'bbox','frames'}}).
+The reference's --cpu_only has no counterpart: there is deliberately no CPU fallback.
+"""
+import argparse
+import importlib
+import os
+import os.path as osp
+import sys
+import time
+
+import numpy as np
+
+ROOT = osp.dirname(osp.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "video-based-gait-analysis-for-dementia_amd"
+MIN_NUM_FRAMES = 25          # demo.py:41
+
+
+def load_cfg(path):
+    """The two values the reference consumes from the yaml (demo.py:109-110): DATASET.SEQLEN, MODEL.FEAT_CORR."""
+    import yaml
+    cfg = {"DATASET": {"SEQLEN": 100}, "MODEL": {"FEAT_CORR": None}}
+    if path and osp.isfile(path):
+        with open(path) as f:
+            y = yaml.safe_load(f) or {}
+        cfg["DATASET"].update(y.get("DATASET", {}))
+        cfg["MODEL"].update(y.get("MODEL", {}))
+    return cfg
+
+
+def build_model(pkg, args, seqlen):
+    import torch
+    if args.synthetic_weights:
+        return pkg.build_synthetic_model(max_frames=args.max_frames, with_gru=False)
+    if not args.ckpt:
+        sys.exit("!!! Please provide a pretrained checkpoint (--ckpt) or --synthetic_weights !!!")
+    model = pkg.GRNet(writer=None, seqlen=seqlen, featcorr=None, max_frames=args.max_frames)
+    ckpt = torch.load(args.ckpt, map_location="cpu")["gen_state_dict"]
+    print(f"Load pretrained weights from '{args.ckpt}'")
+    res = model.load_state_dict(ckpt, strict=False)
+    if not model._smpl_loaded:
+        smpl = osp.join(args.smpl_dir, "SMPL_NEUTRAL.npz")
+        if not osp.isfile(smpl):
+            sys.exit(f"the checkpoint holds no SMPL tables and {smpl} is missing")
+        d = dict(np.load(smpl))
+        d["J_regressor_extra"] = np.load(osp.join(args.smpl_dir, "J_regressor_extra.npy"))
+        model.load_smpl(d)
+    if res.missing_keys:
+        print(f"warning: {len(res.missing_keys)} tensors missing from the checkpoint, e.g. {res.missing_keys[:3]}")
+    return model.finalize()
+
+
+def main(args):
+    import joblib
+    pkg = importlib.import_module(PKG)
+    pipe = importlib.import_module(PKG + ".pipeline")
+    cfg = load_cfg(args.cfg)
+    if not args.img_folder or not osp.isdir(args.img_folder):
+        sys.exit(f'Input image folder "{args.img_folder}" does not exist! (video decoding is out of scope: extract frames first)')
+    if not args.tracking_path:
+        sys.exit("--tracking_path is required (the YOLOv3+SORT tracker is a separate third-party model)")
+    video_name = osp.basename(osp.normpath(args.vid_file)).split(".")[0] if args.vid_file else osp.basename(osp.normpath(args.img_folder))
+    output_path = osp.join(args.output_folder, video_name, "normal" + time.strftime("-%m%d"))
+    os.makedirs(output_path, exist_ok=True)
+
+    tracking = joblib.load(args.tracking_path)
+    for pid in list(tracking.keys()):                         # demo.py:101-103
+        if tracking[pid]["frames"].shape[0] < MIN_NUM_FRAMES:
+            del tracking[pid]
+    model = build_model(pkg, args, cfg["DATASET"]["SEQLEN"])
+    t0 = time.time()
+    results, n_frames = {}, 0
+    for pid, tr in tracking.items():
+        bboxes, frames = np.asarray(tr["bbox"], np.float32).copy(), np.asarray(tr["frames"])
+        ds = pipe.InferenceFrames(args.img_folder, frames, bboxes, scale=1.0)
+        pred = pipe.run_tracklet(model, ds.batches(args.grnet_batch_size))
+        w, h = ds.image_size()
+        results[pid] = pipe.make_demo_result(pred, ds.bboxes, ds.frames, w, h)
+        n_frames += len(ds)
+    dt = time.time() - t0
+    print(f"GRNet FPS: {n_frames / max(dt, 1e-9):.2f}")
+    stem = osp.basename(args.ckpt).split(".")[0] if args.ckpt else "synthetic"
+    out = osp.join(output_path, stem + ".pkl")
+    idx = 0
+    while osp.isfile(out):                                     # demo.py:258-266: never overwrite
+        idx += 1
+        out = osp.join(output_path, f"{stem}{idx}.pkl")
+    joblib.dump(results, out)
+    print(f'Saving output results to "{out}".')
+    return out
+
+
+def parser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--vid_file", type=str, default="", help="input video path (used for the output folder name only)")
+    p.add_argument("--cfg", type=str, default="configs/config_grnet.yaml")
+    p.add_argument("--ckpt", type=str, default="", help="path to the pretrained checkpoint.")
+    p.add_argument("--output_folder", type=str, default="output/")
+    p.add_argument("--detector", type=str, default="yolo", choices=["yolo"])
+    p.add_argument("--yolo_img_size", type=int, default=416)
+    p.add_argument("--tracker_batch_size", type=int, default=12)
+    p.add_argument("--grnet_batch_size", type=int, default=450)
+    p.add_argument("--display", action="store_true")
+    p.add_argument("--mesh_render", action="store_true")
+    p.add_argument("--wireframe", action="store_true")
+    p.add_argument("--sideview", action="store_true")
+    p.add_argument("--save_obj", action="store_true")
+    p.add_argument("--smooth", action="store_true")
+    p.add_argument("--smooth_min_cutoff", type=float, default=0.004)
+    p.add_argument("--smooth_beta", type=float, default=0.7)
+    p.add_argument("--tracking_path", type=str, default=None)
+    p.add_argument("--img_folder", type=str, default=None)
+    p.add_argument("--joint_type", type=str, default="spin")
+    p.add_argument("--save_vid", action="store_false")
+    # additions of this implementation
+    p.add_argument("--synthetic_weights", action="store_true", help="seed-defined weights (no checkpoint exists offline)")
+    p.add_argument("--smpl_dir", type=str, default="data/smpl_data")
+    p.add_argument("--max_frames", type=int, default=64, help="frames per grnet_forward call (activation buffers are sized for it)")
+    return p
+
+
+if __name__ == "__main__":
+    a = parser().parse_args()
+    for flag in ("smooth", "mesh_render", "display", "save_obj"):
+        if getattr(a, flag):
+            sys.exit(f"--{flag} belongs to steps outside the per-frame path (SURVEY 8f) and is not implemented")
+    main(a)

@@ -1,0 +1,82 @@
+"""The two entry points end to end on the GPU with synthetic frames / weights: flags, model loop,
+output schema (.pkl of demo.py:211-222 and the joblib db of batch_generation.py:265-267)."""
+import importlib
+import os
+import sys
+
+import joblib
+import numpy as np
+import pytest
+import torch
+
+from .conftest import ROOT, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_frames(folder, frames):
+    os.makedirs(folder, exist_ok=True)
+    for i, f in enumerate(frames):
+        np.save(os.path.join(folder, f"{i:06d}.npy"), f)
+
+
+def test_demo_entry_point(pkg, tmp_path):
+    sys.path.insert(0, ROOT)
+    demo = importlib.import_module("demo")
+    frames = pkg.synth.make_frames(30)
+    img_dir = str(tmp_path / "vid")
+    _write_frames(img_dir, frames)
+    bbox = np.tile(np.array([[112.0, 112.0, 224.0, 224.0]], np.float32), (30, 1))
+    tracking = {1: {"bbox": bbox.copy(), "frames": np.arange(30)},
+                2: {"bbox": bbox[:10].copy(), "frames": np.arange(10)}}         # < 25 frames: dropped (demo.py:101-103)
+    tp = str(tmp_path / "tracking.pkl")
+    joblib.dump(tracking, tp)
+    args = demo.parser().parse_args(["--img_folder", img_dir, "--tracking_path", tp, "--output_folder", str(tmp_path / "out"),
+                                     "--synthetic_weights", "--grnet_batch_size", "16", "--max_frames", "16"])
+    out = demo.main(args)
+    assert out.endswith("synthetic.pkl") and os.path.isfile(out)
+    assert os.path.basename(os.path.dirname(out)).startswith("normal-")
+    res = joblib.load(out)
+    assert list(res.keys()) == [1]
+    r = res[1]
+    want = {"pred_cam": (30, 3), "orig_cam": (30, 4), "verts": (30, 6890, 3), "pose": (30, 72), "betas": (30, 10),
+            "joints3d": (30, 29, 3), "joints2d": (30, 29, 2), "bboxes": (30, 4), "frame_ids": (30,)}
+    assert set(r) == set(want)
+    for k, shp in want.items():
+        assert r[k].shape == shp, k
+    # same numbers as a direct call of the model on the same frames
+    m = pkg.build_synthetic_model(max_frames=30, with_gru=False)
+    direct = m(torch.from_numpy(frames).cuda())[-1]
+    torch.cuda.synchronize()
+    assert rel_err(r["joints3d"], direct["kp_3d"][0].cpu().numpy()) < 2e-5
+    assert rel_err(r["pose"], direct["theta"][0, :, 3:75].cpu().numpy()) < 2e-5
+    m.close()
+    # a second run must not overwrite the first (demo.py:258-266)
+    out2 = demo.main(args)
+    assert out2.endswith("synthetic1.pkl")
+
+
+def test_batch_generation_entry_point(pkg, tmp_path):
+    sys.path.insert(0, ROOT)
+    bg = importlib.import_module("batch_generation")
+    names = ["S001C001P001R001A002", "S001C001P001R001A001"]
+    annos = {}
+    for vi, name in enumerate(names):
+        n = 5 + vi
+        _write_frames(str(tmp_path / "vids" / name), pkg.synth.make_frames(n, start=100 * vi))
+        annos[name] = np.tile(np.array([[112.0, 112.0, 200.0, 200.0]], np.float32), (n, 1))
+    bp = str(tmp_path / "bbox.pkl")
+    joblib.dump(annos, bp)
+    written = bg.prepare_data(fv=bp, vid_folder=str(tmp_path / "vids"), outpath=str(tmp_path / "db.json"),
+                              synthetic_weights=True, max_frames=8)
+    assert [os.path.basename(w) for w in written] == ["db_0.json"]
+    db = joblib.load(written[0])
+    assert db["vid_name"].shape == (11,) and db["bbox"].shape == (11, 4) and db["joints3D"].shape == (11, 25, 3)
+    assert list(db["vid_name"][:6]) == ["S001C001P001R001A001"] * 6            # sorted by the digits of the name
+    assert db["joints3D"].dtype == np.float32 and np.isfinite(db["joints3D"]).all()
+    # kinectv2 joint 0 is spin2 joint 0 (pelvis), joint 20 is the thorax (index 28)
+    m = pkg.build_synthetic_model(max_frames=8, with_gru=False)
+    f = torch.from_numpy(pkg.synth.make_frames(6, start=100)).cuda()
+    kp = m(f)[-1]["kp_3d"][0].cpu().numpy()
+    assert rel_err(db["joints3D"][:6, 20], kp[:, 28]) < 2e-5 and rel_err(db["joints3D"][:6, 1], kp[:, 6]) < 2e-5
+    m.close()

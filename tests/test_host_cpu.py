@@ -116,3 +116,51 @@ def test_synth_is_deterministic(pkg):
     assert np.array_equal(f[1], pkg.synth.make_frames(1, start=6)[0])      # rank shards see the clip's own frames
     t = pkg.synth.make_smpl_tables()
     assert np.allclose(t["lbs_weights"].sum(1), 1, atol=1e-6) and np.allclose(t["J_regressor"].sum(1), 1, atol=1e-6)
+
+
+def test_output_conversions_match_reference(pkg, golden):
+    """demo_utils.py:176-209 and convert_kps(spin2 -> kinectv2): goldens produced by the reference functions."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "harness.npz"))
+    pipe = pkg.pipeline
+    assert np.allclose(pipe.convert_crop_cam_to_orig_img(g["cam"], g["bbox"], 1920, 1080), g["orig_cam"], rtol=1e-6)
+    assert np.allclose(pipe.convert_crop_coords_to_orig_img(g["bbox"], g["kp2d"], 224), g["joints2d_img"], rtol=1e-6, atol=1e-4)
+    k = pipe.spin2_to_kinectv2(g["j3d"])
+    assert k.shape == (7, 25, 3) and np.array_equal(k, g["kinectv2"])
+
+
+def test_batch_db_schema_and_chunk_names(pkg, tmp_path):
+    import joblib
+    pipe = pkg.pipeline
+    with pytest.raises(AssertionError):
+        pipe.BatchDb(str(tmp_path / "out"))                   # the reference asserts a .json suffix
+    db = pipe.BatchDb(str(tmp_path / "out.json"))
+    db.add("S001C001P001R001A001", np.ones((3, 4), np.float32), np.zeros((3, 25, 3)))
+    db.add("S001C001P001R001A002", np.ones((2, 4), np.float32), np.zeros((2, 25, 3)))
+    f0 = db.flush()
+    db.add("S001C001P001R001A003", np.ones((1, 4), np.float32), np.zeros((1, 25, 3)))
+    f1 = db.flush()
+    assert f0.endswith("out_0.json") and f1.endswith("out_1.json") and db.flush() is None
+    d = joblib.load(f0)
+    assert set(d) == {"vid_name", "bbox", "joints3D"}
+    assert d["vid_name"].shape == (5,) and d["bbox"].shape == (5, 4) and d["joints3D"].shape == (5, 25, 3)
+    assert d["bbox"].dtype == np.float32 and d["joints3D"].dtype == np.float32
+
+
+def test_inference_frames_scale_quirk_and_crop(pkg, tmp_path):
+    """bbox w,h are scaled in place at construction and again inside the crop (inference.py:48,80)."""
+    from PIL import Image
+    pipe = pkg.pipeline
+    img = np.zeros((300, 400, 3), np.uint8)
+    img[100:200, 150:250] = 255
+    for i in range(3):
+        Image.fromarray(img).save(tmp_path / f"{i:06d}.png")
+    bb = np.tile(np.array([[200.0, 150.0, 100.0, 100.0]], np.float32), (3, 1))
+    ds = pipe.InferenceFrames(str(tmp_path), np.arange(3), bb, scale=1.1)
+    assert np.allclose(bb[:, 2:], 110.0)                       # mutated in place like the reference
+    x = ds[0]
+    assert x.shape == (3, 224, 224) and x.dtype == np.float32
+    white = (1.0 - pipe.IMAGENET_MEAN) / pipe.IMAGENET_STD
+    assert np.allclose(x[:, 112, 112], white, atol=1e-5)       # centre of the box is the white square
+    assert np.allclose(x[:, 2, 2], (0.0 - pipe.IMAGENET_MEAN) / pipe.IMAGENET_STD, atol=1e-5)
+    assert ds.image_size() == (400, 300)
+    assert sum(b.shape[0] for b in ds.batches(2)) == 3

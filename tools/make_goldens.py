@@ -61,6 +61,12 @@ STUBS = {
     "torchvision/models/__init__.py": "",
     "torchvision/models/resnet.py": "",
     "torchvision/transforms.py": "",
+    # plumbing-only shims so that lib/utils/demo_utils.py (cam / coordinate conversion) can be imported
+    "cv2.py": "",
+    "pytube.py": "class YouTube: pass\n",
+    "skimage/__init__.py": "",
+    "skimage/util/__init__.py": "",
+    "skimage/util/shape.py": "def view_as_windows(*a, **k):\n    raise NotImplementedError\n",
     "timm/__init__.py": "",
     "timm/models/__init__.py": "",
     "timm/models/layers.py": "from torch.nn.init import trunc_normal_\n",
@@ -322,6 +328,26 @@ def main():
     p = os.path.join(ROOT, "tests/golden/gru.npz")
     np.savez_compressed(p, **outs)
     print(f"wrote {p}")
+
+    # --- output-side conversions of the two entry points (demo_utils.py:176-209, kp_utils.py:26-36) -----
+    try:
+        from lib.data_utils.kp_utils import convert_kps
+        from lib.utils.demo_utils import convert_crop_cam_to_orig_img, convert_crop_coords_to_orig_img
+        hg = np.random.Generator(np.random.Philox(key=[11, 11]))
+        F_ = 7
+        j3d = hg.standard_normal((F_, 29, 3)).astype(np.float32)
+        bbox = np.stack([hg.uniform(200, 800, F_), hg.uniform(150, 500, F_), hg.uniform(120, 400, F_)], 1).astype(np.float32)
+        bbox = np.concatenate([bbox, bbox[:, 2:3]], 1)
+        cam = np.stack([hg.uniform(0.6, 1.2, F_), hg.standard_normal(F_) * 0.1, hg.standard_normal(F_) * 0.1], 1).astype(np.float32)
+        kp2d = hg.uniform(-1, 1, (F_, 29, 2)).astype(np.float32)
+        p = os.path.join(ROOT, "tests/golden/harness.npz")
+        np.savez_compressed(p, j3d=j3d, bbox=bbox, cam=cam, kp2d=kp2d,
+                            kinectv2=convert_kps(j3d, src="spin2", dst="kinectv2"),
+                            orig_cam=convert_crop_cam_to_orig_img(cam=cam, bbox=bbox, img_width=1920, img_height=1080),
+                            joints2d_img=convert_crop_coords_to_orig_img(bbox=bbox, keypoints=kp2d.copy(), crop_size=224))
+        print(f"wrote {p}")
+    except Exception as e:                                   # pragma: no cover
+        print("harness goldens skipped:", repr(e))
 
     if "--time" in sys.argv:
         x16 = torch.from_numpy(synth.make_frames(16)).reshape(1, 16, 3, 224, 224)

@@ -295,7 +295,7 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
 #undef GRK_W
 }
 
-constexpr int kRing = 3;   // LDS-DMA stages per wave in the split-K kernel (stage i+1, i+2 in flight under the MFMAs of stage i)
+constexpr int kRing = 2;   // LDS-DMA stages per wave in the split-K kernel (stage i+1, i+2 in flight under the MFMAs of stage i)
 
 template <bool ROWS, int KS, int S, int PSW, int CSW, int NW>
 __global__ __launch_bounds__(NW * 64) void conv_splitk_f32(const ConvArgs a) {
@@ -525,7 +525,7 @@ size_t lds_bytes(const ConvArgs& a, const Cfg& c) {
     const size_t tab = a.rows ? 0 : a.PSTR;
     if (c.family == 0) return sizeof(float) * (2 * (size_t)taps * kConvCK * TC + 2 * (size_t)kConvCK * a.PSTR + tab);
     const size_t stage = (size_t)taps * 4 * TC + 4 * (size_t)a.PSTR;
-    const size_t staging = kSplitWaves * 3 * stage + tab, red = (size_t)kSplitWaves * c.tps * c.tcs * 256;   // 3 = kRing
+    const size_t staging = kSplitWaves * 2 * stage + tab, red = (size_t)kSplitWaves * c.tps * c.tcs * 256;   // 2 = kRing
     return sizeof(float) * (staging > red ? staging : red);
 }
 
