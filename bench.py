@@ -104,6 +104,17 @@ def main():
     conv_ms = min(model.time_convs(n) for _ in range(5))
     conv_flops = model.conv_flops_per_frame() * n
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+    # the same launches one after another on one stream (no overlap): comparable with rocprofv3's per-kernel averages
+    model.set_option(pkg._lib.OPT_MULTI_LANE, 0)
+    conv_ms_serial = min(model.time_convs(n) for _ in range(3))
+    model.set_option(pkg._lib.OPT_MULTI_LANE, 1)
+    n_conv = model.num_conv_launches()                         # 316: the reference's 317 convolutions, two of them merged
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            traffic = json.load(f).get("hbm_bytes_per_step_conv_kernels")
+    except OSError:
+        pass
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -118,8 +129,15 @@ def main():
                        "kernel_launches_per_step": model.num_kernel_launches(),
                        "exchange": "none (1 GPU)" if world == 1 else "RCCL all-gather of per-frame pose results"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                         "kernel": "conv_mfma_f32 (all instantiations)", "conv_ms_per_step": round(conv_ms, 4),
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "traffic": traffic if (n == FRAMES_PER_GPU and traffic) else None,
+                         "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                                           "FETCH x2 gfx950 correction), bytes of all conv launches of one step",
+                         "kernel": "conv_mfma_f32 + conv_splitk_f32 (fp32 MFMA implicit-GEMM convolution, all launches of a step)",
+                         "conv_launches_per_step": n_conv, "conv_ms_per_step": round(conv_ms, 4),
+                         "conv_ms_per_step_serial": round(conv_ms_serial, 4),
+                         "avg_launch_us": round(conv_ms * 1e3 / n_conv, 3), "avg_launch_us_serial": round(conv_ms_serial * 1e3 / n_conv, 3),
+                         "gflop_per_launch": round(conv_flops / 1e9 / n_conv, 4),
                          "conv_gflop_per_step": round(conv_flops / 1e9, 3)},
         }
         if world == 1 and not args.no_cpu_baseline:

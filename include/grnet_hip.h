@@ -95,6 +95,7 @@ int grnet_set_option(grnet_t* h, int option, int value);
 
 /* Introspection used by bench.py / tests. */
 int grnet_num_kernel_launches(grnet_t* h);      /* launches enqueued by one grnet_forward */
+int grnet_num_conv_launches(grnet_t* h);        /* convolution launches of one grnet_forward */
 double grnet_conv_flops_per_frame(grnet_t* h);  /* 2 * MACs of all convolutions on the path */
 /* Re-enqueue ONLY the convolution launches of the last forward, bracketed by HIP events on
  * `stream`; returns elapsed ms in *ms_out (synchronises the stream). */

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Copy the rocprofv3 summaries produced on the GPU box (gpurun_out/, scratch) into profiles/ (tracked).
+
+  profiles/rNN_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline`
+  profiles/rNN_pmc_traffic.json   FETCH_SIZE / WRITE_SIZE (separate --pmc passes) of `bench.py --steps 3 --warmup 1 --no-graph`,
+                                  summed over the conv launches of ONE forward, with the gfx950 correction of
+                                  MI355X_MICROARCH.md (FETCH_SIZE counts 128-B requests at 64 B: x2 for wide reads)
+"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src, dst = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+stats = os.path.join(src, "prof", "bench_kernel_stats.csv")
+if os.path.isfile(stats):
+    shutil.copy(stats, os.path.join(dst, f"{rnd}_kernel_stats.csv"))
+    rows = list(csv.DictReader(open(stats)))
+    conv = [r for r in rows if "conv_" in r["Name"]]
+    tot = sum(float(r["TotalDurationNs"]) for r in conv)
+    calls = sum(int(r["Calls"]) for r in conv)
+    print(f"conv kernels: {calls} launches, {tot / 1e6:.2f} ms total, avg {tot / calls / 1e3:.2f} us/launch")
+    for line in open(os.path.join(src, "prof", "bench_stdout.log")):
+        if line.startswith("{"):
+            open(os.path.join(dst, f"{rnd}_bench_under_rocprof.json"), "w").write(line)
+
+out = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = os.path.join(src, "pmc", f"{c}_counter_collection.csv")
+    if not os.path.isfile(f):
+        continue
+    rows = list(csv.DictReader(open(f)))
+    per_kernel = collections.defaultdict(lambda: [0.0, 0])
+    for r in rows:
+        n = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        per_kernel[n][0] += float(r["Counter_Value"])
+        per_kernel[n][1] += 1
+    big = [k for k in per_kernel if "conv_mfma_f32<true, 3, 1, 14, 4, 2, 2>" in k]
+    n_forwards = per_kernel[big[0]][1] // 5 if big else 1          # that instantiation runs 5x per forward
+    conv_kb = sum(v[0] for k, v in per_kernel.items() if "conv_" in k)
+    conv_launches = sum(v[1] for k, v in per_kernel.items() if "conv_" in k)
+    all_kb = sum(v[0] for v in per_kernel.values())
+    out[c] = {"unit": "KB (rocprofv3 derived counter)", "forwards_in_run": n_forwards,
+              "conv_kernels_kb_per_forward": conv_kb / n_forwards, "all_kernels_kb_per_forward": all_kb / n_forwards,
+              "conv_launches_per_forward": conv_launches / n_forwards,
+              "per_kernel_kb_per_dispatch": {k: v[0] / v[1] for k, v in sorted(per_kernel.items(), key=lambda x: -x[1][0])[:12]}}
+if out:
+    f, w = out.get("FETCH_SIZE"), out.get("WRITE_SIZE")
+    if f and w:
+        out["hbm_bytes_per_step_conv_kernels"] = (2.0 * f["conv_kernels_kb_per_forward"] + w["conv_kernels_kb_per_forward"]) * 1024.0
+        out["correction"] = "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B for 16 B/lane streaming reads), WRITE_SIZE x1"
+        out["note"] = ("memory-side (fabric) requests of the L2: Infinity-Cache hits are counted, so this is an upper bound on HBM "
+                       "bytes; the 16-frame working set (~1.7 GB of activations) does not fit the 256 MiB cache")
+    json.dump(out, open(os.path.join(dst, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
+    print(json.dumps({k: v for k, v in out.items() if not isinstance(v, dict)}, indent=1))

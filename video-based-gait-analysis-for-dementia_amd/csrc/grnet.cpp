@@ -728,6 +728,7 @@ int grnet_create(grnet_t** out_handle, int device_id, int dtype, int max_frames)
     std::unique_ptr<grnet> h(new grnet());
     h->device = device_id;
     h->max_frames = max_frames;
+    if (const char* ml = getenv("GRNET_MULTI_LANE")) h->multi_lane = atoi(ml) != 0;   // profiling: per-kernel times without overlap
     h->build_plan();
     int rc = h->allocate();
     if (rc) { fprintf(stderr, "grnet_create: %s\n", h->err.c_str()); return rc; }
@@ -848,6 +849,8 @@ int grnet_set_option(grnet_t* h, int option, int value) {
 }
 
 int grnet_num_kernel_launches(grnet_t* h) { return h ? h->launches_last : GRNET_EINVAL; }
+
+int grnet_num_conv_launches(grnet_t* h) { return h ? (int)h->convs.size() : GRNET_EINVAL; }
 
 double grnet_conv_flops_per_frame(grnet_t* h) {
     if (!h) return 0;

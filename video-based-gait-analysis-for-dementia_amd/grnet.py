@@ -200,6 +200,9 @@ class GRNet:
     def num_kernel_launches(self):
         return self._lib.grnet_num_kernel_launches(self._h)
 
+    def num_conv_launches(self):
+        return self._lib.grnet_num_conv_launches(self._h)
+
     def conv_flops_per_frame(self):
         return self._lib.grnet_conv_flops_per_frame(self._h)
 
