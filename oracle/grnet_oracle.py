@@ -56,7 +56,13 @@ def conv2d(x, w, stride=1, bias=None):
 
 
 def batchnorm(x, sd, prefix):
-    """BatchNorm2d in eval mode: (x-mean)/sqrt(var+1e-5)*gamma+beta."""
+    """BatchNorm2d in eval mode: (x-mean)/sqrt(var+1e-5)*gamma+beta; torch's CPU kernel, as the
+    reference's own CPU path uses (the explicit formula is ``batchnorm_explicit``, checked equal in the tests)."""
+    return F.batch_norm(x, _t(sd[prefix + ".running_mean"]), _t(sd[prefix + ".running_var"]), _t(sd[prefix + ".weight"]),
+                        _t(sd[prefix + ".bias"]), training=False, eps=BN_EPS)
+
+
+def batchnorm_explicit(x, sd, prefix):
     g, b = _t(sd[prefix + ".weight"]), _t(sd[prefix + ".bias"])
     m, v = _t(sd[prefix + ".running_mean"]), _t(sd[prefix + ".running_var"])
     scale = g / torch.sqrt(v + BN_EPS)
@@ -66,16 +72,22 @@ def batchnorm(x, sd, prefix):
 def conv_bn(x, sd, conv_key, bn_prefix, stride=1, relu=False, residual=None):
     y = batchnorm(conv2d(x, sd[conv_key], stride), sd, bn_prefix)
     if residual is not None:
-        y = y + residual
-    return torch.relu(y) if relu else y
+        y += residual
+    return torch.relu_(y) if relu else y
 
 
 def upsample_nearest(x, factor):
     """nn.Upsample(scale_factor=2**k, mode='nearest') (hrnet.py:208): out[y,x] = in[y//f, x//f]."""
-    return x.repeat_interleave(factor, dim=2).repeat_interleave(factor, dim=3)
+    return F.interpolate(x, scale_factor=factor, mode="nearest")
 
 
 def upsample_bilinear2x(x):
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (hrnet.py:443), torch's CPU kernel
+    (the explicit two-tap formula is ``upsample_bilinear2x_explicit``, checked equal in the tests)."""
+    return F.interpolate(_t(x), scale_factor=2, mode="bilinear", align_corners=True)
+
+
+def upsample_bilinear2x_explicit(x):
     """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (hrnet.py:443).
 
     src = dst * (in-1)/(out-1); the two taps are floor(src) and min(floor+1, in-1).
@@ -133,7 +145,7 @@ def hr_module(xs, sd, p):
                 for k in range(i - j):
                     t = conv_bn(t, sd, q + f"{k}.0.weight", q + f"{k}.1", stride=2, relu=(k != i - j - 1))
             y = t if y is None else y + t
-        outs.append(torch.relu(y))
+        outs.append(torch.relu_(y))
     return outs
 
 

@@ -100,3 +100,15 @@ def test_spec_counts(pkg):
     assert sum(k.startswith("head.") for k in spec) == 37
     n_conv = sum(1 for k, (s, r) in spec.items() if len(s) == 4 and not k.startswith("backbone.final_layer"))
     assert n_conv == 317                                               # 317 conv calls per frame
+
+
+def test_explicit_formulas_equal_torch_kernels(oracle, synth_weights):
+    """The oracle uses torch's CPU batch-norm / interpolate kernels for speed; their spelled-out formulas agree."""
+    g = np.random.Generator(np.random.Philox(key=[5, 5]))
+    x = torch.from_numpy(g.standard_normal((2, 64, 14, 14)).astype(np.float32))
+    a = oracle.batchnorm(x, synth_weights, "backbone.bn1")
+    b = oracle.batchnorm_explicit(x, synth_weights, "backbone.bn1")
+    assert rel_err(a.numpy(), b.numpy()) < 1e-6
+    assert rel_err(oracle.upsample_bilinear2x(x).numpy(), oracle.upsample_bilinear2x_explicit(x).numpy()) < 5e-6
+    n = oracle.upsample_nearest(x, 4)
+    assert torch.equal(n, x.repeat_interleave(4, 2).repeat_interleave(4, 3))
