@@ -297,7 +297,10 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
 
 constexpr int kRing = 2;   // LDS-DMA stages per wave in the split-K kernel (stage i+1, i+2 in flight under the MFMAs of stage i)
 
-template <bool ROWS, int KS, int S, int PSW, int CSW, int NW>
+// MODE: 0 = gather (source-offset table), 1 = rows (contiguous image rows), 2 = planes (the 4 channel planes of a
+// k-group of ONE whole small image are contiguous in NCHW: one 16-byte LDS-DMA per k-group; all zero padding is
+// applied through a per-lane 9-bit tap-validity mask when the A operand is read).
+template <int MODE, int KS, int S, int PSW, int CSW, int NW>
 __global__ __launch_bounds__(NW * 64) void conv_splitk_f32(const ConvArgs a) {
     constexpr int TC = CSW * 16, TAPS = KS * KS, WFL = TAPS * 4 * TC, NT = PSW * CSW;
     extern __shared__ __align__(16) float smem[];
@@ -313,8 +316,9 @@ __global__ __launch_bounds__(NW * 64) void conv_splitk_f32(const ConvArgs a) {
     constexpr int pad = KS / 2;
     const float* inb = a.in + ((size_t)g0 * a.in_ctot + a.in_coff) * HW;
 
+    constexpr bool ROWS = MODE == 1, PLANES = MODE == 2;
     const int gal = floor4((y0 * S - pad) * a.W - 1);
-    if constexpr (!ROWS) {
+    if constexpr (MODE == 0) {
         for (int idx = tid; idx < a.PSTR; idx += NW * 64) {
             const int gl = idx / RinWp, rem = idx - gl * RinWp;
             const int ry = rem / a.Wp, rx = rem - ry * a.Wp;
@@ -327,13 +331,23 @@ __global__ __launch_bounds__(NW * 64) void conv_splitk_f32(const ConvArgs a) {
 
     int abase[PSW];
     unsigned lmask = 0, rmask = 0;
+    unsigned vmask[PLANES ? PSW : 1] = {};                  // PLANES: bit tap = that tap of this pixel is inside the image
 #pragma unroll
     for (int ps = 0; ps < PSW; ++ps) {
         const int q = ps * 16 + l15;
         const int gl = q / RW, rem = q - gl * RW;
         const int yl = rem / a.Wo, x = rem - yl * a.Wo;
         int off;
-        if constexpr (ROWS) {
+        if constexpr (PLANES) {
+            off = (q < RW) ? (yl * S - pad) * a.W + x * S - pad : 0;     // may be negative: lands in the weight slab, masked
+            if (q < RW) {
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    const int yy = yl * S + t / KS - pad, xx = x * S + t % KS - pad;
+                    if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) vmask[ps] |= 1u << t;
+                }
+            }
+        } else if constexpr (ROWS) {
             off = (q < RW) ? (y0 * S - pad + yl * S) * a.W + x * S - pad - gal : 0;
             if (x == 0) lmask |= 1u << ps;
             if (x * S + KS - 1 - pad >= a.W) rmask |= 1u << ps;
@@ -361,7 +375,12 @@ __global__ __launch_bounds__(NW * 64) void conv_splitk_f32(const ConvArgs a) {
                 stage16(src, dst + ub * 4, lane);
             }
         }
-        if constexpr (ROWS) {
+        if constexpr (PLANES) {
+            for (int ub = 0; ub < HW; ub += 64) {           // 4 planes x HW floats = HW 16-byte units, contiguous in HBM
+                const int u2 = ub + lane;
+                if (u2 < HW) stage16(inb + (size_t)c0 * HW + 4 * u2, dst + WFL + ub * 4, lane);
+            }
+        } else if constexpr (ROWS) {
             const int upc = a.PSTR >> 2;
             for (int ub = 0; ub < 4 * upc; ub += 64) {
                 const int u2 = ub + lane;
@@ -400,7 +419,7 @@ __global__ __launch_bounds__(NW * 64) void conv_splitk_f32(const ConvArgs a) {
     const int ngroups = a.CinPad / 4;
     const int my_stages = ngroups > wave ? (ngroups - wave + NW - 1) / NW : 0;
     constexpr int NWI = (WFL / 4 + 63) / 64;
-    const int ni = NWI + (ROWS ? (a.PSTR + 63) / 64 : 4 * ((a.PSTR + 63) / 64));
+    const int ni = NWI + (PLANES ? (HW + 63) / 64 : ROWS ? (a.PSTR + 63) / 64 : 4 * ((a.PSTR + 63) / 64));
 #pragma unroll
     for (int d = 0; d < kRing; ++d)
         if (d < my_stages) issue(wave + d * NW, d);
@@ -435,6 +454,7 @@ __global__ __launch_bounds__(NW * 64) void conv_splitk_f32(const ConvArgs a) {
                         if (tap % KS == 0) v[ps] = (lmask >> ps & 1) ? 0.f : v[ps];
                         if (tap % KS == 2 && S == 1) v[ps] = (rmask >> ps & 1) ? 0.f : v[ps];
                     }
+                    if constexpr (PLANES) v[ps] = (vmask[ps] >> tap & 1) ? v[ps] : 0.f;
                     asm volatile("" : "+v"(v[ps]));
                 }
 #pragma unroll
@@ -482,7 +502,7 @@ namespace {
 constexpr size_t kMaxLds = 160 * 1024;
 constexpr int kSplitWaves = 4;
 
-void plan_tile(ConvArgs& a, int tps) {
+void plan_tile(ConvArgs& a, int tps, int family) {
     const int TP = tps * 16, HoWo = a.Ho * a.Wo;
     if (HoWo <= TP) {
         a.G = TP / HoWo;
@@ -498,6 +518,12 @@ void plan_tile(ConvArgs& a, int tps) {
     a.groups = (a.N + a.G - 1) / a.G;
     a.Rin = (a.R - 1) * a.stride + a.ks;
     a.rows = (a.G == 1 && (a.H * a.W) % 4 == 0) ? 1 : 0;
+    if (family == 1 && !a.rows && a.G == 1 && a.R == a.Ho && a.Cin % 4 == 0 && a.in_ctot % 4 == 0 && a.in_coff % 4 == 0 && a.H * a.W <= 256) {
+        a.rows = 2;                                       // planes mode (split-K family only)
+        a.Wp = a.W;
+        a.PSTR = a.H * a.W;                               // plane stride = plane size: the 4 planes of a k-group stay contiguous
+        return;
+    }
     if (a.rows) {
         a.Wp = a.W;                                       // row pitch in LDS = image row pitch
         const int need = (a.Rin * a.W + 5 + 3) & ~3;      // phase (<=3) + 1 + rows + right overhang, in whole 16-byte units
@@ -532,7 +558,7 @@ size_t lds_bytes(const ConvArgs& a, const Cfg& c) {
 // MFMA-issue model: the chip has 1024 SIMDs; a wave issues `chain` MFMAs of 32 cycles back to back.
 // cost ~ chain x number of rounds the waves need; split-K pays its extra staging traffic as a 15 % penalty.
 double cfg_cost(ConvArgs a, const Cfg& c, bool* ok) {
-    plan_tile(a, c.tps);
+    plan_tile(a, c.tps, c.family);
     *ok = a.R >= 1 && lds_bytes(a, c) <= kMaxLds && a.CoutPad % (c.tcs * 16) == 0;
     if (!*ok) return 0;
     const double blocks = (double)a.tiles_y * a.groups * (a.CoutPad / (c.tcs * 16));
@@ -564,16 +590,25 @@ hipError_t init_ks() {
     if ((e = set_lds(conv_mfma_f32<ROWS, KS, S, 14, 2, 2, 2>)) != hipSuccess) return e;
     if ((e = set_lds(conv_mfma_f32<ROWS, KS, S, 7, 4, 1, 4>)) != hipSuccess) return e;
     if ((e = set_lds(conv_mfma_f32<ROWS, KS, S, 7, 2, 1, 2>)) != hipSuccess) return e;
-    if ((e = set_lds(conv_splitk_f32<ROWS, KS, S, 7, 1, kSplitWaves>)) != hipSuccess) return e;
-    if ((e = set_lds(conv_splitk_f32<ROWS, KS, S, 7, 2, kSplitWaves>)) != hipSuccess) return e;
-    if ((e = set_lds(conv_splitk_f32<ROWS, KS, S, 4, 1, kSplitWaves>)) != hipSuccess) return e;
-    if ((e = set_lds(conv_splitk_f32<ROWS, KS, S, 4, 2, kSplitWaves>)) != hipSuccess) return e;
+    if ((e = set_lds(conv_splitk_f32<ROWS ? 1 : 0, KS, S, 7, 1, kSplitWaves>)) != hipSuccess) return e;
+    if ((e = set_lds(conv_splitk_f32<ROWS ? 1 : 0, KS, S, 7, 2, kSplitWaves>)) != hipSuccess) return e;
+    if ((e = set_lds(conv_splitk_f32<ROWS ? 1 : 0, KS, S, 4, 1, kSplitWaves>)) != hipSuccess) return e;
+    if ((e = set_lds(conv_splitk_f32<ROWS ? 1 : 0, KS, S, 4, 2, kSplitWaves>)) != hipSuccess) return e;
+    if (!ROWS) {
+        if ((e = set_lds(conv_splitk_f32<2, KS, S, 4, 1, kSplitWaves>)) != hipSuccess) return e;
+        if ((e = set_lds(conv_splitk_f32<2, KS, S, 4, 2, kSplitWaves>)) != hipSuccess) return e;
+    }
     return hipSuccess;
 }
 
 template <bool ROWS, int KS, int S>
 hipError_t dispatch(const ConvArgs& a, const Cfg& c, size_t lds, hipStream_t s) {
     const dim3 grid(a.tiles_y * a.groups, a.CoutPad / (c.tcs * 16));
+    if (a.rows == 2) {
+        if (c.family == 1 && c.tps == 4 && c.tcs == 1) return launch_k(conv_splitk_f32<2, KS, S, 4, 1, kSplitWaves>, grid, dim3(kSplitWaves * 64), lds, s, a);
+        if (c.family == 1 && c.tps == 4 && c.tcs == 2) return launch_k(conv_splitk_f32<2, KS, S, 4, 2, kSplitWaves>, grid, dim3(kSplitWaves * 64), lds, s, a);
+        return hipErrorInvalidValue;
+    }
 #define GRK_LAUNCH(KERN, THREADS) return launch_k(KERN, grid, dim3(THREADS), lds, s, a)
     if (c.family == 0) {
         if (c.tps == 14 && c.tcs == 4) GRK_LAUNCH((conv_mfma_f32<ROWS, KS, S, 14, 4, 2, 2>), 256);
@@ -581,10 +616,10 @@ hipError_t dispatch(const ConvArgs& a, const Cfg& c, size_t lds, hipStream_t s) 
         if (c.tps == 7 && c.tcs == 4) GRK_LAUNCH((conv_mfma_f32<ROWS, KS, S, 7, 4, 1, 4>), 256);
         if (c.tps == 7 && c.tcs == 2) GRK_LAUNCH((conv_mfma_f32<ROWS, KS, S, 7, 2, 1, 2>), 128);
     } else {
-        if (c.tps == 7 && c.tcs == 1) GRK_LAUNCH((conv_splitk_f32<ROWS, KS, S, 7, 1, kSplitWaves>), kSplitWaves * 64);
-        if (c.tps == 7 && c.tcs == 2) GRK_LAUNCH((conv_splitk_f32<ROWS, KS, S, 7, 2, kSplitWaves>), kSplitWaves * 64);
-        if (c.tps == 4 && c.tcs == 1) GRK_LAUNCH((conv_splitk_f32<ROWS, KS, S, 4, 1, kSplitWaves>), kSplitWaves * 64);
-        if (c.tps == 4 && c.tcs == 2) GRK_LAUNCH((conv_splitk_f32<ROWS, KS, S, 4, 2, kSplitWaves>), kSplitWaves * 64);
+        if (c.tps == 7 && c.tcs == 1) GRK_LAUNCH((conv_splitk_f32<ROWS ? 1 : 0, KS, S, 7, 1, kSplitWaves>), kSplitWaves * 64);
+        if (c.tps == 7 && c.tcs == 2) GRK_LAUNCH((conv_splitk_f32<ROWS ? 1 : 0, KS, S, 7, 2, kSplitWaves>), kSplitWaves * 64);
+        if (c.tps == 4 && c.tcs == 1) GRK_LAUNCH((conv_splitk_f32<ROWS ? 1 : 0, KS, S, 4, 1, kSplitWaves>), kSplitWaves * 64);
+        if (c.tps == 4 && c.tcs == 2) GRK_LAUNCH((conv_splitk_f32<ROWS ? 1 : 0, KS, S, 4, 2, kSplitWaves>), kSplitWaves * 64);
     }
 #undef GRK_LAUNCH
     return hipErrorInvalidValue;
@@ -640,10 +675,10 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s, int tile_hint) {
         }
     }
     if (!found) return hipErrorInvalidValue;
-    plan_tile(a, best.tps);
+    plan_tile(a, best.tps, best.family);
     a.TC = best.tcs * 16;
     const size_t lds = lds_bytes(a, best);
-    return a.rows ? dispatch_ks<true>(a, best, lds, s) : dispatch_ks<false>(a, best, lds, s);
+    return a.rows == 1 ? dispatch_ks<true>(a, best, lds, s) : dispatch_ks<false>(a, best, lds, s);
 }
 
 }  // namespace grk

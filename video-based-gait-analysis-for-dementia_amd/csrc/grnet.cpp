@@ -380,7 +380,7 @@ struct grnet {
         int rc;
         if ((rc = dev_alloc(&d_plf, n * 128 * 24))) return rc;
         if ((rc = dev_alloc(&d_csf, n * 64 * 24))) return rc;
-        if ((rc = dev_alloc(&d_stats, n * 24 * 2))) return rc;
+        if ((rc = dev_alloc(&d_stats, softmax_pool_ws_floats((int)n)))) return rc;
         if ((rc = dev_alloc(&d_rot6d, n * 144))) return rc;
         if ((rc = dev_alloc(&d_shape, n * 10))) return rc;
         if ((rc = dev_alloc(&d_cam, n * 3))) return rc;
@@ -650,7 +650,7 @@ struct grnet {
                     launches += 2;
                     break;
                 case Op::TAIL:
-                    HIP_TRY(launch_head_tail(plf, csf, tailw, rot6d, d_shape, d_cam, rotmat, theta, n, s));
+                    HIP_TRY(launch_head_tail(d_stats, plf, csf, tailw, rot6d, d_shape, d_cam, rotmat, theta, n, s));
                     ++launches;
                     break;
                 case Op::SMPL:

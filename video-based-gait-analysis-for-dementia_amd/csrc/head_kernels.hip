@@ -127,12 +127,14 @@ __global__ __launch_bounds__(256) void softmax_stats_kernel(const float* __restr
     }
 }
 
-// block = (frame n, 32 channels of the stacked [featA | featB] map); 256 threads =
-// 16 channel pairs x 4 joint groups of 6 x 4 pixel phases; pixel tiles of 64 staged in LDS.
+// block = (frame n, 32 channels of the stacked [featA | featB] map, one of kPoolSplit pixel ranges);
+// 256 threads = 16 channel pairs x 4 joint groups of 6 x 4 pixel phases; pixel tiles of 64 staged in
+// LDS.  Each block writes a partial sum; head_tail_kernel adds the kPoolSplit partials in a fixed order.
 constexpr int kPoolPT = 64;
+constexpr int kPoolSplit = 7;                                // 3136 pixels = 7 x 448
 __global__ __launch_bounds__(256) void attn_pool_kernel(const float* __restrict__ heat, int heat_ctot, const float* __restrict__ stats,
                                                           const float* __restrict__ featA, int CA, const float* __restrict__ featB,
-                                                          int CB, float* __restrict__ outA, float* __restrict__ outB, int P) {
+                                                          int CB, float* __restrict__ part, int P) {
     __shared__ float prob[24][kPoolPT + 1];
     __shared__ float feat[32][kPoolPT + 1];
     __shared__ float red[4][32][24];
@@ -148,15 +150,17 @@ __global__ __launch_bounds__(256) void attn_pool_kernel(const float* __restrict_
 #pragma unroll
         for (int b = 0; b < 6; ++b) acc[a][b] = 0.f;
 
-    for (int p0 = 0; p0 < P; p0 += kPoolPT) {
+    const int chunk = (P + kPoolSplit - 1) / kPoolSplit;
+    const int pbeg = blockIdx.z * chunk, pend = min(P, pbeg + chunk);
+    for (int p0 = pbeg; p0 < pend; p0 += kPoolPT) {
         for (int e = tid; e < 24 * kPoolPT; e += 256) {
             const int j = e / kPoolPT, pp = e % kPoolPT;
             const float m = stats[2 * (n * 24 + j)], inv = stats[2 * (n * 24 + j) + 1];
-            prob[j][pp] = (p0 + pp < P) ? expf(hbase[(size_t)j * P + p0 + pp] - m) * inv : 0.f;
+            prob[j][pp] = (p0 + pp < pend) ? expf(hbase[(size_t)j * P + p0 + pp] - m) * inv : 0.f;
         }
         for (int e = tid; e < 32 * kPoolPT; e += 256) {
             const int c = e / kPoolPT, pp = e % kPoolPT;
-            feat[c][pp] = (p0 + pp < P) ? fbase[(size_t)c * P + p0 + pp] : 0.f;
+            feat[c][pp] = (p0 + pp < pend) ? fbase[(size_t)c * P + p0 + pp] : 0.f;
         }
         __syncthreads();
 #pragma unroll 4
@@ -179,17 +183,20 @@ __global__ __launch_bounds__(256) void attn_pool_kernel(const float* __restrict_
     for (int e = tid; e < 32 * 24; e += 256) {
         const int c = e / 24, j = e % 24;
         const float v = red[0][c][j] + red[1][c][j] + red[2][c][j] + red[3][c][j];
-        if (isA) outA[((size_t)n * CA + cb + c) * 24 + j] = v;
-        else outB[((size_t)n * CB + (cb - CA) + c) * 24 + j] = v;
+        part[(((size_t)n * kPoolSplit + blockIdx.z) * (CA + CB) + cb + c) * 24 + j] = v;      // [n][split][192][24]
     }
 }
 
+size_t softmax_pool_ws_floats(int N) { return (size_t)N * 48 + (size_t)N * kPoolSplit * 192 * 24; }
+
 hipError_t launch_softmax_pool(const float* heat, int heat_ctot, const float* featA, int CA, const float* featB, int CB,
                                float* outA, float* outB, float* stats_ws, int N, int P, hipStream_t s) {
-    if (CA % 32 != 0 || CB % 32 != 0) return hipErrorInvalidValue;
+    (void)outA; (void)outB;                                  // written by head_tail_kernel from the partial sums
+    if (CA != 128 || CB != 64) return hipErrorInvalidValue;
+    float* part = stats_ws + (size_t)N * 48;
     GRK_TRY(launch_k(softmax_stats_kernel, dim3(N * 24), dim3(256), 0, s, heat, heat_ctot, stats_ws, P));
-    GRK_TRY(launch_k(attn_pool_kernel, dim3(N, (CA + CB) / 32), dim3(256), 0, s, heat, heat_ctot, stats_ws, featA, CA, featB,
-                       CB, outA, outB, P));
+    GRK_TRY(launch_k(attn_pool_kernel, dim3(N, (CA + CB) / 32, kPoolSplit), dim3(256), 0, s, heat, heat_ctot, stats_ws, featA, CA, featB,
+                       CB, part, P));
     return hipGetLastError();
 }
 
@@ -239,7 +246,7 @@ __device__ __forceinline__ void rotmat_to_aa_dev(const float* R, float* aa) {
     aa[2] = isnan(a2) ? 0.f : a2;
 }
 
-__global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict__ plf, const float* __restrict__ csf, TailWeights w,
+__global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict__ part, float* __restrict__ plf, float* __restrict__ csf, TailWeights w,
                                                           float* __restrict__ rot6d, float* __restrict__ shape,
                                                           float* __restrict__ cam, float* __restrict__ rotmat,
                                                           float* __restrict__ theta) {
@@ -248,8 +255,13 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
     __shared__ float s_pose[24 * 6];
     __shared__ float s_sc[13];
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int e = tid; e < 128 * 24; e += 256) s_plf[e] = plf[(size_t)n * 128 * 24 + e];
-    for (int e = tid; e < 64 * 24; e += 256) s_csf[e] = csf[(size_t)n * 64 * 24 + e];
+    for (int e = tid; e < 192 * 24; e += 256) {              // add the pixel-range partials of the pooling, fixed order
+        float v = 0.f;
+#pragma unroll
+        for (int sp = 0; sp < kPoolSplit; ++sp) v += part[((size_t)n * kPoolSplit + sp) * (192 * 24) + e];
+        if (e < 128 * 24) { s_plf[e] = v; plf[(size_t)n * 128 * 24 + e] = v; }
+        else { s_csf[e - 128 * 24] = v; csf[(size_t)n * 64 * 24 + e - 128 * 24] = v; }
+    }
     __syncthreads();
     if (tid < 144) {
         const int j = tid / 6, o = tid % 6;
@@ -288,9 +300,9 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
     }
 }
 
-hipError_t launch_head_tail(const float* plf, const float* csf, TailWeights w, float* rot6d, float* shape, float* cam,
+hipError_t launch_head_tail(const float* pool_ws, float* plf, float* csf, TailWeights w, float* rot6d, float* shape, float* cam,
                             float* rotmat, float* theta, int N, hipStream_t s) {
-    GRK_TRY(launch_k(head_tail_kernel, dim3(N), dim3(256), 0, s, plf, csf, w, rot6d, shape, cam, rotmat, theta));
+    GRK_TRY(launch_k(head_tail_kernel, dim3(N), dim3(256), 0, s, pool_ws + (size_t)N * 48, plf, csf, w, rot6d, shape, cam, rotmat, theta));
     return hipGetLastError();
 }
 

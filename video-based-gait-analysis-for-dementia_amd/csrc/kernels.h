@@ -113,8 +113,10 @@ struct TailWeights {
     const float* cam_b;
 };
 // plf (N,128,24), csf (N,64,24) -> rot6d (N,24,6), shape (N,10), cam (N,3), rotmat (N,24,9), theta (N,85)
-hipError_t launch_head_tail(const float* plf, const float* csf, TailWeights w, float* rot6d, float* shape, float* cam,
+// pool_ws: the workspace launch_softmax_pool filled (per-range partial sums); plf / csf are WRITTEN here
+hipError_t launch_head_tail(const float* pool_ws, float* plf, float* csf, TailWeights w, float* rot6d, float* shape, float* cam,
                             float* rotmat, float* theta, int N, hipStream_t s);
+size_t softmax_pool_ws_floats(int N);
 
 struct SmplTables {
     const float* v_template;   // (6890,3)
