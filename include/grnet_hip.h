@@ -91,7 +91,13 @@ int grnet_gru_forward(grnet_t* h, const float* x_dev, const float* cparams_dev, 
 #define GRNET_OPT_USE_GRAPH 1     /* 1: capture each distinct (n, pointers) forward into a hipGraph and replay it */
 #define GRNET_OPT_CONV_TILE 2     /* 0 = cost model; 7 / 14 = whole-K tiles; 1071/1072/1041/1042 = split-K (psw,csw) (tests / tuning) */
 #define GRNET_OPT_MULTI_LANE 3    /* 1 (default): independent HR-module branches run on parallel streams / graph branches */
+#define GRNET_OPT_GROUPING 4      /* 1 (default): same-depth convolutions of an HR module are one grouped launch */
 int grnet_set_option(grnet_t* h, int option, int value);
+
+/* Optional, once per distinct n_frames after grnet_finalize_weights: times every launch configuration of every
+ * distinct convolution shape (and grouped vs parallel-lane scheduling of the HR modules) on this GPU and keeps the
+ * fastest.  Synchronises the stream; overwrites the activation buffers.  Without it the cost model decides. */
+int grnet_tune(grnet_t* h, int n_frames, void* stream);
 
 /* Introspection used by bench.py / tests. */
 int grnet_num_kernel_launches(grnet_t* h);      /* launches enqueued by one grnet_forward */

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libgrnet_hip.so")
 
 OK, EINVAL, ENOENT, ENOMEM, EHIP, ESTATE = 0, -22, -2, -12, -5, -1
 DTYPE_F32, DTYPE_I64 = 0, 1
-OPT_USE_GRAPH, OPT_CONV_TILE, OPT_MULTI_LANE = 1, 2, 3
+OPT_USE_GRAPH, OPT_CONV_TILE, OPT_MULTI_LANE, OPT_GROUPING = 1, 2, 3, 4
 
 
 class Outputs(C.Structure):
@@ -30,6 +30,7 @@ EXPORTS = {
     "grnet_gru_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
     "grnet_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "grnet_tune": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "grnet_num_kernel_launches": (C.c_int, [C.c_void_p]),
     "grnet_num_conv_launches": (C.c_int, [C.c_void_p]),
     "grnet_conv_flops_per_frame": (C.c_double, [C.c_void_p]),

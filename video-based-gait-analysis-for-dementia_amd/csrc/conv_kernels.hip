@@ -17,6 +17,8 @@
 // ReLU, store into a channel slice of the destination buffer.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace grk {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -59,7 +61,9 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const EpiCtx& e, f
         const int img = e.g0 + gl, pix = e.y0 * a.Wo + rem;
         if (img >= a.N || pix >= e.HoWo) return;
         v += bias;
-        for (int k = 0; k < a.n_add; ++k) {
+#pragma unroll
+        for (int k = 0; k < kMaxAdd; ++k) {                  // static indices: ConvArgs may live in registers
+            if (k >= a.n_add) break;
             const int sh = a.add_shift[k];
             if (sh == 0) {
                 const float* ap = a.add[k] + ((size_t)img * a.add_ctot[k] + a.add_coff[k] + co) * e.HoWo + pix;
@@ -89,7 +93,9 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const EpiCtx& e, f
             const int img = e.g0 + gl, pix = e.y0 * a.Wo + rem;
             if (img >= a.N || pix >= e.HoWo) continue;
             float o = v[r] + bias;
-            for (int k = 0; k < a.n_add; ++k) {
+#pragma unroll
+            for (int k = 0; k < kMaxAdd; ++k) {
+                if (k >= a.n_add) break;
                 const int sh = a.add_shift[k];
                 const int hs = a.Ho >> sh, ws = a.Wo >> sh;
                 const int y = pix / a.Wo, x = pix - y * a.Wo;
@@ -295,23 +301,24 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
 #undef GRK_W
 }
 
-constexpr int kRing = 2;   // LDS-DMA stages per wave in the split-K kernel (stage i+1, i+2 in flight under the MFMAs of stage i)
+// LDS-DMA stages per wave in the split-K kernel: a.ring (2..4, chosen by the launcher so that a workgroup stays
+// near 48 KB of LDS): stages i+1 .. i+ring-1 are in flight under the MFMAs of stage i.
 
 // MODE: 0 = gather (source-offset table), 1 = rows (contiguous image rows), 2 = planes (the 4 channel planes of a
 // k-group of ONE whole small image are contiguous in NCHW: one 16-byte LDS-DMA per k-group; all zero padding is
 // applied through a per-lane 9-bit tap-validity mask when the A operand is read).
 template <int MODE, int KS, int S, int PSW, int CSW, int NW>
-__global__ __launch_bounds__(NW * 64) void conv_splitk_f32(const ConvArgs a) {
+__device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, const int by, float* smem) {
     constexpr int TC = CSW * 16, TAPS = KS * KS, WFL = TAPS * 4 * TC, NT = PSW * CSW;
-    extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     const int stage_floats = WFL + 4 * a.PSTR;           // [weights TAPS*4 x TC | input 4 x PSTR]
-    int* tab = reinterpret_cast<int*>(smem + NW * kRing * stage_floats);
-    float* mine = smem + wave * kRing * stage_floats;
+    const int ring = a.ring;
+    int* tab = reinterpret_cast<int*>(smem + NW * ring * stage_floats);
+    float* mine = smem + wave * ring * stage_floats;
 
-    const int ty = blockIdx.x % a.tiles_y, grp = blockIdx.x / a.tiles_y;
-    const int y0 = ty * a.R, g0 = grp * a.G, co0 = blockIdx.y * TC;
+    const int ty = bx % a.tiles_y, grp = bx / a.tiles_y;
+    const int y0 = ty * a.R, g0 = grp * a.G, co0 = by * TC;
     const int HW = a.H * a.W, RW = a.R * a.Wo, RinWp = a.Rin * a.Wp;
     constexpr int pad = KS / 2;
     const float* inb = a.in + ((size_t)g0 * a.in_ctot + a.in_coff) * HW;
@@ -420,19 +427,19 @@ __global__ __launch_bounds__(NW * 64) void conv_splitk_f32(const ConvArgs a) {
     const int my_stages = ngroups > wave ? (ngroups - wave + NW - 1) / NW : 0;
     constexpr int NWI = (WFL / 4 + 63) / 64;
     const int ni = NWI + (PLANES ? (HW + 63) / 64 : ROWS ? (a.PSTR + 63) / 64 : 4 * ((a.PSTR + 63) / 64));
-#pragma unroll
-    for (int d = 0; d < kRing; ++d)
-        if (d < my_stages) issue(wave + d * NW, d);
+    for (int d = 0; d < ring && d < my_stages; ++d) issue(wave + d * NW, d);
     int buf = 0;
     for (int i = 0; i < my_stages; ++i) {
         const int left = my_stages - 1 - i;
         if (a.dbg & 2) wait_vmcnt_le(0); else
-        wait_vmcnt_le((left < kRing - 1 ? left : kRing - 1) * ni);
+        wait_vmcnt_le((left < ring - 1 ? left : ring - 1) * ni);
         const float* st = mine + buf * stage_floats;
         if (!(a.dbg & 1)) {
             // software pipeline over the filter taps: the LDS reads of tap t+1 are in flight under the
             // MFMAs of tap t (one exposed LDS latency per stage instead of one per tap)
-            float av[2][PSW], bv[2][CSW];
+            // LD = taps prefetched ahead: 2 when a tap is only 4 MFMAs (128 cycles < LDS latency), else 1
+            constexpr int LD = (PSW * CSW <= 4) ? 2 : 1;
+            float av[LD + 1][PSW], bv[LD + 1][CSW];
             auto load_tap = [&](int tap, float* ar, float* br) {
                 const int toff = (tap / KS) * a.Wp + (tap % KS);
 #pragma unroll
@@ -440,12 +447,13 @@ __global__ __launch_bounds__(NW * 64) void conv_splitk_f32(const ConvArgs a) {
 #pragma unroll
                 for (int ps = 0; ps < PSW; ++ps) ar[ps] = st[abase[ps] + toff];
             };
-            load_tap(0, av[0], bv[0]);
+#pragma unroll
+            for (int t = 0; t < LD && t < TAPS; ++t) load_tap(t, av[t], bv[t]);
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
-                const int cur = tap & 1;
-                // (1) take this tap's operands out of the LDS queue while they are the ONLY pending reads
-                //     (lgkmcnt is a 4-bit counter: two taps of 8 reads in flight would force a full drain)
+                const int cur = tap % (LD + 1);
+                // (1) take this tap's operands out of the LDS queue while only the later prefetched taps are pending
+                //     (lgkmcnt is a 4-bit counter: more than 15 reads in flight would force a full drain)
                 float v[PSW], b[CSW];
 #pragma unroll
                 for (int ps = 0; ps < PSW; ++ps) {
@@ -460,8 +468,8 @@ __global__ __launch_bounds__(NW * 64) void conv_splitk_f32(const ConvArgs a) {
 #pragma unroll
                 for (int cs = 0; cs < CSW; ++cs) { b[cs] = bv[cur][cs]; asm volatile("" : "+v"(b[cs])); }
                 __builtin_amdgcn_sched_barrier(0);
-                // (2) prefetch the next tap, (3) this tap's MFMAs cover its LDS latency
-                if (tap + 1 < TAPS) load_tap(tap + 1, av[cur ^ 1], bv[cur ^ 1]);
+                // (2) prefetch tap + LD, (3) this tap's MFMAs cover its LDS latency
+                if (tap + LD < TAPS) load_tap(tap + LD, av[(tap + LD) % (LD + 1)], bv[(tap + LD) % (LD + 1)]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ps = 0; ps < PSW; ++ps)
@@ -471,8 +479,8 @@ __global__ __launch_bounds__(NW * 64) void conv_splitk_f32(const ConvArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (i + kRing < my_stages && !(a.dbg & 2)) issue(wave + (i + kRing) * NW, buf);   // refill the buffer just consumed
-        buf = buf + 1 == kRing ? 0 : buf + 1;
+        if (i + ring < my_stages && !(a.dbg & 2)) issue(wave + (i + ring) * NW, buf);   // refill the buffer just consumed
+        buf = buf + 1 == ring ? 0 : buf + 1;
     }
 
     // ---- cross-wave reduction (fixed order -> deterministic), then the shared epilogue
@@ -491,6 +499,53 @@ __global__ __launch_bounds__(NW * 64) void conv_splitk_f32(const ConvArgs a) {
         for (int w = 1; w < NW; ++w) v += red[(w * NT + t) * 64 + lane];
         const int ps = t / CSW, cs = t - ps * CSW;
         store_tile(a, ec, v, ps * 16 + lq * 4, co0 + cs * 16 + l15);
+    }
+}
+
+template <int MODE, int KS, int S, int PSW, int CSW, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_splitk_f32(const ConvArgs a) {
+    extern __shared__ __align__(16) float smem[];
+    splitk_body<MODE, KS, S, PSW, CSW, NW>(a, blockIdx.x, blockIdx.y, smem);
+}
+
+// Grouped launch: up to kMaxGroup independent convolutions (the same-depth convolutions of the
+// branches of an HR module, the 1x1 fuse convolutions, ...) share ONE launch; the blocks of the grid are
+// partitioned over the problems.  Independent small layers then co-reside on the CUs by construction
+// (no reliance on how the runtime maps streams / graph branches to hardware queues) and the launch
+// count of a forward drops.  Every member runs the split-K body in its own (mode, tile) variant.
+struct GroupArgs {
+    int n;
+    int first_block[kMaxGroup + 1];
+    int grid_x[kMaxGroup];
+    int variant[kMaxGroup];      // 0: rows 7x1, 1: rows 7x2, 2: rows 4x1, 3: planes 4x1, 4: gather 4x1, 5: gather 7x1
+    ConvArgs c[kMaxGroup];
+};
+
+template <int KS, int S>
+__global__ __launch_bounds__(256) void conv_group_f32(const GroupArgs g) {
+    extern __shared__ __align__(16) float smem[];
+    int b = blockIdx.x, p = 0;
+    if (1 < g.n && b >= g.first_block[1]) p = 1;
+    if (2 < g.n && b >= g.first_block[2]) p = 2;
+    if (3 < g.n && b >= g.first_block[3]) p = 3;
+    if (4 < g.n && b >= g.first_block[4]) p = 4;
+    if (5 < g.n && b >= g.first_block[5]) p = 5;
+    // select the member with compile-time indices only: a run-time index into the kernel-argument struct
+    // would make hipcc copy the whole array to scratch
+    ConvArgs a = g.c[0];
+    int first = g.first_block[0], gx = g.grid_x[0], variant = g.variant[0];
+#define GRK_PICK(I) if (p == I) { a = g.c[I]; first = g.first_block[I]; gx = g.grid_x[I]; variant = g.variant[I]; }
+    GRK_PICK(1) GRK_PICK(2) GRK_PICK(3) GRK_PICK(4) GRK_PICK(5)
+#undef GRK_PICK
+    b -= first;
+    const int bx = b % gx, by = b / gx;
+    switch (variant) {
+        case 0: splitk_body<1, KS, S, 7, 1, 4>(a, bx, by, smem); break;
+        case 1: splitk_body<1, KS, S, 7, 2, 4>(a, bx, by, smem); break;
+        case 2: splitk_body<1, KS, S, 4, 1, 4>(a, bx, by, smem); break;
+        case 3: splitk_body<2, KS, S, 4, 1, 4>(a, bx, by, smem); break;
+        case 4: splitk_body<0, KS, S, 4, 1, 4>(a, bx, by, smem); break;
+        default: splitk_body<0, KS, S, 7, 1, 4>(a, bx, by, smem); break;
     }
 }
 
@@ -546,12 +601,22 @@ void plan_tile(ConvArgs& a, int tps, int family) {
 // family 1 = split-K independent waves (conv_splitk_f32).
 struct Cfg { int family, tps, tcs; };
 
+// split-K DMA ring depth: as deep as ~48 KB of LDS per workgroup allows (2..4)
+void plan_ring(ConvArgs& a, const Cfg& c) {
+    a.ring = 2;
+    if (c.family != 1) return;
+    const size_t stage_bytes = 4 * ((size_t)a.ks * a.ks * 4 * c.tcs * 16 + 4 * (size_t)a.PSTR);
+    static const int ring_cap = getenv("GRNET_RING_CAP") ? atoi(getenv("GRNET_RING_CAP")) : 2;   // measured: deeper rings buy nothing
+    int r = (int)((48 * 1024) / (kSplitWaves * stage_bytes));
+    a.ring = r < 2 ? 2 : (r > ring_cap ? ring_cap : r);
+}
+
 size_t lds_bytes(const ConvArgs& a, const Cfg& c) {
     const int taps = a.ks * a.ks, TC = c.tcs * 16;
     const size_t tab = a.rows ? 0 : a.PSTR;
     if (c.family == 0) return sizeof(float) * (2 * (size_t)taps * kConvCK * TC + 2 * (size_t)kConvCK * a.PSTR + tab);
     const size_t stage = (size_t)taps * 4 * TC + 4 * (size_t)a.PSTR;
-    const size_t staging = kSplitWaves * 2 * stage + tab, red = (size_t)kSplitWaves * c.tps * c.tcs * 256;   // 2 = kRing
+    const size_t staging = kSplitWaves * (size_t)a.ring * stage + tab, red = (size_t)kSplitWaves * c.tps * c.tcs * 256;
     return sizeof(float) * (staging > red ? staging : red);
 }
 
@@ -559,6 +624,7 @@ size_t lds_bytes(const ConvArgs& a, const Cfg& c) {
 // cost ~ chain x number of rounds the waves need; split-K pays its extra staging traffic as a 15 % penalty.
 double cfg_cost(ConvArgs a, const Cfg& c, bool* ok) {
     plan_tile(a, c.tps, c.family);
+    plan_ring(a, c);
     *ok = a.R >= 1 && lds_bytes(a, c) <= kMaxLds && a.CoutPad % (c.tcs * 16) == 0;
     if (!*ok) return 0;
     const double blocks = (double)a.tiles_y * a.groups * (a.CoutPad / (c.tcs * 16));
@@ -641,7 +707,82 @@ hipError_t conv_init() {
     if ((e = init_ks<true, 1, 1>()) != hipSuccess) return e;
     if ((e = init_ks<true, 3, 1>()) != hipSuccess) return e;
     if ((e = init_ks<true, 3, 2>()) != hipSuccess) return e;
+    if ((e = set_lds(conv_group_f32<1, 1>)) != hipSuccess) return e;
+    if ((e = set_lds(conv_group_f32<3, 1>)) != hipSuccess) return e;
+    if ((e = set_lds(conv_group_f32<3, 2>)) != hipSuccess) return e;
     return hipSuccess;
+}
+
+// Grouped launch of n (<= kMaxGroup) convolutions with identical (ks, stride).  Members must fit one of the
+// split-K variants; the launcher falls back to separate launches when they do not.
+hipError_t launch_conv_group(const ConvArgs* list, int n, hipStream_t s) {
+    if (n < 1 || n > kMaxGroup) return hipErrorInvalidValue;
+    GroupArgs g{};
+    g.n = n;
+    size_t lds = 0;
+    long total_waves = 0;
+    bool ok_all = true;
+    static const int allow_csw2 = getenv("GRNET_GROUP_CSW2") ? atoi(getenv("GRNET_GROUP_CSW2")) : 1;
+    // members with the longest per-wave MFMA chain first: their blocks are dispatched first and the short
+    // ones fill the tail of the launch
+    int order[kMaxGroup];
+    double chain_len[kMaxGroup];
+    for (int i = 0; i < n; ++i) {
+        order[i] = i;
+        chain_len[i] = (double)list[i].CinPad * list[i].ks * list[i].ks;
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j)
+            if (chain_len[order[j]] > chain_len[order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+    for (int i = 0; i < n && ok_all; ++i) {
+        ConvArgs a = list[order[i]];
+        if (a.ks != list[0].ks || a.stride != list[0].stride) { ok_all = false; break; }
+        const int TCpack = conv_pick_tc(a.Cout);
+        if (a.CoutPad % TCpack != 0 || a.CinPad % kConvCK != 0) return hipErrorInvalidValue;
+        // candidate variants in order of preference: larger tiles first (less staging traffic)
+        const Cfg cands[] = {{1, 7, 2}, {1, 7, 1}, {1, 4, 1}};
+        bool found = false;
+        Cfg best{1, 7, 1};
+        double best_cost = 0;
+        for (const Cfg& c : cands) {
+            if (a.Wo > c.tps * 16) continue;
+            if (c.tcs == 2 && !allow_csw2) continue;
+            bool ok;
+            double cost = cfg_cost(a, c, &ok);
+            if (!ok) continue;
+            if (c.tcs == 2) cost *= 0.9;                  // grouped launches have waves to spare: prefer the wider cout tile
+            if (!found || cost < best_cost) { best = c; best_cost = cost; found = true; }
+        }
+        if (!found) { ok_all = false; break; }
+        plan_tile(a, best.tps, 1);
+        plan_ring(a, best);
+        a.TC = best.tcs * 16;
+        int variant;
+        if (a.rows == 1) variant = best.tps == 7 ? (best.tcs == 2 ? 1 : 0) : 2;
+        else if (a.rows == 2) variant = 3;
+        else variant = best.tps == 4 ? 4 : 5;
+        if ((variant == 2 || variant == 3 || variant == 4) && best.tcs != 1) { ok_all = false; break; }
+        if (variant == 5 && best.tcs != 1) { ok_all = false; break; }
+        g.c[i] = a;
+        g.variant[i] = variant;
+        g.grid_x[i] = a.tiles_y * a.groups;
+        const int blocks = g.grid_x[i] * (a.CoutPad / a.TC);
+        g.first_block[i + 1] = g.first_block[i] + blocks;
+        const size_t l = lds_bytes(a, best);
+        if (l > lds) lds = l;
+        total_waves += (long)blocks * 4;
+    }
+    if (!ok_all) {                                        // not groupable: separate launches, same results
+        for (int i = 0; i < n; ++i) {
+            hipError_t e = launch_conv(list[i], s, 0);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    const dim3 grid(g.first_block[n]);
+    if (list[0].ks == 1) return launch_k(conv_group_f32<1, 1>, grid, dim3(256), lds, s, g);
+    return list[0].stride == 1 ? launch_k(conv_group_f32<3, 1>, grid, dim3(256), lds, s, g)
+                               : launch_k(conv_group_f32<3, 2>, grid, dim3(256), lds, s, g);
 }
 
 const char* conv_dominant_kernel_name() { return "conv_mfma_f32 / conv_splitk_f32"; }
@@ -676,6 +817,7 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s, int tile_hint) {
     }
     if (!found) return hipErrorInvalidValue;
     plan_tile(a, best.tps, best.family);
+    plan_ring(a, best);
     a.TC = best.tcs * 16;
     const size_t lds = lds_bytes(a, best);
     return a.rows == 1 ? dispatch_ks<true>(a, best, lds, s) : dispatch_ks<false>(a, best, lds, s);

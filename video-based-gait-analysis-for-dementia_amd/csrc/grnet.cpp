@@ -54,11 +54,14 @@ struct ConvLayer {
     float* b_dev = nullptr;
     int cin_pad = 0, cout_pad = 0;
     double macs_per_frame = 0;
+    int lane_hint = 0;          // lane of this convolution when it is launched on its own (not as a group member)
+    std::map<int, int> tuned;   // n_frames -> launch configuration (tile hint) measured fastest by grnet_tune
 };
 
 struct Op {
-    enum Kind { CONV, SUM, BILINEAR, POOL, TAIL, SMPL } kind;
+    enum Kind { CONV, GROUP, SUM, BILINEAR, POOL, TAIL, SMPL } kind;
     int conv_idx = -1;
+    std::vector<int> group;   // GROUP: indices into convs[] launched together (independent, same ks/stride)
     SumArgs sum{};
     View bin, bout;   // bilinear
     // multi-lane execution: independent branches of the HR modules run on parallel HIP streams
@@ -87,7 +90,9 @@ struct grnet {
 
     std::unordered_map<std::string, HostTensor> tensors;
     std::vector<ConvLayer> convs;
-    std::vector<Op> ops;
+    std::vector<Op> ops;        // schedule A: grouped launches (GROUP ops) on lane 0 + lanes for the heads
+    std::vector<Op> ops_flat;   // schedule B: every GROUP expanded into per-member launches on the members' lanes
+    std::vector<hipEvent_t> op_events_flat;
 
     // planned buffers: (pointer slot, floats per image)
     std::vector<std::pair<float**, size_t>> pending;   // pointers patched after the arena exists
@@ -122,6 +127,7 @@ struct grnet {
     std::vector<hipEvent_t> op_events;
     int cur_lane = 0;
     bool multi_lane = true;
+    bool grouping = true;      // GROUP ops as one grouped launch (false: one launch per member; same results)
     int launches_last = 0;
 
     int fail(int code, const std::string& msg) {
@@ -163,13 +169,39 @@ struct grnet {
         L.cout = cout; L.ks = ks; L.stride = stride; L.relu = relu;
         L.adds = std::move(adds);
         L.macs_per_frame = (double)ho * wo * cout * in.c * ks * ks;
+        L.lane_hint = cur_lane;
         convs.push_back(L);
+        if (group_open) {
+            open_group.push_back((int)convs.size() - 1);
+            return convs.back().out;
+        }
         Op op;
         op.kind = Op::CONV;
         op.conv_idx = (int)convs.size() - 1;
         op.lane = cur_lane;
         ops.push_back(op);
         return convs.back().out;
+    }
+    // Convolutions added between begin_group() and end_group() are independent of each other and have
+    // the same kernel size / stride: they become ONE grouped launch.
+    bool group_open = false;
+    std::vector<int> open_group;
+    void begin_group() { group_open = true; open_group.clear(); }
+    void end_group() {
+        group_open = false;
+        if (open_group.empty()) return;
+        Op op;
+        op.lane = 0;                                         // a grouped launch runs on lane 0; its members keep their own lane hints
+        if (open_group.size() == 1) {
+            op.lane = convs[open_group[0]].lane_hint;
+            op.kind = Op::CONV;
+            op.conv_idx = open_group[0];
+        } else {
+            op.kind = Op::GROUP;
+            op.group = open_group;
+        }
+        ops.push_back(op);
+        open_group.clear();
     }
     View conv_bn(View in, const std::string& wkey, const std::string& bn, int cout, int ks, int stride, bool relu,
                  std::vector<AddRef> adds = {}, const View* out_override = nullptr) {
@@ -187,62 +219,83 @@ struct grnet {
     }
 
     // HighResolutionModule (hrnet.py:249-267).  out0 (optional) receives fused output 0.
+    // The branches advance in lock step: the same-depth convolutions of all branches are one grouped launch
+    // (8 launches for the 4 BasicBlocks of every branch), and the fuse layer is grouped by dependency level.
     std::vector<View> hr_module(std::vector<View> xs, const std::string& p, const View* out0) {
         const int nb = (int)xs.size();
-        for (int b = 0; b < nb; ++b) {
-            const int c = kBranchCh[b];
-            cur_lane = b;                                   // the branches are independent chains
-            for (int k = 0; k < 4; ++k) {
+        cur_lane = 0;
+        for (int k = 0; k < 4; ++k) {
+            std::vector<View> y(nb);
+            begin_group();
+            for (int b = 0; b < nb; ++b) {
+                cur_lane = b;
                 const std::string q = p + "branches." + std::to_string(b) + "." + std::to_string(k) + ".";
-                View y = conv_bn(xs[b], q + "conv1.weight", q + "bn1", c, 3, 1, true);
-                xs[b] = conv_bn(y, q + "conv2.weight", q + "bn2", c, 3, 1, true, {AddRef{xs[b], 0}});
+                y[b] = conv_bn(xs[b], q + "conv1.weight", q + "bn1", kBranchCh[b], 3, 1, true);
             }
+            end_group();
+            begin_group();
+            for (int b = 0; b < nb; ++b) {
+                cur_lane = b;
+                const std::string q = p + "branches." + std::to_string(b) + "." + std::to_string(k) + ".";
+                xs[b] = conv_bn(y[b], q + "conv2.weight", q + "bn2", kBranchCh[b], 3, 1, true, {AddRef{xs[b], 0}});
+            }
+            end_group();
         }
         // up terms t[i][j], j > i: conv1x1 + BN at the resolution of branch j (nearest upsample is
-        // applied where the term is consumed: it commutes with the per-pixel conv/BN)
+        // applied where the term is consumed: it commutes with the per-pixel conv/BN) -- one grouped launch
         std::vector<std::vector<View>> t(nb, std::vector<View>(nb));
+        begin_group();
         for (int i = 0; i < nb; ++i)
             for (int j = i + 1; j < nb; ++j) {
                 const std::string q = p + "fuse_layers." + std::to_string(i) + "." + std::to_string(j) + ".";
-                cur_lane = j;                               // computed where its input lives
+                cur_lane = j;
                 t[i][j] = conv_bn(xs[j], q + "0.weight", q + "1", kBranchCh[i], 1, 1, false);
             }
+        end_group();
+        cur_lane = 0;
         std::vector<View> outs(nb);
-        for (int i = 0; i < nb; ++i) {
-            cur_lane = i;
-            if (i == 0) {
-                View o = out0 ? *out0 : new_buffer(kBranchCh[0], xs[0].h, xs[0].w);
-                Op op;
-                op.kind = Op::SUM;
-                op.lane = 0;
-                SumArgs& s = op.sum;
-                s.C = kBranchCh[0]; s.H = xs[0].h; s.W = xs[0].w; s.relu = 1;
-                s.n_add = nb;
-                sum_views.push_back({o, {}});
-                sum_views.back().second.push_back(AddRef{xs[0], 0});
-                for (int j = 1; j < nb; ++j) sum_views.back().second.push_back(AddRef{t[0][j], j});
-                op.conv_idx = (int)sum_views.size() - 1;
-                ops.push_back(op);
-                outs[0] = o;
-                continue;
-            }
-            std::vector<AddRef> adds;
-            adds.push_back(AddRef{xs[i], 0});
-            for (int j = 0; j < i - 1; ++j) {          // down chains of length >= 2, into temporaries
-                cur_lane = j;
-                View d = xs[j];
-                for (int k = 0; k < i - j; ++k) {
-                    const bool last = k == i - j - 1;
-                    const std::string q = p + "fuse_layers." + std::to_string(i) + "." + std::to_string(j) + "." + std::to_string(k) + ".";
-                    d = conv_bn(d, q + "0.weight", q + "1", last ? kBranchCh[i] : kBranchCh[j], 3, 2, !last);
+        {   // output 0: elementwise sum of the identity and the upsampled terms
+            View o = out0 ? *out0 : new_buffer(kBranchCh[0], xs[0].h, xs[0].w);
+            Op op;
+            op.kind = Op::SUM;
+            op.lane = 0;
+            SumArgs& sa = op.sum;
+            sa.C = kBranchCh[0]; sa.H = xs[0].h; sa.W = xs[0].w; sa.relu = 1;
+            sa.n_add = nb;
+            sum_views.push_back({o, {}});
+            sum_views.back().second.push_back(AddRef{xs[0], 0});
+            for (int j = 1; j < nb; ++j) sum_views.back().second.push_back(AddRef{t[0][j], j});
+            op.conv_idx = (int)sum_views.size() - 1;
+            ops.push_back(op);
+            outs[0] = o;
+        }
+        // down paths (all 3x3 stride 2), by dependency level: chain conv k of (i,j) is level k; the conv that
+        // finishes output i (the single stride-2 conv from branch i-1, which also adds the identity, the
+        // finished down chains and the upsampled terms, then applies the ReLU) is level 0 for i = 1, else i.
+        std::vector<std::vector<View>> d(nb, std::vector<View>(nb));       // running tensor of chain (i,j)
+        for (int i = 2; i < nb; ++i)
+            for (int j = 0; j < i - 1; ++j) d[i][j] = xs[j];
+        for (int level = 0; level < nb; ++level) {
+            begin_group();
+            for (int i = 2; i < nb; ++i)
+                for (int j = 0; j < i - 1; ++j) {
+                    if (level >= i - j) continue;
+                    const bool last = level == i - j - 1;
+                    cur_lane = j;
+                    const std::string q = p + "fuse_layers." + std::to_string(i) + "." + std::to_string(j) + "." + std::to_string(level) + ".";
+                    d[i][j] = conv_bn(d[i][j], q + "0.weight", q + "1", last ? kBranchCh[i] : kBranchCh[j], 3, 2, !last);
                 }
-                adds.push_back(AddRef{d, 0});
+            for (int i = 1; i < nb; ++i) {
+                if ((i == 1 ? 0 : i) != level) continue;
+                std::vector<AddRef> adds;
+                adds.push_back(AddRef{xs[i], 0});
+                for (int j = 0; j < i - 1; ++j) adds.push_back(AddRef{d[i][j], 0});
+                for (int j = i + 1; j < nb; ++j) adds.push_back(AddRef{t[i][j], j - i});
+                cur_lane = i;
+                const std::string q = p + "fuse_layers." + std::to_string(i) + "." + std::to_string(i - 1) + ".0.";
+                outs[i] = conv_bn(xs[i - 1], q + "0.weight", q + "1", kBranchCh[i], 3, 2, true, adds);
             }
-            for (int j = i + 1; j < nb; ++j) adds.push_back(AddRef{t[i][j], j - i});
-            // the single stride-2 conv from branch i-1 finishes the sum and applies the ReLU
-            cur_lane = i;
-            const std::string q = p + "fuse_layers." + std::to_string(i) + "." + std::to_string(i - 1) + ".0.";
-            outs[i] = conv_bn(xs[i - 1], q + "0.weight", q + "1", kBranchCh[i], 3, 2, true, adds);
+            end_group();
         }
         cur_lane = 0;
         return outs;
@@ -365,7 +418,19 @@ struct grnet {
         for (auto& sv : sum_views) { resolve(sv.first); for (auto& a : sv.second) resolve(a.v); }
         for (auto& nv : named) resolve(nv.second);
         resolve(v_cat); resolve(v_heat); resolve(v_smpl_feats); resolve(v_csmap);
-        analyze_dependencies();
+        ops_flat.clear();
+        for (const Op& op : ops) {
+            if (op.kind != Op::GROUP) { ops_flat.push_back(op); continue; }
+            for (int ci : op.group) {
+                Op m;
+                m.kind = Op::CONV;
+                m.conv_idx = ci;
+                m.lane = convs[ci].lane_hint;
+                ops_flat.push_back(m);
+            }
+        }
+        analyze_dependencies(ops, op_events);
+        analyze_dependencies(ops_flat, op_events_flat);
         // streams / events of the parallel lanes are created here, never inside a stream capture
         if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return fail(GRNET_EHIP, "hipEventCreate failed");
         for (int l = 1; l < kLanes; ++l) {
@@ -374,6 +439,9 @@ struct grnet {
         }
         for (size_t i = 0; i < ops.size(); ++i)
             if (ops[i].record && hipEventCreateWithFlags(&op_events[i], hipEventDisableTiming) != hipSuccess)
+                return fail(GRNET_EHIP, "hipEventCreate failed");
+        for (size_t i = 0; i < ops_flat.size(); ++i)
+            if (ops_flat[i].record && hipEventCreateWithFlags(&op_events_flat[i], hipEventDisableTiming) != hipSuccess)
                 return fail(GRNET_EHIP, "hipEventCreate failed");
         if (hipStreamCreateWithFlags(&capture_stream, hipStreamNonBlocking) != hipSuccess) return fail(GRNET_EHIP, "hipStreamCreate failed");
         const size_t n = max_frames;
@@ -396,7 +464,7 @@ struct grnet {
     // Read-after-write edges between lanes.  Every op writes a buffer nobody has written before (no
     // buffer reuse; the writers of the concat buffer own disjoint channel slices), so RAW edges are the
     // only hazards inside one forward; forwards are separated by the join at the end of enqueue().
-    void analyze_dependencies() {
+    void analyze_dependencies(std::vector<Op>& ops, std::vector<hipEvent_t>& op_events) {
         std::map<const float*, std::vector<int>> writers;      // buffer base -> ops that wrote (part of) it
         auto reads_of = [&](const Op& op, std::vector<const float*>& r) {
             r.clear();
@@ -407,6 +475,12 @@ struct grnet {
                     for (auto& a : L.adds) r.push_back(a.v.p);
                     break;
                 }
+                case Op::GROUP:
+                    for (int ci : op.group) {
+                        r.push_back(convs[ci].in.p);
+                        for (auto& a : convs[ci].adds) r.push_back(a.v.p);
+                    }
+                    break;
                 case Op::SUM:
                     for (auto& a : sum_views[op.conv_idx].second) r.push_back(a.v.p);
                     break;
@@ -435,6 +509,8 @@ struct grnet {
             else if (op.kind == Op::SUM) out = sum_views[op.conv_idx].first.p;
             else if (op.kind == Op::BILINEAR) out = op.bout.p;
             if (out) writers[out].push_back(i);
+            if (op.kind == Op::GROUP)
+                for (int ci : op.group) writers[convs[ci].out.p].push_back(i);
         }
         op_events.assign(ops.size(), nullptr);
     }
@@ -567,6 +643,86 @@ struct grnet {
         return 0;
     }
 
+    // ------------------------------------------------------------------ tuning
+    int hint_for(const ConvLayer& L, int n) const {
+        if (conv_tile_hint) return conv_tile_hint;
+        auto m = tuned_mode.find(n);
+        if (m == tuned_mode.end() || !(m->second & 1)) return 0;      // cost model
+        auto it = L.tuned.find(n);
+        return it == L.tuned.end() ? 0 : it->second;
+    }
+
+    // Measure, don't guess: time every launch configuration of every distinct convolution shape on this GPU
+    // for n frames (3 launches each, HIP events) and keep the fastest; then time whole forwards with the HR-module
+    // convolutions grouped vs on parallel lanes and keep the faster schedule.  Activation buffers are used as
+    // scratch (contents are garbage afterwards, like after any forward).
+    std::map<int, int> tuned_mode;     // n -> bit0: per-shape measured configurations (else cost model), bit1: grouped launches
+    int tune(int n, hipStream_t s) {
+        if (!finalized) return fail(GRNET_ESTATE, "grnet_tune before grnet_finalize_weights");
+        if (n < 1 || n > max_frames) return fail(GRNET_EINVAL, "n_frames outside [1, max_frames]");
+        static const int cands[] = {0, 14, 7, 1071, 1072, 1041, 1042};
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        std::map<std::tuple<int, int, int, int, int, int, int>, int> by_shape;
+        for (auto& L : convs) {
+            const auto key = std::make_tuple(L.in.c, L.cout, L.ks, L.stride, L.in.h, (int)L.adds.size(), L.out.ctot);
+            auto it = by_shape.find(key);
+            if (it != by_shape.end()) { L.tuned[n] = it->second; continue; }
+            float best = 1e30f;
+            int best_hint = 0;
+            for (int hint : cands) {
+                ConvArgs a = conv_args(L, v_cat.p, n);        // any readable buffer stands in for the caller's frames
+                if (launch_conv(a, s, hint) != hipSuccess) { (void)hipGetLastError(); continue; }
+                HIP_TRY(hipEventRecord(e0, s));
+                for (int r = 0; r < 3; ++r) (void)launch_conv(a, s, hint);
+                HIP_TRY(hipEventRecord(e1, s));
+                HIP_TRY(hipEventSynchronize(e1));
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best) { best = ms; best_hint = hint; }
+            }
+            L.tuned[n] = best_hint;
+            by_shape[key] = best_hint;
+        }
+        // schedule: grouped launches vs parallel lanes, whole forward as a replayed hipGraph (how it will run)
+        float t_mode[4] = {0, 0, 0, 0};
+        const bool keep = grouping, keep_graph = use_graph;
+        use_graph = true;
+        for (int mode = 0; mode < 4; ++mode) {
+            grouping = true;
+            tuned_mode[n] = mode;
+            for (auto& g : graphs) hipGraphExecDestroy(g.second);
+            graphs.clear();
+            int rc = forward(v_cat.p, n, nullptr, s);          // builds the graph, first replay
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(e0, s));
+            for (int r = 0; r < 3; ++r) if ((rc = forward(v_cat.p, n, nullptr, s))) return rc;
+            HIP_TRY(hipEventRecord(e1, s));
+            HIP_TRY(hipEventSynchronize(e1));
+            HIP_TRY(hipEventElapsedTime(&t_mode[mode], e0, e1));
+        }
+        grouping = keep;
+        use_graph = keep_graph;
+        int best_mode = 0;
+        for (int mode = 1; mode < 4; ++mode)
+            if (t_mode[mode] < t_mode[best_mode]) best_mode = mode;
+        tuned_mode[n] = best_mode;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        for (auto& g : graphs) hipGraphExecDestroy(g.second);
+        graphs.clear();
+        if (getenv("GRNET_TRACE"))
+            fprintf(stderr, "[grnet] tuned n=%d: forward ms lanes/model %.3f lanes/measured %.3f grouped/model %.3f grouped/measured %.3f -> mode %d\n",
+                    n, t_mode[0] / 3, t_mode[1] / 3, t_mode[2] / 3, t_mode[3] / 3, best_mode);
+        return 0;
+    }
+    bool grouping_for(int n) const {
+        if (conv_tile_hint || !grouping) return false;
+        auto it = tuned_mode.find(n);
+        return it == tuned_mode.end() ? false : (it->second & 2) != 0;
+    }
+
     // ------------------------------------------------------------------ execution
     ConvArgs conv_args(const ConvLayer& L, const float* frames, int n) const {
         ConvArgs a{};
@@ -596,6 +752,9 @@ struct grnet {
         float* verts = o.verts ? o.verts : d_verts;
         float* kp3d = o.kp_3d ? o.kp_3d : d_kp3d;
         float* kp2d = o.kp_2d ? o.kp_2d : d_kp2d;
+        const bool group_now = grouping_for(n);
+        const std::vector<Op>& ops = group_now ? this->ops : ops_flat;
+        const std::vector<hipEvent_t>& op_events = group_now ? this->op_events : op_events_flat;
         GraphRecorder* rec = g_recorder;                          // non-null: build graph nodes instead of launching
         const bool lanes = multi_lane && !rec;
         std::vector<hipGraphNode_t> lane_last(kLanes, nullptr), op_node(rec ? ops.size() : 0, nullptr);
@@ -610,7 +769,7 @@ struct grnet {
         hipStream_t caller = s;
         for (size_t oi = 0; oi < ops.size(); ++oi) {
             const Op& op = ops[oi];
-            if (convs_only && op.kind != Op::CONV) continue;
+            if (convs_only && op.kind != Op::CONV && op.kind != Op::GROUP) continue;
             s = lane_stream[op.lane];
             const int lane = multi_lane ? op.lane : 0;
             if (lanes)
@@ -624,8 +783,21 @@ struct grnet {
             }
             switch (op.kind) {
                 case Op::CONV: {
-                    HIP_TRY(launch_conv(conv_args(convs[op.conv_idx], frames, n), s, conv_tile_hint));
+                    HIP_TRY(launch_conv(conv_args(convs[op.conv_idx], frames, n), s, hint_for(convs[op.conv_idx], n)));
                     ++launches;
+                    break;
+                }
+                case Op::GROUP: {
+                    ConvArgs list[kMaxGroup];
+                    const int cnt = (int)op.group.size();
+                    for (int gi = 0; gi < cnt; ++gi) list[gi] = conv_args(convs[op.group[gi]], frames, n);
+                    if (group_now) {
+                        HIP_TRY(launch_conv_group(list, cnt, s));
+                        ++launches;
+                    } else {
+                        for (int gi = 0; gi < cnt; ++gi) HIP_TRY(launch_conv(list[gi], s, hint_for(convs[op.group[gi]], n)));
+                        launches += cnt;
+                    }
                     break;
                 }
                 case Op::SUM: {
@@ -832,9 +1004,17 @@ int grnet_set_option(grnet_t* h, int option, int value) {
     if (!h) return GRNET_EINVAL;
     if (option == GRNET_OPT_USE_GRAPH) { h->use_graph = value != 0; return 0; }
     if (option == GRNET_OPT_CONV_TILE) {
+        if (value != 0) h->grouping = false;                   // forced tiles apply to individual launches
+        else h->grouping = true;
         if (value != 0 && value != 7 && value != 14 && value != 1071 && value != 1072 && value != 1041 && value != 1042)
             return h->fail(GRNET_EINVAL, "conv tile must be 0, 7, 14 or a split-K code 1071/1072/1041/1042");
         h->conv_tile_hint = value;
+        for (auto& g : h->graphs) hipGraphExecDestroy(g.second);
+        h->graphs.clear();
+        return 0;
+    }
+    if (option == GRNET_OPT_GROUPING) {
+        h->grouping = value != 0;
         for (auto& g : h->graphs) hipGraphExecDestroy(g.second);
         h->graphs.clear();
         return 0;
@@ -846,6 +1026,10 @@ int grnet_set_option(grnet_t* h, int option, int value) {
         return 0;
     }
     return h->fail(GRNET_EINVAL, "unknown option");
+}
+
+int grnet_tune(grnet_t* h, int n_frames, void* stream) {
+    return h ? h->tune(n_frames, static_cast<hipStream_t>(stream)) : GRNET_EINVAL;
 }
 
 int grnet_num_kernel_launches(grnet_t* h) { return h ? h->launches_last : GRNET_EINVAL; }
@@ -960,6 +1144,7 @@ void grnet_destroy(grnet_t* h) {
     }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     for (hipEvent_t e : h->op_events) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : h->op_events_flat) if (e) hipEventDestroy(e);
     for (void* p : h->dev_allocs) hipFree(p);
     if (h->arena) hipFree(h->arena);
     delete h;

@@ -78,12 +78,15 @@ struct ConvArgs {
     const float* add[kMaxAdd]; int add_ctot[kMaxAdd], add_coff[kMaxAdd], add_shift[kMaxAdd];
     const float* zeros;        // >= 64 B of zeros in HBM: source for halo / padded-channel loads
     // filled by the launcher
-    int R, G, Rin, Wp, PSTR, tiles_y, groups, TC, rows;
+    int R, G, Rin, Wp, PSTR, tiles_y, groups, TC, rows, ring;
     int dbg;                   // timing-only ablation bits (tools/conv_micro.py); 0 in the product path
 };
 
 // Returns hipSuccess or the launch error.  `tile_hint`: 0 = auto, 7 / 14 = force pixel sub-tiles.
 hipError_t launch_conv(ConvArgs a, hipStream_t s, int tile_hint = 0);
+constexpr int kMaxGroup = 6;
+// n independent convolutions with identical (ks, stride) in ONE launch (falls back to n launches if a member does not fit)
+hipError_t launch_conv_group(const ConvArgs* list, int n, hipStream_t s);
 int conv_pick_tc(int Cout);                 // cout tile (32 or 64) -> defines CoutPad at pack time
 hipError_t conv_init();                     // sets max dynamic LDS on every instantiation
 const char* conv_dominant_kernel_name();

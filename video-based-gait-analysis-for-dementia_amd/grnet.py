@@ -196,6 +196,13 @@ class GRNet:
 
     __call__ = forward
 
+    def tune(self, n_frames):
+        """Measure-and-pick launch configurations for calls of ``n_frames`` frames (see grnet_tune)."""
+        self.finalize()
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self._lib, self._h, self._lib.grnet_tune(self._h, int(n_frames), stream), "grnet_tune")
+        return self
+
     # ------------------------------------------------------------------ introspection (bench / tests)
     def num_kernel_launches(self):
         return self._lib.grnet_num_kernel_launches(self._h)

@@ -87,6 +87,7 @@ class ClipRunner:
         self.out.verts = self.verts.data_ptr()
         self.out.rotmat = self.rotmat.data_ptr()
         model.finalize()
+        model.tune(n)                      # per-shape launch configurations measured on this GPU for this clip length
         if use_graph:
             model.set_option(_lib.OPT_USE_GRAPH, 1)
         self._lib, self._h = model._lib, model._h
