@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step (default: configs[1])")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune-level", type=int, default=1, help="0: cost model only, 1: per-shape measurement (~0.1 s), "
+                    "2: + in-context greedy refinement (~20 s, untimed)")
+    ap.add_argument("--tune-cache", default=None, help="tuning table file (default: the packaged table for this clip length, if any)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -79,7 +82,11 @@ def main():
     model = pkg.build_synthetic_model(max_frames=n, device_id=local_rank, with_gru=False)
     frames_np = pkg.synth.make_frames(n, start=rank * n)
     frames = torch.from_numpy(frames_np).cuda()
-    runner = harness.ClipRunner(model, frames, use_graph=not args.no_graph, world=world, rank=rank, dist=dist)
+    cache = args.tune_cache or os.path.join(ROOT, PKG, "tuning", f"mi355x_f32_n{n}.txt")
+    if not (args.tune_cache or os.path.isfile(cache)):
+        cache = None
+    runner = harness.ClipRunner(model, frames, use_graph=not args.no_graph, world=world, rank=rank, dist=dist,
+                                tune_level=args.tune_level, tune_cache=cache)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -127,6 +134,7 @@ def main():
                                    "(HRNet-W32 + PARE head + SMPL LBS), seed-defined synthetic weights",
                        "frames_per_gpu": n, "launch": "eager" if args.no_graph else "hipGraph replay",
                        "kernel_launches_per_step": model.num_kernel_launches(),
+                       "launch_configs": ("stored table " + os.path.relpath(cache, ROOT)) if cache else f"grnet_tune level {args.tune_level}",
                        "exchange": "none (1 GPU)" if world == 1 else "RCCL all-gather of per-frame pose results"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),

@@ -97,7 +97,10 @@ int grnet_set_option(grnet_t* h, int option, int value);
 /* Optional, once per distinct n_frames after grnet_finalize_weights: times every launch configuration of every
  * distinct convolution shape (and grouped vs parallel-lane scheduling of the HR modules) on this GPU and keeps the
  * fastest.  Synchronises the stream; overwrites the activation buffers.  Without it the cost model decides. */
-int grnet_tune(grnet_t* h, int n_frames, void* stream);
+int grnet_tune(grnet_t* h, int n_frames, void* stream, int level /* 1: per shape in isolation, 2: + greedy in-context refinement (seconds) */);
+/* The tuned table of n_frames as text (returns its length) / re-apply a stored table without measuring. */
+int grnet_get_tuning(grnet_t* h, int n_frames, char* buf, int buf_size);
+int grnet_set_tuning(grnet_t* h, int n_frames, const char* text);
 
 /* Introspection used by bench.py / tests. */
 int grnet_num_kernel_launches(grnet_t* h);      /* launches enqueued by one grnet_forward */

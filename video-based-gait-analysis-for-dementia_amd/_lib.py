@@ -30,7 +30,9 @@ EXPORTS = {
     "grnet_gru_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
     "grnet_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
-    "grnet_tune": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "grnet_tune": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "grnet_get_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
+    "grnet_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p]),
     "grnet_num_kernel_launches": (C.c_int, [C.c_void_p]),
     "grnet_num_conv_launches": (C.c_int, [C.c_void_p]),
     "grnet_conv_flops_per_frame": (C.c_double, [C.c_void_p]),

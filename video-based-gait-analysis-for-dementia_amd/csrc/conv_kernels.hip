@@ -639,7 +639,11 @@ double cfg_cost(ConvArgs a, const Cfg& c, bool* ok) {
         chain = (double)((kgroups + kSplitWaves - 1) / kSplitWaves) * taps * c.tps * c.tcs;
     }
     const double rounds = waves / 1024.0 < 1.0 ? 1.0 : waves / 1024.0;
-    return chain * rounds * (c.family == 1 ? 1.15 : 1.0) + 300.0;   // + fixed prologue/epilogue
+    double cost = chain * rounds * (c.family == 1 ? 1.15 : 1.0) + 300.0;   // + fixed prologue/epilogue
+    // whole-K tiles of a 1x1 convolution do ~14 MFMAs per 8-channel chunk: with less than one workgroup per CU
+    // nothing covers the chunk's DMA + barrier latency (measured: 128->25 @56x56 took 108 us instead of 19)
+    if (c.family == 0 && a.ks == 1 && blocks < 256) cost += (kgroups / 2.0) * 400.0;
+    return cost;
 }
 
 template <typename K>

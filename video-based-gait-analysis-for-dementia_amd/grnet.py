@@ -196,11 +196,25 @@ class GRNet:
 
     __call__ = forward
 
-    def tune(self, n_frames):
-        """Measure-and-pick launch configurations for calls of ``n_frames`` frames (see grnet_tune)."""
+    def tune(self, n_frames, level=1, cache=None):
+        """Measure-and-pick launch configurations for calls of ``n_frames`` frames (see grnet_tune).
+
+        ``cache``: path of a text file holding a previously measured table; applied if present, written after tuning."""
         self.finalize()
+        import os
+        if cache and os.path.isfile(cache):
+            with open(cache) as f:
+                rc = self._lib.grnet_set_tuning(self._h, int(n_frames), f.read().encode())
+            if rc == 0:
+                return self
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        _lib.check(self._lib, self._h, self._lib.grnet_tune(self._h, int(n_frames), stream), "grnet_tune")
+        _lib.check(self._lib, self._h, self._lib.grnet_tune(self._h, int(n_frames), stream, int(level)), "grnet_tune")
+        if cache:
+            buf = C.create_string_buffer(1 << 16)
+            if self._lib.grnet_get_tuning(self._h, int(n_frames), buf, len(buf)) > 0:
+                os.makedirs(os.path.dirname(os.path.abspath(cache)), exist_ok=True)
+                with open(cache, "w") as f:
+                    f.write(buf.value.decode())
         return self
 
     # ------------------------------------------------------------------ introspection (bench / tests)

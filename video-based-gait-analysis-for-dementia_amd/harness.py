@@ -72,7 +72,7 @@ class ClipRunner:
     the exchange needs no packing kernel.  ``verts`` / ``rotmat`` stay sharded (rank-local).
     """
 
-    def __init__(self, model, frames, use_graph=True, world=1, rank=0, dist=None):
+    def __init__(self, model, frames, use_graph=True, world=1, rank=0, dist=None, tune_level=1, tune_cache=None):
         self.model, self.frames, self.world, self.rank, self.dist = model, frames.contiguous(), world, rank, dist
         self.n = n = frames.shape[0]
         dev = frames.device
@@ -87,7 +87,8 @@ class ClipRunner:
         self.out.verts = self.verts.data_ptr()
         self.out.rotmat = self.rotmat.data_ptr()
         model.finalize()
-        model.tune(n)                      # per-shape launch configurations measured on this GPU for this clip length
+        if tune_level:                     # launch configurations measured on this GPU for this clip length (or a stored table)
+            model.tune(n, level=tune_level, cache=tune_cache)
         if use_graph:
             model.set_option(_lib.OPT_USE_GRAPH, 1)
         self._lib, self._h = model._lib, model._h
