@@ -30,6 +30,18 @@ if os.path.isfile(stats):
         if line.startswith("{"):
             open(os.path.join(dst, f"{rnd}_bench_under_rocprof.json"), "w").write(line)
 
+serial = os.path.join(src, "prof_serial", "bench_kernel_stats.csv")
+if os.path.isfile(serial):                      # GRNET_MULTI_LANE=0: launches strictly one after another
+    shutil.copy(serial, os.path.join(dst, f"{rnd}_kernel_stats_serial.csv"))
+    rows = list(csv.DictReader(open(serial)))
+    conv = [r for r in rows if "conv_" in r["Name"]]
+    tot = sum(float(r["TotalDurationNs"]) for r in conv)
+    calls = sum(int(r["Calls"]) for r in conv)
+    print(f"serial run: conv kernels {calls} launches, {tot / 1e6:.2f} ms total, avg {tot / calls / 1e3:.2f} us/launch")
+    for line in open(os.path.join(src, "prof_serial", "bench_stdout.log")):
+        if line.startswith("{"):
+            open(os.path.join(dst, f"{rnd}_bench_under_rocprof_serial.json"), "w").write(line)
+
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = os.path.join(src, "pmc", f"{c}_counter_collection.csv")
