@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step (default: configs[1])")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=1, help="clips in flight per GPU: 1 = strictly one clip at a time (headline); "
+                    "k > 1 alternates k independent model instances on k streams so consecutive clips overlap (throughput mode)")
     ap.add_argument("--tune-level", type=int, default=1, help="0: cost model only, 1: per-shape measurement (~0.1 s), "
                     "2: + in-context greedy refinement (~20 s, untimed)")
     ap.add_argument("--tune-cache", default=None, help="tuning table file (default: the packaged table for this clip length, if any)")
@@ -87,6 +89,24 @@ def main():
         cache = None
     runner = harness.ClipRunner(model, frames, use_graph=not args.no_graph, world=world, rank=rank, dist=dist,
                                 tune_level=args.tune_level, tune_cache=cache)
+    runners, streams = [runner], [torch.cuda.current_stream()]
+    for k in range(1, max(1, args.inflight)):                 # extra clips in flight: own buffers, own stream
+        m_k = pkg.build_synthetic_model(max_frames=n, device_id=local_rank, with_gru=False)
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            runners.append(harness.ClipRunner(m_k, frames, use_graph=not args.no_graph, world=world, rank=rank, dist=dist,
+                                              tune_level=args.tune_level, tune_cache=cache))
+        streams.append(st)
+    step_no = [0]
+
+    def do_step():
+        k = step_no[0] % len(runners)
+        step_no[0] += 1
+        if len(runners) == 1:
+            runner.step()
+        else:
+            with torch.cuda.stream(streams[k]):
+                runners[k].step()
 
     def sync_all():
         torch.cuda.synchronize()
@@ -95,11 +115,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        runner.step()
+        do_step()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        runner.step()
+        do_step()
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -132,7 +152,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"1 clip x {n} frames x 3x224x224 per GPU, fp32, MAX-GRNet per-frame path "
                                    "(HRNet-W32 + PARE head + SMPL LBS), seed-defined synthetic weights",
-                       "frames_per_gpu": n, "launch": "eager" if args.no_graph else "hipGraph replay",
+                       "frames_per_gpu": n, "clips_in_flight": len(runners), "launch": "eager" if args.no_graph else "hipGraph replay",
                        "kernel_launches_per_step": model.num_kernel_launches(),
                        "launch_configs": ("stored table " + os.path.relpath(cache, ROOT)) if cache else f"grnet_tune level {args.tune_level}",
                        "exchange": "none (1 GPU)" if world == 1 else "RCCL all-gather of per-frame pose results"},

@@ -213,3 +213,35 @@ def test_errors_are_loud(model, pkg):
         model(torch.zeros(1, 3, 224, 224))          # host tensor: no CPU fallback
     with pytest.raises(RuntimeError):
         pkg.GRNet(max_frames=1).load_state_dict({"backbone.conv1.weight": np.zeros((64, 3, 3, 3), np.float32)}, strict=True)
+
+
+def test_schedules_and_tuning_agree(pkg):
+    """Grouped launches, parallel lanes, measured launch tables and a re-applied stored table are all
+    the same arithmetic in a different launch shape: results agree to fp32 re-association noise."""
+    import ctypes as C
+    m = pkg.build_synthetic_model(max_frames=6, with_gru=False)
+    frames = torch.from_numpy(pkg.synth.make_frames(6)).cuda()
+    base = {k: v.clone() for k, v in m(frames)[-1].items()}
+    lib = pkg._lib
+    outs = {}
+    m.set_option(lib.OPT_GROUPING, 0)
+    outs["no_grouping"] = {k: v.clone() for k, v in m(frames)[-1].items()}
+    m.set_option(lib.OPT_GROUPING, 1)
+    m.set_option(lib.OPT_MULTI_LANE, 0)
+    outs["one_lane"] = {k: v.clone() for k, v in m(frames)[-1].items()}
+    m.set_option(lib.OPT_MULTI_LANE, 1)
+    m.tune(6, level=1)
+    outs["tuned"] = {k: v.clone() for k, v in m(frames)[-1].items()}
+    buf = C.create_string_buffer(1 << 16)
+    n = m._lib.grnet_get_tuning(m._h, 6, buf, len(buf))
+    assert n > 0 and buf.value.decode().startswith("mode ")
+    for forced_mode in (0, 1, 2, 3):                          # lanes/grouped x cost-model/measured
+        text = "mode %d\n" % forced_mode + buf.value.decode().split("\n", 1)[1]
+        assert m._lib.grnet_set_tuning(m._h, 6, text.encode()) == 0
+        outs[f"mode{forced_mode}"] = {k: v.clone() for k, v in m(frames)[-1].items()}
+    assert m._lib.grnet_set_tuning(m._h, 6, b"mode 1\n99999 7\n") != 0          # a table of another plan is refused
+    torch.cuda.synchronize()
+    for name, o in outs.items():
+        for k in ("theta", "kp_3d", "kp_2d", "verts", "rotmat"):
+            assert rel_err(o[k].cpu().numpy(), base[k].cpu().numpy()) < 5e-5, (name, k)
+    m.close()

@@ -116,9 +116,11 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const EpiCtx& e, f
 // [G][Rin][Wp] gathered float by float through the source-offset table.
 __device__ __forceinline__ int floor4(int v) { return v & ~3; }   // two's complement: floors negatives too
 
-template <bool ROWS, int KS, int S, int TPS, int TCS, int WP, int WC>
+// CK = input channels per K-chunk: 8 for 3x3 (72 k-steps of 4 per chunk ... 18 MFMA steps), 32 for 1x1 convolutions,
+// whose chunks would otherwise hold only 2 MFMA steps between barriers and run latency-bound.
+template <bool ROWS, int KS, int S, int TPS, int TCS, int WP, int WC, int CK = (KS == 1 ? 32 : kConvCK)>
 __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
-    constexpr int NT = WP * WC * 64, CK = kConvCK, TC = TCS * 16;
+    constexpr int NT = WP * WC * 64, TC = TCS * 16;
     constexpr int PSW = TPS / WP, CSW = TCS / WC, TAPS = KS * KS;
     constexpr int WFLOATS = TAPS * CK * TC;              // weight slab of one chunk
     static_assert(TPS % WP == 0 && TCS % WC == 0, "wave grid must divide the tile");
@@ -614,7 +616,8 @@ void plan_ring(ConvArgs& a, const Cfg& c) {
 size_t lds_bytes(const ConvArgs& a, const Cfg& c) {
     const int taps = a.ks * a.ks, TC = c.tcs * 16;
     const size_t tab = a.rows ? 0 : a.PSTR;
-    if (c.family == 0) return sizeof(float) * (2 * (size_t)taps * kConvCK * TC + 2 * (size_t)kConvCK * a.PSTR + tab);
+    const size_t ck = a.ks == 1 ? 32 : kConvCK;
+    if (c.family == 0) return sizeof(float) * (2 * (size_t)taps * ck * TC + 2 * ck * a.PSTR + tab);
     const size_t stage = (size_t)taps * 4 * TC + 4 * (size_t)a.PSTR;
     const size_t staging = kSplitWaves * (size_t)a.ring * stage + tab, red = (size_t)kSplitWaves * c.tps * c.tcs * 256;
     return sizeof(float) * (staging > red ? staging : red);
@@ -625,7 +628,8 @@ size_t lds_bytes(const ConvArgs& a, const Cfg& c) {
 double cfg_cost(ConvArgs a, const Cfg& c, bool* ok) {
     plan_tile(a, c.tps, c.family);
     plan_ring(a, c);
-    *ok = a.R >= 1 && lds_bytes(a, c) <= kMaxLds && a.CoutPad % (c.tcs * 16) == 0;
+    *ok = a.R >= 1 && lds_bytes(a, c) <= kMaxLds && a.CoutPad % (c.tcs * 16) == 0 &&
+          !(c.family == 0 && a.ks == 1 && a.CinPad % 32 != 0);       // whole-K 1x1 tiles stage 32 channels per chunk
     if (!*ok) return 0;
     const double blocks = (double)a.tiles_y * a.groups * (a.CoutPad / (c.tcs * 16));
     const int kgroups = a.CinPad / 4, taps = a.ks * a.ks;
