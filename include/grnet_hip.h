@@ -117,6 +117,13 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
                     float* out_dev, int tile_hint, void* stream);
 int grnet_op_bilinear2x(grnet_t* h, const float* in_dev, int n, int c, int hgt, int wid, float* out_dev, void* stream);
 
+/* Inference.__getitem__ -- lib/dataset/inference.py:71-87 (get_single_image_crop_demo + ToTensor + Normalize,
+ * lib/data_utils/img_utils.py:252-285,355-363; rot = 0): n uint8 HWC frames (n,H,W,3) [one_image_for_all: a single
+ * (H,W,3) frame shared by all boxes] and boxes (n,4) [cx,cy,w,h] -> (n,3,224,224) fp32 normalised crops, all device
+ * pointers.  `scale` multiplies w,h (the reference applies its bbox scale here a second time). */
+int grnet_crop_normalise(grnet_t* h, const unsigned char* images_dev, int n, int height, int width, int one_image_for_all,
+                         const float* bboxes_dev, float scale, int bgr, float* out_dev, void* stream);
+
 /* Copy a named intermediate of the LAST forward (first n_frames images) into out_dev as a dense
  * (n,C,H,W) tensor; shape_out[3] receives C,H,W (out_dev may be NULL to query the shape).  Names:
  * stem_conv1, stem_conv2, layer1, stage{2,3,4}.{branch}, up{2,3,4}.{layer}.{bilinear,conv}.

@@ -431,3 +431,38 @@ def gru_forward(x, cparams, sd):
     y = np.concatenate([_mlp(hcat, sd, "speed_mlp"), _mlp(hcat, sd, "step_mlp")], -1)
     phase = _mlp(h_in, sd, "phase_mlp", act_tanh=True)
     return y.astype(np.float32), phase.astype(np.float32), xc
+
+
+# ----------------------------------------------------------------------------- preprocessing (row f1)
+IMAGENET_MEAN = np.array([0.485, 0.456, 0.406], np.float32)
+IMAGENET_STD = np.array([0.229, 0.224, 0.225], np.float32)
+
+
+def crop_normalise(img_u8, bbox, scale=1.0, crop=224):
+    """get_single_image_crop_demo + ToTensor + Normalize (img_utils.py:252-285, 90-113, 54-88, 355-363), rot = 0.
+
+    warpAffine semantics restated: dst(u,v) = bilinear(src, x=(u-112)*w*s/224+cx, y=(v-112)*h*s/224+cy), integer
+    coordinates are pixel centres, constant border 0, result rounded to uint8.  PARITY UNPINNED vs OpenCV's own
+    fixed-point (1/32 pixel) interpolation -- cv2 is absent offline.
+    """
+    img = np.asarray(img_u8, np.float32)
+    H, W = img.shape[:2]
+    cx, cy, w, h = [np.float32(v) for v in bbox]
+    u = np.arange(crop, dtype=np.float32)
+    x = (u - np.float32(112.0)) * (w * np.float32(scale) / np.float32(224.0)) + cx
+    y = (u - np.float32(112.0)) * (h * np.float32(scale) / np.float32(224.0)) + cy
+    x0 = np.floor(x).astype(np.int64); y0 = np.floor(y).astype(np.int64)
+    ax = (x - np.floor(x)).astype(np.float32); ay = (y - np.floor(y)).astype(np.float32)
+    pad = np.zeros((H + 2, W + 2, 3), np.float32)
+    pad[1:-1, 1:-1] = img
+
+    def take(yy, xx):
+        yy = np.clip(yy + 1, 0, H + 1); xx = np.clip(xx + 1, 0, W + 1)
+        ok = ((yy >= 1) & (yy <= H))[:, None] & ((xx >= 1) & (xx <= W))[None, :]
+        return pad[yy][:, xx] * ok[..., None]
+
+    top = take(y0, x0) * (1 - ax)[None, :, None] + take(y0, x0 + 1) * ax[None, :, None]
+    bot = take(y0 + 1, x0) * (1 - ax)[None, :, None] + take(y0 + 1, x0 + 1) * ax[None, :, None]
+    val = np.floor(top * (1 - ay)[:, None, None] + bot * ay[:, None, None] + np.float32(0.5))
+    val = np.clip(val, 0, 255) / np.float32(255.0)
+    return np.ascontiguousarray(((val - IMAGENET_MEAN) / IMAGENET_STD).transpose(2, 0, 1)).astype(np.float32)

@@ -245,3 +245,22 @@ def test_schedules_and_tuning_agree(pkg):
         for k in ("theta", "kp_3d", "kp_2d", "verts", "rotmat"):
             assert rel_err(o[k].cpu().numpy(), base[k].cpu().numpy()) < 5e-5, (name, k)
     m.close()
+
+
+def test_crop_normalise_kernel(model, oracle):
+    """Row f1: uint8 frame + box -> normalised 224x224 crop on the GPU vs the numpy restatement."""
+    g = np.random.Generator(np.random.Philox(key=[3, 3]))
+    imgs = g.integers(0, 256, (3, 180, 320, 3), dtype=np.uint8)
+    boxes = np.array([[160.0, 90.0, 150.0, 150.0], [20.5, 30.25, 200.0, 120.0], [300.0, 170.0, 90.0, 260.0]], np.float32)
+    got = model.crop_normalise(torch.from_numpy(imgs).cuda(), torch.from_numpy(boxes), scale=1.1).cpu().numpy()
+    one = model.crop_normalise(torch.from_numpy(imgs[0]).cuda(), torch.from_numpy(boxes), scale=1.1).cpu().numpy()
+    lsb = 1.0 / 255 / 0.224                                      # one grey level after normalisation
+    for i in range(3):
+        ref = oracle.crop_normalise(imgs[i], boxes[i], scale=1.1)
+        d = np.abs(got[i] - ref)
+        assert d.max() <= lsb * 1.01 and (d > 1e-5).mean() < 2e-3, (i, d.max(), (d > 1e-5).mean())   # rounding ties only
+        ref0 = oracle.crop_normalise(imgs[0], boxes[i], scale=1.1)
+        assert np.abs(one[i] - ref0).max() <= lsb * 1.01
+    bgr = model.crop_normalise(torch.from_numpy(imgs[:1, :, :, ::-1].copy()).cuda(), torch.from_numpy(boxes[:1]), scale=1.1,
+                               bgr=True).cpu().numpy()
+    assert np.array_equal(bgr[0], got[0])

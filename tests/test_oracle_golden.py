@@ -112,3 +112,20 @@ def test_explicit_formulas_equal_torch_kernels(oracle, synth_weights):
     assert rel_err(oracle.upsample_bilinear2x(x).numpy(), oracle.upsample_bilinear2x_explicit(x).numpy()) < 5e-6
     n = oracle.upsample_nearest(x, 4)
     assert torch.equal(n, x.repeat_interleave(4, 2).repeat_interleave(4, 3))
+
+
+def test_crop_normalise_restatement(oracle):
+    """Geometry of gen_trans_from_patch_cv / warpAffine (img_utils.py:54-113) on cases with a known answer."""
+    img = np.zeros((300, 400, 3), np.uint8)
+    img[100:200, 150:250] = (255, 128, 0)
+    x = oracle.crop_normalise(img, [200.0, 150.0, 224.0, 224.0], scale=1.0)        # identity scale: crop == image window
+    assert x.shape == (3, 224, 224)
+    want = (np.array([255, 128, 0], np.float32) / 255 - oracle.IMAGENET_MEAN) / oracle.IMAGENET_STD
+    assert np.allclose(x[:, 112, 112], want, atol=1e-6)                              # dst (112,112) <- src (cx,cy)
+    u = 112 + (150 - 200)                                                            # src x = 150 is the square's first column
+    assert np.allclose(x[:, 112, u], want, atol=1e-6) and not np.allclose(x[:, 112, u - 1], want, atol=1e-3)
+    black = (0 - oracle.IMAGENET_MEAN) / oracle.IMAGENET_STD
+    y = oracle.crop_normalise(img, [10.0, 10.0, 224.0, 224.0], scale=1.0)           # window hangs over the border: zeros
+    assert np.allclose(y[:, 0, 0], black, atol=1e-6)
+    z = oracle.crop_normalise(img, [200.0, 150.0, 112.0, 112.0], scale=2.0)         # scale multiplies the box
+    assert np.allclose(z, x)

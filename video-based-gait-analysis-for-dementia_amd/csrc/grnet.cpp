@@ -1228,6 +1228,15 @@ int grnet_debug_tensor(grnet_t* h, const char* name, int n_frames, float* out_de
     return h->fail(GRNET_EINVAL, std::string("unknown debug tensor ") + name);
 }
 
+int grnet_crop_normalise(grnet_t* h, const unsigned char* images_dev, int n, int height, int width, int one_image_for_all,
+                         const float* bboxes_dev, float scale, int bgr, float* out_dev, void* stream) {
+    if (!h || !images_dev || !bboxes_dev || !out_dev || n < 1 || height < 1 || width < 1 || !(scale > 0.f)) return GRNET_EINVAL;
+    hipError_t e = launch_crop_normalise(images_dev, height, width, one_image_for_all ? 0 : 1, bboxes_dev, scale, bgr, out_dev, n,
+                                         static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("crop_normalise: ") + hipGetErrorString(e));
+    return 0;
+}
+
 const char* grnet_last_error(grnet_t* h) { return h ? h->err.c_str() : "null handle"; }
 
 void grnet_destroy(grnet_t* h) {

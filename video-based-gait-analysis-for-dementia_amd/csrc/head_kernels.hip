@@ -100,6 +100,47 @@ hipError_t launch_bilinear2x(const float* in, float* out, int N, int C, int H, i
 }
 
 // ---------------------------------------------------------------------------------------------
+// Crop + normalise (the step right before the path; reference: Inference.__getitem__ lib/dataset/inference.py:71-87
+// -> get_single_image_crop_demo / generate_patch_image_cv / gen_trans_from_patch_cv lib/data_utils/img_utils.py:252-285,
+// 90-113,54-88 with rot = 0, then ToTensor + Normalize :355-363).  For a box [cx,cy,w,h] and scale s the affine map
+// sends the box of size (w*s, h*s) centred at (cx,cy) to the 224x224 patch: destination pixel (u,v) samples the source
+// at x = (u-112)*w*s/224 + cx, y = (v-112)*h*s/224 + cy (cv2.warpAffine: integer coordinates are pixel centres),
+// bilinear, constant border 0, result rounded to uint8 as warpAffine returns it; then /255, (x-mean)/std, HWC -> CHW.
+// OpenCV's 1/32-pixel fixed-point interpolation is third-party arithmetic absent offline: parity with it is UNPINNED.
+__global__ __launch_bounds__(256) void crop_normalise_kernel(const unsigned char* __restrict__ img, int H, int W, int per_image,
+                                                             const float* __restrict__ bbox, float scale, int bgr,
+                                                             float* __restrict__ out) {
+    const int n = blockIdx.y;
+    const unsigned char* src = img + (size_t)(per_image ? n : 0) * H * W * 3;
+    const float cx = bbox[n * 4 + 0], cy = bbox[n * 4 + 1], bw = bbox[n * 4 + 2] * scale, bh = bbox[n * 4 + 3] * scale;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 224 * 224; i += gridDim.x * 256) {
+        const int v = i / 224, u = i - v * 224;
+        const float x = (u - 112.f) * (bw / 224.f) + cx, y = (v - 112.f) * (bh / 224.f) + cy;
+        const float xf = floorf(x), yf = floorf(y);
+        const int x0 = (int)xf, y0 = (int)yf;
+        const float ax = x - xf, ay = y - yf;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int cs = bgr ? 2 - c : c;
+            auto px = [&](int yy, int xx) -> float {
+                return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (float)src[((size_t)yy * W + xx) * 3 + cs] : 0.f;
+            };
+            const float top = px(y0, x0) * (1.f - ax) + px(y0, x0 + 1) * ax;
+            const float bot = px(y0 + 1, x0) * (1.f - ax) + px(y0 + 1, x0 + 1) * ax;
+            const float val = floorf(top * (1.f - ay) + bot * ay + 0.5f);          // warpAffine returns uint8
+            out[((size_t)n * 3 + c) * (224 * 224) + i] = (fminf(fmaxf(val, 0.f), 255.f) / 255.f - mean[c]) / stdv[c];
+        }
+    }
+}
+
+hipError_t launch_crop_normalise(const unsigned char* img, int H, int W, int per_image, const float* bbox, float scale, int bgr,
+                                 float* out, int N, hipStream_t s) {
+    GRK_TRY(launch_k(crop_normalise_kernel, dim3(49, N), dim3(256), 0, s, img, H, W, per_image, bbox, scale, bgr, out));
+    return hipSuccess;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Part attention (KeypointAttention.forward, keypoint_attention.py:42-48; called twice with the
 // same heat-maps, pare.py:331-332): softmax over the 3136 positions of each (frame, joint), then
 // out[n,c,j] = sum_p prob[n,j,p] * feat[n,c,p].  Pass 1: per-row max and 1/sum.  Pass 2: both

@@ -102,6 +102,10 @@ hipError_t launch_fuse_sum(const SumArgs& a, hipStream_t s);
 // nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (hrnet.py:443)
 hipError_t launch_bilinear2x(const float* in, float* out, int N, int C, int H, int W, hipStream_t s);
 
+// crop + normalise: uint8 HWC frames (n,H,W,3) [or one shared frame] + boxes (n,4) -> (n,3,224,224) f32 (img_utils.py:252-285,355-363)
+hipError_t launch_crop_normalise(const unsigned char* img, int H, int W, int per_image, const float* bbox, float scale, int bgr,
+                                 float* out, int N, hipStream_t s);
+
 // PARE head tail ---------------------------------------------------------------------------
 // softmax over H*W of heat[:,1+j] and attention pooling of feat channels (keypoint_attention.py:42-48)
 // heat: (N,25,P) with channel 0 = background; featA (N,CA,P) -> outA (N,CA,24); featB (N,CB,P) -> outB (N,CB,24)

@@ -233,6 +233,24 @@ class GRNet:
         _lib.check(self._lib, self._h, self._lib.grnet_time_convs(self._h, n_frames, stream, C.byref(ms)), "grnet_time_convs")
         return ms.value
 
+    def crop_normalise(self, images, bboxes, scale=1.0, bgr=False):
+        """uint8 frames (n,H,W,3) [or one (H,W,3) frame] + boxes (n,4) -> (n,3,224,224) normalised crops, on the GPU."""
+        shared = images.dim() == 3
+        if images.dtype != torch.uint8 or images.shape[-1] != 3 or not images.is_cuda:
+            raise ValueError("images must be a uint8 CUDA tensor (n,H,W,3) or (H,W,3)")
+        images = images.contiguous()
+        bb = bboxes.to(device=images.device, dtype=torch.float32).contiguous()
+        n = bb.shape[0]
+        if bb.shape != (n, 4) or (not shared and images.shape[0] != n):
+            raise ValueError("bboxes must be (n,4) and match the number of frames")
+        hgt, wid = images.shape[-3], images.shape[-2]
+        out = torch.empty(n, 3, 224, 224, dtype=torch.float32, device=images.device)
+        stream = C.c_void_p(torch.cuda.current_stream(images.device).cuda_stream)
+        rc = self._lib.grnet_crop_normalise(self._h, images.data_ptr(), n, hgt, wid, int(shared), bb.data_ptr(), float(scale),
+                                            int(bgr), out.data_ptr(), stream)
+        _lib.check(self._lib, self._h, rc, "grnet_crop_normalise")
+        return out
+
     def debug_tensor(self, name, n_frames):
         """Named intermediate of the last forward as an (n,C,H,W) tensor (see grnet_debug_tensor)."""
         shp = (C.c_int64 * 3)()

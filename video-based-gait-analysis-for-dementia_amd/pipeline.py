@@ -62,12 +62,12 @@ def crop_and_normalise(img_rgb_u8, bbox, scale=1.0, crop_size=224):
     """
     from PIL import Image
     cx, cy, w, h = [float(v) for v in bbox]
-    bw, bh = w * scale, h * scale
+    a, e = w * scale / crop_size, h * scale / crop_size
+    # cv2.warpAffine geometry (integer coordinates are pixel centres): x = (u - 112) * a + cx.  PIL samples at pixel
+    # centres u + 0.5 and expects source coordinates in the same half-pixel convention, hence the +-0.5 terms.
+    c0 = cx - 0.5 * crop_size * a + 0.5 - 0.5 * a
+    f0 = cy - 0.5 * crop_size * e + 0.5 - 0.5 * e
     img = Image.fromarray(img_rgb_u8)
-    # affine map from crop pixel (u,v) to source pixel: x = cx - bw/2 + (u+0.5)*bw/crop - 0.5
-    a, e = bw / crop_size, bh / crop_size
-    c0 = cx - bw / 2.0 + 0.5 * a - 0.5
-    f0 = cy - bh / 2.0 + 0.5 * e - 0.5
     crop = img.transform((crop_size, crop_size), Image.AFFINE, (a, 0.0, c0, 0.0, e, f0), resample=Image.BILINEAR, fillcolor=0)
     x = np.asarray(crop, np.float32) / 255.0
     x = (x - IMAGENET_MEAN) / IMAGENET_STD
@@ -109,9 +109,19 @@ class InferenceFrames:
         with Image.open(f) as im:
             return im.size
 
-    def batches(self, batch_size):
+    def batches(self, batch_size, model=None):
+        """(<=batch,3,224,224) crops.  With ``model`` (a GRNet) and image files, the raw uint8 frames are uploaded and
+        cropped + normalised by the HIP kernel (grnet_crop_normalise) instead of on the host."""
+        from PIL import Image
+        device_crop = model is not None and len(self) and not self.files[0].endswith(".npy")
         for s in range(0, len(self), batch_size):
-            yield np.stack([self[i] for i in range(s, min(s + batch_size, len(self)))])
+            idx = range(s, min(s + batch_size, len(self)))
+            if not device_crop:
+                yield np.stack([self[i] for i in idx])
+                continue
+            raw = np.stack([np.asarray(Image.open(self.files[i]).convert("RGB")) for i in idx])
+            yield model.crop_normalise(torch.from_numpy(raw).cuda(), torch.from_numpy(np.ascontiguousarray(self.bboxes[list(idx)])),
+                                       scale=self.scale)
 
 
 # ----------------------------------------------------------------------------- model loops
