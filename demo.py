@@ -74,13 +74,24 @@ def main(args):
         if tracking[pid]["frames"].shape[0] < MIN_NUM_FRAMES:
             del tracking[pid]
     model = build_model(pkg, args, cfg["DATASET"]["SEQLEN"])
+    smpl_tables = None
+    if args.smooth:
+        if args.synthetic_weights:
+            smpl_tables = pkg.synth.make_smpl_tables()
+        else:
+            smpl_tables = {"J_regressor_extra": np.load(osp.join(args.smpl_dir, "J_regressor_extra.npy"))}
     t0 = time.time()
     results, n_frames = {}, 0
     for pid, tr in tracking.items():
         bboxes, frames = np.asarray(tr["bbox"], np.float32).copy(), np.asarray(tr["frames"])
         ds = pipe.InferenceFrames(args.img_folder, frames, bboxes, scale=1.0)
-        pred = pipe.run_tracklet(model, ds.batches(args.grnet_batch_size))
+        pred = pipe.run_tracklet(model, ds.batches(args.grnet_batch_size, model=model))
         w, h = ds.image_size()
+        if args.smooth:                                        # demo.py:191-196
+            print(f"Running smoothing on person {pid}, min_cutoff: {args.smooth_min_cutoff}, beta: {args.smooth_beta}")
+            pred["verts"], pred["pose"], pred["joints3d"] = pipe.smooth_pose(
+                model, pred["pose"], pred["betas"], min_cutoff=args.smooth_min_cutoff, beta=args.smooth_beta,
+                smpl_tables=smpl_tables)
         results[pid] = pipe.make_demo_result(pred, ds.bboxes, ds.frames, w, h)
         n_frames += len(ds)
     dt = time.time() - t0
@@ -127,7 +138,7 @@ def parser():
 
 if __name__ == "__main__":
     a = parser().parse_args()
-    for flag in ("smooth", "mesh_render", "display", "save_obj"):
+    for flag in ("mesh_render", "display", "save_obj"):
         if getattr(a, flag):
             sys.exit(f"--{flag} belongs to steps outside the per-frame path (SURVEY 8f) and is not implemented")
     main(a)

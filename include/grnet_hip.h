@@ -117,6 +117,13 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
                     float* out_dev, int tile_hint, void* stream);
 int grnet_op_bilinear2x(grnet_t* h, const float* in_dev, int n, int c, int hgt, int wid, float* out_dev, void* stream);
 
+/* SMPL(...) forward with rotation matrices -- lib/models/smpl.py:108-130 (smplx LBS + the 29 "spin2" joints) and, when
+ * cam_dev != NULL, the projection of smpl.py:172-186.  Used by the --smooth step (lib/utils/smooth_pose.py:59-100), which
+ * re-evaluates SMPL on the filtered pose.  betas (n,10), rotmat (n,24,3,3), cam (n,3) or NULL -> verts (n,6890,3),
+ * kp3d (n,29,3), kp2d (n,29,2) or NULL; device pointers; n <= max_frames. */
+int grnet_smpl_forward(grnet_t* h, const float* betas_dev, const float* rotmat_dev, const float* cam_dev, int n, float* verts_dev,
+                       float* kp3d_dev, float* kp2d_dev, void* stream);
+
 /* Inference.__getitem__ -- lib/dataset/inference.py:71-87 (get_single_image_crop_demo + ToTensor + Normalize,
  * lib/data_utils/img_utils.py:252-285,355-363; rot = 0): n uint8 HWC frames (n,H,W,3) [one_image_for_all: a single
  * (H,W,3) frame shared by all boxes] and boxes (n,4) [cx,cy,w,h] -> (n,3,224,224) fp32 normalised crops, all device

@@ -80,3 +80,24 @@ def test_batch_generation_entry_point(pkg, tmp_path):
     kp = m(f)[-1]["kp_3d"][0].cpu().numpy()
     assert rel_err(db["joints3D"][:6, 20], kp[:, 28]) < 2e-5 and rel_err(db["joints3D"][:6, 1], kp[:, 6]) < 2e-5
     m.close()
+
+
+def test_smooth_pose_row_f3(pkg, oracle, synth_smpl):
+    """--smooth (smooth_pose.py:28-116): filtered pose -> SMPL re-evaluated with the betas of frame 0, one LBS launch."""
+    pipe = pkg.pipeline
+    m = pkg.build_synthetic_model(max_frames=8, with_gru=False)
+    g = np.random.Generator(np.random.Philox(key=[17, 17]))
+    T = 20                                                    # > max_frames: smpl_forward chunks
+    pose = np.cumsum(g.standard_normal((T, 72)) * 0.03, axis=0).astype(np.float32)
+    betas = (g.standard_normal((T, 10)) * 0.5).astype(np.float32)
+    verts, pose_hat, j49 = pipe.smooth_pose(m, pose, betas, smpl_tables=synth_smpl)
+    assert verts.shape == (T, 6890, 3) and pose_hat.shape == (T, 72) and j49.shape == (T, 49, 3)
+    assert np.array_equal(pose_hat[0], pose[0])               # the filter starts at the first pose
+    # CPU check of the same composition: filter -> rodrigues -> oracle LBS with betas[0]
+    R = pipe.rodrigues(pose_hat.reshape(-1, 3)).reshape(T, 24, 3, 3)
+    v_ref, j24 = oracle.smpl_lbs(np.repeat(betas[:1], T, 0), R, synth_smpl)
+    assert rel_err(verts, v_ref) < 1e-4
+    assert rel_err(j49[:, 8], j24[:, 0]) < 1e-4               # SPIN joint 8 'OP MidHip' is SMPL joint 0
+    _, _, k25 = pipe.smooth_pose(m, pose, betas, kinectv2=True)
+    assert k25.shape == (T, 25, 3)
+    m.close()

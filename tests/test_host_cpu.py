@@ -164,3 +164,18 @@ def test_inference_frames_scale_quirk_and_crop(pkg, tmp_path):
     assert np.allclose(x[:, 2, 2], (0.0 - pipe.IMAGENET_MEAN) / pipe.IMAGENET_STD, atol=1e-5)
     assert ds.image_size() == (400, 300)
     assert sum(b.shape[0] for b in ds.batches(2)) == 3
+
+
+def test_one_euro_filter_matches_reference(pkg):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "one_euro.npz"))      # produced by the reference's OneEuroFilter
+    hat = pkg.pipeline.one_euro_filter(g["seq"], min_cutoff=0.004, beta=0.7)
+    assert hat.shape == g["hat"].shape and np.allclose(hat, g["hat"], rtol=1e-6, atol=1e-7)
+
+
+def test_rodrigues_is_a_rotation(pkg):
+    aa = np.array([[0, 0, 0], [0.3, -0.2, 0.9], [3.1, 0, 0], [1e-6, 0, 0]], np.float32)
+    R = pkg.pipeline.rodrigues(aa)
+    assert np.allclose(R @ R.transpose(0, 2, 1), np.eye(3), atol=1e-5) and np.allclose(np.linalg.det(R), 1, atol=1e-5)
+    assert np.allclose(R[0], np.eye(3), atol=1e-6)
+    v = aa[1] / np.linalg.norm(aa[1])
+    assert np.allclose(R[1] @ v, v, atol=1e-6)                # the axis is fixed by its rotation

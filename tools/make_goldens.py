@@ -349,6 +349,19 @@ def main():
     except Exception as e:                                   # pragma: no cover
         print("harness goldens skipped:", repr(e))
 
+    # --- One-Euro filter exactly as smooth_pose.py:47-52,84-88 drives it ----------------------------------------
+    from lib.utils.one_euro_filter import OneEuroFilter
+    og = np.random.Generator(np.random.Philox(key=[13, 13]))
+    seq = np.cumsum(og.standard_normal((40, 24, 3)) * 0.05, axis=0).astype(np.float32)
+    filt = OneEuroFilter(np.zeros_like(seq[0]), seq[0], min_cutoff=0.004, beta=0.7)
+    hat = np.zeros_like(seq)
+    hat[0] = seq[0]
+    for idx in range(1, seq.shape[0]):
+        hat[idx] = filt(np.ones_like(seq[idx]) * idx, seq[idx])
+    p = os.path.join(ROOT, "tests/golden/one_euro.npz")
+    np.savez_compressed(p, seq=seq, hat=hat)
+    print(f"wrote {p}")
+
     if "--time" in sys.argv:
         x16 = torch.from_numpy(synth.make_frames(16)).reshape(1, 16, 3, 224, 224)
         with torch.no_grad():

@@ -1228,6 +1228,17 @@ int grnet_debug_tensor(grnet_t* h, const char* name, int n_frames, float* out_de
     return h->fail(GRNET_EINVAL, std::string("unknown debug tensor ") + name);
 }
 
+int grnet_smpl_forward(grnet_t* h, const float* betas_dev, const float* rotmat_dev, const float* cam_dev, int n, float* verts_dev,
+                       float* kp3d_dev, float* kp2d_dev, void* stream) {
+    if (!h || !betas_dev || !rotmat_dev || !verts_dev || !kp3d_dev || n < 1) return GRNET_EINVAL;
+    if (!h->smpl_loaded) return h->fail(GRNET_ESTATE, "SMPL tables were not loaded");
+    if (n > h->max_frames) return h->fail(GRNET_EINVAL, "n exceeds max_frames (the skinning-matrix workspace is sized for it)");
+    hipError_t e = launch_smpl(betas_dev, rotmat_dev, cam_dev, h->smpl, h->d_A, verts_dev, kp3d_dev, kp2d_dev, n,
+                               static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("smpl: ") + hipGetErrorString(e));
+    return 0;
+}
+
 int grnet_crop_normalise(grnet_t* h, const unsigned char* images_dev, int n, int height, int width, int one_image_for_all,
                          const float* bboxes_dev, float scale, int bgr, float* out_dev, void* stream) {
     if (!h || !images_dev || !bboxes_dev || !out_dev || n < 1 || height < 1 || width < 1 || !(scale > 0.f)) return GRNET_EINVAL;

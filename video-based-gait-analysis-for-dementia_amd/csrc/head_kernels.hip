@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void smpl_joints_kernel(const float* __restric
     if (tid < 3) sj[28][tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
     __syncthreads();
     if (tid < 87) kp3d[(size_t)n * 87 + tid] = sj[tid / 3][tid % 3];
-    if (tid < 29) {
+    if (tid < 29 && cam != nullptr && kp2d != nullptr) {
         const float s = cam[(size_t)n * 3], tx = cam[(size_t)n * 3 + 1], ty = cam[(size_t)n * 3 + 2];
         const float tz = 2.f * 5000.f / (224.f * s + 1e-9f);
         const float X = sj[tid][0] + tx, Y = sj[tid][1] + ty, Z = sj[tid][2] + tz;

@@ -233,6 +233,26 @@ class GRNet:
         _lib.check(self._lib, self._h, self._lib.grnet_time_convs(self._h, n_frames, stream, C.byref(ms)), "grnet_time_convs")
         return ms.value
 
+    def smpl_forward(self, betas, rotmat, cam=None):
+        """SMPL LBS on the GPU: betas (n,10), rotmat (n,24,3,3) [, cam (n,3)] -> verts, kp_3d (29 spin2 joints) [, kp_2d]."""
+        self.finalize()
+        n = betas.shape[0]
+        dev = self.device
+        b = betas.to(dev, torch.float32).contiguous()
+        r = rotmat.to(dev, torch.float32).reshape(n, 24, 9).contiguous()
+        c = cam.to(dev, torch.float32).contiguous() if cam is not None else None
+        verts = torch.empty(n, 6890, 3, dtype=torch.float32, device=dev)
+        kp3d = torch.empty(n, 29, 3, dtype=torch.float32, device=dev)
+        kp2d = torch.empty(n, 29, 2, dtype=torch.float32, device=dev) if cam is not None else None
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        for s0 in range(0, n, self.max_frames):
+            m = min(self.max_frames, n - s0)
+            rc = self._lib.grnet_smpl_forward(self._h, b[s0:].data_ptr(), r[s0:].data_ptr(), c[s0:].data_ptr() if c is not None else None,
+                                              m, verts[s0:].data_ptr(), kp3d[s0:].data_ptr(),
+                                              kp2d[s0:].data_ptr() if kp2d is not None else None, stream)
+            _lib.check(self._lib, self._h, rc, "grnet_smpl_forward")
+        return verts, kp3d, kp2d
+
     def crop_normalise(self, images, bboxes, scale=1.0, bgr=False):
         """uint8 frames (n,H,W,3) [or one (H,W,3) frame] + boxes (n,4) -> (n,3,224,224) normalised crops, on the GPU."""
         shared = images.dim() == 3

@@ -30,6 +30,9 @@ SMPL_PARENTS = [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17
 # smplx VertexJointSelector ids appended after the 24 joints.
 SMPL_EXTRA_VERT_IDS = [332, 6260, 2800, 4071, 583, 3216, 3226, 3387, 6617, 6624, 6787,
                        2746, 2319, 2445, 2556, 2673, 6191, 5782, 5905, 6016, 6133]
+# 49 SPIN joints out of [45 smplx joints ++ 9 extra regressed joints]: [JOINT_MAP[n] for n in JOINT_NAMES] (smpl.py:16-87,102)
+SPIN49_FROM_54 = [24, 12, 17, 19, 21, 16, 18, 20, 0, 2, 5, 8, 1, 4, 7, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 8, 5, 45, 46, 4, 7,
+                  21, 19, 17, 16, 18, 20, 47, 48, 49, 50, 51, 52, 53, 24, 35, 40, 10, 11]
 # spin2 (29 joints) -> kinectv2 (25 joints) index map (kp_utils.py:211-242,904-931).
 SPIN2_TO_KINECTV2 = [0, 6, 12, 15, 16, 18, 20, 22, 17, 19, 21, 23, 1, 4, 7, 10, 2, 5, 8, 11,
                      28, 25, 24, 27, 26]

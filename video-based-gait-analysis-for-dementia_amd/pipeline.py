@@ -53,6 +53,64 @@ def spin2_to_kinectv2(joints):
     return joints[:, netspec.SPIN2_TO_KINECTV2].astype(np.float64)      # the reference returns float64 zeros-based arrays
 
 
+# ----------------------------------------------------------------------------- --smooth (row f3)
+def one_euro_filter(x, min_cutoff=0.004, beta=0.7, d_cutoff=1.0):
+    """The One-Euro filter as smooth_pose drives it (one_euro_filter.py:5-46, smooth_pose.py:47-52,84-88): unit time
+    steps, state initialised with x[0] and dx = 0; x (T, ...) -> filtered (T, ...), element-wise."""
+    x = np.asarray(x)
+    out = np.zeros_like(x)
+    out[0] = x[0]
+    x_prev, dx_prev = x[0], np.zeros_like(x[0])
+
+    def alpha(cutoff):                                       # smoothing_factor with t_e = 1
+        r = 2 * np.pi * cutoff
+        return r / (r + 1)
+
+    a_d = alpha(d_cutoff)
+    for t in range(1, x.shape[0]):
+        dx = x[t] - x_prev
+        dx_hat = a_d * dx + (1 - a_d) * dx_prev
+        a = alpha(min_cutoff + beta * np.abs(dx_hat))
+        x_hat = a * x[t] + (1 - a) * x_prev
+        out[t] = x_hat
+        x_prev, dx_prev = x_hat, dx_hat
+    return out
+
+
+def rodrigues(aa):
+    """Axis-angle (n,3) -> rotation matrices (n,3,3): smplx's batch_rodrigues (angle = |aa + 1e-8|, R = I + sin K +
+    (1 - cos) K^2), the conversion smplx.SMPL applies when smooth_pose passes axis-angle poses.  Third-party: unpinned."""
+    aa = np.asarray(aa, np.float32)
+    angle = np.linalg.norm(aa + np.float32(1e-8), axis=1, keepdims=True)
+    d = aa / angle
+    K = np.zeros((aa.shape[0], 3, 3), np.float32)
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -d[:, 2], d[:, 1], d[:, 2], -d[:, 0], -d[:, 1], d[:, 0]
+    s, c = np.sin(angle)[..., None], np.cos(angle)[..., None]
+    return (np.eye(3, dtype=np.float32)[None] + s * K + (1 - c) * (K @ K)).astype(np.float32)
+
+
+def smooth_pose(model, pred_pose, pred_betas, min_cutoff=0.004, beta=0.7, kinectv2=False, smpl_tables=None):
+    """lib/utils/smooth_pose.py:28-116: One-Euro filter over the axis-angle pose, then SMPL re-evaluated per frame with
+    the betas of frame 0 (smooth_pose.py:97) -- batched into one LBS launch here.  Returns (verts, pose_hat, joints3d)
+    with joints3d in the 49-joint SPIN order (kinectv2=False, what demo.py gets) or 25 kinectv2 joints."""
+    T = pred_betas.shape[0]
+    pose = np.asarray(pred_pose, np.float32).reshape(T, 24, 3)
+    pose_hat = one_euro_filter(pose, min_cutoff, beta).astype(np.float32)
+    rot = rodrigues(pose_hat.reshape(-1, 3)).reshape(T, 24, 3, 3)
+    betas0 = np.repeat(np.asarray(pred_betas, np.float32)[:1], T, axis=0)
+    verts, kp29, _ = model.smpl_forward(torch.from_numpy(betas0), torch.from_numpy(rot))
+    verts, kp29 = verts.cpu().numpy(), kp29.cpu().numpy()
+    if kinectv2:
+        joints = spin2_to_kinectv2(kp29)
+    else:
+        if smpl_tables is None:
+            raise ValueError("the 49-joint SPIN output needs J_regressor_extra (smpl_tables)")
+        j45 = np.concatenate([kp29[:, :24], verts[:, netspec.SMPL_EXTRA_VERT_IDS]], 1)
+        extra = np.einsum("jv,nvk->njk", np.asarray(smpl_tables["J_regressor_extra"], np.float32), verts)
+        joints = np.concatenate([j45, extra], 1)[:, netspec.SPIN49_FROM_54]
+    return verts, pose_hat.reshape(T, 72), joints
+
+
 # ----------------------------------------------------------------------------- frame sources
 def crop_and_normalise(img_rgb_u8, bbox, scale=1.0, crop_size=224):
     """One frame: uint8 HxWx3 RGB + [cx,cy,w,h] -> float32 (3,224,224), ImageNet-normalised.
