@@ -153,29 +153,6 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
         __syncthreads();
     }
 
-    // A operand: lane holds pixel (lane&15) of its sub-tile, channel (lane>>4) of the k-group.
-    int abase[PSW];
-    unsigned lmask = 0, rmask = 0;                         // ROWS: sub-tiles whose pixel sits on the left / right image edge
-#pragma unroll
-    for (int ps = 0; ps < PSW; ++ps) {
-        const int q = (wp * PSW + ps) * 16 + l15;
-        const int gl = q / RW, rem = q - gl * RW;
-        const int yl = rem / a.Wo, x = rem - yl * a.Wo;
-        int off;
-        if constexpr (ROWS) {
-            off = (q < RW) ? (y0 * S - pad + yl * S) * a.W + x * S - pad - gal : 0;
-            if (x == 0) lmask |= 1u << ps;
-            if (x * S + KS - 1 - pad >= a.W) rmask |= 1u << ps;
-        } else {
-            off = (q < a.G * RW) ? gl * RinWp + yl * S * a.Wp + x * S : 0;   // masked rows read slot 0
-        }
-        abase[ps] = lq * a.PSTR + off;
-    }
-    // B operand: lane holds cout (lane&15) of its sub-tile, row (lane>>4) of the k-group.
-    int bbase[CSW];
-#pragma unroll
-    for (int cs = 0; cs < CSW; ++cs) bbase[cs] = lq * TC + (((wc * CSW + cs) * 16 + l15) ^ ((lq & 1) << 4));
-
     auto issue = [&](int chunk, int buf) {
         const int c0 = chunk * CK;
         float* dst_in = in_lds + buf * CK * a.PSTR;
@@ -223,7 +200,30 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
         for (int cs = 0; cs < CSW; ++cs) acc[ps][cs] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nchunks = a.CinPad / CK;
-    issue(0, 0);
+    issue(0, 0);                                          // first chunk in flight while the lane offsets are computed
+    // A operand: lane holds pixel (lane&15) of its sub-tile, channel (lane>>4) of the k-group.
+    int abase[PSW];
+    unsigned lmask = 0, rmask = 0;                         // ROWS: sub-tiles whose pixel sits on the left / right image edge
+#pragma unroll
+    for (int ps = 0; ps < PSW; ++ps) {
+        const int q = (wp * PSW + ps) * 16 + l15;
+        const int gl = q / RW, rem = q - gl * RW;
+        const int yl = rem / a.Wo, x = rem - yl * a.Wo;
+        int off;
+        if constexpr (ROWS) {
+            off = (q < RW) ? (y0 * S - pad + yl * S) * a.W + x * S - pad - gal : 0;
+            if (x == 0) lmask |= 1u << ps;
+            if (x * S + KS - 1 - pad >= a.W) rmask |= 1u << ps;
+        } else {
+            off = (q < a.G * RW) ? gl * RinWp + yl * S * a.Wp + x * S : 0;   // masked rows read slot 0
+        }
+        abase[ps] = lq * a.PSTR + off;
+    }
+    // B operand: lane holds cout (lane&15) of its sub-tile, row (lane>>4) of the k-group.
+    int bbase[CSW];
+#pragma unroll
+    for (int cs = 0; cs < CSW; ++cs) bbase[cs] = lq * TC + (((wc * CSW + cs) * 16 + l15) ^ ((lq & 1) << 4));
+
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of chunk ch has landed
@@ -338,37 +338,6 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
         __syncthreads();
     }
 
-    int abase[PSW];
-    unsigned lmask = 0, rmask = 0;
-    unsigned vmask[PLANES ? PSW : 1] = {};                  // PLANES: bit tap = that tap of this pixel is inside the image
-#pragma unroll
-    for (int ps = 0; ps < PSW; ++ps) {
-        const int q = ps * 16 + l15;
-        const int gl = q / RW, rem = q - gl * RW;
-        const int yl = rem / a.Wo, x = rem - yl * a.Wo;
-        int off;
-        if constexpr (PLANES) {
-            off = (q < RW) ? (yl * S - pad) * a.W + x * S - pad : 0;     // may be negative: lands in the weight slab, masked
-            if (q < RW) {
-#pragma unroll
-                for (int t = 0; t < TAPS; ++t) {
-                    const int yy = yl * S + t / KS - pad, xx = x * S + t % KS - pad;
-                    if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) vmask[ps] |= 1u << t;
-                }
-            }
-        } else if constexpr (ROWS) {
-            off = (q < RW) ? (y0 * S - pad + yl * S) * a.W + x * S - pad - gal : 0;
-            if (x == 0) lmask |= 1u << ps;
-            if (x * S + KS - 1 - pad >= a.W) rmask |= 1u << ps;
-        } else {
-            off = (q < a.G * RW) ? gl * RinWp + yl * S * a.Wp + x * S : 0;
-        }
-        abase[ps] = WFL + lq * a.PSTR + off;
-    }
-    int bbase[CSW];
-#pragma unroll
-    for (int cs = 0; cs < CSW; ++cs) bbase[cs] = lq * TC + ((cs * 16 + l15) ^ (TC == 32 ? ((lq & 1) << 4) : 0));
-
     auto issue = [&](int grp4, int buf) {
         const int c0 = grp4 * 4;
         float* dst = mine + buf * stage_floats;
@@ -430,6 +399,38 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
     constexpr int NWI = (WFL / 4 + 63) / 64;
     const int ni = NWI + (PLANES ? (HW + 63) / 64 : ROWS ? (a.PSTR + 63) / 64 : 4 * ((a.PSTR + 63) / 64));
     for (int d = 0; d < ring && d < my_stages; ++d) issue(wave + d * NW, d);
+    // (the first stages are in flight while the lane offsets and edge masks are computed)
+    int abase[PSW];
+    unsigned lmask = 0, rmask = 0;
+    unsigned vmask[PLANES ? PSW : 1] = {};                  // PLANES: bit tap = that tap of this pixel is inside the image
+#pragma unroll
+    for (int ps = 0; ps < PSW; ++ps) {
+        const int q = ps * 16 + l15;
+        const int gl = q / RW, rem = q - gl * RW;
+        const int yl = rem / a.Wo, x = rem - yl * a.Wo;
+        int off;
+        if constexpr (PLANES) {
+            off = (q < RW) ? (yl * S - pad) * a.W + x * S - pad : 0;     // may be negative: lands in the weight slab, masked
+            if (q < RW) {
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    const int yy = yl * S + t / KS - pad, xx = x * S + t % KS - pad;
+                    if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) vmask[ps] |= 1u << t;
+                }
+            }
+        } else if constexpr (ROWS) {
+            off = (q < RW) ? (y0 * S - pad + yl * S) * a.W + x * S - pad - gal : 0;
+            if (x == 0) lmask |= 1u << ps;
+            if (x * S + KS - 1 - pad >= a.W) rmask |= 1u << ps;
+        } else {
+            off = (q < a.G * RW) ? gl * RinWp + yl * S * a.Wp + x * S : 0;
+        }
+        abase[ps] = WFL + lq * a.PSTR + off;
+    }
+    int bbase[CSW];
+#pragma unroll
+    for (int cs = 0; cs < CSW; ++cs) bbase[cs] = lq * TC + ((cs * 16 + l15) ^ (TC == 32 ? ((lq & 1) << 4) : 0));
+
     int buf = 0;
     for (int i = 0; i < my_stages; ++i) {
         const int left = my_stages - 1 - i;
@@ -608,9 +609,10 @@ void plan_ring(ConvArgs& a, const Cfg& c) {
     a.ring = 2;
     if (c.family != 1) return;
     const size_t stage_bytes = 4 * ((size_t)a.ks * a.ks * 4 * c.tcs * 16 + 4 * (size_t)a.PSTR);
-    static const int ring_cap = getenv("GRNET_RING_CAP") ? atoi(getenv("GRNET_RING_CAP")) : 2;   // measured: deeper rings buy nothing
+    static const int ring_cap = getenv("GRNET_RING_CAP") ? atoi(getenv("GRNET_RING_CAP")) : 1;   // measured: 1 (more workgroups per CU) beats 2..4
     int r = (int)((48 * 1024) / (kSplitWaves * stage_bytes));
     a.ring = r < 2 ? 2 : (r > ring_cap ? ring_cap : r);
+    if (ring_cap == 1) a.ring = 1;                            // single-buffered stages: the co-resident workgroups hide the DMA
 }
 
 size_t lds_bytes(const ConvArgs& a, const Cfg& c) {
