@@ -143,6 +143,11 @@ def main():
     except OSError:
         pass
 
+    tm = model.tuned_mode(n) or {}
+    eager = args.no_graph or tm.get("eager", False)
+    launch_desc = ("eager launches on 4 lane streams" if eager else "hipGraph replay") + \
+                  (", grouped HR-module launches" if tm.get("grouped") else ", one launch per convolution") + \
+                  (" (schedule picked by grnet_tune)" if tm else "")
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         total_frames = n * world * args.steps
@@ -152,7 +157,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"1 clip x {n} frames x 3x224x224 per GPU, fp32, MAX-GRNet per-frame path "
                                    "(HRNet-W32 + PARE head + SMPL LBS), seed-defined synthetic weights",
-                       "frames_per_gpu": n, "clips_in_flight": len(runners), "launch": "eager" if args.no_graph else "hipGraph replay",
+                       "frames_per_gpu": n, "clips_in_flight": len(runners), "launch": launch_desc,
                        "kernel_launches_per_step": model.num_kernel_launches(),
                        "launch_configs": ("stored table " + os.path.relpath(cache, ROOT)) if cache else f"grnet_tune level {args.tune_level}",
                        "exchange": "none (1 GPU)" if world == 1 else "RCCL all-gather of per-frame pose results"},

@@ -657,7 +657,8 @@ struct grnet {
     // for n frames (3 launches each, HIP events) and keep the fastest; then time whole forwards with the HR-module
     // convolutions grouped vs on parallel lanes and keep the faster schedule.  Activation buffers are used as
     // scratch (contents are garbage afterwards, like after any forward).
-    std::map<int, int> tuned_mode;     // n -> bit0: per-shape measured configurations (else cost model), bit1: grouped launches
+    std::map<int, int> tuned_mode;     // n -> bit0: measured per-shape configurations (else cost model), bit1: grouped launches,
+                                       //      bit2: eager launches on the lane streams even if graphs are enabled
     int tune(int n, hipStream_t s, int level = 1) {
         if (!finalized) return fail(GRNET_ESTATE, "grnet_tune before grnet_finalize_weights");
         if (n < 1 || n > max_frames) return fail(GRNET_EINVAL, "n_frames outside [1, max_frames]");
@@ -690,11 +691,14 @@ struct grnet {
             L.tuned[n] = best_hint;
             by_shape[key] = best_hint;
         }
-        // schedule: grouped launches vs parallel lanes, whole forward as a replayed hipGraph (how it will run)
-        float t_mode[4] = {0, 0, 0, 0};
+        // schedule: {parallel lanes, grouped launches} x {cost model, measured table} x {replayed hipGraph, eager launches
+        // on the four lane streams} -- the graph executor of ROCm 7.2 maps parallel branches to fewer hardware queues
+        // than explicit streams do, so eager multi-stream launching can win although it costs CPU time per launch
+        float t_mode[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const bool keep = grouping, keep_graph = use_graph;
-        use_graph = true;
-        for (int mode = 0; mode < 4; ++mode) {
+        for (int mode = 0; mode < 8; ++mode) {
+            if ((mode & 4) == 0 && !keep_graph) { t_mode[mode] = 1e30f; continue; }   // graphs not enabled by the caller
+            use_graph = (mode & 4) == 0;
             grouping = true;
             tuned_mode[n] = mode;
             for (auto& g : graphs) hipGraphExecDestroy(g.second);
@@ -710,13 +714,13 @@ struct grnet {
         grouping = keep;
         use_graph = keep_graph;
         int best_mode = 0;
-        for (int mode = 1; mode < 4; ++mode)
+        for (int mode = 1; mode < 8; ++mode)
             if (t_mode[mode] < t_mode[best_mode]) best_mode = mode;
         tuned_mode[n] = best_mode;
         // in-context refinement (level 2): greedy coordinate descent on the time of the whole replayed forward --
         // a configuration that wins alone can lose when four lanes share the CUs.  Shapes in order of their FLOP share.
         if (level >= 2) {
-            use_graph = true;
+            use_graph = (best_mode & 4) == 0;
             tuned_mode[n] = best_mode | 1;                      // refine the measured table under the winning schedule
             auto time_forward = [&](float* out_ms) -> int {
                 for (auto& g : graphs) hipGraphExecDestroy(g.second);
@@ -776,8 +780,9 @@ struct grnet {
         for (auto& g : graphs) hipGraphExecDestroy(g.second);
         graphs.clear();
         if (getenv("GRNET_TRACE"))
-            fprintf(stderr, "[grnet] tuned n=%d: forward ms lanes/model %.3f lanes/measured %.3f grouped/model %.3f grouped/measured %.3f -> mode %d\n",
-                    n, t_mode[0] / 3, t_mode[1] / 3, t_mode[2] / 3, t_mode[3] / 3, best_mode);
+            fprintf(stderr, "[grnet] tuned n=%d: forward ms graph[lanes/model %.3f lanes/measured %.3f grouped/model %.3f grouped/measured %.3f] "
+                    "eager[%.3f %.3f %.3f %.3f] -> mode %d\n",
+                    n, t_mode[0] / 3, t_mode[1] / 3, t_mode[2] / 3, t_mode[3] / 3, t_mode[4] / 3, t_mode[5] / 3, t_mode[6] / 3, t_mode[7] / 3, best_mode);
         return 0;
     }
     bool grouping_for(int n) const {
@@ -927,7 +932,11 @@ struct grnet {
             return fail(GRNET_EINVAL, "n_frames " + std::to_string(n) + " outside [1, max_frames=" + std::to_string(max_frames) + "]");
         grnet_outputs_t o{};
         if (out) o = *out;
-        if (!use_graph) return enqueue(frames, n, o, s);
+        {
+            auto tm = tuned_mode.find(n);
+            const bool eager_tuned = tm != tuned_mode.end() && (tm->second & 4);
+            if (!use_graph || eager_tuned) return enqueue(frames, n, o, s);
+        }
         GraphKey key{n, frames, o};
         auto it = graphs.find(key);
         if (it == graphs.end()) {

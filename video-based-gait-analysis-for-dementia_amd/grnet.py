@@ -217,6 +217,14 @@ class GRNet:
                     f.write(buf.value.decode())
         return self
 
+    def tuned_mode(self, n_frames):
+        """Schedule chosen by tune(): dict(measured_table, grouped, eager) or None if not tuned for n_frames."""
+        buf = C.create_string_buffer(1 << 16)
+        if self._lib.grnet_get_tuning(self._h, int(n_frames), buf, len(buf)) <= 0:
+            return None
+        mode = int(buf.value.decode().split("\n", 1)[0].split()[1])
+        return {"measured_table": bool(mode & 1), "grouped": bool(mode & 2), "eager": bool(mode & 4)}
+
     # ------------------------------------------------------------------ introspection (bench / tests)
     def num_kernel_launches(self):
         return self._lib.grnet_num_kernel_launches(self._h)

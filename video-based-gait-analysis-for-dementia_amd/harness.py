@@ -87,10 +87,10 @@ class ClipRunner:
         self.out.verts = self.verts.data_ptr()
         self.out.rotmat = self.rotmat.data_ptr()
         model.finalize()
-        if tune_level:                     # launch configurations measured on this GPU for this clip length (or a stored table)
-            model.tune(n, level=tune_level, cache=tune_cache)
         if use_graph:
             model.set_option(_lib.OPT_USE_GRAPH, 1)
+        if tune_level:                     # launch configurations AND schedule (lanes/grouped, graph/eager) measured on this GPU
+            model.tune(n, level=tune_level, cache=tune_cache)
         self._lib, self._h = model._lib, model._h
         self._stream = torch.cuda.current_stream(dev)
 
