@@ -115,6 +115,9 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const EpiCtx& e, f
 // falls outside the row select 0).  Otherwise (multi-image tiles of the 7x7 maps): a zero-padded patch
 // [G][Rin][Wp] gathered float by float through the source-offset table.
 __device__ __forceinline__ int floor4(int v) { return v & ~3; }   // two's complement: floors negatives too
+// q / d for 0 <= q < 2^20, 0 < d < 2^20 through one fp32 reciprocal-multiply (exact: the +0.5 keeps the quotient of an
+// exact multiple away from the rounding edge); an integer division by a run-time value costs ~20 VALU instructions
+__device__ __forceinline__ int fdiv(int q, float inv_d) { return (int)(((float)q + 0.5f) * inv_d); }
 
 // CK = input channels per K-chunk: 8 for 3x3 (72 k-steps of 4 per chunk ... 18 MFMA steps), 32 for 1x1 convolutions,
 // whose chunks would otherwise hold only 2 MFMA steps between barriers and run latency-bound.
@@ -153,17 +156,49 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
         __syncthreads();
     }
 
+    // per-thread source offsets of the DMA units repeat every chunk (only the channel base moves): computed once
+    constexpr int UW = WFLOATS / 4, UPRW = TC / 4, NWI = (UW + NT - 1) / NT;   // weight units (16 B) per thread
+    int woff[NWI];
+#pragma unroll
+    for (int it = 0; it < NWI; ++it) {
+        const int u = it * NT + tid;
+        const int row = u / UPRW, j = u - row * UPRW;
+        const int tap = row / CK, c = row - tap * CK;
+        woff[it] = u < UW ? (tap * a.CinPad + c) * a.CoutPad + co0 + 4 * (j ^ ((row & 1) << 2)) : -1;
+    }
+    constexpr int NII = 4;                                  // row-mode input units per thread kept in registers
+    const int upc_i = a.PSTR >> 2;
+    const bool fast_in = ROWS && CK * upc_i <= NII * NT && (a.Cin % CK) == 0;
+    int ioff[NII];
+    if constexpr (ROWS) {
+        const float inv_upc = 1.0f / (float)upc_i;
+#pragma unroll
+        for (int it = 0; it < NII; ++it) {
+            const int u = it * NT + tid;
+            const int c = fdiv(u, inv_upc), gi = gal + 4 * (u - c * upc_i);
+            ioff[it] = (u < CK * upc_i) ? ((gi >= 0 && gi < HW) ? c * HW + gi : -2) : -1;
+        }
+    }
+
     auto issue = [&](int chunk, int buf) {
         const int c0 = chunk * CK;
         float* dst_in = in_lds + buf * CK * a.PSTR;
         if constexpr (ROWS) {
-            const int upc = a.PSTR >> 2;                   // 16-byte units per channel plane
-            for (int ub = wave * 64; ub < CK * upc; ub += NT) {
-                const int u = ub + lane;
-                if (u < CK * upc) {
-                    const int c = u / upc, gi = gal + 4 * (u - c * upc);
-                    const bool ok = (c0 + c) < a.Cin && gi >= 0 && gi < HW;
-                    stage16(ok ? inb + (size_t)(c0 + c) * HW + gi : a.zeros, dst_in + ub * 4, lane);
+            if (fast_in) {
+                const float* isrc = inb + (size_t)c0 * HW;
+#pragma unroll
+                for (int it = 0; it < NII; ++it)
+                    if (it * NT + wave * 64 < CK * upc_i && ioff[it] != -1)
+                        stage16(ioff[it] >= 0 ? isrc + ioff[it] : a.zeros, dst_in + (it * NT + wave * 64) * 4, lane);
+            } else {
+                const int upc = a.PSTR >> 2;                   // 16-byte units per channel plane
+                for (int ub = wave * 64; ub < CK * upc; ub += NT) {
+                    const int u = ub + lane;
+                    if (u < CK * upc) {
+                        const int c = u / upc, gi = gal + 4 * (u - c * upc);
+                        const bool ok = (c0 + c) < a.Cin && gi >= 0 && gi < HW;
+                        stage16(ok ? inb + (size_t)(c0 + c) * HW + gi : a.zeros, dst_in + ub * 4, lane);
+                    }
                 }
             }
         } else {
@@ -181,16 +216,10 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
             }
         }
         float* dst_w = w_lds + buf * WFLOATS;
-        constexpr int U = WFLOATS / 4, UPR = TC / 4;     // 16-byte units, units per weight row
+        const float* wsrc = a.w + (size_t)c0 * a.CoutPad;   // cout index XOR-swizzled by row parity: same involution as the read side
 #pragma unroll
-        for (int ub = wave * 64; ub < U; ub += NT) {
-            const int u = ub + lane;
-            const int row = u / UPR, j = u - row * UPR;
-            const int tap = row / CK, c = row - tap * CK;
-            const int js = j ^ ((row & 1) << 2);         // same involution as the read side (rule 21)
-            const float* src = a.w + ((size_t)(tap * a.CinPad + c0 + c) * a.CoutPad + co0 + 4 * js);
-            stage16(src, dst_w + ub * 4, lane);
-        }
+        for (int it = 0; it < NWI; ++it)
+            if (it * NT + wave * 64 < UW) stage16(wsrc + woff[it], dst_w + (it * NT + wave * 64) * 4, lane);   // UW % 64 == 0
     };
 
     f32x4 acc[PSW][CSW];
@@ -204,11 +233,12 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
     // A operand: lane holds pixel (lane&15) of its sub-tile, channel (lane>>4) of the k-group.
     int abase[PSW];
     unsigned lmask = 0, rmask = 0;                         // ROWS: sub-tiles whose pixel sits on the left / right image edge
+    const float inv_RW = 1.0f / (float)RW, inv_Wo = 1.0f / (float)a.Wo;
 #pragma unroll
     for (int ps = 0; ps < PSW; ++ps) {
         const int q = (wp * PSW + ps) * 16 + l15;
-        const int gl = q / RW, rem = q - gl * RW;
-        const int yl = rem / a.Wo, x = rem - yl * a.Wo;
+        const int gl = fdiv(q, inv_RW), rem = q - gl * RW;
+        const int yl = fdiv(rem, inv_Wo), x = rem - yl * a.Wo;
         int off;
         if constexpr (ROWS) {
             off = (q < RW) ? (y0 * S - pad + yl * S) * a.W + x * S - pad - gal : 0;
@@ -314,10 +344,9 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
     constexpr int TC = CSW * 16, TAPS = KS * KS, WFL = TAPS * 4 * TC, NT = PSW * CSW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
-    const int stage_floats = WFL + 4 * a.PSTR;           // [weights TAPS*4 x TC | input 4 x PSTR]
-    const int ring = a.ring;
-    int* tab = reinterpret_cast<int*>(smem + NW * ring * stage_floats);
-    float* mine = smem + wave * ring * stage_floats;
+    const int stage_floats = WFL + 4 * a.PSTR;           // [weights TAPS*4 x TC | input 4 x PSTR], ONE stage per wave:
+    int* tab = reinterpret_cast<int*>(smem + NW * stage_floats);   // the co-resident workgroups hide the DMA, and a fixed
+    float* mine = smem + wave * stage_floats;                        // buffer makes every LDS address loop-invariant
 
     const int ty = bx % a.tiles_y, grp = bx / a.tiles_y;
     const int y0 = ty * a.R, g0 = grp * a.G, co0 = by * TC;
@@ -338,34 +367,60 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
         __syncthreads();
     }
 
-    auto issue = [&](int grp4, int buf) {
-        const int c0 = grp4 * 4;
-        float* dst = mine + buf * stage_floats;
-        constexpr int U = WFL / 4, UPR = TC / 4;
+    // per-lane source offsets of this wave's DMA units are the same for every stage (only the channel group moves):
+    // computed once, so a stage costs one 64-bit add per DMA instruction instead of divisions
+    constexpr int U = WFL / 4, UPR = TC / 4, NWI = (U + 63) / 64;
+    int woff[NWI];
 #pragma unroll
-        for (int ub = 0; ub < U; ub += 64) {
-            const int u = ub + lane;
-            if (u < U) {
-                const int row = u / UPR, j = u - row * UPR;
-                const int tap = row >> 2, c = row & 3;
-                const int js = TC == 32 ? (j ^ ((row & 1) << 2)) : j;
-                const float* src = a.w + ((size_t)(tap * a.CinPad + c0 + c) * a.CoutPad + co0 + 4 * js);
-                stage16(src, dst + ub * 4, lane);
-            }
+    for (int it = 0; it < NWI; ++it) {
+        const int u = it * 64 + lane;
+        const int row = u / UPR, j = u - row * UPR;
+        const int tap = row >> 2, c = row & 3;
+        const int js = TC == 32 ? (j ^ ((row & 1) << 2)) : j;
+        woff[it] = u < U ? (tap * a.CinPad + c) * a.CoutPad + co0 + 4 * js : -1;
+    }
+    constexpr int NII = 4;                                  // row-mode input units per lane kept in registers (PSTR <= 256)
+    const bool fast_in = ROWS && a.PSTR <= 64 * NII && (a.Cin & 3) == 0;
+    int ioff[NII];
+    if constexpr (ROWS) {
+        const int upc = a.PSTR >> 2;
+        const float inv_upc = 1.0f / (float)upc;
+#pragma unroll
+        for (int it = 0; it < NII; ++it) {
+            const int u2 = it * 64 + lane;
+            const int c = fdiv(u2, inv_upc), gi = gal + 4 * (u2 - c * upc);
+            ioff[it] = (u2 < 4 * upc) ? ((gi >= 0 && gi < HW) ? c * HW + gi : -2) : -1;     // -2: zero block, -1: no unit
         }
+    }
+
+    auto issue = [&](int grp4, int) {
+        const int c0 = grp4 * 4;
+        float* dst = mine;
+        const float* wsrc = a.w + (size_t)c0 * a.CoutPad;
+#pragma unroll
+        for (int it = 0; it < NWI; ++it)
+            if (woff[it] >= 0) stage16(wsrc + woff[it], dst + it * 256, lane);
         if constexpr (PLANES) {
             for (int ub = 0; ub < HW; ub += 64) {           // 4 planes x HW floats = HW 16-byte units, contiguous in HBM
                 const int u2 = ub + lane;
                 if (u2 < HW) stage16(inb + (size_t)c0 * HW + 4 * u2, dst + WFL + ub * 4, lane);
             }
         } else if constexpr (ROWS) {
-            const int upc = a.PSTR >> 2;
-            for (int ub = 0; ub < 4 * upc; ub += 64) {
-                const int u2 = ub + lane;
-                if (u2 < 4 * upc) {
-                    const int c = u2 / upc, gi = gal + 4 * (u2 - c * upc);
-                    const bool ok = (c0 + c) < a.Cin && gi >= 0 && gi < HW;
-                    stage16(ok ? inb + (size_t)(c0 + c) * HW + gi : a.zeros, dst + WFL + ub * 4, lane);
+            if (fast_in) {
+                const float* isrc = inb + (size_t)c0 * HW;
+                const int nin = (a.PSTR + 63) >> 6;
+#pragma unroll
+                for (int it = 0; it < NII; ++it)
+                    if (it < nin && ioff[it] != -1) stage16(ioff[it] >= 0 ? isrc + ioff[it] : a.zeros, dst + WFL + it * 256, lane);
+            } else {
+                const int upc = a.PSTR >> 2;
+                for (int ub = 0; ub < 4 * upc; ub += 64) {
+                    const int u2 = ub + lane;
+                    if (u2 < 4 * upc) {
+                        const int c = u2 / upc, gi = gal + 4 * (u2 - c * upc);
+                        const bool ok = (c0 + c) < a.Cin && gi >= 0 && gi < HW;
+                        stage16(ok ? inb + (size_t)(c0 + c) * HW + gi : a.zeros, dst + WFL + ub * 4, lane);
+                    }
                 }
             }
         } else {
@@ -391,23 +446,20 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
 #pragma unroll
         for (int cs = 0; cs < CSW; ++cs) acc[ps][cs] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // Per-wave ring of kRing stages.  Every stage is exactly `ni` vector-memory instructions of this wave
-    // (each loop below runs its last iteration with at least one active lane), so "all but the newest
-    // `ahead` stages have landed" is s_waitcnt vmcnt(ahead * ni).
+    // One stage per wave at a time: issue -> wait -> MFMAs -> issue the next into the same buffer.
     const int ngroups = a.CinPad / 4;
     const int my_stages = ngroups > wave ? (ngroups - wave + NW - 1) / NW : 0;
-    constexpr int NWI = (WFL / 4 + 63) / 64;
-    const int ni = NWI + (PLANES ? (HW + 63) / 64 : ROWS ? (a.PSTR + 63) / 64 : 4 * ((a.PSTR + 63) / 64));
-    for (int d = 0; d < ring && d < my_stages; ++d) issue(wave + d * NW, d);
+    if (my_stages > 0) issue(wave, 0);
     // (the first stages are in flight while the lane offsets and edge masks are computed)
     int abase[PSW];
     unsigned lmask = 0, rmask = 0;
     unsigned vmask[PLANES ? PSW : 1] = {};                  // PLANES: bit tap = that tap of this pixel is inside the image
+    const float inv_RW = 1.0f / (float)RW, inv_Wo = 1.0f / (float)a.Wo;
 #pragma unroll
     for (int ps = 0; ps < PSW; ++ps) {
         const int q = ps * 16 + l15;
-        const int gl = q / RW, rem = q - gl * RW;
-        const int yl = rem / a.Wo, x = rem - yl * a.Wo;
+        const int gl = fdiv(q, inv_RW), rem = q - gl * RW;
+        const int yl = fdiv(rem, inv_Wo), x = rem - yl * a.Wo;
         int off;
         if constexpr (PLANES) {
             off = (q < RW) ? (yl * S - pad) * a.W + x * S - pad : 0;     // may be negative: lands in the weight slab, masked
@@ -431,12 +483,17 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
 #pragma unroll
     for (int cs = 0; cs < CSW; ++cs) bbase[cs] = lq * TC + ((cs * 16 + l15) ^ (TC == 32 ? ((lq & 1) << 4) : 0));
 
-    int buf = 0;
+    // loop-invariant LDS row pointers: the kx offset of a tap becomes the immediate of ds_read_b32
+    const float* arow[PSW][KS];
+    const float* brow[CSW];
+#pragma unroll
+    for (int ps = 0; ps < PSW; ++ps)
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) arow[ps][ky] = mine + abase[ps] + ky * a.Wp;
+#pragma unroll
+    for (int cs = 0; cs < CSW; ++cs) brow[cs] = mine + bbase[cs];
     for (int i = 0; i < my_stages; ++i) {
-        const int left = my_stages - 1 - i;
-        if (a.dbg & 2) wait_vmcnt_le(0); else
-        wait_vmcnt_le((left < ring - 1 ? left : ring - 1) * ni);
-        const float* st = mine + buf * stage_floats;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's stage has landed
         if (!(a.dbg & 1)) {
             // software pipeline over the filter taps: the LDS reads of tap t+1 are in flight under the
             // MFMAs of tap t (one exposed LDS latency per stage instead of one per tap)
@@ -444,11 +501,10 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
             constexpr int LD = (PSW * CSW <= 4) ? 2 : 1;
             float av[LD + 1][PSW], bv[LD + 1][CSW];
             auto load_tap = [&](int tap, float* ar, float* br) {
-                const int toff = (tap / KS) * a.Wp + (tap % KS);
 #pragma unroll
-                for (int cs = 0; cs < CSW; ++cs) br[cs] = st[tap * 4 * TC + bbase[cs]];
+                for (int cs = 0; cs < CSW; ++cs) br[cs] = brow[cs][tap * 4 * TC];
 #pragma unroll
-                for (int ps = 0; ps < PSW; ++ps) ar[ps] = st[abase[ps] + toff];
+                for (int ps = 0; ps < PSW; ++ps) ar[ps] = arow[ps][tap / KS][tap % KS];
             };
 #pragma unroll
             for (int t = 0; t < LD && t < TAPS; ++t) load_tap(t, av[t], bv[t]);
@@ -482,8 +538,7 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (i + ring < my_stages && !(a.dbg & 2)) issue(wave + (i + ring) * NW, buf);   // refill the buffer just consumed
-        buf = buf + 1 == ring ? 0 : buf + 1;
+        if (i + 1 < my_stages && !(a.dbg & 2)) issue(wave + (i + 1) * NW, 0);          // refill the buffer just consumed
     }
 
     // ---- cross-wave reduction (fixed order -> deterministic), then the shared epilogue
@@ -621,7 +676,7 @@ size_t lds_bytes(const ConvArgs& a, const Cfg& c) {
     const size_t ck = a.ks == 1 ? 32 : kConvCK;
     if (c.family == 0) return sizeof(float) * (2 * (size_t)taps * ck * TC + 2 * ck * a.PSTR + tab);
     const size_t stage = (size_t)taps * 4 * TC + 4 * (size_t)a.PSTR;
-    const size_t staging = kSplitWaves * (size_t)a.ring * stage + tab, red = (size_t)kSplitWaves * c.tps * c.tcs * 256;
+    const size_t staging = kSplitWaves * stage + tab, red = (size_t)kSplitWaves * c.tps * c.tcs * 256;
     return sizeof(float) * (staging > red ? staging : red);
 }
 
