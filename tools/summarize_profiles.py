@@ -53,8 +53,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         n = r["Kernel_Name"].split("(")[0].replace("void ", "")
         per_kernel[n][0] += float(r["Counter_Value"])
         per_kernel[n][1] += 1
-    big = [k for k in per_kernel if "conv_mfma_f32<true, 3, 1, 14, 4, 2, 2>" in k]
-    n_forwards = per_kernel[big[0]][1] // 5 if big else 1          # that instantiation runs 5x per forward
+    conv_launches_total = sum(v[1] for k, v in per_kernel.items() if "conv_" in k)
+    n_forwards = max(1, round(conv_launches_total / 316))     # every forward / conv-only timing pass has 316 conv launches
     conv_kb = sum(v[0] for k, v in per_kernel.items() if "conv_" in k)
     conv_launches = sum(v[1] for k, v in per_kernel.items() if "conv_" in k)
     all_kb = sum(v[0] for v in per_kernel.values())
