@@ -45,25 +45,43 @@ __device__ __forceinline__ void stage16(const float* src, float* lds_wave_base, 
 
 // Epilogue shared by both kernel families: + bias, + addends (optionally nearest-upsampled), ReLU,
 // 16-byte store when the 4 pixels of the lane are contiguous and aligned in the NCHW plane.
-struct EpiCtx { int y0, g0, HoWo, RW, qlimit; bool vec_ok; };
+__device__ __forceinline__ int floor4(int v) { return v & ~3; }   // two's complement: floors negatives too
+// q / d for 0 <= q < 2^20, 0 < d < 2^20 through one fp32 reciprocal-multiply (exact: the +0.5 keeps the quotient of an
+// exact multiple away from the rounding edge); an integer division by a run-time value costs ~20 VALU instructions
+__device__ __forceinline__ int fdiv(int q, float inv_d) { return (int)(((float)q + 0.5f) * inv_d); }
+
+struct EpiCtx { int y0, g0, HoWo, RW, qlimit; float inv_RW, inv_Wo; bool vec_ok, pre0; };
 __device__ __forceinline__ EpiCtx make_epi_ctx(const ConvArgs& a, int y0, int g0) {
     EpiCtx e;
     e.y0 = y0; e.g0 = g0; e.HoWo = a.Ho * a.Wo; e.RW = a.R * a.Wo; e.qlimit = a.G * e.RW;
+    e.inv_RW = 1.0f / (float)e.RW; e.inv_Wo = 1.0f / (float)a.Wo;
     e.vec_ok = (e.RW % 4 == 0) && (e.HoWo % 4 == 0) && ((y0 * a.Wo) % 4 == 0);
+    e.pre0 = e.vec_ok && a.n_add >= 1 && a.add_shift[0] == 0;     // addend 0 (the residual) can be fetched before the main loop
     return e;
 }
-__device__ __forceinline__ void store_tile(const ConvArgs& a, const EpiCtx& e, f32x4 v, int q, int co) {
+// The residual / identity addend of a tile, loaded at kernel start so its HBM latency is hidden under the main loop.
+__device__ __forceinline__ f32x4 prefetch_add0(const ConvArgs& a, const EpiCtx& e, int q, int co) {
+    f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!e.pre0 || co >= a.Cout || q >= e.qlimit) return z;
+    const int gl = fdiv(q, e.inv_RW), rem = q - gl * e.RW;
+    const int img = e.g0 + gl, pix = e.y0 * a.Wo + rem;
+    if (img >= a.N || pix >= e.HoWo) return z;
+    return *reinterpret_cast<const f32x4*>(a.add[0] + ((size_t)img * a.add_ctot[0] + a.add_coff[0] + co) * e.HoWo + pix);
+}
+__device__ __forceinline__ void store_tile(const ConvArgs& a, const EpiCtx& e, f32x4 v, int q, int co, f32x4 pre) {
     if (co >= a.Cout) return;
     const float bias = a.bias[co];
     if (e.vec_ok) {
         if (q >= e.qlimit) return;
-        const int gl = q / e.RW, rem = q - gl * e.RW;
+        const int gl = fdiv(q, e.inv_RW), rem = q - gl * e.RW;
         const int img = e.g0 + gl, pix = e.y0 * a.Wo + rem;
         if (img >= a.N || pix >= e.HoWo) return;
         v += bias;
+        if (e.pre0) v += pre;
 #pragma unroll
         for (int k = 0; k < kMaxAdd; ++k) {                  // static indices: ConvArgs may live in registers
             if (k >= a.n_add) break;
+            if (k == 0 && e.pre0) continue;
             const int sh = a.add_shift[k];
             if (sh == 0) {
                 const float* ap = a.add[k] + ((size_t)img * a.add_ctot[k] + a.add_coff[k] + co) * e.HoWo + pix;
@@ -73,7 +91,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const EpiCtx& e, f
                 const float* ap = a.add[k] + ((size_t)img * a.add_ctot[k] + a.add_coff[k] + co) * (hs * ws);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int y = (pix + r) / a.Wo, x = (pix + r) - y * a.Wo;
+                    const int y = fdiv(pix + r, e.inv_Wo), x = (pix + r) - y * a.Wo;
                     v[r] += ap[(y >> sh) * ws + (x >> sh)];
                 }
             }
@@ -89,7 +107,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const EpiCtx& e, f
         for (int r = 0; r < 4; ++r) {
             const int qq = q + r;
             if (qq >= e.qlimit) continue;
-            const int gl = qq / e.RW, rem = qq - gl * e.RW;
+            const int gl = fdiv(qq, e.inv_RW), rem = qq - gl * e.RW;
             const int img = e.g0 + gl, pix = e.y0 * a.Wo + rem;
             if (img >= a.N || pix >= e.HoWo) continue;
             float o = v[r] + bias;
@@ -98,7 +116,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const EpiCtx& e, f
                 if (k >= a.n_add) break;
                 const int sh = a.add_shift[k];
                 const int hs = a.Ho >> sh, ws = a.Wo >> sh;
-                const int y = pix / a.Wo, x = pix - y * a.Wo;
+                const int y = fdiv(pix, e.inv_Wo), x = pix - y * a.Wo;
                 o += a.add[k][((size_t)img * a.add_ctot[k] + a.add_coff[k] + co) * (hs * ws) + (y >> sh) * ws + (x >> sh)];
             }
             if (a.relu) o = fmaxf(o, 0.f);
@@ -114,10 +132,6 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const EpiCtx& e, f
 // zero block, and the left/right zero padding is applied when the A operand is read (lanes whose tap
 // falls outside the row select 0).  Otherwise (multi-image tiles of the 7x7 maps): a zero-padded patch
 // [G][Rin][Wp] gathered float by float through the source-offset table.
-__device__ __forceinline__ int floor4(int v) { return v & ~3; }   // two's complement: floors negatives too
-// q / d for 0 <= q < 2^20, 0 < d < 2^20 through one fp32 reciprocal-multiply (exact: the +0.5 keeps the quotient of an
-// exact multiple away from the rounding edge); an integer division by a run-time value costs ~20 VALU instructions
-__device__ __forceinline__ int fdiv(int q, float inv_d) { return (int)(((float)q + 0.5f) * inv_d); }
 
 // CK = input channels per K-chunk: 8 for 3x3 (72 k-steps of 4 per chunk ... 18 MFMA steps), 32 for 1x1 convolutions,
 // whose chunks would otherwise hold only 2 MFMA steps between barriers and run latency-bound.
@@ -230,6 +244,13 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
 
     const int nchunks = a.CinPad / CK;
     issue(0, 0);                                          // first chunk in flight while the lane offsets are computed
+    const EpiCtx ec = make_epi_ctx(a, y0, g0);
+    f32x4 pre[PSW][CSW];
+#pragma unroll
+    for (int ps = 0; ps < PSW; ++ps)
+#pragma unroll
+        for (int cs = 0; cs < CSW; ++cs)
+            pre[ps][cs] = prefetch_add0(a, ec, (wp * PSW + ps) * 16 + lq * 4, co0 + (wc * CSW + cs) * 16 + l15);
     // A operand: lane holds pixel (lane&15) of its sub-tile, channel (lane>>4) of the k-group.
     int abase[PSW];
     unsigned lmask = 0, rmask = 0;                         // ROWS: sub-tiles whose pixel sits on the left / right image edge
@@ -303,12 +324,11 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
     }
 
     // ---- epilogue.  D: column (lane&15) = cout, rows (lane>>4)*4 + r = 4 consecutive pixels.
-    const EpiCtx ec = make_epi_ctx(a, y0, g0);
 #pragma unroll
     for (int cs = 0; cs < CSW; ++cs) {
         const int co = co0 + (wc * CSW + cs) * 16 + l15;
 #pragma unroll
-        for (int ps = 0; ps < PSW; ++ps) store_tile(a, ec, acc[ps][cs], (wp * PSW + ps) * 16 + lq * 4, co);
+        for (int ps = 0; ps < PSW; ++ps) store_tile(a, ec, acc[ps][cs], (wp * PSW + ps) * 16 + lq * 4, co, pre[ps][cs]);
     }
 }
 
@@ -450,6 +470,14 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
     const int ngroups = a.CinPad / 4;
     const int my_stages = ngroups > wave ? (ngroups - wave + NW - 1) / NW : 0;
     if (my_stages > 0) issue(wave, 0);
+    const EpiCtx ec = make_epi_ctx(a, y0, g0);
+    constexpr int MAXT = (NT + NW - 1) / NW;                 // output tiles this wave finishes after the reduction
+    f32x4 pre[MAXT];
+#pragma unroll
+    for (int i2 = 0; i2 < MAXT; ++i2) {
+        const int t = wave + i2 * NW, ps = t / CSW, cs = t - ps * CSW;
+        pre[i2] = t < NT ? prefetch_add0(a, ec, ps * 16 + lq * 4, co0 + cs * 16 + l15) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     // (the first stages are in flight while the lane offsets and edge masks are computed)
     int abase[PSW];
     unsigned lmask = 0, rmask = 0;
@@ -549,14 +577,16 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
 #pragma unroll
         for (int cs = 0; cs < CSW; ++cs) red[(wave * NT + ps * CSW + cs) * 64 + lane] = acc[ps][cs];
     __syncthreads();
-    const EpiCtx ec = make_epi_ctx(a, y0, g0);
     if (a.dbg & 4) return;
-    for (int t = wave; t < NT; t += NW) {
+#pragma unroll
+    for (int i2 = 0; i2 < MAXT; ++i2) {
+        const int t = wave + i2 * NW;
+        if (t >= NT) break;
         f32x4 v = red[t * 64 + lane];
 #pragma unroll
         for (int w = 1; w < NW; ++w) v += red[(w * NT + t) * 64 + lane];
         const int ps = t / CSW, cs = t - ps * CSW;
-        store_tile(a, ec, v, ps * 16 + lq * 4, co0 + cs * 16 + l15);
+        store_tile(a, ec, v, ps * 16 + lq * 4, co0 + cs * 16 + l15, pre[i2]);
     }
 }
 
