@@ -1,4 +1,7 @@
 """Per-layer timing of the conv kernels with phase ablation (timing only, outputs are wrong when dbg != 0).
+The ablation bits (dbg 1: no MFMAs, 2: no re-staging, 4: no epilogue) only act in a diagnostic build of the library:
+    make -C video-based-gait-analysis-for-dementia_amd/csrc clean all ABLATION=1
+In the product build every dbg value times the full kernel.
 usage: python tools/conv_micro.py [cin,cout,k,s,h,hint ...]"""
 import importlib, os, sys
 import numpy as np, torch

@@ -22,6 +22,14 @@
 namespace grk {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Phase-ablation switches of tools/conv_micro.py (skip MFMAs / re-staging / epilogue to see what a launch spends where).
+// They exist only in a diagnostic build (make ABLATION=1); in the product build the conditions fold to false.
+#ifdef GRNET_ABLATION
+#define GRK_DBG(a, bit) (((a).dbg & (bit)) != 0)
+#else
+#define GRK_DBG(a, bit) false
+#endif
 #define GRNET_GLOBAL_AS __attribute__((address_space(1)))
 #define GRNET_LDS_AS __attribute__((address_space(3)))
 
@@ -522,7 +530,7 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
     for (int cs = 0; cs < CSW; ++cs) brow[cs] = mine + bbase[cs];
     for (int i = 0; i < my_stages; ++i) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's stage has landed
-        if (!(a.dbg & 1)) {
+        if (!GRK_DBG(a, 1)) {
             // software pipeline over the filter taps: the LDS reads of tap t+1 are in flight under the
             // MFMAs of tap t (one exposed LDS latency per stage instead of one per tap)
             // LD = taps prefetched ahead: 2 when a tap is only 4 MFMAs (128 cycles < LDS latency), else 1
@@ -566,7 +574,7 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (i + 1 < my_stages && !(a.dbg & 2)) issue(wave + (i + 1) * NW, 0);          // refill the buffer just consumed
+        if (i + 1 < my_stages && !GRK_DBG(a, 2)) issue(wave + (i + 1) * NW, 0);          // refill the buffer just consumed
     }
 
     // ---- cross-wave reduction (fixed order -> deterministic), then the shared epilogue
@@ -577,7 +585,7 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
 #pragma unroll
         for (int cs = 0; cs < CSW; ++cs) red[(wave * NT + ps * CSW + cs) * 64 + lane] = acc[ps][cs];
     __syncthreads();
-    if (a.dbg & 4) return;
+    if (GRK_DBG(a, 4)) return;
 #pragma unroll
     for (int i2 = 0; i2 < MAXT; ++i2) {
         const int t = wave + i2 * NW;
