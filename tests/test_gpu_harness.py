@@ -101,3 +101,26 @@ def test_smooth_pose_row_f3(pkg, oracle, synth_smpl):
     _, _, k25 = pipe.smooth_pose(m, pose, betas, kinectv2=True)
     assert k25.shape == (T, 25, 3)
     m.close()
+
+
+def test_clip_runner_sequence_feeds_gru(pkg, oracle):
+    """The reassembled per-frame records (what the all-gather delivers) are the GRU's input: point_local_feat
+    (T,128,24) -> (1,T,3072) in the c*24+j layout of grnet.py:163, cparams from the predicted camera."""
+    h = pkg.harness
+    m = pkg.build_synthetic_model(max_frames=12, with_gru=True)
+    frames = torch.from_numpy(pkg.synth.make_frames(12)).cuda()
+    runner = h.ClipRunner(m, frames, use_graph=True, tune_level=0)
+    runner.step()
+    runner.step()                                             # second step replays the captured graph
+    torch.cuda.synchronize()
+    seq = runner.sequence()
+    assert seq["theta"].shape == (12, 85) and seq["kp_3d"].shape == (12, 29, 3) and seq["point_local_feat"].shape == (12, 128, 24)
+    direct = m(frames, extras=("point_local_feat",))[-1]
+    assert rel_err(seq["theta"].cpu().numpy(), direct["theta"][0].cpu().numpy()) < 2e-5
+    assert rel_err(seq["point_local_feat"].cpu().numpy(), direct["point_local_feat"].cpu().numpy()) < 2e-5
+    x = seq["point_local_feat"].reshape(1, 12, 3072).contiguous()
+    cp = seq["theta"][:, :3].reshape(1, 12, 3).contiguous()
+    y, phase, _ = m.gru_forward(x, cp)
+    ry, rph, _ = oracle.gru_forward(x.cpu().numpy(), cp.cpu().numpy(), pkg.synth.make_gru_state_dict())
+    assert rel_err(y.cpu().numpy(), ry) < 1e-4 and rel_err(phase.cpu().numpy(), rph) < 1e-4
+    m.close()
