@@ -13,7 +13,9 @@ results (theta, kp_3d, kp_2d, point_local_feat = the GRU input).  Weak scaling.
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel family (conv_mfma_f32, the fp32
 MFMA implicit-GEMM convolution): algorithmic FLOPs of all conv launches of a step / their summed
 duration, measured live with HIP events on the launch stream.  `cpu_baseline` times the oracle (a
-port of the reference's CPU path; the reference itself cannot travel to the GPU box) on the host cores.
+port of the reference's CPU path; the reference itself cannot travel to the GPU box) on the host cores;
+`parity` is BASELINE.json's second metric (MPJPE / max relative error of the GPU outputs vs that oracle
+on the same 16 frames).
 """
 import argparse
 import importlib
@@ -34,7 +36,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA = vect
 
 def cpu_baseline(pkg, frames_np, budget_s=20.0):
     """The oracle (port of the reference's CPU path) on the host cores, bounded sample.  oneDNN oversubscribes badly on
-    a 128-thread host for 16-frame batches, so the thread count is probed first and the fastest one is used and reported."""
+    a 128-thread host for 16-frame batches, so the thread count is probed first and the fastest one is used and reported.
+    Returns (cpu_baseline object, the oracle's outputs for `frames_np` -- the checker for the `parity` object)."""
     oracle = importlib.import_module("oracle.grnet_oracle")
     sd, smpl = pkg.synth.make_state_dict(), pkg.synth.make_smpl_tables()
     oracle.grnet_forward(frames_np[:2], sd, smpl)           # warm-up (oneDNN primitive caches)
@@ -53,14 +56,27 @@ def cpu_baseline(pkg, frames_np, budget_s=20.0):
     t_all, passes = 0.0, 0
     while t_all < budget_s and passes < 12:
         t0 = time.perf_counter()
-        oracle.grnet_forward(frames_np, sd, smpl)
+        ref = oracle.grnet_forward(frames_np, sd, smpl)
         t_all += time.perf_counter() - t0
         passes += 1
     torch.set_num_threads(all_threads)
     n = frames_np.shape[0] * passes
     return {"value": round(n / t_all, 3), "unit": "frames/s", "cores": best_t, "kind": "port",
             "sample": f"{passes} passes of the oracle (torch-CPU oneDNN convs + numpy tail) over the same {frames_np.shape[0]} frames, "
-                      f"fp32, {best_t} threads (fastest of a probe over 8..{all_threads})"}
+                      f"fp32, {best_t} threads (fastest of a probe over 8..{all_threads})"}, ref
+
+
+def parity_vs_oracle(got, ref):
+    """BASELINE.json's second metric: MPJPE of kp_3d and max relative error (max|a-b| / max|b| per tensor, the 1e-3 bar of
+    the north star) of the GPU path's outputs against the CPU oracle on the same frames."""
+    rel = {}
+    for k in ("theta", "kp_3d", "kp_2d", "verts", "rotmat"):
+        a, b = np.asarray(got[k], np.float64), np.asarray(ref[k], np.float64).reshape(got[k].shape)
+        rel[k] = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    d = np.asarray(got["kp_3d"], np.float64) - np.asarray(ref["kp_3d"], np.float64).reshape(got["kp_3d"].shape)
+    return {"mpjpe_m": float(np.linalg.norm(d, axis=-1).mean()), "max_rel_err": {k: float(f"{v:.3e}") for k, v in rel.items()},
+            "tolerance": 1e-3, "ok": bool(max(rel.values()) < 1e-3),
+            "vs": "oracle (CPU port of the reference path) on the same frames and weights"}
 
 
 def main():
@@ -190,7 +206,12 @@ def main():
                          "conv_gflop_per_step": round(conv_flops / 1e9, 3)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(pkg, frames_np)
+            line["cpu_baseline"], ref = cpu_baseline(pkg, frames_np)
+            runner.step()
+            torch.cuda.synchronize()
+            got = {k: v.cpu().numpy() for k, v in runner.sequence().items() if k != "point_local_feat"}
+            got.update(verts=runner.verts.cpu().numpy(), rotmat=runner.rotmat.cpu().numpy())
+            line["parity"] = parity_vs_oracle(got, ref)
         print(json.dumps(line), flush=True)
     model.close()
     if dist is not None:
