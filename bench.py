@@ -168,12 +168,15 @@ def main():
     conv_ms_serial = min(model.time_convs(n) for _ in range(3))
     model.set_option(pkg._lib.OPT_MULTI_LANE, 1)
     n_conv = model.num_conv_launches()                         # 316: the reference's 317 convolutions, two of them merged
-    traffic = None
+    traffic = traffic_cal = alg_bytes = None
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            traffic = json.load(f).get("hbm_bytes_per_step_conv_kernels")
+            tj = json.load(f)
+        traffic, traffic_cal = tj.get("hbm_bytes_per_step_conv_kernels"), tj.get("hbm_bytes_per_step_conv_kernels_calibrated")
+        alg_bytes = tj.get("algorithmic_bytes_per_step_conv_kernels")
     except OSError:
         pass
+    at_cfg = n == FRAMES_PER_GPU
 
     tm = model.tuned_mode(n) or {}
     eager = args.no_graph or tm.get("eager", False)
@@ -195,9 +198,13 @@ def main():
                        "exchange": "none (1 GPU)" if world == 1 else "RCCL all-gather of per-frame pose results"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                         "traffic": traffic if (n == FRAMES_PER_GPU and traffic) else None,
+                         "traffic": traffic if (at_cfg and traffic) else None,
                          "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                                            "FETCH x2 gfx950 correction), bytes of all conv launches of one step",
+                         "traffic_calibrated": traffic_cal if at_cfg else None,
+                         "algorithmic_bytes": alg_bytes if at_cfg else None,
+                         "traffic_note": "x2 is exact only for long 16 B/lane streams; on the conv kernels' row staging the counter reads "
+                                         "bytes x (1/2 + 128 B / staged segment) (profiles/r01_fetch_calibration.json), hence traffic_calibrated",
                          "kernel": "conv_mfma_f32 + conv_splitk_f32 (fp32 MFMA implicit-GEMM convolution, all launches of a step)",
                          "conv_launches_per_step": n_conv, "conv_ms_per_step": round(conv_ms, 4),
                          "conv_ms_per_step_serial": round(conv_ms_serial, 4),

@@ -106,6 +106,11 @@ int grnet_set_tuning(grnet_t* h, int n_frames, const char* text);
 int grnet_num_kernel_launches(grnet_t* h);      /* launches enqueued by one grnet_forward */
 int grnet_num_conv_launches(grnet_t* h);        /* convolution launches of one grnet_forward */
 double grnet_conv_flops_per_frame(grnet_t* h);  /* 2 * MACs of all convolutions on the path */
+/* The pos-th convolution launch of one forward in the un-grouped launch order (the dispatch order of a
+ * GRNET_OPT_MULTI_LANE=0, un-tuned run -- what tools/layer_table.py joins per-dispatch profiler rows on):
+ * info[0..11] = Cin, Cout, kernel, stride, Hin, Win, Hout, Wout, fused addends, relu, lane, addend elements per
+ * frame; name = state_dict key of its weight (hrnet.py / pare.py module path).  Returns 0 or GRNET_EINVAL. */
+int grnet_describe_conv(grnet_t* h, int pos, int32_t* info /* 12 */, char* name, int name_size);
 /* Re-enqueue ONLY the convolution launches of the last forward, bracketed by HIP events on
  * `stream`; returns elapsed ms in *ms_out (synchronises the stream). */
 int grnet_time_convs(grnet_t* h, int n_frames, void* stream, float* ms_out);

@@ -264,3 +264,16 @@ def test_crop_normalise_kernel(model, oracle):
     bgr = model.crop_normalise(torch.from_numpy(imgs[:1, :, :, ::-1].copy()).cuda(), torch.from_numpy(boxes[:1]), scale=1.1,
                                bgr=True).cpu().numpy()
     assert np.array_equal(bgr[0], got[0])
+
+
+def test_describe_convs_matches_survey_counts(pkg):
+    """grnet_describe_conv lists the 316 convolution launches (317 convolutions, the two 480->128 PARE
+    branch heads merged into one 480->256 launch) and their MACs add up to SURVEY 8(d)'s 15 441 563 648 per frame."""
+    m = pkg.build_synthetic_model(max_frames=2, with_gru=False)
+    convs = m.describe_convs()
+    assert len(convs) == m.num_conv_launches() == 316
+    macs = sum(c["cout"] * c["hout"] * c["wout"] * c["cin"] * c["ks"] ** 2 for c in convs)
+    assert macs == 15441563648 and 2.0 * macs == m.conv_flops_per_frame()
+    assert convs[0]["name"] == "backbone.conv1.weight" and (convs[0]["cin"], convs[0]["cout"], convs[0]["stride"], convs[0]["hin"]) == (3, 64, 2, 224)
+    assert sum(c["name"].startswith("head.") for c in convs) == 5
+    m.close()

@@ -69,5 +69,11 @@ if out:
         out["correction"] = "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B for 16 B/lane streaming reads), WRITE_SIZE x1"
         out["note"] = ("memory-side (fabric) requests of the L2: Infinity-Cache hits are counted, so this is an upper bound on HBM "
                        "bytes; the 16-frame working set (~1.7 GB of activations) does not fit the 256 MiB cache")
+    lt = os.path.join(dst, f"{rnd}_layer_traffic.json")          # tools/layer_table.py: the same counters joined per launch + calibration
+    if os.path.isfile(lt):
+        t = json.load(open(lt))
+        out["algorithmic_bytes_per_step_conv_kernels"] = t["algorithmic_read_bytes"] + t["algorithmic_write_bytes"]
+        out["hbm_bytes_per_step_conv_kernels_calibrated"] = t["fetch_calibrated_bytes"] + t["write_size_bytes"]
+        out["calibration"] = t["calibration"] + f" (profiles/{rnd}_fetch_calibration.json, profiles/{rnd}_layer_table.md)"
     json.dump(out, open(os.path.join(dst, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if not isinstance(v, dict)}, indent=1))

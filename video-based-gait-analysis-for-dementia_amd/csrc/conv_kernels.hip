@@ -54,6 +54,30 @@ __device__ __forceinline__ void stage16(const float* src, float* lds_wave_base, 
 // Epilogue shared by both kernel families: + bias, + addends (optionally nearest-upsampled), ReLU,
 // 16-byte store when the 4 pixels of the lane are contiguous and aligned in the NCHW plane.
 __device__ __forceinline__ int floor4(int v) { return v & ~3; }   // two's complement: floors negatives too
+
+// Block -> (pixel tile bx, output-channel block by) of the 1-D grid.  Workgroups go to the 8 XCDs round-robin in
+// dispatch order and every XCD has its own 4 MB L2, so the gy channel blocks that read the SAME input tile are
+// made consecutive blocks of ONE XCD (ids congruent mod 8): they are co-resident, stream the tile's channels in
+// step and the second..gy-th read of every line hits that L2 instead of the fabric (measured, tools/fetch_calib.py:
+// plain (tile, block) order re-fetches the 480-channel head input once per channel block).  The tiles of an XCD
+// are a contiguous range, so the halo rows two neighbouring row tiles both read are fetched once as well.  The placement is a
+// speed heuristic only -- no correctness depends on it.  Tiles past gx (grid rounded up to 8) exit at once.
+__device__ __forceinline__ bool xcd_block(const ConvArgs& a, int& bx, int& by) {
+    const int id = blockIdx.x;
+    if (!a.xcd) { by = id / a.gx; bx = id - by * a.gx; return true; }
+    const int j = id >> 3;
+    if (a.xcd == 2) {                  // weights larger than the input (7x7 maps): an XCD owns channel blocks instead, so
+        const int gyp = a.gy >> 3;     // every weight slab is fetched by one L2 only (gy is a multiple of 8 here)
+        bx = j / gyp;
+        by = (j - bx * gyp) * 8 + (id & 7);
+        return true;
+    }
+    const int q = j / a.gy;
+    by = j - q * a.gy;
+    const int x = id & 7, first = (x * a.gx) >> 3;      // an XCD owns a contiguous, balanced range of tiles: vertically
+    bx = first + q;                                      // adjacent tiles share their halo rows in its L2
+    return bx < (((x + 1) * a.gx) >> 3);
+}
 // q / d for 0 <= q < 2^20, 0 < d < 2^20 through one fp32 reciprocal-multiply (exact: the +0.5 keeps the quotient of an
 // exact multiple away from the rounding edge); an integer division by a run-time value costs ~20 VALU instructions
 __device__ __forceinline__ int fdiv(int q, float inv_d) { return (int)(((float)q + 0.5f) * inv_d); }
@@ -160,8 +184,10 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
     const int wp = wave / WC, wc = wave % WC;
     const int l15 = lane & 15, lq = lane >> 4;
 
-    const int ty = blockIdx.x % a.tiles_y, grp = blockIdx.x / a.tiles_y;
-    const int y0 = ty * a.R, g0 = grp * a.G, co0 = blockIdx.y * TC;
+    int bx, by;
+    if (!xcd_block(a, bx, by)) return;
+    const int ty = bx % a.tiles_y, grp = bx / a.tiles_y;
+    const int y0 = ty * a.R, g0 = grp * a.G, co0 = by * TC;
     const int HW = a.H * a.W, RW = a.R * a.Wo, RinWp = a.Rin * a.Wp;
     constexpr int pad = KS / 2;
     const float* inb = a.in + ((size_t)g0 * a.in_ctot + a.in_coff) * HW;
@@ -601,7 +627,9 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
 template <int MODE, int KS, int S, int PSW, int CSW, int NW>
 __global__ __launch_bounds__(NW * 64) void conv_splitk_f32(const ConvArgs a) {
     extern __shared__ __align__(16) float smem[];
-    splitk_body<MODE, KS, S, PSW, CSW, NW>(a, blockIdx.x, blockIdx.y, smem);
+    int bx, by;
+    if (!xcd_block(a, bx, by)) return;
+    splitk_body<MODE, KS, S, PSW, CSW, NW>(a, bx, by, smem);
 }
 
 // Grouped launch: up to kMaxGroup independent convolutions (the same-depth convolutions of the
@@ -771,8 +799,17 @@ hipError_t init_ks() {
 }
 
 template <bool ROWS, int KS, int S>
-hipError_t dispatch(const ConvArgs& a, const Cfg& c, size_t lds, hipStream_t s) {
-    const dim3 grid(a.tiles_y * a.groups, a.CoutPad / (c.tcs * 16));
+hipError_t dispatch(const ConvArgs& a_in, const Cfg& c, size_t lds, hipStream_t s) {
+    ConvArgs a = a_in;
+    a.gx = a.tiles_y * a.groups;
+    a.gy = a.CoutPad / (c.tcs * 16);
+    static const int xcd_env = getenv("GRNET_XCD_ORDER") ? atoi(getenv("GRNET_XCD_ORDER")) : 3;   // A/B runs: 0 plain (tile, block) order, 1 tile-major only
+    const double in_bytes = 4.0 * a.N * a.Cin * a.H * a.W, w_bytes = 4.0 * a.ks * a.ks * a.Cin * a.Cout;
+    a.gx8 = (a.gx + 7) / 8;
+    a.xcd = 0;
+    if ((xcd_env & 2) && a.gy % 8 == 0 && w_bytes > in_bytes) a.xcd = 2;
+    else if ((xcd_env & 1) && (a.gy > 1 || a.ks > 1) && a.gx >= 16) a.xcd = 1;
+    const dim3 grid((a.xcd == 1 ? a.gx8 * 8 : a.gx) * a.gy);
     if (a.rows == 2) {
         if (c.family == 1 && c.tps == 4 && c.tcs == 1) return launch_k(conv_splitk_f32<2, KS, S, 4, 1, kSplitWaves>, grid, dim3(kSplitWaves * 64), lds, s, a);
         if (c.family == 1 && c.tps == 4 && c.tcs == 2) return launch_k(conv_splitk_f32<2, KS, S, 4, 2, kSplitWaves>, grid, dim3(kSplitWaves * 64), lds, s, a);

@@ -1148,6 +1148,24 @@ double grnet_conv_flops_per_frame(grnet_t* h) {
     return 2.0 * m;
 }
 
+int grnet_describe_conv(grnet_t* h, int pos, int32_t* info, char* name, int name_size) {
+    if (!h || !info || !h->finalized || pos < 0) return GRNET_EINVAL;
+    int seen = 0;
+    for (const Op& op : h->ops_flat) {
+        if (op.kind != Op::CONV) continue;
+        if (seen++ != pos) continue;
+        const ConvLayer& L = h->convs[op.conv_idx];
+        int64_t add_elems = 0;
+        for (const AddRef& r : L.adds) add_elems += (int64_t)L.cout * (L.out.h >> r.shift) * (L.out.w >> r.shift);
+        const int32_t v[12] = {L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, L.out.h, L.out.w, (int32_t)L.adds.size(), L.relu,
+                               op.lane, (int32_t)add_elems};
+        memcpy(info, v, sizeof(v));
+        if (name && name_size > 0) snprintf(name, name_size, "%s", L.segs.empty() ? "" : L.segs[0].wkey.c_str());
+        return 0;
+    }
+    return GRNET_EINVAL;
+}
+
 int grnet_time_convs(grnet_t* h, int n_frames, void* stream, float* ms_out) {
     if (!h || !ms_out || !h->finalized) return GRNET_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);

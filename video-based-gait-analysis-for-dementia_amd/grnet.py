@@ -235,6 +235,19 @@ class GRNet:
     def conv_flops_per_frame(self):
         return self._lib.grnet_conv_flops_per_frame(self._h)
 
+    def describe_convs(self):
+        """The convolution launches of one forward in un-grouped launch order: list of dicts (shape, fused addends, weight key)."""
+        self.finalize()
+        keys = ("cin", "cout", "ks", "stride", "hin", "win", "hout", "wout", "n_add", "relu", "lane", "add_elems")
+        out = []
+        for pos in range(self.num_conv_launches()):
+            info, name = (C.c_int32 * 12)(), C.create_string_buffer(160)
+            _lib.check(self._lib, self._h, self._lib.grnet_describe_conv(self._h, pos, info, name, 160), "grnet_describe_conv")
+            d = dict(zip(keys, list(info)))
+            d["name"] = name.value.decode()
+            out.append(d)
+        return out
+
     def time_convs(self, n_frames):
         ms = C.c_float()
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
