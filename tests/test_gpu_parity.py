@@ -38,11 +38,11 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
-@pytest.mark.parametrize("tile", [7, 14, 1071, 1072, 1041, 1042])   # whole-K tiles and split-K (psw, csw) variants
+@pytest.mark.parametrize("tile", [7, 14, 1071, 1072, 1041, 1042, 1171, 1141])   # whole-K tiles, split-K (psw, csw) variants, 8-wave split-K
 def test_conv_kernel(model, oracle, case, tile):
     cin, cout, k, stride, h = case
     wo = (h + 2 * (k // 2) - k) // stride + 1
-    if tile in (1041, 1042) and wo > 64:
+    if tile in (1041, 1042, 1141) and wo > 64:
         pytest.skip("a 64-pixel tile cannot hold one output row")
     if tile == 1072 and stride == 2 and h >= 112:
         pytest.skip("split-K staging ring of this tile exceeds the 160 KB LDS")

@@ -398,9 +398,10 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
     constexpr int TC = CSW * 16, TAPS = KS * KS, WFL = TAPS * 4 * TC, NT = PSW * CSW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
-    const int stage_floats = WFL + 4 * a.PSTR;           // [weights TAPS*4 x TC | input 4 x PSTR], ONE stage per wave:
-    int* tab = reinterpret_cast<int*>(smem + NW * stage_floats);   // the co-resident workgroups hide the DMA, and a fixed
-    float* mine = smem + wave * stage_floats;                        // buffer makes every LDS address loop-invariant
+    const int stage_floats = WFL + 4 * a.PSTR;           // [weights TAPS*4 x TC | input 4 x PSTR]; a.ring stages per wave:
+    const bool db = a.ring == 2;                          // 1: the co-resident workgroups hide the DMA (more of them fit);
+    int* tab = reinterpret_cast<int*>(smem + NW * a.ring * stage_floats);   // 2: launches with about one workgroup per CU
+    float* mine = smem + wave * a.ring * stage_floats;                       // overlap their own next stage with the MFMAs
 
     const int ty = bx % a.tiles_y, grp = bx / a.tiles_y;
     const int y0 = ty * a.R, g0 = grp * a.G, co0 = by * TC;
@@ -447,9 +448,9 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
         }
     }
 
-    auto issue = [&](int grp4, int) {
+    auto issue = [&](int grp4, int boff) {
         const int c0 = grp4 * 4;
-        float* dst = mine;
+        float* dst = mine + boff;
         const float* wsrc = a.w + (size_t)c0 * a.CoutPad;
 #pragma unroll
         for (int it = 0; it < NWI; ++it)
@@ -554,8 +555,10 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
         for (int ky = 0; ky < KS; ++ky) arow[ps][ky] = mine + abase[ps] + ky * a.Wp;
 #pragma unroll
     for (int cs = 0; cs < CSW; ++cs) brow[cs] = mine + bbase[cs];
+    int boff = 0;                                              // float offset of the stage buffer being consumed
     for (int i = 0; i < my_stages; ++i) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's stage has landed
+        if (db && i + 1 < my_stages && !GRK_DBG(a, 2)) issue(wave + (i + 1) * NW, boff ^ stage_floats);   // next stage -> other buffer
         if (!GRK_DBG(a, 1)) {
             // software pipeline over the filter taps: the LDS reads of tap t+1 are in flight under the
             // MFMAs of tap t (one exposed LDS latency per stage instead of one per tap)
@@ -564,9 +567,9 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
             float av[LD + 1][PSW], bv[LD + 1][CSW];
             auto load_tap = [&](int tap, float* ar, float* br) {
 #pragma unroll
-                for (int cs = 0; cs < CSW; ++cs) br[cs] = brow[cs][tap * 4 * TC];
+                for (int cs = 0; cs < CSW; ++cs) br[cs] = (brow[cs] + boff)[tap * 4 * TC];
 #pragma unroll
-                for (int ps = 0; ps < PSW; ++ps) ar[ps] = arow[ps][tap / KS][tap % KS];
+                for (int ps = 0; ps < PSW; ++ps) ar[ps] = (arow[ps][tap / KS] + boff)[tap % KS];
             };
 #pragma unroll
             for (int t = 0; t < LD && t < TAPS; ++t) load_tap(t, av[t], bv[t]);
@@ -600,7 +603,8 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (i + 1 < my_stages && !GRK_DBG(a, 2)) issue(wave + (i + 1) * NW, 0);          // refill the buffer just consumed
+        if (!db && i + 1 < my_stages && !GRK_DBG(a, 2)) issue(wave + (i + 1) * NW, 0);   // refill the buffer just consumed
+        if (db) boff ^= stage_floats;
     }
 
     // ---- cross-wave reduction (fixed order -> deterministic), then the shared epilogue
@@ -723,17 +727,16 @@ void plan_tile(ConvArgs& a, int tps, int family) {
 
 // A launch configuration: family 0 = whole-K tiles with a workgroup barrier per chunk (conv_mfma_f32),
 // family 1 = split-K independent waves (conv_splitk_f32).
-struct Cfg { int family, tps, tcs; };
+struct Cfg { int family, tps, tcs; int nw = 4; };   // nw: split-K waves per workgroup (4, or 8 = two per SIMD for launches of about one workgroup per CU)
 
 // split-K DMA ring depth: as deep as ~48 KB of LDS per workgroup allows (2..4)
 void plan_ring(ConvArgs& a, const Cfg& c) {
     a.ring = 2;
     if (c.family != 1) return;
     const size_t stage_bytes = 4 * ((size_t)a.ks * a.ks * 4 * c.tcs * 16 + 4 * (size_t)a.PSTR);
-    static const int ring_cap = getenv("GRNET_RING_CAP") ? atoi(getenv("GRNET_RING_CAP")) : 1;   // measured: 1 (more workgroups per CU) beats 2..4
-    int r = (int)((48 * 1024) / (kSplitWaves * stage_bytes));
-    a.ring = r < 2 ? 2 : (r > ring_cap ? ring_cap : r);
-    if (ring_cap == 1) a.ring = 1;                            // single-buffered stages: the co-resident workgroups hide the DMA
+    static const int ring_env = getenv("GRNET_RING") ? atoi(getenv("GRNET_RING")) : 0;           // 1 / 2 force, 0 = rule below
+    (void)stage_bytes;
+    a.ring = ring_env ? (ring_env >= 2 ? 2 : 1) : 1;
 }
 
 size_t lds_bytes(const ConvArgs& a, const Cfg& c) {
@@ -742,7 +745,7 @@ size_t lds_bytes(const ConvArgs& a, const Cfg& c) {
     const size_t ck = a.ks == 1 ? 32 : kConvCK;
     if (c.family == 0) return sizeof(float) * (2 * (size_t)taps * ck * TC + 2 * ck * a.PSTR + tab);
     const size_t stage = (size_t)taps * 4 * TC + 4 * (size_t)a.PSTR;
-    const size_t staging = kSplitWaves * stage + tab, red = (size_t)kSplitWaves * c.tps * c.tcs * 256;
+    const size_t staging = c.nw * (a.ring == 2 ? 2 : 1) * stage + tab, red = (size_t)c.nw * c.tps * c.tcs * 256;
     return sizeof(float) * (staging > red ? staging : red);
 }
 
@@ -762,8 +765,8 @@ double cfg_cost(ConvArgs a, const Cfg& c, bool* ok) {
         waves = blocks * nw;
         chain = (double)kgroups * taps * 7 * (c.tps == 14 ? c.tcs / 2 : 1);
     } else {
-        waves = blocks * kSplitWaves;
-        chain = (double)((kgroups + kSplitWaves - 1) / kSplitWaves) * taps * c.tps * c.tcs;
+        waves = blocks * c.nw;
+        chain = (double)((kgroups + c.nw - 1) / c.nw) * taps * c.tps * c.tcs;
     }
     const double rounds = waves / 1024.0 < 1.0 ? 1.0 : waves / 1024.0;
     double cost = chain * rounds * (c.family == 1 ? 1.15 : 1.0) + 300.0;   // + fixed prologue/epilogue
@@ -791,9 +794,12 @@ hipError_t init_ks() {
     if ((e = set_lds(conv_splitk_f32<ROWS ? 1 : 0, KS, S, 7, 2, kSplitWaves>)) != hipSuccess) return e;
     if ((e = set_lds(conv_splitk_f32<ROWS ? 1 : 0, KS, S, 4, 1, kSplitWaves>)) != hipSuccess) return e;
     if ((e = set_lds(conv_splitk_f32<ROWS ? 1 : 0, KS, S, 4, 2, kSplitWaves>)) != hipSuccess) return e;
+    if ((e = set_lds(conv_splitk_f32<ROWS ? 1 : 0, KS, S, 7, 1, 8>)) != hipSuccess) return e;
+    if ((e = set_lds(conv_splitk_f32<ROWS ? 1 : 0, KS, S, 4, 1, 8>)) != hipSuccess) return e;
     if (!ROWS) {
         if ((e = set_lds(conv_splitk_f32<2, KS, S, 4, 1, kSplitWaves>)) != hipSuccess) return e;
         if ((e = set_lds(conv_splitk_f32<2, KS, S, 4, 2, kSplitWaves>)) != hipSuccess) return e;
+        if ((e = set_lds(conv_splitk_f32<2, KS, S, 4, 1, 8>)) != hipSuccess) return e;
     }
     return hipSuccess;
 }
@@ -811,6 +817,7 @@ hipError_t dispatch(const ConvArgs& a_in, const Cfg& c, size_t lds, hipStream_t 
     else if ((xcd_env & 1) && (a.gy > 1 || a.ks > 1) && a.gx >= 16) a.xcd = 1;
     const dim3 grid((a.xcd == 1 ? a.gx8 * 8 : a.gx) * a.gy);
     if (a.rows == 2) {
+        if (c.family == 1 && c.tps == 4 && c.tcs == 1 && c.nw == 8) return launch_k(conv_splitk_f32<2, KS, S, 4, 1, 8>, grid, dim3(512), lds, s, a);
         if (c.family == 1 && c.tps == 4 && c.tcs == 1) return launch_k(conv_splitk_f32<2, KS, S, 4, 1, kSplitWaves>, grid, dim3(kSplitWaves * 64), lds, s, a);
         if (c.family == 1 && c.tps == 4 && c.tcs == 2) return launch_k(conv_splitk_f32<2, KS, S, 4, 2, kSplitWaves>, grid, dim3(kSplitWaves * 64), lds, s, a);
         return hipErrorInvalidValue;
@@ -822,6 +829,8 @@ hipError_t dispatch(const ConvArgs& a_in, const Cfg& c, size_t lds, hipStream_t 
         if (c.tps == 7 && c.tcs == 4) GRK_LAUNCH((conv_mfma_f32<ROWS, KS, S, 7, 4, 1, 4>), 256);
         if (c.tps == 7 && c.tcs == 2) GRK_LAUNCH((conv_mfma_f32<ROWS, KS, S, 7, 2, 1, 2>), 128);
     } else {
+        if (c.tps == 7 && c.tcs == 1 && c.nw == 8) GRK_LAUNCH((conv_splitk_f32<ROWS ? 1 : 0, KS, S, 7, 1, 8>), 512);
+        if (c.tps == 4 && c.tcs == 1 && c.nw == 8) GRK_LAUNCH((conv_splitk_f32<ROWS ? 1 : 0, KS, S, 4, 1, 8>), 512);
         if (c.tps == 7 && c.tcs == 1) GRK_LAUNCH((conv_splitk_f32<ROWS ? 1 : 0, KS, S, 7, 1, kSplitWaves>), kSplitWaves * 64);
         if (c.tps == 7 && c.tcs == 2) GRK_LAUNCH((conv_splitk_f32<ROWS ? 1 : 0, KS, S, 7, 2, kSplitWaves>), kSplitWaves * 64);
         if (c.tps == 4 && c.tcs == 1) GRK_LAUNCH((conv_splitk_f32<ROWS ? 1 : 0, KS, S, 4, 1, kSplitWaves>), kSplitWaves * 64);
@@ -928,7 +937,7 @@ hipError_t launch_conv_group(const ConvArgs* list, int n, hipStream_t s) {
 const char* conv_dominant_kernel_name() { return "conv_mfma_f32 / conv_splitk_f32"; }
 
 // tile_hint: 0 = cost model; 7 / 14 = whole-K family with that pixel tile; 1000 + 10*psw + csw = split-K
-// family (1071, 1072, 1041, 1042).  Hints exist for the per-kernel parity tests and for tuning.
+// family (1071, 1072, 1041, 1042), + 100 = eight split-K waves per workgroup (1171, 1141).  Hints exist for the per-kernel parity tests and for tuning.
 hipError_t launch_conv(ConvArgs a, hipStream_t s, int tile_hint) {
     const int TCpack = conv_pick_tc(a.Cout);
     if (a.CoutPad % TCpack != 0 || a.CinPad % kConvCK != 0) return hipErrorInvalidValue;
@@ -941,8 +950,9 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s, int tile_hint) {
         cfg_cost(a, best, &found);
         if (!found && tile_hint == 14) { best.tps = 7; cfg_cost(a, best, &found); }
     } else if (tile_hint >= 1000) {
-        best = Cfg{1, (tile_hint - 1000) / 10, (tile_hint - 1000) % 10};
-        if (!((best.tps == 7 || best.tps == 4) && (best.tcs == 1 || best.tcs == 2))) return hipErrorInvalidValue;
+        const int code = tile_hint - 1000, wide = code >= 100;                   // 11xx: 8 split-K waves (csw 1 only)
+        best = Cfg{1, (code % 100) / 10, code % 10, wide ? 8 : 4};
+        if (!((best.tps == 7 || best.tps == 4) && (best.tcs == 1 || (best.tcs == 2 && !wide)))) return hipErrorInvalidValue;
         cfg_cost(a, best, &found);
     } else {
         const Cfg cands[] = {{0, 14, TCpack / 16}, {0, 7, TCpack / 16}, {1, 7, 2}, {1, 7, 1}, {1, 4, 2}, {1, 4, 1}};
@@ -953,6 +963,20 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s, int tile_hint) {
             bool ok;
             const double cost = cfg_cost(a, c, &ok);
             if (ok && (!found || cost < best_cost)) { best = c; best_cost = cost; found = true; }
+        }
+        // a split-K launch of at most ~2 workgroups per CU leaves each SIMD one or two waves: eight waves per workgroup
+        // (half the channels each) give the MFMA pipe a second wave to switch to (measured: 7x7 25.0 -> 21.3 us,
+        // 14x14 17.9 -> 15.7, 28x28 16.0 -> 15.4; the 896-block 56x56 launches lose)
+        static const int nw8_env = getenv("GRNET_NW8") ? atoi(getenv("GRNET_NW8")) : 1;
+        if (found && nw8_env && best.family == 1 && best.tcs == 1) {
+            ConvArgs t = a;
+            plan_tile(t, best.tps, 1);
+            const long blocks = (long)t.tiles_y * t.groups * (a.CoutPad / 16);
+            Cfg wide = best;
+            wide.nw = 8;
+            bool ok;
+            cfg_cost(a, wide, &ok);
+            if (ok && blocks <= 512 && a.CinPad >= 64) best = wide;
         }
     }
     if (!found) return hipErrorInvalidValue;

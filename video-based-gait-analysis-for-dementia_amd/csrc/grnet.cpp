@@ -430,6 +430,8 @@ struct grnet {
                 ops_flat.push_back(m);
             }
         }
+        static const int sched_env = getenv("GRNET_LANE_SCHED") ? atoi(getenv("GRNET_LANE_SCHED")) : 1;   // 0: lanes as written in the plan
+        if (sched_env) schedule_lanes(ops_flat, max_frames);
         analyze_dependencies(ops, op_events);
         analyze_dependencies(ops_flat, op_events_flat);
         // streams / events of the parallel lanes are created here, never inside a stream capture
@@ -465,6 +467,130 @@ struct grnet {
     // Read-after-write edges between lanes.  Every op writes a buffer nobody has written before (no
     // buffer reuse; the writers of the concat buffer own disjoint channel slices), so RAW edges are the
     // only hazards inside one forward; forwards are separated by the join at the end of enqueue().
+    // Buffers an op reads / the buffer it writes (nullptr: caller-owned outputs).
+    void op_reads(const Op& op, std::vector<const float*>& r) const {
+        r.clear();
+        switch (op.kind) {
+            case Op::CONV: {
+                const ConvLayer& L = convs[op.conv_idx];
+                r.push_back(L.in.p);
+                for (auto& a : L.adds) r.push_back(a.v.p);
+                break;
+            }
+            case Op::SUM:
+                for (auto& a : sum_views[op.conv_idx].second) r.push_back(a.v.p);
+                break;
+            case Op::BILINEAR: r.push_back(op.bin.p); break;
+            case Op::POOL: r.push_back(v_heat.p); r.push_back(v_smpl_feats.p); r.push_back(v_csmap.p); break;
+            default: break;
+        }
+    }
+    const float* op_writes(const Op& op) const {
+        if (op.kind == Op::CONV) return convs[op.conv_idx].out.p;
+        if (op.kind == Op::SUM) return sum_views[op.conv_idx].first.p;
+        if (op.kind == Op::BILINEAR) return op.bout.p;
+        return nullptr;
+    }
+
+    // Static list scheduling of the un-grouped op list onto the kLanes streams.  The plan writes "branch b on lane b",
+    // which leaves the fuse layer of an HR module as a chain of small launches on the lane of the slowest branch
+    // (measured: ~210 us per stage-4 module in which mostly one small kernel runs at a time).  Here every op gets an
+    // estimated duration, and ops are placed earliest-start-first (ties: longest remaining path first) on the lane
+    // that lets them start first, preferring the lane of their latest producer (no cross-lane event).  Streams are FIFO,
+    // so the resulting list is both the enqueue order and a topological order; analyze_dependencies() then derives
+    // the cross-lane events from it exactly as for the hand-written lanes.
+    void schedule_lanes(std::vector<Op>& list, int n) const {
+        const int m = (int)list.size();
+        std::vector<double> est(m), blevel(m, 0.0);
+        std::vector<std::vector<int>> deps(m), users(m);
+        std::map<const float*, std::vector<int>> writers;
+        std::vector<const float*> r;
+        int prev_tail = -1;
+        for (int i = 0; i < m; ++i) {
+            const Op& op = list[i];
+            switch (op.kind) {
+                case Op::CONV: {
+                    const double gf = 2.0 * convs[op.conv_idx].macs_per_frame * n / 1e9;
+                    est[i] = 6.0 + gf / (gf > 20 ? 0.105 : gf > 3 ? 0.085 : 0.060);     // us; GFLOP per us = TFLOP/s / 1000
+                    break;
+                }
+                case Op::POOL: est[i] = 50; break;
+                case Op::TAIL: est[i] = 50; break;
+                case Op::SMPL: est[i] = 60; break;
+                default: est[i] = 8; break;
+            }
+            op_reads(op, r);
+            for (const float* b : r) {
+                auto it = writers.find(b);
+                if (it == writers.end()) continue;
+                for (int w : it->second)
+                    if (std::find(deps[i].begin(), deps[i].end(), w) == deps[i].end()) deps[i].push_back(w);
+            }
+            if (op.kind == Op::POOL || op.kind == Op::TAIL || op.kind == Op::SMPL) {   // the tail is a chain on the caller's stream
+                if (prev_tail >= 0) deps[i].push_back(prev_tail);
+                prev_tail = i;
+            }
+            if (const float* o = op_writes(op)) writers[o].push_back(i);
+        }
+        for (int i = 0; i < m; ++i)
+            for (int d : deps[i]) users[d].push_back(i);
+        for (int i = m - 1; i >= 0; --i) {
+            double b = 0;
+            for (int u : users[i]) b = std::max(b, blevel[u]);
+            blevel[i] = b + est[i];
+        }
+        std::vector<int> pending(m), lane_of(m, 0), order;
+        std::vector<double> finish(m, 0.0);
+        std::vector<char> done(m, 0);
+        for (int i = 0; i < m; ++i) pending[i] = (int)deps[i].size();
+        double lane_free[kLanes] = {};
+        order.reserve(m);
+        for (int step = 0; step < m; ++step) {
+            int best = -1, best_lane = 0;
+            double best_start = 0;
+            for (int i = 0; i < m; ++i) {
+                if (done[i] || pending[i]) continue;
+                double ready = 0;
+                int from = -1;
+                for (int d : deps[i])
+                    if (finish[d] >= ready) { ready = finish[d]; from = d; }
+                const bool pinned = list[i].kind == Op::POOL || list[i].kind == Op::TAIL || list[i].kind == Op::SMPL;
+                int lane = 0;
+                double start = std::max(ready, lane_free[0]);
+                if (!pinned) {
+                    const int pref = from >= 0 ? lane_of[from] : 0;
+                    lane = pref;
+                    start = std::max(ready, lane_free[pref]);
+                    for (int l = 0; l < kLanes; ++l) {
+                        const double st = std::max(ready, lane_free[l]);
+                        if (st + 4.0 < start) { start = st; lane = l; }      // a cross-lane hop costs an event: ~4 us
+                    }
+                }
+                if (best < 0 || start < best_start - 1e-9 || (start < best_start + 1e-9 && blevel[i] > blevel[best])) {
+                    best = i; best_lane = lane; best_start = start;
+                }
+            }
+            done[best] = 1;
+            lane_of[best] = best_lane;
+            finish[best] = best_start + est[best];
+            lane_free[best_lane] = finish[best];
+            for (int u : users[best]) --pending[u];
+            order.push_back(best);
+        }
+        std::vector<Op> out;
+        out.reserve(m);
+        for (int i : order) {
+            Op op = list[i];
+            op.lane = lane_of[i];
+            op.waits.clear();
+            op.record = false;
+            out.push_back(std::move(op));
+        }
+        if (getenv("GRNET_TRACE")) fprintf(stderr, "[grnet] lane schedule: %d ops, estimated makespan %.0f us (sum of estimates %.0f us)\n", m,
+                                           *std::max_element(lane_free, lane_free + kLanes), [&] { double t = 0; for (double e : est) t += e; return t; }());
+        list.swap(out);
+    }
+
     void analyze_dependencies(std::vector<Op>& ops, std::vector<hipEvent_t>& op_events) {
         std::map<const float*, std::vector<int>> writers;      // buffer base -> ops that wrote (part of) it
         auto reads_of = [&](const Op& op, std::vector<const float*>& r) {
@@ -662,7 +788,7 @@ struct grnet {
     int tune(int n, hipStream_t s, int level = 1) {
         if (!finalized) return fail(GRNET_ESTATE, "grnet_tune before grnet_finalize_weights");
         if (n < 1 || n > max_frames) return fail(GRNET_EINVAL, "n_frames outside [1, max_frames]");
-        static const int cands[] = {0, 14, 7, 1071, 1072, 1041, 1042};
+        static const int cands[] = {0, 14, 7, 1071, 1072, 1041, 1042, 1171, 1141};
         hipEvent_t e0, e1;
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
@@ -1078,8 +1204,8 @@ int grnet_set_option(grnet_t* h, int option, int value) {
     if (option == GRNET_OPT_CONV_TILE) {
         if (value != 0) h->grouping = false;                   // forced tiles apply to individual launches
         else h->grouping = true;
-        if (value != 0 && value != 7 && value != 14 && value != 1071 && value != 1072 && value != 1041 && value != 1042)
-            return h->fail(GRNET_EINVAL, "conv tile must be 0, 7, 14 or a split-K code 1071/1072/1041/1042");
+        if (value != 0 && value != 7 && value != 14 && value != 1071 && value != 1072 && value != 1041 && value != 1042 && value != 1171 && value != 1141)
+            return h->fail(GRNET_EINVAL, "conv tile must be 0, 7, 14 or a split-K code 1071/1072/1041/1042/1171/1141");
         h->conv_tile_hint = value;
         for (auto& g : h->graphs) hipGraphExecDestroy(g.second);
         h->graphs.clear();
