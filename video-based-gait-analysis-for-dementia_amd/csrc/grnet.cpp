@@ -72,7 +72,7 @@ struct Op {
     bool record = false;      // some op on another lane consumes this op's output
 };
 
-constexpr int kLanes = 4;
+constexpr int kLanes = 8;            // streams available to the lane scheduler (the hand-written plan uses 4)
 
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
@@ -123,8 +123,8 @@ struct grnet {
     };
     std::map<GraphKey, hipGraphExec_t> graphs;
     hipStream_t capture_stream = nullptr;   // the caller's stream may be the (uncapturable) null stream
-    hipStream_t side[kLanes] = {nullptr, nullptr, nullptr, nullptr};   // lanes 1..3 (lane 0 = the caller's stream)
-    hipEvent_t ev_fork = nullptr, ev_join[kLanes] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t side[kLanes] = {};      // lanes 1.. (lane 0 = the caller's stream)
+    hipEvent_t ev_fork = nullptr, ev_join[kLanes] = {};
     std::vector<hipEvent_t> op_events;
     int cur_lane = 0;
     bool multi_lane = true;
@@ -506,12 +506,14 @@ struct grnet {
         std::map<const float*, std::vector<int>> writers;
         std::vector<const float*> r;
         int prev_tail = -1;
+        static const double fix_us = getenv("GRNET_SCHED_FIX") ? atof(getenv("GRNET_SCHED_FIX")) : 6.0;
+        static const double hop_us = getenv("GRNET_SCHED_HOP") ? atof(getenv("GRNET_SCHED_HOP")) : 4.0;
         for (int i = 0; i < m; ++i) {
             const Op& op = list[i];
             switch (op.kind) {
                 case Op::CONV: {
                     const double gf = 2.0 * convs[op.conv_idx].macs_per_frame * n / 1e9;
-                    est[i] = 6.0 + gf / (gf > 20 ? 0.105 : gf > 3 ? 0.085 : 0.060);     // us; GFLOP per us = TFLOP/s / 1000
+                    est[i] = fix_us + gf / (gf > 20 ? 0.105 : gf > 3 ? 0.085 : 0.060);     // us; GFLOP per us = TFLOP/s / 1000
                     break;
                 }
                 case Op::POOL: est[i] = 50; break;
@@ -544,6 +546,7 @@ struct grnet {
         std::vector<char> done(m, 0);
         for (int i = 0; i < m; ++i) pending[i] = (int)deps[i].size();
         double lane_free[kLanes] = {};
+        static const int n_lanes = std::min(kLanes, std::max(1, getenv("GRNET_LANES") ? atoi(getenv("GRNET_LANES")) : 4));
         order.reserve(m);
         for (int step = 0; step < m; ++step) {
             int best = -1, best_lane = 0;
@@ -561,9 +564,9 @@ struct grnet {
                     const int pref = from >= 0 ? lane_of[from] : 0;
                     lane = pref;
                     start = std::max(ready, lane_free[pref]);
-                    for (int l = 0; l < kLanes; ++l) {
+                    for (int l = 0; l < n_lanes; ++l) {
                         const double st = std::max(ready, lane_free[l]);
-                        if (st + 4.0 < start) { start = st; lane = l; }      // a cross-lane hop costs an event: ~4 us
+                        if (st + hop_us < start) { start = st; lane = l; }   // a cross-lane hop costs an event
                     }
                 }
                 if (best < 0 || start < best_start - 1e-9 || (start < best_start + 1e-9 && blevel[i] > blevel[best])) {
@@ -952,7 +955,8 @@ struct grnet {
         GraphRecorder* rec = g_recorder;                          // non-null: build graph nodes instead of launching
         const bool lanes = multi_lane && !rec;
         std::vector<hipGraphNode_t> lane_last(kLanes, nullptr), op_node(rec ? ops.size() : 0, nullptr);
-        hipStream_t lane_stream[kLanes] = {s, s, s, s};
+        hipStream_t lane_stream[kLanes];
+        for (int l = 0; l < kLanes; ++l) lane_stream[l] = s;
         if (lanes) {
             HIP_TRY(hipEventRecord(ev_fork, s));                 // fork: side lanes start after everything before this forward
             for (int l = 1; l < kLanes; ++l) {
