@@ -313,7 +313,8 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
         const int buf = ch & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of chunk ch has landed
         __syncthreads();                                     // ... and everybody else's; buf^1 is free
-        if (ch + 1 < nchunks) issue(ch + 1, buf ^ 1);
+        if (ch + 1 < nchunks && !GRK_DBG(a, 2)) issue(ch + 1, buf ^ 1);
+        if (GRK_DBG(a, 1)) continue;
         const float* wi = w_lds + buf * WFLOATS;
         const float* xi = in_lds + buf * CK * a.PSTR;
         // k-steps of the chunk = (tap, channel group of 4); software pipeline: the LDS reads of step s+1
@@ -358,6 +359,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
     }
 
     // ---- epilogue.  D: column (lane&15) = cout, rows (lane>>4)*4 + r = 4 consecutive pixels.
+    if (GRK_DBG(a, 4)) return;
 #pragma unroll
     for (int cs = 0; cs < CSW; ++cs) {
         const int co = co0 + (wc * CSW + cs) * 16 + l15;
@@ -387,8 +389,6 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
 #undef GRK_W
 }
 
-// LDS-DMA stages per wave in the split-K kernel: a.ring (2..4, chosen by the launcher so that a workgroup stays
-// near 48 KB of LDS): stages i+1 .. i+ring-1 are in flight under the MFMAs of stage i.
 
 // MODE: 0 = gather (source-offset table), 1 = rows (contiguous image rows), 2 = planes (the 4 channel planes of a
 // k-group of ONE whole small image are contiguous in NCHW: one 16-byte LDS-DMA per k-group; all zero padding is
@@ -398,10 +398,9 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
     constexpr int TC = CSW * 16, TAPS = KS * KS, WFL = TAPS * 4 * TC, NT = PSW * CSW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
-    const int stage_floats = WFL + 4 * a.PSTR;           // [weights TAPS*4 x TC | input 4 x PSTR]; a.ring stages per wave:
-    const bool db = a.ring == 2;                          // 1: the co-resident workgroups hide the DMA (more of them fit);
-    int* tab = reinterpret_cast<int*>(smem + NW * a.ring * stage_floats);   // 2: launches with about one workgroup per CU
-    float* mine = smem + wave * a.ring * stage_floats;                       // overlap their own next stage with the MFMAs
+    const int stage_floats = WFL + 4 * a.PSTR;           // [weights TAPS*4 x TC | input 4 x PSTR], ONE stage per wave:
+    int* tab = reinterpret_cast<int*>(smem + NW * stage_floats);   // the co-resident waves hide the DMA (a second stage per wave
+    float* mine = smem + wave * stage_floats;                        // measured no faster), and a fixed buffer keeps LDS addresses loop-invariant
 
     const int ty = bx % a.tiles_y, grp = bx / a.tiles_y;
     const int y0 = ty * a.R, g0 = grp * a.G, co0 = by * TC;
@@ -448,9 +447,9 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
         }
     }
 
-    auto issue = [&](int grp4, int boff) {
+    auto issue = [&](int grp4, int) {
         const int c0 = grp4 * 4;
-        float* dst = mine + boff;
+        float* dst = mine;
         const float* wsrc = a.w + (size_t)c0 * a.CoutPad;
 #pragma unroll
         for (int it = 0; it < NWI; ++it)
@@ -555,10 +554,8 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
         for (int ky = 0; ky < KS; ++ky) arow[ps][ky] = mine + abase[ps] + ky * a.Wp;
 #pragma unroll
     for (int cs = 0; cs < CSW; ++cs) brow[cs] = mine + bbase[cs];
-    int boff = 0;                                              // float offset of the stage buffer being consumed
     for (int i = 0; i < my_stages; ++i) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's stage has landed
-        if (db && i + 1 < my_stages && !GRK_DBG(a, 2)) issue(wave + (i + 1) * NW, boff ^ stage_floats);   // next stage -> other buffer
         if (!GRK_DBG(a, 1)) {
             // software pipeline over the filter taps: the LDS reads of tap t+1 are in flight under the
             // MFMAs of tap t (one exposed LDS latency per stage instead of one per tap)
@@ -567,9 +564,9 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
             float av[LD + 1][PSW], bv[LD + 1][CSW];
             auto load_tap = [&](int tap, float* ar, float* br) {
 #pragma unroll
-                for (int cs = 0; cs < CSW; ++cs) br[cs] = (brow[cs] + boff)[tap * 4 * TC];
+                for (int cs = 0; cs < CSW; ++cs) br[cs] = brow[cs][tap * 4 * TC];
 #pragma unroll
-                for (int ps = 0; ps < PSW; ++ps) ar[ps] = (arow[ps][tap / KS] + boff)[tap % KS];
+                for (int ps = 0; ps < PSW; ++ps) ar[ps] = arow[ps][tap / KS][tap % KS];
             };
 #pragma unroll
             for (int t = 0; t < LD && t < TAPS; ++t) load_tap(t, av[t], bv[t]);
@@ -603,8 +600,7 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (!db && i + 1 < my_stages && !GRK_DBG(a, 2)) issue(wave + (i + 1) * NW, 0);   // refill the buffer just consumed
-        if (db) boff ^= stage_floats;
+        if (i + 1 < my_stages && !GRK_DBG(a, 2)) issue(wave + (i + 1) * NW, 0);          // refill the buffer just consumed
     }
 
     // ---- cross-wave reduction (fixed order -> deterministic), then the shared epilogue
@@ -729,23 +725,13 @@ void plan_tile(ConvArgs& a, int tps, int family) {
 // family 1 = split-K independent waves (conv_splitk_f32).
 struct Cfg { int family, tps, tcs; int nw = 4; };   // nw: split-K waves per workgroup (4, or 8 = two per SIMD for launches of about one workgroup per CU)
 
-// split-K DMA ring depth: as deep as ~48 KB of LDS per workgroup allows (2..4)
-void plan_ring(ConvArgs& a, const Cfg& c) {
-    a.ring = 2;
-    if (c.family != 1) return;
-    const size_t stage_bytes = 4 * ((size_t)a.ks * a.ks * 4 * c.tcs * 16 + 4 * (size_t)a.PSTR);
-    static const int ring_env = getenv("GRNET_RING") ? atoi(getenv("GRNET_RING")) : 0;           // 1 / 2 force, 0 = rule below
-    (void)stage_bytes;
-    a.ring = ring_env ? (ring_env >= 2 ? 2 : 1) : 1;
-}
-
 size_t lds_bytes(const ConvArgs& a, const Cfg& c) {
     const int taps = a.ks * a.ks, TC = c.tcs * 16;
     const size_t tab = a.rows ? 0 : a.PSTR;
     const size_t ck = a.ks == 1 ? 32 : kConvCK;
     if (c.family == 0) return sizeof(float) * (2 * (size_t)taps * ck * TC + 2 * ck * a.PSTR + tab);
     const size_t stage = (size_t)taps * 4 * TC + 4 * (size_t)a.PSTR;
-    const size_t staging = c.nw * (a.ring == 2 ? 2 : 1) * stage + tab, red = (size_t)c.nw * c.tps * c.tcs * 256;
+    const size_t staging = c.nw * stage + tab, red = (size_t)c.nw * c.tps * c.tcs * 256;
     return sizeof(float) * (staging > red ? staging : red);
 }
 
@@ -753,7 +739,6 @@ size_t lds_bytes(const ConvArgs& a, const Cfg& c) {
 // cost ~ chain x number of rounds the waves need; split-K pays its extra staging traffic as a 15 % penalty.
 double cfg_cost(ConvArgs a, const Cfg& c, bool* ok) {
     plan_tile(a, c.tps, c.family);
-    plan_ring(a, c);
     *ok = a.R >= 1 && lds_bytes(a, c) <= kMaxLds && a.CoutPad % (c.tcs * 16) == 0 &&
           !(c.family == 0 && a.ks == 1 && a.CinPad % 32 != 0);       // whole-K 1x1 tiles stage 32 channels per chunk
     if (!*ok) return 0;
@@ -773,6 +758,9 @@ double cfg_cost(ConvArgs a, const Cfg& c, bool* ok) {
     // whole-K tiles of a 1x1 convolution do ~14 MFMAs per 8-channel chunk: with less than one workgroup per CU
     // nothing covers the chunk's DMA + barrier latency (measured: 128->25 @56x56 took 108 us instead of 19)
     if (c.family == 0 && a.ks == 1 && blocks < 256) cost += (kgroups / 2.0) * 400.0;
+    // bandwidth-leaning layers (1x1 on 56x56 maps, the 3-channel stem) run their load / MFMA / store phases back to back
+    // inside a workgroup: twice as many half-size workgroups overlap them better (measured 39.5 -> 34.6 us, 51.5 -> 39.8 us)
+    if (c.family == 0 && c.tps == 14 && (a.ks == 1 || a.Cin <= 8)) cost *= 1.05;
     return cost;
 }
 
@@ -904,7 +892,6 @@ hipError_t launch_conv_group(const ConvArgs* list, int n, hipStream_t s) {
         }
         if (!found) { ok_all = false; break; }
         plan_tile(a, best.tps, 1);
-        plan_ring(a, best);
         a.TC = best.tcs * 16;
         int variant;
         if (a.rows == 1) variant = best.tps == 7 ? (best.tcs == 2 ? 1 : 0) : 2;
@@ -981,7 +968,6 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s, int tile_hint) {
     }
     if (!found) return hipErrorInvalidValue;
     plan_tile(a, best.tps, best.family);
-    plan_ring(a, best);
     a.TC = best.tcs * 16;
     const size_t lds = lds_bytes(a, best);
     return a.rows == 1 ? dispatch_ks<true>(a, best, lds, s) : dispatch_ks<false>(a, best, lds, s);

@@ -78,7 +78,7 @@ struct ConvArgs {
     const float* add[kMaxAdd]; int add_ctot[kMaxAdd], add_coff[kMaxAdd], add_shift[kMaxAdd];
     const float* zeros;        // >= 64 B of zeros in HBM: source for halo / padded-channel loads
     // filled by the launcher
-    int R, G, Rin, Wp, PSTR, tiles_y, groups, TC, rows, ring;
+    int R, G, Rin, Wp, PSTR, tiles_y, groups, TC, rows;
     int gx, gy, gx8, xcd;           // pixel tiles x output-channel blocks of the 1-D grid; xcd: XCD-aware block order (see xcd_block)
     int dbg;                   // timing-only ablation bits (tools/conv_micro.py); 0 in the product path
 };
