@@ -277,3 +277,47 @@ def test_describe_convs_matches_survey_counts(pkg):
     assert convs[0]["name"] == "backbone.conv1.weight" and (convs[0]["cin"], convs[0]["cout"], convs[0]["stride"], convs[0]["hin"]) == (3, 64, 2, 224)
     assert sum(c["name"].startswith("head.") for c in convs) == 5
     m.close()
+
+
+def test_config3_shape_256_frames_one_call(pkg, golden):
+    """BASELINE configs[2] shape (8 clips x 32 frames = 256 frames per call; fp32 here -- the bf16 variant is a later row):
+    size-independent properties at full size.  Frames are independent, so the (8, 32, ...) call must reproduce 16-frame
+    calls on slices of it; frames repeat the 4 golden frames cyclically, so every golden vector must reappear 64 times."""
+    m = pkg.build_synthetic_model(max_frames=256, with_gru=False)
+    base = pkg.synth.make_frames(4)
+    frames = torch.from_numpy(np.tile(base, (64, 1, 1, 1))).cuda().reshape(8, 32, 3, 224, 224)
+    out = m(frames)[-1]
+    torch.cuda.synchronize()
+    assert out["theta"].shape == (8, 32, 85) and out["verts"].shape == (8, 32, 6890, 3) and out["rotmat"].shape == (8, 32, 24, 3, 3)
+    flat = {k: v.reshape(256, *v.shape[2:]) for k, v in out.items()}
+    for k in ("theta", "kp_3d", "kp_2d"):
+        g = golden["grnet_n4"][k].reshape(4, *flat[k].shape[1:])
+        got = flat[k].cpu().numpy().reshape(64, 4, *flat[k].shape[1:])
+        assert rel_err(got, np.broadcast_to(g, got.shape)) < 5e-5, k
+        assert rel_err(got[17], got[0]) < 2e-5, k                      # position in the batch does not matter
+    sl = m(frames.reshape(256, 3, 224, 224)[96:112])[-1]               # a 16-frame call on a slice
+    torch.cuda.synchronize()
+    for k in ("theta", "kp_3d", "verts", "rotmat"):
+        assert rel_err(flat[k][96:112].cpu().numpy(), sl[k][0].cpu().numpy()) < 2e-5, k
+    m.close()
+
+
+def test_config4_frame_sharding_equals_one_process(pkg):
+    """BASELINE configs[3] in miniature on one GPU: G 'ranks' each run their shard_range() of a clip (with the padded
+    last shard, as batch_generation.py does) and the concatenation of the shards equals the one-process result."""
+    h = pkg.harness
+    n_total, world = 37, 4
+    frames = torch.from_numpy(pkg.synth.make_frames(n_total)).cuda()
+    m = pkg.build_synthetic_model(max_frames=16, with_gru=False)
+    whole = m(frames)[-1]                                               # chunked by max_frames inside the shim
+    parts = []
+    for rank in range(world):
+        lo, hi = h.shard_range(n_total, world, rank)
+        if hi > lo:
+            parts.append(m(frames[lo:hi])[-1])
+    torch.cuda.synchronize()
+    assert sum(p["theta"].shape[1] for p in parts) == n_total
+    for k in ("theta", "kp_3d", "kp_2d", "verts", "rotmat"):
+        cat = torch.cat([p[k][0] for p in parts], 0)
+        assert rel_err(cat.cpu().numpy(), whole[k][0].cpu().numpy()) < 2e-5, k
+    m.close()
