@@ -88,6 +88,14 @@ int grnet_forward(grnet_t* h, const float* frames_dev, int n_frames, const grnet
 int grnet_gru_forward(grnet_t* h, const float* x_dev, const float* cparams_dev, int b, int T, float* y_dev,
                       float* phase_dev, float* xc_dev, void* stream);
 
+/* TSAttnBlock.forward (use_jwff=True, eval) -- lib/models/layers/attention_utils.py:261-270: MultiAttention :164-217
+ * (temporal attention over the n frames of a clip + spatial attention over the 25 tokens of a frame, softmax-gated),
+ * JointWiseFeedForward :123-130 and the reference's own LayerNormalization :17-27, in the one-layer configuration of
+ * feature_correction.py:92-101 (3072 -> 1000 -> 3072, 4 heads, 24 joints + 1 gait token).  Weights are loaded under
+ * their reference keys with prefix "tsattn." or "pfeat_corrector.featTencoder.0.".  x (b,n,128,24), xs (b,n,128,25)
+ * -> y (b,n,3072); device pointers. */
+int grnet_tsattn_forward(grnet_t* h, const float* x_dev, const float* xs_dev, int b, int n, float* y_dev, void* stream);
+
 #define GRNET_OPT_USE_GRAPH 1     /* 1: capture each distinct (n, pointers) forward into a hipGraph and replay it */
 #define GRNET_OPT_CONV_TILE 2     /* 0 = cost model; 7 / 14 = whole-K tiles; 1071/1072/1041/1042 = split-K (psw,csw) (tests / tuning) */
 #define GRNET_OPT_MULTI_LANE 3    /* 1 (default): independent HR-module branches run on parallel streams / graph branches */

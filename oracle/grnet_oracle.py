@@ -466,3 +466,70 @@ def crop_normalise(img_u8, bbox, scale=1.0, crop=224):
     val = np.floor(top * (1 - ay)[:, None, None] + bot * ay[:, None, None] + np.float32(0.5))
     val = np.clip(val, 0, 255) / np.float32(255.0)
     return np.ascontiguousarray(((val - IMAGENET_MEAN) / IMAGENET_STD).transpose(2, 0, 1)).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------- temporal/spatial attention block (row f2)
+def layer_normalization(z, gamma, beta, eps=1e-6):
+    """The reference's own LayerNormalization (attention_utils.py:10-27): UNBIASED std and (std + eps), not nn.LayerNorm."""
+    z = np.asarray(z, np.float32)
+    mean = z.mean(-1, keepdims=True, dtype=np.float32)
+    std = z.std(-1, keepdims=True, ddof=1, dtype=np.float32)
+    return (np.asarray(gamma, np.float32) * ((z - mean) / (std + np.float32(eps))) + np.asarray(beta, np.float32)).astype(np.float32)
+
+
+def _softmax(a, axis=-1):
+    a = a - a.max(axis, keepdims=True)
+    e = np.exp(a)
+    return (e / e.sum(axis, keepdims=True)).astype(np.float32)
+
+
+def _gelu(x):
+    """nn.GELU() default (exact erf form)."""
+    from math import sqrt
+    from scipy.special import erf
+    return (0.5 * x * (1.0 + erf(x / sqrt(2.0)))).astype(np.float32)
+
+
+def multi_attention(x, xs, sd, p, num_heads=4):
+    """MultiAttention.forward (attention_utils.py:164-217): temporal attention over the n frames of a clip and spatial
+    attention over the 25 tokens of a frame run side by side and are mixed by a softmax gate computed from their clip mean.
+    x (b,n,128,24), xs (b,n,128,25) -> (b,n,3072)."""
+    x, xs = np.asarray(x, np.float32), np.asarray(xs, np.float32)
+    b, n = x.shape[:2]
+    n_tks = xs.shape[-1]
+    W = lambda k: np.asarray(sd[p + k], np.float32)
+    lin = lambda v, name: v @ W(name + ".weight").T + W(name + ".bias")
+    E = W("qkv_t.weight").shape[0] // 3
+    dh = E // num_heads
+    qkv_t = lin(x.reshape(b, n, -1), "qkv_t").reshape(b, n, 3, num_heads, dh).transpose(2, 0, 3, 1, 4)      # :170-172
+    qt, kt, vt = qkv_t[0], qkv_t[1], qkv_t[2]                                                               # (b,H,n,dh)
+    attn = _softmax(qt @ kt.transpose(0, 1, 3, 2) / np.float32(np.sqrt(dh)))                                # :197-199
+    x_t = (attn @ vt).transpose(0, 2, 1, 3).reshape(b, n, num_heads * dh)                                   # :203-204
+    qkv_s = lin(xs.reshape(b, n, -1), "qkv_s").reshape(b, n, 3, num_heads, dh).transpose(2, 0, 1, 3, 4)     # :175-177
+    qkv_s = qkv_s.reshape(3, b * n, num_heads, dh // n_tks, n_tks)                                          # :178  (C, tokens)
+    qs, ks, vs = qkv_s[0], qkv_s[1], qkv_s[2]
+    attn_s = _softmax(qs.transpose(0, 1, 3, 2) @ ks)                                                        # :209-210 (no scaling)
+    x_s = (attn_s @ vs.transpose(0, 1, 3, 2)).transpose(0, 1, 3, 2).reshape(b, n, -1)                       # :214-217, :181
+    alpha = np.concatenate([x_t, x_s], -1).mean(1, keepdims=True, dtype=np.float32)                         # :183-184
+    alpha = _softmax(lin(alpha, "ts_attn").reshape(b, 1, -1, 2))                                            # :185-186
+    return (lin(x_t * alpha[..., 0], "fc_t") + lin(x_s * alpha[..., 1], "fc_s")).astype(np.float32)         # :188
+
+
+def joint_wise_ffn(x, sd, p, num_token=24):
+    """JointWiseFeedForward.forward (attention_utils.py:123-130): two per-token locally connected layers
+    (locallyconnected2d.py:39-48, kernel 1) with an exact GELU in between.  x (b,n,3072) index c*24+j."""
+    b, n, f = x.shape
+    w1 = np.asarray(sd[p + "jwff_layer1.weight"], np.float32)[0, :, :, :, 0, 0]      # (64,128,24)
+    w2 = np.asarray(sd[p + "jwff_layer2.weight"], np.float32)[0, :, :, :, 0, 0]      # (128,64,24)
+    v = x.reshape(b * n, f // num_token, num_token)
+    h = _gelu(np.einsum("rcj,ocj->roj", v, w1))
+    return np.einsum("roj,poj->rpj", h, w2).reshape(b, n, -1).astype(np.float32)
+
+
+def ts_attn_block(x, xs, sd, p="", num_heads=4, num_token=24):
+    """TSAttnBlock.forward with use_jwff=True, eval (attention_utils.py:261-270)."""
+    x = np.asarray(x, np.float32)
+    b, n = x.shape[:2]
+    y = x.reshape(b, n, -1) + multi_attention(x, xs, sd, p + "mulattn.", num_heads)
+    y = layer_normalization(y, sd[p + "norm1.gamma"], sd[p + "norm1.beta"])
+    return layer_normalization(joint_wise_ffn(y, sd, p + "ffn.", num_token) + y, sd[p + "norm2.gamma"], sd[p + "norm2.beta"])

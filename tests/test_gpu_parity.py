@@ -321,3 +321,34 @@ def test_config4_frame_sharding_equals_one_process(pkg):
         cat = torch.cat([p[k][0] for p in parts], 0)
         assert rel_err(cat.cpu().numpy(), whole[k][0].cpu().numpy()) < 2e-5, k
     m.close()
+
+
+def test_tsattn_block_matches_reference_golden_and_oracle(pkg, oracle):
+    """Row f2: the HIP attention block vs the reference module's own outputs (tests/golden/tsattn.npz) and vs the oracle
+    on a longer clip; plus the properties the block has by construction: clips of a batch are independent, and the
+    block is NOT frame-wise (temporal attention and the clip-mean gate couple the frames of a clip)."""
+    import os
+    from .conftest import ROOT
+    g = np.load(os.path.join(ROOT, "tests", "golden", "tsattn.npz"))
+    m = pkg.build_synthetic_model(max_frames=2, with_gru=False, with_tsattn=True)
+    sd = pkg.synth.make_tsattn_state_dict()
+    for (b, t) in ((2, 8), (1, 16)):
+        x, xs = pkg.synth.make_tsattn_inputs(b, t)
+        y = m.tsattn_forward(torch.from_numpy(x).cuda(), torch.from_numpy(xs).cuda()).cpu().numpy()
+        assert y.shape == (b, t, 3072)
+        assert rel_err(y, g[f"y_{b}_{t}"]) < 2e-5, (b, t, rel_err(y, g[f"y_{b}_{t}"]))
+    x, xs = pkg.synth.make_tsattn_inputs(3, 40)
+    xd, xsd = torch.from_numpy(x).cuda(), torch.from_numpy(xs).cuda()
+    y = m.tsattn_forward(xd, xsd)
+    assert rel_err(y.cpu().numpy(), oracle.ts_attn_block(x, xs, sd)) < 2e-5
+    y1 = m.tsattn_forward(xd[1:2], xsd[1:2])
+    assert torch.equal(y[1:2], y1)                                        # clips are independent, bit for bit
+    yh = m.tsattn_forward(xd[1:2, :20], xsd[1:2, :20])
+    assert rel_err(yh.cpu().numpy(), y[1:2, :20].cpu().numpy()) > 1e-3   # frames of a clip are coupled
+    with pytest.raises(ValueError):
+        m.tsattn_forward(xd[..., :23], xsd)
+    m.close()
+    m2 = pkg.build_synthetic_model(max_frames=2, with_gru=False)          # weights absent: loud, not a fallback
+    with pytest.raises(pkg._lib.GrnetError):
+        m2.tsattn_forward(xd[:1, :4], xsd[:1, :4])
+    m2.close()

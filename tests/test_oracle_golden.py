@@ -3,11 +3,13 @@
 tests/golden/*.npz were produced by tools/make_goldens.py, which imports the reference
 from /root/reference in the build container and runs it on the seed-defined inputs of synth.py.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 
-from .conftest import rel_err
+from .conftest import ROOT, rel_err
 
 TOL = 2e-5          # fp32 re-association noise through ~110 layers (SURVEY: 1e-6 self-noise)
 
@@ -129,3 +131,27 @@ def test_crop_normalise_restatement(oracle):
     assert np.allclose(y[:, 0, 0], black, atol=1e-6)
     z = oracle.crop_normalise(img, [200.0, 150.0, 112.0, 112.0], scale=2.0)         # scale multiplies the box
     assert np.allclose(z, x)
+
+
+def test_tsattn_block_oracle_matches_reference_golden(pkg, oracle):
+    """Row f2: TSAttnBlock (attention_utils.py:219-270) restated in oracle.ts_attn_block vs outputs of the reference module
+    itself (tools/make_goldens.py), same seeded weights and inputs."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "tsattn.npz"))
+    sd = pkg.synth.make_tsattn_state_dict()
+    for (b, t) in ((2, 8), (1, 16)):
+        x, xs = pkg.synth.make_tsattn_inputs(b, t)
+        a = oracle.multi_attention(x, xs, sd, "mulattn.")
+        assert rel_err(a[:, :, ::8], g[f"attn_{b}_{t}"]) < 2e-5
+        y = oracle.ts_attn_block(x, xs, sd)
+        assert y.shape == (b, t, 3072)
+        assert rel_err(y, g[f"y_{b}_{t}"]) < 2e-5
+
+
+def test_layer_normalization_is_the_reference_variant(oracle):
+    """Unbiased std and (std + eps): differs from nn.LayerNorm by sqrt(n/(n-1)) -- 1.6e-4 relative at n = 3072."""
+    rng = np.random.default_rng(3)
+    z = rng.standard_normal((5, 3072)).astype(np.float32)
+    out = oracle.layer_normalization(z, np.ones(3072, np.float32), np.zeros(3072, np.float32))
+    ref = torch.nn.functional.layer_norm(torch.from_numpy(z), (3072,), eps=0.0).numpy() * np.sqrt(3071.0 / 3072.0)
+    assert rel_err(out, ref) < 1e-5
+    assert abs(out.std(-1, ddof=1).mean() - 1.0) < 1e-4

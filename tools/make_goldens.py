@@ -329,6 +329,29 @@ def main():
     np.savez_compressed(p, **outs)
     print(f"wrote {p}")
 
+    # --- temporal/spatial attention block standalone (attention_utils.py:219-270), row f2 -----------------
+    from lib.models.layers.attention_utils import TSAttnBlock
+    tsd = synth.make_tsattn_state_dict()
+    blk = TSAttnBlock(use_jwff=True, **netspec.TSATTN).eval()
+    tspec = netspec.tsattn_spec()
+    assert list(blk.state_dict().keys()) == list(tspec.keys()), set(blk.state_dict()) ^ set(tspec)
+    for k, (shape, _) in tspec.items():
+        assert tuple(blk.state_dict()[k].shape) == tuple(shape), k
+    blk.load_state_dict({k: torch.from_numpy(v) for k, v in tsd.items()}, strict=True)
+    outs = {}
+    for (b, t) in ((2, 8), (1, 16)):
+        x, xs = synth.make_tsattn_inputs(b, t)
+        with torch.no_grad():
+            y = blk(torch.from_numpy(x), torch.from_numpy(xs))
+            a = blk.mulattn(x=torch.from_numpy(x), xs=torch.from_numpy(xs))
+        outs[f"y_{b}_{t}"] = y.numpy()
+        outs[f"attn_{b}_{t}"] = a.numpy()[:, :, ::8]
+        stat(f"tsattn y b{b} t{t}", y)
+        stat(f"tsattn mulattn b{b} t{t}", a)
+    p = os.path.join(ROOT, "tests/golden/tsattn.npz")
+    np.savez_compressed(p, **outs)
+    print(f"wrote {p}")
+
     # --- output-side conversions of the two entry points (demo_utils.py:176-209, kp_utils.py:26-36) -----
     try:
         from lib.data_utils.kp_utils import convert_kps

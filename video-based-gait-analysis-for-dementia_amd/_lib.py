@@ -29,6 +29,7 @@ EXPORTS = {
     "grnet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Outputs), C.c_void_p]),
     "grnet_gru_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
+    "grnet_tsattn_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "grnet_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "grnet_tune": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "grnet_get_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),

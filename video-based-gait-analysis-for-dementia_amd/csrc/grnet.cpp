@@ -84,7 +84,8 @@ constexpr int kLanes = 8;            // streams available to the lane scheduler 
 
 struct grnet {
     int device = 0, max_frames = 0;
-    bool finalized = false, smpl_loaded = false, gru_ready = false;
+    bool finalized = false, smpl_loaded = false, gru_ready = false, tsattn_ready = false;
+    TsAttnWeights tsw{};
     bool use_graph = false;
     int conv_tile_hint = 0;
     std::string err;
@@ -754,6 +755,30 @@ struct grnet {
         return 0;
     }
 
+    // The attention block of the pose-feature corrector is optional as well: "tsattn." (standalone) or
+    // "pfeat_corrector.featTencoder.0." (inside a MAX-GRNet checkpoint, feature_correction.py:95).
+    int finalize_tsattn() {
+        std::string pre;
+        if (find("tsattn.mulattn.qkv_t.weight")) pre = "tsattn.";
+        else if (find("pfeat_corrector.featTencoder.0.mulattn.qkv_t.weight")) pre = "pfeat_corrector.featTencoder.0.";
+        else return 0;
+        const size_t D = 3072, E = 1000;
+        struct { const char* key; size_t n; const float** dst; } items[] = {
+            {"norm1.gamma", D, &tsw.n1_g}, {"norm1.beta", D, &tsw.n1_b}, {"norm2.gamma", D, &tsw.n2_g}, {"norm2.beta", D, &tsw.n2_b},
+            {"mulattn.qkv_t.weight", 3 * E * D, &tsw.qkv_t_w}, {"mulattn.qkv_t.bias", 3 * E, &tsw.qkv_t_b},
+            {"mulattn.ts_attn.weight", 4 * E * E, &tsw.ts_w}, {"mulattn.ts_attn.bias", 2 * E, &tsw.ts_b},
+            {"mulattn.qkv_s.weight", 3 * E * (D + 128), &tsw.qkv_s_w}, {"mulattn.qkv_s.bias", 3 * E, &tsw.qkv_s_b},
+            {"mulattn.fc_s.weight", D * E, &tsw.fc_s_w}, {"mulattn.fc_s.bias", D, &tsw.fc_s_b},
+            {"mulattn.fc_t.weight", D * E, &tsw.fc_t_w}, {"mulattn.fc_t.bias", D, &tsw.fc_t_b},
+            {"ffn.jwff_layer1.weight", 64 * 128 * 24, &tsw.jw1}, {"ffn.jwff_layer2.weight", 128 * 64 * 24, &tsw.jw2}};
+        for (auto& it : items) {
+            int rc = upload_key(pre + it.key, it.n, it.dst);
+            if (rc) return rc;
+        }
+        tsattn_ready = true;
+        return 0;
+    }
+
     int finalize() {
         if (finalized) return fail(GRNET_ESTATE, "weights already finalized");
         for (auto& L : convs) {
@@ -767,6 +792,7 @@ struct grnet {
         if ((rc = upload_key("head.cam_mlp.weight", 3 * 1536, &tailw.cam_w))) return rc;
         if ((rc = upload_key("head.cam_mlp.bias", 3, &tailw.cam_b))) return rc;
         if ((rc = finalize_gru())) return rc;
+        if ((rc = finalize_tsattn())) return rc;
         if (!smpl_loaded) return fail(GRNET_ESTATE, "grnet_load_smpl must be called before grnet_finalize_weights");
         tensors.clear();                                    // host copies no longer needed
         finalized = true;
@@ -1199,6 +1225,20 @@ int grnet_gru_forward(grnet_t* h, const float* x, const float* cp, int b, int T,
     hipError_t e = launch_gru(x, cp, h->gruw, w, y, phase, xc_buf, b, T, s);
     hipFreeAsync(ws, s);
     if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("launch_gru: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int grnet_tsattn_forward(grnet_t* h, const float* x, const float* xs, int b, int n, float* y, void* stream) {
+    if (!h || !x || !xs || !y || b < 1 || n < 1 || n > 4096) return GRNET_EINVAL;
+    if (!h->tsattn_ready)
+        return h->fail(GRNET_ESTATE, "attention-block weights were not loaded (keys tsattn.* or pfeat_corrector.featTencoder.0.*)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* ws = nullptr;                                   // per call, like the GRU: not on the per-frame hot path
+    if (hipMallocAsync(reinterpret_cast<void**>(&ws), tsattn_ws_floats(b, n) * sizeof(float), s) != hipSuccess)
+        return h->fail(GRNET_ENOMEM, "attention-block workspace");
+    hipError_t e = launch_tsattn(x, xs, h->tsw, ws, y, b, n, s);
+    hipFreeAsync(ws, s);
+    if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("launch_tsattn: ") + hipGetErrorString(e));
     return 0;
 }
 

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bias_f32(const float* __restrict_
         }
 }
 
-static hipError_t gemm(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int ldc, hipStream_t s) {
+hipError_t launch_gemm_nt_bias(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int ldc, hipStream_t s) {
     if (K % 4 != 0) return hipErrorInvalidValue;
     GRK_TRY(launch_k(gemm_nt_bias_f32, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, s, A, B, bias, C, M, N, K, ldc));
     return hipGetLastError();
@@ -171,7 +171,7 @@ hipError_t launch_gru(const float* x, const float* cparams, GruWeights w, GruWor
     float* layer_out[2] = {ws.l0, ws.l1};
     for (int layer = 0; layer < 2; ++layer) {
         for (int d = 0; d < 2; ++d) {
-            e = gemm(layer_in, w.w_ih[layer][d], w.b_ih[layer][d], ws.gi + (size_t)d * rows * 900, (int)rows, 900, in_size, 900, s);
+            e = launch_gemm_nt_bias(layer_in, w.w_ih[layer][d], w.b_ih[layer][d], ws.gi + (size_t)d * rows * 900, (int)rows, 900, in_size, 900, s);
             if (e != hipSuccess) return e;
         }
         GRK_TRY(launch_k(gru_recurrent_kernel, dim3(b, 2), dim3(1024), 0, s, ws.gi, w.w_hh[layer][0], w.w_hh[layer][1],
@@ -181,13 +181,13 @@ hipError_t launch_gru(const float* x, const float* cparams, GruWeights w, GruWor
     }
     // heads: hidden activations reuse the gi workspace
     float* hid = ws.gi;
-    if ((e = gemm(ws.hfin, w.speed_w0, w.speed_b0, hid, b, 100, 1200, 100, s)) != hipSuccess) return e;
+    if ((e = launch_gemm_nt_bias(ws.hfin, w.speed_w0, w.speed_b0, hid, b, 100, 1200, 100, s)) != hipSuccess) return e;
     GRK_TRY(launch_k(mlp_out_kernel, dim3(b), dim3(64), 0, s, hid, w.speed_w2, w.speed_b2, y, 1, 3, 0, 0));
     float* hid2 = hid + (size_t)b * 100;
-    if ((e = gemm(ws.hfin, w.step_w0, w.step_b0, hid2, b, 100, 1200, 100, s)) != hipSuccess) return e;
+    if ((e = launch_gemm_nt_bias(ws.hfin, w.step_w0, w.step_b0, hid2, b, 100, 1200, 100, s)) != hipSuccess) return e;
     GRK_TRY(launch_k(mlp_out_kernel, dim3(b), dim3(64), 0, s, hid2, w.step_w2, w.step_b2, y, 2, 3, 1, 0));
     float* hid3 = hid2 + (size_t)b * 100;
-    if ((e = gemm(ws.l1, w.phase_w0, w.phase_b0, hid3, (int)rows, 100, 600, 100, s)) != hipSuccess) return e;
+    if ((e = launch_gemm_nt_bias(ws.l1, w.phase_w0, w.phase_b0, hid3, (int)rows, 100, 600, 100, s)) != hipSuccess) return e;
     GRK_TRY(launch_k(mlp_out_kernel, dim3((unsigned)rows), dim3(64), 0, s, hid3, w.phase_w2, w.phase_b2, phase, 4, 4, 0, 1));
     return hipGetLastError();
 }

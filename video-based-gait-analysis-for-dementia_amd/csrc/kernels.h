@@ -155,6 +155,19 @@ struct GruWorkspace {
     float* l1;       // (b*T, 600)
     float* hfin;     // (b, 1200)
 };
+// C[M][N] = A[M][K] . B[N][K]^T + bias[N] on the fp32 matrix cores (row-major, K % 4 == 0, 16-byte aligned rows).
+hipError_t launch_gemm_nt_bias(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int ldc, hipStream_t s);
+
+// TSAttnBlock (attention_utils.py:219-270) weights, reference layouts: Linear weights (out, in); jw1 (64,128,24), jw2 (128,64,24).
+struct TsAttnWeights {
+    const float *n1_g, *n1_b, *n2_g, *n2_b;
+    const float *qkv_t_w, *qkv_t_b, *ts_w, *ts_b, *qkv_s_w, *qkv_s_b, *fc_s_w, *fc_s_b, *fc_t_w, *fc_t_b;
+    const float *jw1, *jw2;
+};
+size_t tsattn_ws_floats(int b, int n);
+// x (b,n,3072) index c*24+j, xs (b,n,3200) index c*25+t -> y (b,n,3072); ws: tsattn_ws_floats(b, n) floats of scratch.
+hipError_t launch_tsattn(const float* x, const float* xs, const TsAttnWeights& w, float* ws, float* y, int b, int n, hipStream_t s);
+
 hipError_t launch_gru(const float* x, const float* cparams, GruWeights w, GruWorkspace ws, float* y, float* phase,
                       float* xc, int b, int T, hipStream_t s);
 

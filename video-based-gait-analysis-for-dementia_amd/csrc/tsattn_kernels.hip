@@ -1,0 +1,226 @@
+// Temporal / spatial attention block of the pose-feature corrector.
+// Reference: TSAttnBlock.forward with use_jwff=True, eval -- lib/models/layers/attention_utils.py:261-270, built from
+//   MultiAttention.forward :164-217, JointWiseFeedForward.forward :123-130, LayerNormalization.forward :17-27,
+//   LocallyConnected2d.forward (locallyconnected2d.py:39-48); configuration of feature_correction.py:92-101 for one layer:
+//   in_dim = out_dim = 3072 (128 features x 24 joints, index c*24+j), encode_dim 1000, 4 heads, 24 (+1) tokens.
+// With R = b*n rows (frames) the block is
+//   1. QT = X . Wqkv_t^T + b (R x 3000)   QS = XS . Wqkv_s^T + b (R x 3000)        fp32 MFMA GEMMs
+//   2. temporal attention per (clip, head): softmax over the n frames, dim_head 250, scaled by 1/sqrt(250)
+//   3. spatial attention per (frame, head): the 250 dims are (C=10, tokens=25); 25x25 scores, NOT scaled
+//   4. gate: clip mean of [x_t | x_s] -> Linear 2000x2000 -> pairs (2e, 2e+1) -> softmax -> scales x_t / x_s
+//   5. Y = fc_t(x_t') + fc_s(x_s')        two GEMMs (R x 3072)
+//   6. X1 = LN1(X + Y);  out = LN2(JWFF(X1) + X1)   LN = the reference's own: unbiased std, (std + eps)
+// Everything is fp32; reductions run in a fixed order (deterministic).
+#include "kernels.h"
+
+namespace grk {
+
+#define GRK_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return _e; } while (0)
+
+namespace {
+
+constexpr int kD = 3072, kE = 1000, kH = 4, kDh = 250, kTok = 24, kTokS = 25, kC = 10, kFF = 64, kF = 128;
+
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+    const int tid = threadIdx.x;
+    red[tid] = v;
+    __syncthreads();
+    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = is_max ? fmaxf(red[tid], red[tid + s]) : red[tid] + red[tid + s];
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// grid (n, H, b): one query frame i of one head of one clip.  attention_utils.py:190-205.
+__global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restrict__ qkv, float* __restrict__ xt, int n) {
+    extern __shared__ float sm[];
+    float* q = sm;               // [250]
+    float* p = sm + 256;         // [n]
+    float* red = p + n;          // [256]
+    const int i = blockIdx.x, h = blockIdx.y, bi = blockIdx.z, tid = threadIdx.x;
+    const float* base = qkv + (size_t)bi * n * 3 * kE;
+    const float* qrow = base + (size_t)i * 3 * kE + (0 * kH + h) * kDh;
+    if (tid < kDh) q[tid] = qrow[tid];
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)kDh);
+    float lmax = -INFINITY;
+    for (int j = tid; j < n; j += 256) {
+        const float* krow = base + (size_t)j * 3 * kE + (1 * kH + h) * kDh;
+        float s = 0.f;
+        for (int d = 0; d < kDh; ++d) s = fmaf(q[d], krow[d], s);
+        s *= scale;
+        p[j] = s;
+        lmax = fmaxf(lmax, s);
+    }
+    const float m = block_reduce(lmax, red, true);
+    float lsum = 0.f;
+    for (int j = tid; j < n; j += 256) {
+        const float e = expf(p[j] - m);
+        p[j] = e;
+        lsum += e;
+    }
+    const float inv = 1.0f / block_reduce(lsum, red, false);
+    if (tid < kDh) {
+        float acc = 0.f;
+        for (int j = 0; j < n; ++j) acc = fmaf(p[j], base[(size_t)j * 3 * kE + (2 * kH + h) * kDh + tid], acc);
+        xt[((size_t)bi * n + i) * kE + h * kDh + tid] = acc * inv;
+    }
+}
+
+// grid (R, H): the 25 tokens of one frame, one head.  attention_utils.py:207-217.
+__global__ __launch_bounds__(256) void spatial_attn_kernel(const float* __restrict__ qkv, float* __restrict__ xs) {
+    __shared__ float q[kDh], k[kDh], v[kDh], a[kTokS * kTokS];
+    const int r = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+    const float* row = qkv + (size_t)r * 3 * kE;
+    if (tid < kDh) {
+        q[tid] = row[(0 * kH + h) * kDh + tid];
+        k[tid] = row[(1 * kH + h) * kDh + tid];
+        v[tid] = row[(2 * kH + h) * kDh + tid];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < kTokS * kTokS; idx += 256) {
+        const int t1 = idx / kTokS, t2 = idx - t1 * kTokS;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < kC; ++c) s = fmaf(q[c * kTokS + t1], k[c * kTokS + t2], s);
+        a[idx] = s;
+    }
+    __syncthreads();
+    if (tid < kTokS) {
+        float m = -INFINITY, sum = 0.f;
+        for (int t2 = 0; t2 < kTokS; ++t2) m = fmaxf(m, a[tid * kTokS + t2]);
+        for (int t2 = 0; t2 < kTokS; ++t2) { const float e = expf(a[tid * kTokS + t2] - m); a[tid * kTokS + t2] = e; sum += e; }
+        const float inv = 1.0f / sum;
+        for (int t2 = 0; t2 < kTokS; ++t2) a[tid * kTokS + t2] *= inv;
+    }
+    __syncthreads();
+    if (tid < kDh) {
+        const int c = tid / kTokS, t1 = tid - c * kTokS;
+        float acc = 0.f;
+        for (int t2 = 0; t2 < kTokS; ++t2) acc = fmaf(a[t1 * kTokS + t2], v[c * kTokS + t2], acc);
+        xs[(size_t)r * kE + h * kDh + tid] = acc;                         // index c*25 + t1 (the transpose of :214)
+    }
+}
+
+// mean over the n frames of a clip of [x_t | x_s]  -> (b, 2000).  attention_utils.py:183-184.
+__global__ __launch_bounds__(256) void gate_mean_kernel(const float* __restrict__ xt, const float* __restrict__ xs, float* __restrict__ mean, int n) {
+    const int e = blockIdx.x * 256 + threadIdx.x, bi = blockIdx.y;
+    if (e >= 2 * kE) return;
+    const float* src = (e < kE ? xt : xs) + (size_t)bi * n * kE + (e < kE ? e : e - kE);
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += src[(size_t)i * kE];
+    mean[(size_t)bi * 2 * kE + e] = s / (float)n;
+}
+
+// alpha = softmax over the pairs (2e, 2e+1) of the gate logits; x_t *= alpha0, x_s *= alpha1.  attention_utils.py:185-188.
+__global__ __launch_bounds__(256) void gate_apply_kernel(const float* __restrict__ logits, float* __restrict__ xt, float* __restrict__ xs, int n, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / kE;
+        const int e = (int)(i - r * kE), bi = (int)(r / n);
+        const float a0 = logits[(size_t)bi * 2 * kE + 2 * e], a1 = logits[(size_t)bi * 2 * kE + 2 * e + 1];
+        const float m = fmaxf(a0, a1), e0 = expf(a0 - m), e1 = expf(a1 - m), inv = 1.0f / (e0 + e1);
+        xt[i] *= e0 * inv;
+        xs[i] *= e1 * inv;
+    }
+}
+
+// the reference's LayerNormalization on a row held in LDS: unbiased std, (std + eps).  attention_utils.py:17-27.
+__device__ __forceinline__ void layer_norm_row(const float* z, const float* __restrict__ g, const float* __restrict__ b, float* __restrict__ out,
+                                               float* red) {
+    const int tid = threadIdx.x;
+    float s = 0.f;
+    for (int i = tid; i < kD; i += 256) s += z[i];
+    const float mean = block_reduce(s, red, false) / (float)kD;
+    float ss = 0.f;
+    for (int i = tid; i < kD; i += 256) { const float d = z[i] - mean; ss = fmaf(d, d, ss); }
+    const float sd = sqrtf(block_reduce(ss, red, false) / (float)(kD - 1));
+    const float inv = 1.0f / (sd + 1e-6f);
+    for (int i = tid; i < kD; i += 256) out[i] = g[i] * ((z[i] - mean) * inv) + b[i];
+}
+
+// X1 = LN1(x + (y_t + y_s)).  attention_utils.py:188, :265-266.   grid R.
+__global__ __launch_bounds__(256) void residual_ln_kernel(const float* __restrict__ x, const float* __restrict__ yt, const float* __restrict__ ys,
+                                                            const float* __restrict__ g, const float* __restrict__ b, float* __restrict__ out) {
+    __shared__ float z[kD];
+    __shared__ float red[256];
+    const size_t r = blockIdx.x;
+    for (int i = threadIdx.x; i < kD; i += 256) z[i] = x[r * kD + i] + (yt[r * kD + i] + ys[r * kD + i]);
+    __syncthreads();
+    layer_norm_row(z, g, b, out + r * kD, red);
+}
+
+__device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+
+// out = LN2(JWFF(x1) + x1): two per-joint locally connected layers 128 -> 64 -> 128 with an exact GELU between.
+// attention_utils.py:123-130, :267-268; weights w1 [64][128][24], w2 [128][64][24].   grid R.
+__global__ __launch_bounds__(256) void jwff_ln_kernel(const float* __restrict__ x1, const float* __restrict__ w1, const float* __restrict__ w2,
+                                                        const float* __restrict__ g, const float* __restrict__ b, float* __restrict__ out) {
+    __shared__ float xr[kD];
+    __shared__ float hid[kFF * kTok];
+    __shared__ float red[256];
+    const size_t r = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < kD; i += 256) xr[i] = x1[r * kD + i];
+    __syncthreads();
+    for (int idx = tid; idx < kFF * kTok; idx += 256) {
+        const int o = idx / kTok, j = idx - o * kTok;
+        const float* w = w1 + (size_t)o * kF * kTok + j;
+        float s = 0.f;
+        for (int c = 0; c < kF; ++c) s = fmaf(xr[c * kTok + j], w[c * kTok], s);
+        hid[idx] = gelu_exact(s);
+    }
+    __syncthreads();
+    float zreg[kD / 256];
+#pragma unroll
+    for (int u = 0; u < kD / 256; ++u) {
+        const int idx = u * 256 + tid, p = idx / kTok, j = idx - p * kTok;
+        const float* w = w2 + (size_t)p * kFF * kTok + j;
+        float s = 0.f;
+        for (int o = 0; o < kFF; ++o) s = fmaf(hid[o * kTok + j], w[o * kTok], s);
+        zreg[u] = s + xr[idx];
+    }
+    __syncthreads();                                       // every thread is done reading xr
+#pragma unroll
+    for (int u = 0; u < kD / 256; ++u) xr[u * 256 + tid] = zreg[u];
+    __syncthreads();
+    layer_norm_row(xr, g, b, out + r * kD, red);
+}
+
+}  // namespace
+
+size_t tsattn_ws_floats(int b, int n) {
+    const size_t R = (size_t)b * n;
+    return 2 * R * 3 * kE + 2 * R * kE + 2 * (size_t)b * 2 * kE + 3 * R * kD + 64;
+}
+
+hipError_t launch_tsattn(const float* x, const float* xs, const TsAttnWeights& w, float* ws, float* y, int b, int n, hipStream_t s) {
+    if (b < 1 || n < 1 || n > 4096) return hipErrorInvalidValue;
+    const size_t R = (size_t)b * n;
+    float* qkv_t = ws;
+    float* qkv_s = qkv_t + R * 3 * kE;
+    float* xt = qkv_s + R * 3 * kE;
+    float* xsp = xt + R * kE;
+    float* mean = xsp + R * kE;
+    float* logits = mean + (size_t)b * 2 * kE;
+    float* yt = logits + (size_t)b * 2 * kE;
+    float* ys = yt + R * kD;
+    float* x1 = ys + R * kD;
+    GRK_TRY(launch_gemm_nt_bias(x, w.qkv_t_w, w.qkv_t_b, qkv_t, (int)R, 3 * kE, kD, 3 * kE, s));
+    GRK_TRY(launch_gemm_nt_bias(xs, w.qkv_s_w, w.qkv_s_b, qkv_s, (int)R, 3 * kE, kD + kF, 3 * kE, s));
+    GRK_TRY(launch_k(temporal_attn_kernel, dim3(n, kH, b), dim3(256), (size_t)(256 + n + 256) * sizeof(float), s, qkv_t, xt, n));
+    GRK_TRY(launch_k(spatial_attn_kernel, dim3((unsigned)R, kH), dim3(256), 0, s, qkv_s, xsp));
+    GRK_TRY(launch_k(gate_mean_kernel, dim3((2 * kE + 255) / 256, b), dim3(256), 0, s, xt, xsp, mean, n));
+    GRK_TRY(launch_gemm_nt_bias(mean, w.ts_w, w.ts_b, logits, b, 2 * kE, 2 * kE, 2 * kE, s));
+    const long total = (long)R * kE;
+    GRK_TRY(launch_k(gate_apply_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, s, logits, xt, xsp, n, total));
+    GRK_TRY(launch_gemm_nt_bias(xt, w.fc_t_w, w.fc_t_b, yt, (int)R, kD, kE, kD, s));
+    GRK_TRY(launch_gemm_nt_bias(xsp, w.fc_s_w, w.fc_s_b, ys, (int)R, kD, kE, kD, s));
+    GRK_TRY(launch_k(residual_ln_kernel, dim3((unsigned)R), dim3(256), 0, s, x, yt, ys, w.n1_g, w.n1_b, x1));
+    GRK_TRY(launch_k(jwff_ln_kernel, dim3((unsigned)R), dim3(256), 0, s, x1, w.jw1, w.jw2, w.n2_g, w.n2_b, y));
+    return hipGetLastError();
+}
+
+}  // namespace grk

@@ -109,7 +109,7 @@ class GRNet:
                     smpl[name] = v
                 elif name not in _TOLERATED_SMPL_KEYS:
                     unexpected.append(k)
-            elif k in spec or k.startswith("pfeat_corrector.featnet.") or k.startswith("gru."):
+            elif k in spec or k.startswith(("pfeat_corrector.featnet.", "gru.", "pfeat_corrector.featTencoder.0.", "tsattn.")):
                 want = spec.get(k)
                 if want is not None and tuple(np.shape(v)) != tuple(want[0]):
                     raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(np.shape(v))} vs model {tuple(want[0])}")
@@ -320,6 +320,21 @@ class GRNet:
         _lib.check(self._lib, self._h, rc, "grnet_gru_forward")
         return y, ph, xc
 
+    def tsattn_forward(self, x, xs):
+        """TSAttnBlock.forward (attention_utils.py:261-270) on this handle's attention-block weights
+        (keys tsattn.* / pfeat_corrector.featTencoder.0.*): x (b,n,128,24), xs (b,n,128,25) -> (b,n,3072)."""
+        self.finalize()
+        if x.dim() != 4 or tuple(x.shape[2:]) != (128, 24) or tuple(xs.shape) != (x.shape[0], x.shape[1], 128, 25):
+            raise ValueError("x must be (b,n,128,24) and xs (b,n,128,25)")
+        b, n = x.shape[:2]
+        x = x.to(torch.float32).contiguous()
+        xs = xs.to(torch.float32).contiguous()
+        y = torch.empty(b, n, 3072, dtype=torch.float32, device=x.device)
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        rc = self._lib.grnet_tsattn_forward(self._h, x.data_ptr(), xs.data_ptr(), b, n, y.data_ptr(), stream)
+        _lib.check(self._lib, self._h, rc, "grnet_tsattn_forward")
+        return y
+
     # single-op hooks for kernel parity tests
     def op_conv2d(self, x, w, bias=None, stride=1, relu=False, add=None, tile_hint=0):
         n, cin, h, wd = x.shape
@@ -357,13 +372,15 @@ class GRNet:
             pass
 
 
-def build_synthetic_model(max_frames=64, device_id=0, with_gru=True):
+def build_synthetic_model(max_frames=64, device_id=0, with_gru=True, with_tsattn=False):
     """GRNet with the seed-defined weights / SMPL tables of synth.py (no checkpoint exists offline)."""
     from . import synth
     m = GRNet(max_frames=max_frames, device_id=device_id)
     sd = synth.make_state_dict()
     if with_gru:
         sd.update({"gru." + k: v for k, v in synth.make_gru_state_dict().items()})
+    if with_tsattn:
+        sd.update({"tsattn." + k: v for k, v in synth.make_tsattn_state_dict().items()})
     m.load_state_dict(sd, strict=True)
     m.load_smpl(synth.make_smpl_tables())
     return m.finalize()

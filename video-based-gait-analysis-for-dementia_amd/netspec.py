@@ -169,6 +169,33 @@ def gru_spec(prefix=""):
     return s
 
 
+TSATTN = dict(in_dim=128 * NUM_JOINTS, encode_dim=1000, out_dim=128 * NUM_JOINTS, num_heads=4, num_token=NUM_JOINTS)
+
+
+def tsattn_spec(prefix=""):
+    """TSAttnBlock(in_dim=3072, encode_dim=1000, out_dim=3072, num_heads=4, num_token=24, use_jwff=True) tensors
+    (attention_utils.py:219-259; the configuration FeatCorrector builds for one layer, feature_correction.py:92-101:
+    h_size 1024 rounded down to a multiple of heads * (tokens + 1))."""
+    s = OrderedDict()
+    p, D, E, T = prefix, TSATTN["in_dim"], TSATTN["encode_dim"], TSATTN["num_token"]
+    for n in ("norm1", "norm2"):
+        s[f"{p}{n}.gamma"] = ((D,), "ln_gamma")
+        s[f"{p}{n}.beta"] = ((D,), "small")
+    s[p + "mulattn.qkv_t.weight"] = ((3 * E, D), "linear_w")
+    s[p + "mulattn.qkv_t.bias"] = ((3 * E,), "bias")
+    s[p + "mulattn.ts_attn.weight"] = ((2 * E, 2 * E), "linear_w")
+    s[p + "mulattn.ts_attn.bias"] = ((2 * E,), "bias")
+    s[p + "mulattn.qkv_s.weight"] = ((3 * E, D + D // T), "linear_w")
+    s[p + "mulattn.qkv_s.bias"] = ((3 * E,), "bias")
+    s[p + "mulattn.fc_s.weight"] = ((D, E), "linear_w")
+    s[p + "mulattn.fc_s.bias"] = ((D,), "bias")
+    s[p + "mulattn.fc_t.weight"] = ((D, E), "linear_w")
+    s[p + "mulattn.fc_t.bias"] = ((D,), "bias")
+    s[p + "ffn.jwff_layer1.weight"] = ((1, D // 2 // T, D // T, T, 1, 1), "pose_w")
+    s[p + "ffn.jwff_layer2.weight"] = ((1, D // T, D // 2 // T, T, 1, 1), "pose_w")
+    return s
+
+
 def grnet_spec():
     """backbone.* + head.* in the order of the reference's gen_state_dict."""
     s = OrderedDict()

@@ -70,6 +70,8 @@ def _draw(key, shape, role, seed):
         return (g.standard_normal(shape) * np.sqrt(1.0 / shape[2])).astype(f32)
     if role == "cparam_w":
         return (g.standard_normal(shape) * 0.3).astype(f32)
+    if role == "ln_gamma":
+        return g.uniform(0.8, 1.2, shape).astype(f32)
     if role == "gru_w":
         return g.uniform(-1.0, 1.0, shape).astype(f32) * f32(1.0 / np.sqrt(300.0))
     if role == "gru_b":
@@ -86,6 +88,19 @@ def make_state_dict(spec=None, seed=WEIGHT_SEED):
 
 def make_gru_state_dict(seed=WEIGHT_SEED):
     return make_state_dict(netspec.gru_spec(), seed)
+
+
+def make_tsattn_state_dict(seed=WEIGHT_SEED):
+    return make_state_dict(netspec.tsattn_spec(), seed)
+
+
+def make_tsattn_inputs(b, n, seed=FRAME_SEED):
+    """x (b,n,128,24): per-joint pose features; xs (b,n,128,25): the same plus the gait-feature token
+    (feature_correction.py:137-148 builds them as batch-normalised features, i.e. roughly unit variance)."""
+    g = _rng(seed, f"tsattn_{b}_{n}")
+    x = g.standard_normal((b, n, 128, netspec.NUM_JOINTS)).astype(np.float32)
+    tok = g.standard_normal((b, n, 128, 1)).astype(np.float32)
+    return x, np.concatenate([x, tok], -1)
 
 
 def make_smpl_tables(seed=SMPL_SEED):
