@@ -37,7 +37,9 @@ typedef struct grnet grnet_t;
 
 /* GRNet(...).to(device) -- lib/models/grnet.py:27-91, demo.py:106-111.  Allocates every
  * activation buffer for up to max_frames frames per call (the reference's batch axis N = B*T,
- * grnet.py:136-138).  dtype: 0 = fp32 (the only compute type in this round). */
+ * grnet.py:136-138).  dtype: 0 = fp32 (the reference's precision; the 1e-3 parity bar is stated for it);
+ * 1 = bf16 storage (NHWC activations, folded weights) with fp32 accumulation on the bf16 matrix cores and an fp32 tail
+ * (pooling sums, MLPs, SMPL) -- BASELINE configs 3 and 5; inputs and outputs of every entry point stay fp32. */
 int grnet_create(grnet_t** out_handle, int device_id, int dtype, int max_frames);
 
 /* model.load_state_dict(...) -- demo.py:116-122, batch_generation.py:214-218, and

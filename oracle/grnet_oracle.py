@@ -69,11 +69,40 @@ def batchnorm_explicit(x, sd, prefix):
     return x * scale[None, :, None, None] + (b - m * scale)[None, :, None, None]
 
 
+# bf16 emulation of the HIP path's dtype=1 mode (BASELINE configs 3/5: bf16 storage, fp32 accumulation): every tensor the
+# kernels keep in HBM is rounded to bf16 (nearest even) where the kernels round it -- BN-folded weights, each conv / fuse-sum /
+# bilinear output -- while sums run in fp32.  Not a second reference: it shows that the bf16 path's distance from the fp32
+# oracle is rounding noise of that size and nothing else (tests/test_gpu_bf16.py).
+_BF16 = False
+
+
+class bf16_storage:
+    def __enter__(self):
+        global _BF16
+        self._old, _BF16 = _BF16, True
+        return self
+
+    def __exit__(self, *a):
+        global _BF16
+        _BF16 = self._old
+
+
+def _q(t):
+    return t.to(torch.bfloat16).to(torch.float32) if _BF16 else t
+
+
 def conv_bn(x, sd, conv_key, bn_prefix, stride=1, relu=False, residual=None):
-    y = batchnorm(conv2d(x, sd[conv_key], stride), sd, bn_prefix)
+    if _BF16:
+        g, b = _t(sd[bn_prefix + ".weight"]).double(), _t(sd[bn_prefix + ".bias"]).double()
+        m, v = _t(sd[bn_prefix + ".running_mean"]).double(), _t(sd[bn_prefix + ".running_var"]).double()
+        scale = g / torch.sqrt(v + BN_EPS)
+        wf = _q((_t(sd[conv_key]).double() * scale[:, None, None, None]).float())
+        y = conv2d(x, wf, stride) + (b - m * scale).float()[None, :, None, None]
+    else:
+        y = batchnorm(conv2d(x, sd[conv_key], stride), sd, bn_prefix)
     if residual is not None:
         y += residual
-    return torch.relu_(y) if relu else y
+    return _q(torch.relu_(y) if relu else y)
 
 
 def upsample_nearest(x, factor):
@@ -84,7 +113,7 @@ def upsample_nearest(x, factor):
 def upsample_bilinear2x(x):
     """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (hrnet.py:443), torch's CPU kernel
     (the explicit two-tap formula is ``upsample_bilinear2x_explicit``, checked equal in the tests)."""
-    return F.interpolate(_t(x), scale_factor=2, mode="bilinear", align_corners=True)
+    return _q(F.interpolate(_t(x), scale_factor=2, mode="bilinear", align_corners=True))
 
 
 def upsample_bilinear2x_explicit(x):
@@ -145,13 +174,13 @@ def hr_module(xs, sd, p):
                 for k in range(i - j):
                     t = conv_bn(t, sd, q + f"{k}.0.weight", q + f"{k}.1", stride=2, relu=(k != i - j - 1))
             y = t if y is None else y + t
-        outs.append(torch.relu_(y))
+        outs.append(_q(torch.relu_(y)))
     return outs
 
 
 def backbone(x, sd, p="backbone.", taps=None):
     """PoseHighResolutionNet.forward with DOWNSAMPLE=False, USE_CONV=True (hrnet.py:469-536)."""
-    x = _t(x)
+    x = _q(_t(x))
     x = conv_bn(x, sd, p + "conv1.weight", p + "bn1", stride=2, relu=True)
     if taps is not None:
         taps["stem_conv1"] = x
@@ -195,10 +224,10 @@ def head_features(feats, sd, p="head."):
         return conv_bn(y, sd, f"{p}{name}.3.weight", f"{p}{name}.4", relu=True)
 
     part_feats = branch("keypoint_deconv_layers")
-    heat = conv2d(part_feats, sd[p + "keypoint_final_layer.weight"], bias=sd[p + "keypoint_final_layer.bias"])
+    heat = _q(conv2d(part_feats, _q(_t(sd[p + "keypoint_final_layer.weight"])), bias=sd[p + "keypoint_final_layer.bias"]))
     part_attn = heat[:, 1:]                                     # drop background channel (pare.py:316)
     smpl_feats = branch("smpl_deconv_layers")
-    cam_shape = conv2d(smpl_feats, sd[p + "smpl_final_layer.weight"], bias=sd[p + "smpl_final_layer.bias"])
+    cam_shape = _q(conv2d(smpl_feats, _q(_t(sd[p + "smpl_final_layer.weight"])), bias=sd[p + "smpl_final_layer.bias"]))
     return {"part_feats": part_feats, "part_attn": part_attn, "smpl_feats": smpl_feats, "cam_shape_map": cam_shape}
 
 

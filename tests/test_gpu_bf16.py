@@ -1,0 +1,109 @@
+"""bf16 path (grnet_create dtype = 1; BASELINE configs[2] / [4]: bf16 storage, fp32 accumulation on the bf16 matrix cores).
+
+The reference has no bf16 mode, so the bar is stated here: (i) every conv launch equals the fp32 oracle evaluated on the SAME
+bf16-rounded operands up to the one rounding of its bf16 output (2^-9 relative); (ii) over the whole network the distance from
+the fp32 oracle is no larger than what an independent emulation of bf16 storage in the oracle shows (oracle.bf16_storage), and
+the pose error stays in millimetres.  The 1e-3 bar of the north star belongs to the fp32 path (test_gpu_parity.py)."""
+import numpy as np
+import pytest
+import torch
+
+from .conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _rb(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+@pytest.fixture(scope="module")
+def bmodel(pkg):
+    m = pkg.build_synthetic_model(max_frames=16, with_gru=False, dtype="bf16")
+    yield m
+    m.close()
+
+
+CASES = [(3, 64, 3, 2, 224), (64, 64, 3, 2, 112), (64, 256, 1, 1, 56), (256, 64, 1, 1, 56), (32, 32, 3, 1, 56), (64, 64, 3, 1, 28),
+         (128, 128, 3, 1, 14), (256, 256, 3, 1, 7), (32, 64, 3, 2, 56), (128, 256, 3, 2, 14), (256, 32, 1, 1, 7), (128, 25, 1, 1, 56),
+         (480, 256, 3, 1, 56)]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("tile", [0, 7, 14])
+def test_bf16_conv_kernel(bmodel, oracle, case, tile):
+    cin, cout, k, stride, h = case
+    g = np.random.Generator(np.random.Philox(key=[77, cin * 1000 + cout]))
+    n = 3 if h <= 28 else 2
+    x = _rb(g.standard_normal((n, cin, h, h)))
+    w = _rb(g.standard_normal((cout, cin, k, k)) * np.sqrt(2.0 / (cin * k * k)))
+    b = (g.standard_normal((cout,)) * 0.1).astype(np.float32)
+    ho = (h + 2 * (k // 2) - k) // stride + 1
+    add = _rb(g.standard_normal((n, cout, ho, ho)))
+    ref = torch.relu(oracle.conv2d(x, w, stride=stride, bias=b) + torch.from_numpy(add)).numpy()
+    got = bmodel.op_conv2d(torch.from_numpy(x).cuda(), w, b, stride=stride, relu=True, add=torch.from_numpy(add).cuda(), tile_hint=tile).cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.array_equal(got, _rb(got))                                 # the output IS bf16
+    # products of bf16 operands are exact in fp32; what remains is fp32 summation order + ONE output rounding (half an ulp = 2^-9)
+    assert np.all(np.abs(got - ref) <= np.abs(ref) * 2.0 ** -8 + 1e-5), float(np.abs(got - ref).max())
+
+
+def test_bf16_forward_error_is_storage_rounding_noise(bmodel, pkg, oracle, synth_weights, synth_smpl):
+    frames = pkg.synth.make_frames(4)
+    keys = ("features", "part_attn", "smpl_feats", "point_local_feat")
+    out = bmodel(torch.from_numpy(frames).cuda(), extras=keys)[-1]
+    ref = oracle.grnet_forward(frames, synth_weights, synth_smpl, return_intermediates=True)
+    with oracle.bf16_storage():
+        emu = oracle.grnet_forward(frames, synth_weights, synth_smpl, return_intermediates=True)
+    report = {}
+    for k in keys + ("theta", "rotmat", "kp_3d", "kp_2d", "verts"):
+        a = out[k].cpu().numpy()
+        a = a[:, 1:] if k == "part_attn" else a
+        r, e = np.asarray(ref[k]).reshape(a.shape), np.asarray(emu[k]).reshape(a.shape)
+        report[k] = (rel_err(a, r), rel_err(e, r))
+        assert report[k][0] < 1.6 * report[k][1] + 1e-3, (k, report[k])   # no further from fp32 than the emulation is
+    print(report)
+    assert report["features"][0] < 4e-2 and report["point_local_feat"][0] < 1.5e-2
+    d = out["kp_3d"].cpu().numpy().reshape(-1, 29, 3) - np.asarray(ref["kp_3d"]).reshape(-1, 29, 3)
+    assert np.linalg.norm(d, axis=-1).mean() < 0.015                     # MPJPE vs the fp32 oracle: millimetres on a metre-sized body
+    R = out["rotmat"].reshape(-1, 3, 3)
+    assert (R @ R.transpose(1, 2) - torch.eye(3, device=R.device)).abs().max() < 1e-4   # the fp32 tail still returns rotations
+
+
+def test_bf16_frames_are_independent_and_graph_equals_eager(bmodel, pkg):
+    frames = torch.from_numpy(pkg.synth.make_frames(16)).cuda()
+    full = bmodel(frames)[-1]
+    one = bmodel(frames[5:6])[-1]
+    part = bmodel(frames[8:11])[-1]
+    torch.cuda.synchronize()
+    for k in ("theta", "kp_3d", "verts", "rotmat"):
+        assert torch.equal(full[k][0, 5], one[k][0, 0]), k                # same kernel per layer at every batch size: bit for bit
+        assert torch.equal(full[k][0, 8:11], part[k][0]), k
+    bmodel.set_option(pkg._lib.OPT_USE_GRAPH, 1)
+    try:
+        g1 = bmodel(frames)[-1]
+        g2 = bmodel(frames)[-1]                                          # replay
+        torch.cuda.synchronize()
+        for k in ("theta", "verts"):
+            assert torch.equal(g1[k], full[k]) and torch.equal(g2[k], full[k]), k
+    finally:
+        bmodel.set_option(pkg._lib.OPT_USE_GRAPH, 0)
+
+
+def test_bf16_config3_shape(pkg):
+    """BASELINE configs[2]: 8 clips x 32 frames in one call, bf16."""
+    m = pkg.build_synthetic_model(max_frames=256, with_gru=False, dtype="bf16")
+    base = pkg.synth.make_frames(4)
+    frames = torch.from_numpy(np.tile(base, (64, 1, 1, 1))).cuda().reshape(8, 32, 3, 224, 224)
+    out = m(frames)[-1]
+    torch.cuda.synchronize()
+    assert out["theta"].shape == (8, 32, 85) and out["verts"].shape == (8, 32, 6890, 3)
+    th = out["theta"].reshape(64, 4, 85)
+    assert torch.equal(th[0], th[37])                                    # the 4 distinct frames repeat exactly
+    assert torch.isfinite(out["verts"]).all()
+    m.close()
+
+
+def test_bf16_is_a_separate_handle_dtype(pkg):
+    with pytest.raises(ValueError):
+        pkg.GRNet(max_frames=1, dtype="fp8")

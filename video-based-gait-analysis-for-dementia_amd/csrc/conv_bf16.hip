@@ -1,0 +1,427 @@
+// bf16 path (grnet_create dtype = 1; BASELINE configs 3 and 5): activations and weights are bf16 in HBM, every
+// convolution accumulates in fp32 on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16), the tail (pooling sums, MLPs,
+// SMPL) stays fp32.  Same fused op as the fp32 path:
+//     out = act( conv(in, W_folded) + b_folded + sum_k nearest_up(add_k, 2^shift_k) )
+// Layout: NHWC ("channels last"), element (n, y, x, c) at ((n*H + y)*W + x)*ctot + coff + c.  The MFMA wants 8
+// consecutive K elements per lane (16 bytes): with K = (tap, channel) that is 8 consecutive channels of one pixel,
+// one ds_read_b128 -- NCHW planes would need eight 2-byte reads.  Roles are M = output channels, N = pixels, so a
+// lane's 4 accumulator rows are 4 consecutive channels of ONE pixel: one 8-byte NHWC store.
+//   A[row = cout l&15][k = 8(l>>4)+j] = W[tap][cout][cin]      (packed [tap][CoutPad][CinPad] bf16)
+//   B[k = 8(l>>4)+j][col = pixel l&15] = patch[slot(pixel)+tap][cin]
+//   D[row = 4(l>>4)+r][col = l&15]     = out[pixel][cout]
+// A workgroup owns TPS*16 pixels (R whole output rows of one image, or G whole small images) x TCS*16 channels and
+// walks K in chunks of 32 input channels: the zero-padded input patch and the chunk's weights are staged through
+// registers into LDS (80-byte slots: 64 B of data + 16 B of padding keep the 16-lane b128 reads off each other's
+// banks), the next chunk's global loads are in flight under the MFMAs of the current one.
+#include "kernels.h"
+
+namespace grk {
+
+#define GRK_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return _e; } while (0)
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kCK = 32;        // input channels per K chunk (= one MFMA k-step per tap)
+constexpr int kStr = 40;       // LDS slot stride in bf16 (80 B)
+
+__device__ __forceinline__ u16 f2bf(float f) {           // round to nearest even (finite inputs)
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (u16)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ unsigned pack2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+
+template <int KS, int S, int TPS, int TCS, int WP, int WC>
+__global__ __launch_bounds__(WP * WC * 64) void conv_bf16_nhwc(const ConvArgs a) {
+    constexpr int NT = WP * WC * 64, PSW = TPS / WP, CSW = TCS / WC, TC = TCS * 16, TAPS = KS * KS;
+    static_assert(TPS % WP == 0 && TCS % WC == 0, "wave grid must divide the tile");
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    u16* w_lds = reinterpret_cast<u16*>(smem_raw);                       // [TAPS*TC][kStr]
+    u16* a_lds = w_lds + TAPS * TC * kStr;                               // [NSLOT][kStr]
+    int* tab = reinterpret_cast<int*>(a_lds + (size_t)a.PSTR * kStr);    // [NSLOT] input pixel of each patch slot, -1 = zero
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave / WC, wc = wave % WC, l15 = lane & 15, lq = lane >> 4;
+    const int bx = blockIdx.x % a.gx, by = blockIdx.x / a.gx;
+    const int ty = bx % a.tiles_y, grp = bx / a.tiles_y;
+    const int y0 = ty * a.R, g0 = grp * a.G, co0 = by * TC;
+    const int HW = a.H * a.W, RW = a.R * a.Wo, RinWp = a.Rin * a.Wp, HoWo = a.Ho * a.Wo;
+    constexpr int pad = KS / 2;
+    const u16* in = reinterpret_cast<const u16*>(a.in);
+    const u16* wg = reinterpret_cast<const u16*>(a.w);
+
+    for (int idx = tid; idx < a.PSTR; idx += NT) {
+        const int gl = idx / RinWp, rem = idx - gl * RinWp;
+        const int ry = rem / a.Wp, rx = rem - ry * a.Wp;
+        const int yin = y0 * S + ry - pad, xin = rx - pad;
+        const bool ok = gl < a.G && (g0 + gl) < a.N && yin >= 0 && yin < a.H && xin >= 0 && xin < a.W;
+        tab[idx] = ok ? (g0 + gl) * HW + yin * a.W + xin : -1;
+    }
+    __syncthreads();
+
+    // register staging: 16-byte units (8 channels) of the patch and of the weight chunk owned by this thread
+    const int n_au = a.PSTR * 4, n_wu = TAPS * TC * 4;
+    constexpr int MAXA = 20, NWU = (TAPS * TC * 4 + NT - 1) / NT;        // the launcher keeps ceil(n_au / NT) <= MAXA
+    u32x4 ra[MAXA], rw[NWU];
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < MAXA; ++i) {
+            const int u = i * NT + tid;
+            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            if (u < n_au) {
+                const int slot = u >> 2, c = c0 + (u & 3) * 8;
+                const int off = tab[slot];
+                if (off >= 0 && c < a.Cin) v = *reinterpret_cast<const u32x4*>(in + (size_t)off * a.in_ctot + a.in_coff + c);
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NWU; ++i) {
+            const int u = i * NT + tid;
+            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            if (u < n_wu) {
+                const int row = u >> 2, tap = row / TC, co = row - tap * TC;
+                v = *reinterpret_cast<const u32x4*>(wg + ((size_t)tap * a.CoutPad + co0 + co) * a.CinPad + c0 + (u & 3) * 8);
+            }
+            rw[i] = v;
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < MAXA; ++i) {
+            const int u = i * NT + tid;
+            if (u < n_au) *reinterpret_cast<u32x4*>(a_lds + (u >> 2) * kStr + (u & 3) * 8) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NWU; ++i) {
+            const int u = i * NT + tid;
+            if (u < n_wu) *reinterpret_cast<u32x4*>(w_lds + (u >> 2) * kStr + (u & 3) * 8) = rw[i];
+        }
+    };
+
+    f32x4 acc[CSW][PSW];
+#pragma unroll
+    for (int cs = 0; cs < CSW; ++cs)
+#pragma unroll
+        for (int ps = 0; ps < PSW; ++ps) acc[cs][ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int abase[PSW];                                        // LDS slot of tap (0,0) of this lane's pixel, per pixel sub-tile
+#pragma unroll
+    for (int ps = 0; ps < PSW; ++ps) {
+        const int q = (wp * PSW + ps) * 16 + l15;
+        const int gl = q / RW, rem = q - gl * RW;
+        const int yl = rem / a.Wo, x = rem - yl * a.Wo;
+        abase[ps] = (q < a.G * RW) ? gl * RinWp + yl * S * a.Wp + x * S : 0;     // masked pixels read slot 0, never stored
+    }
+
+    const int nchunks = a.CinPad / kCK;
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        if (ch + 1 < nchunks) load_chunk((ch + 1) * kCK);                     // in flight under this chunk's MFMAs
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int toff = (tap / KS) * a.Wp + (tap % KS);
+            bf16x8 af[CSW], bfr[PSW];
+#pragma unroll
+            for (int cs = 0; cs < CSW; ++cs)
+                af[cs] = *reinterpret_cast<const bf16x8*>(w_lds + (tap * TC + (wc * CSW + cs) * 16 + l15) * kStr + lq * 8);
+#pragma unroll
+            for (int ps = 0; ps < PSW; ++ps) bfr[ps] = *reinterpret_cast<const bf16x8*>(a_lds + (abase[ps] + toff) * kStr + lq * 8);
+#pragma unroll
+            for (int cs = 0; cs < CSW; ++cs)
+#pragma unroll
+                for (int ps = 0; ps < PSW; ++ps) acc[cs][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cs], bfr[ps], acc[cs][ps], 0, 0, 0);
+        }
+        __syncthreads();                                                       // everybody is done reading this chunk
+        if (ch + 1 < nchunks) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: lane holds channels cbase..cbase+3 of pixel l15 of each sub-tile
+    u16* out = reinterpret_cast<u16*>(a.out);
+    const int cstore = a.out_ctot - a.out_coff < a.CoutPad ? a.out_ctot - a.out_coff : a.CoutPad;
+#pragma unroll
+    for (int ps = 0; ps < PSW; ++ps) {
+        const int q = (wp * PSW + ps) * 16 + l15;
+        if (q >= a.G * RW) continue;
+        const int gl = q / RW, rem = q - gl * RW;
+        const int img = g0 + gl, pix = y0 * a.Wo + rem;
+        if (img >= a.N || pix >= HoWo) continue;
+        const int y = pix / a.Wo, x = pix - y * a.Wo;
+#pragma unroll
+        for (int cs = 0; cs < CSW; ++cs) {
+            const int co = co0 + (wc * CSW + cs) * 16 + lq * 4;
+            if (co >= cstore) continue;
+            f32x4 v = acc[cs][ps];
+            const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + co);
+            v += b;
+#pragma unroll
+            for (int k = 0; k < kMaxAdd; ++k) {
+                if (k >= a.n_add) break;
+                const int sh = a.add_shift[k], hs = a.Ho >> sh, ws = a.Wo >> sh;
+                const u16* ap = reinterpret_cast<const u16*>(a.add[k]) +
+                                ((size_t)(img * hs + (y >> sh)) * ws + (x >> sh)) * a.add_ctot[k] + a.add_coff[k] + co;
+                const u32x2 r = *reinterpret_cast<const u32x2*>(ap);
+                v[0] += bf2f((u16)(r[0] & 0xffffu)); v[1] += bf2f((u16)(r[0] >> 16));
+                v[2] += bf2f((u16)(r[1] & 0xffffu)); v[3] += bf2f((u16)(r[1] >> 16));
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            *reinterpret_cast<u32x2*>(out + ((size_t)img * HoWo + pix) * a.out_ctot + a.out_coff + co) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+        }
+    }
+}
+
+// (N,C,H,W) f32 -> (N,H,W,Cp) bf16, channels C..Cp-1 zero.  The caller's frames (C = 3 -> 8) and the test hooks.
+__global__ __launch_bounds__(256) void nchw_f32_to_nhwc_bf16_kernel(const float* __restrict__ in, u16* __restrict__ out, int C, int HW, int Cp, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % Cp);
+        const long p = i / Cp, n = p / HW, hw = p - n * HW;
+        out[i] = c < C ? f2bf(in[(n * C + c) * HW + hw]) : (u16)0;
+    }
+}
+// (N,H,W,ctot)[coff .. coff+C) bf16 -> (N,C,H,W) f32 (debug taps, test hooks)
+__global__ __launch_bounds__(256) void nhwc_bf16_to_nchw_f32_kernel(const u16* __restrict__ in, float* __restrict__ out, int C, int HW, int ctot, int coff,
+                                                                      long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long hw = i % HW, nc = i / HW, n = nc / C, c = nc - n * C;
+        out[i] = bf2f(in[(n * HW + hw) * ctot + coff + c]);
+    }
+}
+
+// nn.Upsample(scale_factor=2, bilinear, align_corners=True) on NHWC bf16 (hrnet.py:443); one thread = 8 channels of one output pixel.
+__global__ __launch_bounds__(256) void bilinear2x_bf16_kernel(const u16* __restrict__ in, u16* __restrict__ out, int N, int C, int H, int W) {
+    const int Ho = 2 * H, Wo = 2 * W, C8 = C / 8;
+    const long total = (long)N * Ho * Wo * C8;
+    const float sy = (float)(H - 1) / (float)(Ho - 1), sx = (float)(W - 1) / (float)(Wo - 1);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c8 = (int)(i % C8);
+        long p = i / C8;
+        const int xo = (int)(p % Wo);
+        p /= Wo;
+        const int yo = (int)(p % Ho), n = (int)(p / Ho);
+        const float fy = __fmul_rn((float)yo, sy), fx = __fmul_rn((float)xo, sx);
+        const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1 < H ? y0 + 1 : H - 1, x1 = x0 + 1 < W ? x0 + 1 : W - 1;
+        const float wy = fy - (float)y0, wx = fx - (float)x0;
+        const u16* b = in + (size_t)n * H * W * C + c8 * 8;
+        const u32x4 v00 = *reinterpret_cast<const u32x4*>(b + ((size_t)y0 * W + x0) * C), v01 = *reinterpret_cast<const u32x4*>(b + ((size_t)y0 * W + x1) * C);
+        const u32x4 v10 = *reinterpret_cast<const u32x4*>(b + ((size_t)y1 * W + x0) * C), v11 = *reinterpret_cast<const u32x4*>(b + ((size_t)y1 * W + x1) * C);
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float r[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float a00 = bf2f((u16)(v00[k] >> (16 * h))), a01 = bf2f((u16)(v01[k] >> (16 * h)));
+                const float a10 = bf2f((u16)(v10[k] >> (16 * h))), a11 = bf2f((u16)(v11[k] >> (16 * h)));
+                const float top = __fmaf_rn(wx, a01 - a00, a00), bot = __fmaf_rn(wx, a11 - a10, a10);
+                r[h] = __fmaf_rn(wy, bot - top, top);
+            }
+            o[k] = pack2(r[0], r[1]);
+        }
+        *reinterpret_cast<u32x4*>(out + (((size_t)n * Ho + yo) * Wo + xo) * C + c8 * 8) = o;
+    }
+}
+
+// out = relu?( sum_k nearest_up(add_k) ) on NHWC bf16 (hrnet.py:258-265, output 0 of a fuse layer); one thread = 8 channels of a pixel.
+__global__ __launch_bounds__(256) void fuse_sum_bf16_kernel(const SumArgs a) {
+    const int C8 = a.C / 8;
+    const long total = (long)a.N * a.H * a.W * C8;
+    u16* out = reinterpret_cast<u16*>(a.out);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c8 = (int)(i % C8);
+        long p = i / C8;
+        const int x = (int)(p % a.W);
+        p /= a.W;
+        const int y = (int)(p % a.H), n = (int)(p / a.H);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k >= a.n_add) break;
+            const int sh = a.add_shift[k], hs = a.H >> sh, ws = a.W >> sh;
+            const u16* ap = reinterpret_cast<const u16*>(a.add[k]) + ((size_t)(n * hs + (y >> sh)) * ws + (x >> sh)) * a.add_ctot[k] + a.add_coff[k] + c8 * 8;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(ap);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[2 * j] += bf2f((u16)(v[j] & 0xffffu)); acc[2 * j + 1] += bf2f((u16)(v[j] >> 16)); }
+        }
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = a.relu ? fmaxf(acc[2 * j], 0.f) : acc[2 * j], hi = a.relu ? fmaxf(acc[2 * j + 1], 0.f) : acc[2 * j + 1];
+            o[j] = pack2(lo, hi);
+        }
+        *reinterpret_cast<u32x4*>(out + (((size_t)n * a.H + y) * a.W + x) * a.out_ctot + a.out_coff + c8 * 8) = o;
+    }
+}
+
+// Attention pooling on NHWC bf16 maps (keypoint_attention.py:42-48): the spatial softmax of heat channel 1+j weights the
+// features.  Pass 1: per (image, joint) max and sum of exp over the P positions.  Pass 2: partial sums over a range of
+// positions, written in the fp32 path's workspace layout so head_tail_kernel finishes both paths alike.
+constexpr int kPoolSplitB = 7;
+__global__ __launch_bounds__(256) void softmax_stats_bf16_kernel(const u16* __restrict__ heat, int hc, float* __restrict__ stats, int P) {
+    __shared__ float red[256];
+    const int n = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
+    const u16* h = heat + (size_t)n * P * hc + 1 + j;
+    float m = -INFINITY;
+    for (int p = tid; p < P; p += 256) m = fmaxf(m, bf2f(h[(size_t)p * hc]));
+    red[tid] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]); __syncthreads(); }
+    m = red[0];
+    __syncthreads();
+    float sum = 0.f;
+    for (int p = tid; p < P; p += 256) sum += expf(bf2f(h[(size_t)p * hc]) - m);
+    red[tid] = sum;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+    if (tid == 0) { stats[(n * 24 + j) * 2] = m; stats[(n * 24 + j) * 2 + 1] = 1.0f / red[0]; }
+}
+// grid (N, kPoolSplitB); thread c < CA+CB owns one feature channel and 24 accumulators.
+__global__ __launch_bounds__(256) void attn_pool_bf16_kernel(const u16* __restrict__ heat, int hc, const u16* __restrict__ featA, int CA, int ctA,
+                                                               const u16* __restrict__ featB, int CB, int ctB, const float* __restrict__ stats,
+                                                               float* __restrict__ part, int P) {
+    __shared__ float wgt[32][24];
+    const int n = blockIdx.x, sp = blockIdx.y, tid = threadIdx.x;
+    const int per = (P + kPoolSplitB - 1) / kPoolSplitB, p0 = sp * per, p1 = p0 + per < P ? p0 + per : P;
+    float acc[24];
+#pragma unroll
+    for (int j = 0; j < 24; ++j) acc[j] = 0.f;
+    const u16* src = tid < CA ? featA + (size_t)n * P * ctA + tid : featB + (size_t)n * P * ctB + (tid - CA);
+    const int cs = tid < CA ? ctA : ctB;
+    for (int pb = p0; pb < p1; pb += 32) {
+        __syncthreads();
+        for (int u = tid; u < 32 * 24; u += 256) {
+            const int pp = u / 24, j = u - pp * 24, p = pb + pp;
+            wgt[pp][j] = p < p1 ? expf(bf2f(heat[((size_t)n * P + p) * hc + 1 + j]) - stats[(n * 24 + j) * 2]) * stats[(n * 24 + j) * 2 + 1] : 0.f;
+        }
+        __syncthreads();
+        if (tid < CA + CB) {
+            for (int pp = 0; pp < 32 && pb + pp < p1; ++pp) {
+                const float f = bf2f(src[(size_t)(pb + pp) * cs]);
+#pragma unroll
+                for (int j = 0; j < 24; ++j) acc[j] = fmaf(wgt[pp][j], f, acc[j]);
+            }
+        }
+    }
+    if (tid < CA + CB) {
+#pragma unroll
+        for (int j = 0; j < 24; ++j) part[(((size_t)n * kPoolSplitB + sp) * (CA + CB) + tid) * 24 + j] = acc[j];
+    }
+}
+
+size_t lds_bytes_bf16(const ConvArgs& a, int tc) {
+    return (size_t)a.ks * a.ks * tc * kStr * 2 + (size_t)a.PSTR * kStr * 2 + (size_t)a.PSTR * 4;
+}
+
+bool plan_bf16(ConvArgs& a, int tps, int tc) {
+    const int TP = tps * 16, HoWo = a.Ho * a.Wo;
+    if (a.Wo > TP) return false;
+    if (HoWo <= TP) { a.G = TP / HoWo; if (a.G > a.N) a.G = a.N; a.R = a.Ho; }
+    else { a.G = 1; a.R = TP / a.Wo; if (a.R > a.Ho) a.R = a.Ho; }
+    a.tiles_y = (a.Ho + a.R - 1) / a.R;
+    a.groups = (a.N + a.G - 1) / a.G;
+    a.Rin = (a.R - 1) * a.stride + a.ks;
+    a.Wp = (a.Wo - 1) * a.stride + a.ks;
+    a.PSTR = a.G * a.Rin * a.Wp;                           // patch slots
+    a.gx = a.tiles_y * a.groups;
+    a.gy = a.CoutPad / tc;
+    a.TC = tc;
+    const int nt = (tps == 7 && tc == 32) ? 128 : 256;     // threads of the instantiation; each stages <= MAXA (20) patch units
+    return lds_bytes_bf16(a, tc) <= 160 * 1024 && (a.PSTR * 4 + nt - 1) / nt <= 20;
+}
+
+template <int KS, int S>
+hipError_t dispatch_bf16(const ConvArgs& a, int tps, int tc, hipStream_t s) {
+    const size_t lds = lds_bytes_bf16(a, tc);
+    const dim3 grid(a.gx * a.gy);
+    if (tps == 14 && tc == 64) return launch_k(conv_bf16_nhwc<KS, S, 14, 4, 2, 2>, grid, dim3(256), lds, s, a);
+    if (tps == 14 && tc == 32) return launch_k(conv_bf16_nhwc<KS, S, 14, 2, 2, 2>, grid, dim3(256), lds, s, a);
+    if (tps == 7 && tc == 64) return launch_k(conv_bf16_nhwc<KS, S, 7, 4, 1, 4>, grid, dim3(256), lds, s, a);
+    if (tps == 7 && tc == 32) return launch_k(conv_bf16_nhwc<KS, S, 7, 2, 1, 2>, grid, dim3(128), lds, s, a);
+    return hipErrorInvalidValue;
+}
+
+template <typename K>
+hipError_t set_lds_bf16(K kern) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+template <int KS, int S>
+hipError_t init_bf16_ks() {
+    GRK_TRY(set_lds_bf16(conv_bf16_nhwc<KS, S, 14, 4, 2, 2>));
+    GRK_TRY(set_lds_bf16(conv_bf16_nhwc<KS, S, 14, 2, 2, 2>));
+    GRK_TRY(set_lds_bf16(conv_bf16_nhwc<KS, S, 7, 4, 1, 4>));
+    GRK_TRY(set_lds_bf16(conv_bf16_nhwc<KS, S, 7, 2, 1, 2>));
+    return hipSuccess;
+}
+
+inline int blocks_for(long total) { return (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384); }
+
+}  // namespace
+
+hipError_t conv_bf16_init() {
+    GRK_TRY((init_bf16_ks<1, 1>()));
+    GRK_TRY((init_bf16_ks<3, 1>()));
+    GRK_TRY((init_bf16_ks<3, 2>()));
+    return hipSuccess;
+}
+
+// a.in / a.out / a.w / a.add[] point at bf16 data (NHWC activations, [tap][CoutPad][CinPad] weights); a.bias is fp32.
+// Requirements: CinPad % 32 == 0, CoutPad % 32 == 0, in_ctot / in_coff / out_ctot / out_coff / add_ctot / add_coff multiples of 8 (4 for outputs).
+hipError_t launch_conv_bf16(ConvArgs a, hipStream_t s, int tile_hint) {
+    if (!((a.ks == 1 && a.stride == 1) || (a.ks == 3 && (a.stride == 1 || a.stride == 2)))) return hipErrorInvalidValue;
+    if (a.CinPad % kCK != 0 || a.CoutPad % 32 != 0 || a.in_ctot % 8 != 0 || a.in_coff % 8 != 0 || a.out_ctot % 4 != 0 || a.out_coff % 4 != 0)
+        return hipErrorInvalidValue;
+    const int tc = a.CoutPad % 64 == 0 ? 64 : 32;
+    int tps = (tile_hint == 7 || tile_hint == 14) ? tile_hint : (a.Wo >= 56 ? 14 : 7);
+    if (!plan_bf16(a, tps, tc)) {
+        tps = tps == 14 ? 7 : 14;
+        if (!plan_bf16(a, tps, tc)) return hipErrorInvalidValue;
+    }
+    if (a.ks == 1) return dispatch_bf16<1, 1>(a, tps, tc, s);
+    return a.stride == 1 ? dispatch_bf16<3, 1>(a, tps, tc, s) : dispatch_bf16<3, 2>(a, tps, tc, s);
+}
+
+hipError_t launch_nchw_f32_to_nhwc_bf16(const float* in, void* out, int N, int C, int H, int W, int Cp, hipStream_t s) {
+    const long total = (long)N * H * W * Cp;
+    return launch_k(nchw_f32_to_nhwc_bf16_kernel, dim3(blocks_for(total)), dim3(256), 0, s, in, reinterpret_cast<u16*>(out), C, H * W, Cp, total);
+}
+hipError_t launch_nhwc_bf16_to_nchw_f32(const void* in, float* out, int N, int C, int H, int W, int ctot, int coff, hipStream_t s) {
+    const long total = (long)N * C * H * W;
+    return launch_k(nhwc_bf16_to_nchw_f32_kernel, dim3(blocks_for(total)), dim3(256), 0, s, reinterpret_cast<const u16*>(in), out, C, H * W, ctot, coff, total);
+}
+hipError_t launch_bilinear2x_bf16(const void* in, void* out, int N, int C, int H, int W, hipStream_t s) {
+    if (C % 8 != 0) return hipErrorInvalidValue;
+    const long total = (long)N * 4 * H * W * (C / 8);
+    return launch_k(bilinear2x_bf16_kernel, dim3(blocks_for(total)), dim3(256), 0, s, reinterpret_cast<const u16*>(in), reinterpret_cast<u16*>(out), N, C, H, W);
+}
+hipError_t launch_fuse_sum_bf16(const SumArgs& a, hipStream_t s) {
+    if (a.C % 8 != 0 || a.n_add < 1 || a.n_add > 4) return hipErrorInvalidValue;
+    const long total = (long)a.N * a.H * a.W * (a.C / 8);
+    return launch_k(fuse_sum_bf16_kernel, dim3(blocks_for(total)), dim3(256), 0, s, a);
+}
+// heat (N,P,hc) with channel 0 = background; featA / featB: first channel of the view, ctA / ctB channels per pixel in memory;
+// pool_ws as launch_softmax_pool fills it.
+hipError_t launch_softmax_pool_bf16(const void* heat, int hc, const void* featA, int CA, int ctA, const void* featB, int CB, int ctB, float* pool_ws, int N,
+                                    int P, hipStream_t s) {
+    if (CA != 128 || CB != 64) return hipErrorInvalidValue;
+    float* stats = pool_ws;
+    float* part = pool_ws + (size_t)N * 24 * 2;
+    GRK_TRY(launch_k(softmax_stats_bf16_kernel, dim3(N, 24), dim3(256), 0, s, reinterpret_cast<const u16*>(heat), hc, stats, P));
+    return launch_k(attn_pool_bf16_kernel, dim3(N, kPoolSplitB), dim3(256), 0, s, reinterpret_cast<const u16*>(heat), hc, reinterpret_cast<const u16*>(featA), CA, ctA,
+                    reinterpret_cast<const u16*>(featB), CB, ctB, stats, part, P);
+}
+
+}  // namespace grk

@@ -34,6 +34,13 @@ namespace grk { thread_local GraphRecorder* g_recorder = nullptr; }
 namespace {
 
 constexpr double kBnEps = 1e-5;   // nn.BatchNorm2d default eps
+
+inline uint16_t f32_to_bf16(float f) {                     // round to nearest even, as the kernels do
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
 const int kBranchCh[4] = {32, 64, 128, 256};
 
 struct HostTensor {
@@ -50,6 +57,7 @@ struct ConvLayer {
     View in, out;
     std::vector<ConvSeg> segs;
     int cout = 0, ks = 1, stride = 1, relu = 0;
+    int cin_w = 0;              // input channels of the weight tensor (< in.c only for the bf16 stem: 3 of the 8 stored)
     std::vector<AddRef> adds;
     float* w_dev = nullptr;
     float* b_dev = nullptr;
@@ -60,7 +68,7 @@ struct ConvLayer {
 };
 
 struct Op {
-    enum Kind { CONV, GROUP, SUM, BILINEAR, POOL, TAIL, SMPL } kind;
+    enum Kind { CONV, GROUP, SUM, BILINEAR, POOL, TAIL, SMPL, CONVERT } kind;
     int conv_idx = -1;
     std::vector<int> group;   // GROUP: indices into convs[] launched together (independent, same ks/stride)
     SumArgs sum{};
@@ -84,6 +92,8 @@ constexpr int kLanes = 8;            // streams available to the lane scheduler 
 
 struct grnet {
     int device = 0, max_frames = 0;
+    int dtype = 0;               // 0: fp32 NCHW activations, 1: bf16 NHWC activations (conv_bf16.hip), fp32 tail either way
+    View v_in8;                  // bf16: the caller's frames converted to NHWC bf16 with 8 channels (3 real)
     bool finalized = false, smpl_loaded = false, gru_ready = false, tsattn_ready = false;
     TsAttnWeights tsw{};
     bool use_graph = false;
@@ -140,10 +150,11 @@ struct grnet {
     // ------------------------------------------------------------------ plan construction
     View new_buffer(int c, int h, int w) {
         slots.emplace_back(new float*(nullptr));
-        pending.emplace_back(slots.back().get(), (size_t)c * h * w);
+        const int ct = dtype == 1 ? (c + 7) / 8 * 8 : c;     // NHWC bf16: 16-byte channel groups (the 25 heat channels -> 32)
+        pending.emplace_back(slots.back().get(), (size_t)ct * h * w);
         View v;
         v.p = nullptr;
-        v.ctot = c; v.coff = 0; v.c = c; v.h = h; v.w = w;
+        v.ctot = ct; v.coff = 0; v.c = c; v.h = h; v.w = w;
         // p is resolved through slot index stored in coff-independent table: keep index in a side map
         view_slot[(int)views_created] = slots.size() - 1;
         v.p = reinterpret_cast<float*>(views_created++ + 1);   // temporary tag, replaced in resolve()
@@ -170,7 +181,8 @@ struct grnet {
         L.segs = std::move(segs);
         L.cout = cout; L.ks = ks; L.stride = stride; L.relu = relu;
         L.adds = std::move(adds);
-        L.macs_per_frame = (double)ho * wo * cout * in.c * ks * ks;
+        L.cin_w = (dtype == 1 && in.c == 8 && in.ctot == 8) ? 3 : in.c;     // bf16 stem: 3 real channels stored as 8
+        L.macs_per_frame = (double)ho * wo * cout * L.cin_w * ks * ks;
         L.lane_hint = cur_lane;
         convs.push_back(L);
         if (group_open) {
@@ -311,6 +323,13 @@ struct grnet {
         v_input.p = nullptr; v_input.ctot = 3; v_input.coff = 0; v_input.c = 3; v_input.h = 224; v_input.w = 224;
         View in = v_input;
         in.p = reinterpret_cast<float*>(~(uintptr_t)0);   // tag: caller's frames pointer
+        if (dtype == 1) {                                  // bf16: frames (N,3,224,224) f32 -> NHWC bf16, 8 channels per pixel
+            v_in8 = new_buffer(8, 224, 224);
+            Op cv;
+            cv.kind = Op::CONVERT;
+            ops.push_back(cv);
+            in = v_in8;
+        }
         View x = conv_bn(in, b + "conv1.weight", b + "bn1", 64, 3, 2, true);
         name_view("stem_conv1", x);
         x = conv_bn(x, b + "conv2.weight", b + "bn2", 64, 3, 2, true);
@@ -420,6 +439,7 @@ struct grnet {
         for (auto& sv : sum_views) { resolve(sv.first); for (auto& a : sv.second) resolve(a.v); }
         for (auto& nv : named) resolve(nv.second);
         resolve(v_cat); resolve(v_heat); resolve(v_smpl_feats); resolve(v_csmap);
+        if (dtype == 1) resolve(v_in8);
         ops_flat.clear();
         for (const Op& op : ops) {
             if (op.kind != Op::GROUP) { ops_flat.push_back(op); continue; }
@@ -490,6 +510,7 @@ struct grnet {
         if (op.kind == Op::CONV) return convs[op.conv_idx].out.p;
         if (op.kind == Op::SUM) return sum_views[op.conv_idx].first.p;
         if (op.kind == Op::BILINEAR) return op.bout.p;
+        if (op.kind == Op::CONVERT) return v_in8.p;
         return nullptr;
     }
 
@@ -639,6 +660,7 @@ struct grnet {
             if (op.kind == Op::CONV) out = convs[op.conv_idx].out.p;
             else if (op.kind == Op::SUM) out = sum_views[op.conv_idx].first.p;
             else if (op.kind == Op::BILINEAR) out = op.bout.p;
+            else if (op.kind == Op::CONVERT) out = v_in8.p;
             if (out) writers[out].push_back(i);
             if (op.kind == Op::GROUP)
                 for (int ci : op.group) writers[convs[ci].out.p].push_back(i);
@@ -662,10 +684,11 @@ struct grnet {
 
     // Fold BN (fp64) and pack to [tap][CinPad][CoutPad].
     int pack_conv(ConvLayer& L) {
-        const int cin = L.in.c, ks = L.ks, taps = ks * ks;
+        const int cin = L.cin_w, ks = L.ks, taps = ks * ks;
         const int TC = conv_pick_tc(L.cout);
-        L.cin_pad = (cin + kConvCK - 1) / kConvCK * kConvCK;
-        L.cout_pad = (L.cout + TC - 1) / TC * TC;
+        const bool bf = dtype == 1;                            // bf16: [tap][CoutPad][CinPad] with CinPad % 32 == 0 (one MFMA k-step)
+        L.cin_pad = bf ? (L.in.c + 31) / 32 * 32 : (cin + kConvCK - 1) / kConvCK * kConvCK;
+        L.cout_pad = bf ? (L.cout + 31) / 32 * 32 : (L.cout + TC - 1) / TC * TC;
         std::vector<float> wp((size_t)taps * L.cin_pad * L.cout_pad, 0.f), bp(L.cout_pad, 0.f);
         int co0 = 0;
         for (auto& s : L.segs) {
@@ -694,13 +717,20 @@ struct grnet {
                 bp[co0 + co] = (float)shift[co];
                 for (int ci = 0; ci < cin; ++ci)
                     for (int t = 0; t < taps; ++t)
-                        wp[((size_t)t * L.cin_pad + ci) * L.cout_pad + co0 + co] =
+                        wp[bf ? ((size_t)t * L.cout_pad + co0 + co) * L.cin_pad + ci : ((size_t)t * L.cin_pad + ci) * L.cout_pad + co0 + co] =
                             (float)((double)w->data[((size_t)co * cin + ci) * taps + t] * scale[co]);
             }
             co0 += s.cout;
         }
         int rc;
-        if ((rc = upload(wp, &L.w_dev))) return rc;
+        if (bf) {                                              // round the folded weights to bf16 (nearest even), two per float slot
+            std::vector<float> packed((wp.size() + 1) / 2, 0.f);
+            uint16_t* h16 = reinterpret_cast<uint16_t*>(packed.data());
+            for (size_t i = 0; i < wp.size(); ++i) h16[i] = f32_to_bf16(wp[i]);
+            if ((rc = upload(packed, &L.w_dev))) return rc;
+        } else if ((rc = upload(wp, &L.w_dev))) {
+            return rc;
+        }
         if ((rc = upload(bp, &L.b_dev))) return rc;
         return 0;
     }
@@ -823,6 +853,7 @@ struct grnet {
         HIP_TRY(hipEventCreate(&e1));
         std::map<std::tuple<int, int, int, int, int, int, int>, int> by_shape;
         for (auto& L : convs) {
+            if (dtype == 1) { L.tuned[n] = 0; continue; }          // the bf16 kernel picks its tile by map width; only the schedule is timed
             const auto key = std::make_tuple(L.in.c, L.cout, L.ks, L.stride, L.in.h, (int)L.adds.size(), L.out.ctot);
             auto it = by_shape.find(key);
             if (it != by_shape.end()) { L.tuned[n] = it->second; continue; }
@@ -853,8 +884,9 @@ struct grnet {
         const bool keep = grouping, keep_graph = use_graph;
         for (int mode = 0; mode < 8; ++mode) {
             if ((mode & 4) == 0 && !keep_graph) { t_mode[mode] = 1e30f; continue; }   // graphs not enabled by the caller
+            if (dtype == 1 && (mode & 3)) { t_mode[mode] = 1e30f; continue; }          // bf16: no per-shape table, no grouped launches
             use_graph = (mode & 4) == 0;
-            grouping = true;
+            grouping = dtype != 1;
             tuned_mode[n] = mode;
             for (auto& g : graphs) hipGraphExecDestroy(g.second);
             graphs.clear();
@@ -947,6 +979,7 @@ struct grnet {
     }
 
     // ------------------------------------------------------------------ execution
+    static const void* bf16_at(const View& v) { return reinterpret_cast<const uint16_t*>(v.p) + v.coff; }   // first channel of an NHWC bf16 view
     ConvArgs conv_args(const ConvLayer& L, const float* frames, int n) const {
         ConvArgs a{};
         a.in = reinterpret_cast<uintptr_t>(L.in.p) == ~(uintptr_t)0 ? frames : L.in.p;
@@ -1006,8 +1039,14 @@ struct grnet {
                         if (op_node[w]) rec->deps.push_back(op_node[w]);
             }
             switch (op.kind) {
+                case Op::CONVERT:
+                    HIP_TRY(launch_nchw_f32_to_nhwc_bf16(frames, v_in8.p, n, 3, 224, 224, 8, s));
+                    ++launches;
+                    break;
                 case Op::CONV: {
-                    HIP_TRY(launch_conv(conv_args(convs[op.conv_idx], frames, n), s, hint_for(convs[op.conv_idx], n)));
+                    const ConvLayer& L = convs[op.conv_idx];
+                    if (dtype == 1) HIP_TRY(launch_conv_bf16(conv_args(L, frames, n), s, hint_for(L, n)));
+                    else HIP_TRY(launch_conv(conv_args(L, frames, n), s, hint_for(L, n)));
                     ++launches;
                     break;
                 }
@@ -1019,7 +1058,10 @@ struct grnet {
                         HIP_TRY(launch_conv_group(list, cnt, s));
                         ++launches;
                     } else {
-                        for (int gi = 0; gi < cnt; ++gi) HIP_TRY(launch_conv(list[gi], s, hint_for(convs[op.group[gi]], n)));
+                        for (int gi = 0; gi < cnt; ++gi) {
+                            if (dtype == 1) HIP_TRY(launch_conv_bf16(list[gi], s, hint_for(convs[op.group[gi]], n)));
+                            else HIP_TRY(launch_conv(list[gi], s, hint_for(convs[op.group[gi]], n)));
+                        }
                         launches += cnt;
                     }
                     break;
@@ -1033,16 +1075,22 @@ struct grnet {
                         a.add[k] = sv.second[k].v.p; a.add_ctot[k] = sv.second[k].v.ctot; a.add_coff[k] = sv.second[k].v.coff;
                         a.add_shift[k] = sv.second[k].shift;
                     }
-                    HIP_TRY(launch_fuse_sum(a, s));
+                    if (dtype == 1) HIP_TRY(launch_fuse_sum_bf16(a, s));
+                    else HIP_TRY(launch_fuse_sum(a, s));
                     ++launches;
                     break;
                 }
                 case Op::BILINEAR:
-                    HIP_TRY(launch_bilinear2x(op.bin.p, op.bout.p, n, op.bin.c, op.bin.h, op.bin.w, s));
+                    if (dtype == 1) HIP_TRY(launch_bilinear2x_bf16(op.bin.p, op.bout.p, n, op.bin.c, op.bin.h, op.bin.w, s));
+                    else HIP_TRY(launch_bilinear2x(op.bin.p, op.bout.p, n, op.bin.c, op.bin.h, op.bin.w, s));
                     ++launches;
                     break;
                 case Op::POOL:
-                    HIP_TRY(launch_softmax_pool(v_heat.p, 25, v_smpl_feats.p, 128, v_csmap.p, 64, plf, csf, d_stats, n, 56 * 56, s));
+                    if (dtype == 1)
+                        HIP_TRY(launch_softmax_pool_bf16(v_heat.p, v_heat.ctot, bf16_at(v_smpl_feats), 128, v_smpl_feats.ctot, bf16_at(v_csmap), 64,
+                                                         v_csmap.ctot, d_stats, n, 56 * 56, s));
+                    else
+                        HIP_TRY(launch_softmax_pool(v_heat.p, 25, v_smpl_feats.p, 128, v_csmap.p, 64, plf, csf, d_stats, n, 56 * 56, s));
                     launches += 2;
                     break;
                 case Op::TAIL:
@@ -1074,11 +1122,65 @@ struct grnet {
                 return 0;
             };
             int rc;
+            if (dtype == 1) {                                   // the optional map outputs stay (N,C,56,56) fp32 for the caller
+                auto conv_out = [&](float* dst, const View& v) -> int {
+                    if (!dst) return 0;
+                    if (rec) {
+                        rec->deps.clear();
+                        for (hipGraphNode_t nd : lane_last) if (nd) rec->deps.push_back(nd);
+                    }
+                    HIP_TRY(launch_nhwc_bf16_to_nchw_f32(v.p, dst, n, v.c, v.h, v.w, v.ctot, v.coff, s));
+                    return 0;
+                };
+                if ((rc = conv_out(o.features, v_cat))) return rc;
+                if ((rc = conv_out(o.part_attn, v_heat))) return rc;
+                if ((rc = conv_out(o.smpl_feats, v_smpl_feats))) return rc;
+            } else {
             if ((rc = copy_out(o.features, v_cat.p, (size_t)n * 480 * 3136 * 4))) return rc;
             if ((rc = copy_out(o.part_attn, v_heat.p, (size_t)n * 25 * 3136 * 4))) return rc;
             if ((rc = copy_out(o.smpl_feats, v_smpl_feats.p, (size_t)n * 128 * 3136 * 4))) return rc;
+            }
             launches_last = launches;
         }
+        return 0;
+    }
+
+    // Test hook on a bf16 handle: (n,cin,h,w) f32 NCHW in / out, converted to and from NHWC bf16 around ONE conv launch.
+    int op_conv2d_bf16(const float* in_dev, int n, int cin, int hgt, int wid, const float* w_host, const float* bias_host, int cout, int ks,
+                       int stride, int relu, const float* add_dev, float* out_dev, int tile_hint, hipStream_t s) {
+        const int taps = ks * ks, pad = ks / 2, cin8 = (cin + 7) / 8 * 8, cin_pad = (cin + 31) / 32 * 32, cout_pad = (cout + 31) / 32 * 32;
+        const int ho = (hgt + 2 * pad - ks) / stride + 1, wo = (wid + 2 * pad - ks) / stride + 1, cout8 = (cout + 7) / 8 * 8;
+        std::vector<uint16_t> wp((size_t)taps * cout_pad * cin_pad, 0);
+        std::vector<float> bp(cout_pad, 0.f);
+        for (int co = 0; co < cout; ++co) {
+            if (bias_host) bp[co] = bias_host[co];
+            for (int ci = 0; ci < cin; ++ci)
+                for (int t = 0; t < taps; ++t) wp[((size_t)t * cout_pad + co) * cin_pad + ci] = f32_to_bf16(w_host[((size_t)co * cin + ci) * taps + t]);
+        }
+        void *wd = nullptr, *bd = nullptr, *xin = nullptr, *xadd = nullptr, *xout = nullptr;
+        const size_t in_b = (size_t)n * hgt * wid * cin8 * 2, out_b = (size_t)n * ho * wo * cout8 * 2;
+        if (hipMalloc(&wd, wp.size() * 2) != hipSuccess || hipMalloc(&bd, bp.size() * 4) != hipSuccess || hipMalloc(&xin, in_b) != hipSuccess ||
+            hipMalloc(&xout, out_b) != hipSuccess || (add_dev && hipMalloc(&xadd, out_b) != hipSuccess))
+            return fail(GRNET_ENOMEM, "hipMalloc failed");
+        hipMemcpy(wd, wp.data(), wp.size() * 2, hipMemcpyHostToDevice);
+        hipMemcpy(bd, bp.data(), bp.size() * 4, hipMemcpyHostToDevice);
+        hipError_t e = launch_nchw_f32_to_nhwc_bf16(in_dev, xin, n, cin, hgt, wid, cin8, s);
+        if (e == hipSuccess && add_dev) e = launch_nchw_f32_to_nhwc_bf16(add_dev, xadd, n, cout, ho, wo, cout8, s);
+        ConvArgs a{};
+        a.in = static_cast<const float*>(xin); a.in_ctot = cin8; a.in_coff = 0; a.N = n; a.Cin = cin8; a.H = hgt; a.W = wid;
+        a.Cout = cout; a.Ho = ho; a.Wo = wo;
+        a.out = static_cast<float*>(xout); a.out_ctot = cout8; a.out_coff = 0;
+        a.w = static_cast<const float*>(wd); a.bias = static_cast<const float*>(bd); a.CinPad = cin_pad; a.CoutPad = cout_pad;
+        a.ks = ks; a.stride = stride; a.relu = relu;
+        if (add_dev) { a.n_add = 1; a.add[0] = static_cast<const float*>(xadd); a.add_ctot[0] = cout8; a.add_coff[0] = 0; a.add_shift[0] = 0; }
+        a.zeros = zeros;
+        if (e == hipSuccess) e = launch_conv_bf16(a, s, tile_hint);
+        if (e == hipSuccess) e = launch_nhwc_bf16_to_nchw_f32(xout, out_dev, n, cout, ho, wo, cout8, 0, s);
+        hipError_t e2 = hipStreamSynchronize(s);
+        hipFree(wd); hipFree(bd); hipFree(xin); hipFree(xout);
+        if (xadd) hipFree(xadd);
+        if (e != hipSuccess) return fail(GRNET_EHIP, std::string("bf16 conv: ") + hipGetErrorString(e));
+        if (e2 != hipSuccess) return fail(GRNET_EHIP, std::string("bf16 conv kernel: ") + hipGetErrorString(e2));
         return 0;
     }
 
@@ -1122,17 +1224,19 @@ extern "C" {
 const char* grnet_version(void) { return "grnet_hip 0.1 (gfx950, fp32 MFMA)"; }
 
 int grnet_create(grnet_t** out_handle, int device_id, int dtype, int max_frames) {
-    if (!out_handle || max_frames < 1 || max_frames > 2048 || dtype != 0) return GRNET_EINVAL;
+    if (!out_handle || max_frames < 1 || max_frames > 2048 || (dtype != 0 && dtype != 1)) return GRNET_EINVAL;
     *out_handle = nullptr;
     if (hipSetDevice(device_id) != hipSuccess) return GRNET_EHIP;
     std::unique_ptr<grnet> h(new grnet());
     h->device = device_id;
     h->max_frames = max_frames;
+    h->dtype = dtype;
+    if (dtype == 1) h->grouping = false;                   // grouped launches exist for the fp32 split-K kernels only
     if (const char* ml = getenv("GRNET_MULTI_LANE")) h->multi_lane = atoi(ml) != 0;   // profiling: per-kernel times without overlap
     h->build_plan();
     int rc = h->allocate();
     if (rc) { fprintf(stderr, "grnet_create: %s\n", h->err.c_str()); return rc; }
-    if (conv_init() != hipSuccess) { fprintf(stderr, "grnet_create: conv_init failed\n"); return GRNET_EHIP; }
+    if (conv_init() != hipSuccess || conv_bf16_init() != hipSuccess) { fprintf(stderr, "grnet_create: conv_init failed\n"); return GRNET_EHIP; }
     *out_handle = h.release();
     return 0;
 }
@@ -1356,6 +1460,8 @@ int grnet_time_convs(grnet_t* h, int n_frames, void* stream, float* ms_out) {
 int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, int wid, const float* w_host, const float* bias_host,
                     int cout, int ks, int stride, int relu, const float* add_dev, float* out_dev, int tile_hint, void* stream) {
     if (!h || !in_dev || !w_host || !out_dev) return GRNET_EINVAL;
+    if (h->dtype == 1) return h->op_conv2d_bf16(in_dev, n, cin, hgt, wid, w_host, bias_host, cout, ks, stride, relu, add_dev, out_dev, tile_hint,
+                                                static_cast<hipStream_t>(stream));
     const int taps = ks * ks, TC = conv_pick_tc(cout);
     const int cin_pad = (cin + kConvCK - 1) / kConvCK * kConvCK, cout_pad = (cout + TC - 1) / TC * TC;
     std::vector<float> wp((size_t)taps * cin_pad * cout_pad, 0.f), bp(cout_pad, 0.f);
@@ -1417,6 +1523,11 @@ int grnet_debug_tensor(grnet_t* h, const char* name, int n_frames, float* out_de
         if (shape_out) { shape_out[0] = v.c; shape_out[1] = v.h; shape_out[2] = v.w; }
         if (!out_dev) return 0;
         const size_t plane = (size_t)v.h * v.w;
+        if (h->dtype == 1) {
+            hipError_t eb = launch_nhwc_bf16_to_nchw_f32(v.p, out_dev, n_frames, v.c, v.h, v.w, v.ctot, v.coff, static_cast<hipStream_t>(stream));
+            if (eb != hipSuccess) return h->fail(GRNET_EHIP, std::string("debug convert: ") + hipGetErrorString(eb));
+            return 0;
+        }
         hipError_t e = hipMemcpy2DAsync(out_dev, (size_t)v.c * plane * 4, v.p + (size_t)v.coff * plane, (size_t)v.ctot * plane * 4,
                                         (size_t)v.c * plane * 4, n_frames, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("debug copy: ") + hipGetErrorString(e));

@@ -155,6 +155,16 @@ struct GruWorkspace {
     float* l1;       // (b*T, 600)
     float* hfin;     // (b, 1200)
 };
+// bf16 path (conv_bf16.hip): NHWC bf16 activations, fp32 accumulation on the bf16 matrix cores ----------------------
+hipError_t conv_bf16_init();
+hipError_t launch_conv_bf16(ConvArgs a, hipStream_t s, int tile_hint = 0);     // pointers in `a` address bf16 data (bias fp32)
+hipError_t launch_nchw_f32_to_nhwc_bf16(const float* in, void* out, int N, int C, int H, int W, int Cp, hipStream_t s);
+hipError_t launch_nhwc_bf16_to_nchw_f32(const void* in, float* out, int N, int C, int H, int W, int ctot, int coff, hipStream_t s);
+hipError_t launch_bilinear2x_bf16(const void* in, void* out, int N, int C, int H, int W, hipStream_t s);
+hipError_t launch_fuse_sum_bf16(const SumArgs& a, hipStream_t s);
+hipError_t launch_softmax_pool_bf16(const void* heat, int hc, const void* featA, int CA, int ctA, const void* featB, int CB, int ctB, float* pool_ws, int N,
+                                    int P, hipStream_t s);
+
 // C[M][N] = A[M][K] . B[N][K]^T + bias[N] on the fp32 matrix cores (row-major, K % 4 == 0, 16-byte aligned rows).
 hipError_t launch_gemm_nt_bias(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int ldc, hipStream_t s);
 

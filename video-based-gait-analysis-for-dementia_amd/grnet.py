@@ -41,7 +41,7 @@ class GRNet:
     def __init__(self, num_joints=24, num_input_features=480, num_features_pare=128, num_features_smpl=64,
                  backbone='hrnet_w32', focal_length=5000., img_res=224, pretrained_pare=None, writer=None, seqlen=50,
                  pretrained_hrnet=None, use_gait_feat=False, featcorr=None, use_pose_encoder=False,
-                 use_shpcam_encoder=False, max_frames=64, device_id=0):
+                 use_shpcam_encoder=False, max_frames=64, device_id=0, dtype="f32"):
         if (num_joints, num_input_features, num_features_pare, num_features_smpl) != (24, 480, 128, 64) \
                 or backbone != 'hrnet_w32' or focal_length != 5000. or img_res != 224:
             raise ValueError("the HIP path implements the reference's fixed configuration "
@@ -53,7 +53,10 @@ class GRNet:
         self.max_frames = int(max_frames)
         self.device = torch.device("cuda", device_id)
         h = C.c_void_p()
-        rc = self._lib.grnet_create(C.byref(h), device_id, 0, self.max_frames)
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("dtype must be 'f32' (the reference's precision) or 'bf16' (bf16 storage, fp32 accumulation; BASELINE configs 3/5)")
+        self.dtype = dtype
+        rc = self._lib.grnet_create(C.byref(h), device_id, 1 if dtype == "bf16" else 0, self.max_frames)
         if rc != 0:
             raise _lib.GrnetError(f"grnet_create failed with code {rc} (is a GPU visible?)")
         self._h = h
@@ -372,10 +375,10 @@ class GRNet:
             pass
 
 
-def build_synthetic_model(max_frames=64, device_id=0, with_gru=True, with_tsattn=False):
+def build_synthetic_model(max_frames=64, device_id=0, with_gru=True, with_tsattn=False, dtype="f32"):
     """GRNet with the seed-defined weights / SMPL tables of synth.py (no checkpoint exists offline)."""
     from . import synth
-    m = GRNet(max_frames=max_frames, device_id=device_id)
+    m = GRNet(max_frames=max_frames, device_id=device_id, dtype=dtype)
     sd = synth.make_state_dict()
     if with_gru:
         sd.update({"gru." + k: v for k, v in synth.make_gru_state_dict().items()})
