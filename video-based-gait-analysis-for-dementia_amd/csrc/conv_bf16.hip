@@ -6,13 +6,14 @@
 // consecutive K elements per lane (16 bytes): with K = (tap, channel) that is 8 consecutive channels of one pixel,
 // one ds_read_b128 -- NCHW planes would need eight 2-byte reads.  Roles are M = output channels, N = pixels, so a
 // lane's 4 accumulator rows are 4 consecutive channels of ONE pixel: one 8-byte NHWC store.
-//   A[row = cout l&15][k = 8(l>>4)+j] = W[tap][cout][cin]      (packed [tap][CoutPad][CinPad] bf16)
+//   A[row = cout l&15][k = 8(l>>4)+j] = W[tap][cout][cin]      (packed [cin/32][tap][CoutPad][32] bf16)
 //   B[k = 8(l>>4)+j][col = pixel l&15] = patch[slot(pixel)+tap][cin]
 //   D[row = 4(l>>4)+r][col = l&15]     = out[pixel][cout]
 // A workgroup owns TPS*16 pixels (R whole output rows of one image, or G whole small images) x TCS*16 channels and
-// walks K in chunks of 32 input channels: the zero-padded input patch and the chunk's weights are staged through
-// registers into LDS (80-byte slots: 64 B of data + 16 B of padding keep the 16-lane b128 reads off each other's
-// banks), the next chunk's global loads are in flight under the MFMAs of the current one.
+// walks K in chunks of 32 input channels: the zero-padded input patch and the chunk's weights go HBM/L2 -> LDS by
+// LDS-DMA (no staging registers), double-buffered where two workgroups still fit a CU, one barrier per chunk.
+// Patch slots are 80 bytes (64 B of data + 16 B of padding) and weight rows are XOR-swizzled, so the 16-lane b128
+// operand reads fall on distinct banks.
 #include "kernels.h"
 
 namespace grk {
@@ -28,7 +29,6 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kCK = 32;        // input channels per K chunk (= one MFMA k-step per tap)
-constexpr int kStr = 40;       // LDS slot stride in bf16 (80 B)
 
 __device__ __forceinline__ u16 f2bf(float f) {           // round to nearest even (finite inputs)
     unsigned u = __float_as_uint(f);
@@ -38,14 +38,27 @@ __device__ __forceinline__ u16 f2bf(float f) {           // round to nearest eve
 __device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float((unsigned)h << 16); }
 __device__ __forceinline__ unsigned pack2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
 
+// LDS-DMA: lane l's 16 bytes land at lds_wave_base + 16*l; the source address is per lane.
+#define GRNET_GLOBAL_AS __attribute__((address_space(1)))
+#define GRNET_LDS_AS __attribute__((address_space(3)))
+__device__ __forceinline__ void dma16(const u16* src, u16* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const GRNET_GLOBAL_AS void*)src, (GRNET_LDS_AS void*)lds_wave_base, 16, 0, 0);
+}
+
+constexpr int kSlotU = 5;      // 16-byte DMA units per patch slot: 4 of data + 1 of padding (80-byte stride: conflict-free b128 reads)
+
 template <int KS, int S, int TPS, int TCS, int WP, int WC>
 __global__ __launch_bounds__(WP * WC * 64) void conv_bf16_nhwc(const ConvArgs a) {
     constexpr int NT = WP * WC * 64, PSW = TPS / WP, CSW = TCS / WC, TC = TCS * 16, TAPS = KS * KS;
+    constexpr int WROWS = TAPS * TC, WUNITS = WROWS * 4;                 // weight rows of 64 B (32 channels) per chunk
     static_assert(TPS % WP == 0 && TCS % WC == 0, "wave grid must divide the tile");
+    static_assert(WUNITS % 64 == 0, "weight chunk must be whole wave-instructions");
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    u16* w_lds = reinterpret_cast<u16*>(smem_raw);                       // [TAPS*TC][kStr]
-    u16* a_lds = w_lds + TAPS * TC * kStr;                               // [NSLOT][kStr]
-    int* tab = reinterpret_cast<int*>(a_lds + (size_t)a.PSTR * kStr);    // [NSLOT] input pixel of each patch slot, -1 = zero
+    const int aunits = (a.PSTR * kSlotU + 63) & ~63;                     // patch units per chunk, whole wave-instructions
+    const int nbuf = a.TC;                                               // set by plan_bf16 for this kernel: 2 = double-buffered chunks, 1 = single
+    u16* w_lds = reinterpret_cast<u16*>(smem_raw);                       // [nbuf][WROWS][32]       part index XOR-swizzled by row
+    u16* a_lds = w_lds + (size_t)nbuf * WROWS * 32;                      // [nbuf][aunits][8]       80-byte slots
+    int* tab = reinterpret_cast<int*>(a_lds + (size_t)nbuf * aunits * 8);   // [PSTR] input pixel of each patch slot, -1 = zero
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp = wave / WC, wc = wave % WC, l15 = lane & 15, lq = lane >> 4;
@@ -56,6 +69,7 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_bf16_nhwc(const ConvArgs a)
     constexpr int pad = KS / 2;
     const u16* in = reinterpret_cast<const u16*>(a.in);
     const u16* wg = reinterpret_cast<const u16*>(a.w);
+    const u16* zeros = reinterpret_cast<const u16*>(a.zeros);
 
     for (int idx = tid; idx < a.PSTR; idx += NT) {
         const int gl = idx / RinWp, rem = idx - gl * RinWp;
@@ -66,43 +80,27 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_bf16_nhwc(const ConvArgs a)
     }
     __syncthreads();
 
-    // register staging: 16-byte units (8 channels) of the patch and of the weight chunk owned by this thread
-    const int n_au = a.PSTR * 4, n_wu = TAPS * TC * 4;
-    constexpr int MAXA = 20, NWU = (TAPS * TC * 4 + NT - 1) / NT;        // the launcher keeps ceil(n_au / NT) <= MAXA
-    u32x4 ra[MAXA], rw[NWU];
-    auto load_chunk = [&](int c0) {
-#pragma unroll
-        for (int i = 0; i < MAXA; ++i) {
-            const int u = i * NT + tid;
-            u32x4 v = u32x4{0u, 0u, 0u, 0u};
-            if (u < n_au) {
-                const int slot = u >> 2, c = c0 + (u & 3) * 8;
-                const int off = tab[slot];
-                if (off >= 0 && c < a.Cin) v = *reinterpret_cast<const u32x4*>(in + (size_t)off * a.in_ctot + a.in_coff + c);
+    // One chunk = 32 input channels: weights [tap][TC] rows of 64 B straight from the packed [chunk][tap][CoutPad][32] array
+    // (the 16-byte part a lane fetches is XOR-ed with (row >> 2) & 3, the read side applies the same involution), and the
+    // zero-padded input patch, 5 DMA lanes per slot.
+    auto stage = [&](int chunk, int buf) {
+        u16* wdst = w_lds + (size_t)buf * WROWS * 32;
+        const u16* wsrc = wg + (size_t)chunk * TAPS * a.CoutPad * 32;
+        for (int ub = wave * 64; ub < WUNITS; ub += NT) {
+            const int u = ub + lane, row = u >> 2, part = (u & 3) ^ ((row >> 2) & 3);
+            const int tap = row / TC, co = row - tap * TC;
+            dma16(wsrc + ((size_t)tap * a.CoutPad + co0 + co) * 32 + part * 8, wdst + ub * 8);
+        }
+        u16* adst = a_lds + (size_t)buf * aunits * 8;
+        const int c0 = chunk * kCK;
+        for (int ub = wave * 64; ub < aunits; ub += NT) {
+            const int u = ub + lane, slot = (int)(((unsigned)u * 52429u) >> 18), q = u - slot * kSlotU;      // u / 5 for u < 2^16
+            const u16* src = zeros;
+            if (q < 4 && slot < a.PSTR) {
+                const int off = tab[slot], c = c0 + q * 8;
+                if (off >= 0 && c < a.Cin) src = in + (size_t)off * a.in_ctot + a.in_coff + c;
             }
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < NWU; ++i) {
-            const int u = i * NT + tid;
-            u32x4 v = u32x4{0u, 0u, 0u, 0u};
-            if (u < n_wu) {
-                const int row = u >> 2, tap = row / TC, co = row - tap * TC;
-                v = *reinterpret_cast<const u32x4*>(wg + ((size_t)tap * a.CoutPad + co0 + co) * a.CinPad + c0 + (u & 3) * 8);
-            }
-            rw[i] = v;
-        }
-    };
-    auto store_chunk = [&]() {
-#pragma unroll
-        for (int i = 0; i < MAXA; ++i) {
-            const int u = i * NT + tid;
-            if (u < n_au) *reinterpret_cast<u32x4*>(a_lds + (u >> 2) * kStr + (u & 3) * 8) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NWU; ++i) {
-            const int u = i * NT + tid;
-            if (u < n_wu) *reinterpret_cast<u32x4*>(w_lds + (u >> 2) * kStr + (u & 3) * 8) = rw[i];
+            dma16(src, adst + ub * 8);
         }
     };
 
@@ -112,39 +110,45 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_bf16_nhwc(const ConvArgs a)
 #pragma unroll
         for (int ps = 0; ps < PSW; ++ps) acc[cs][ps] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int abase[PSW];                                        // LDS slot of tap (0,0) of this lane's pixel, per pixel sub-tile
+    const int nchunks = a.CinPad / kCK;
+    stage(0, 0);
+
+    int abase[PSW];                                        // bf16 offset of tap (0,0) of this lane's pixel + its k-group, per pixel sub-tile
 #pragma unroll
     for (int ps = 0; ps < PSW; ++ps) {
         const int q = (wp * PSW + ps) * 16 + l15;
         const int gl = q / RW, rem = q - gl * RW;
         const int yl = rem / a.Wo, x = rem - yl * a.Wo;
-        abase[ps] = (q < a.G * RW) ? gl * RinWp + yl * S * a.Wp + x * S : 0;     // masked pixels read slot 0, never stored
+        const int slot = (q < a.G * RW) ? gl * RinWp + yl * S * a.Wp + x * S : 0;     // masked pixels read slot 0, never stored
+        abase[ps] = slot * (kSlotU * 8) + lq * 8;
     }
+    int wbase[CSW];                                        // row (cout) of this lane inside a tap's TC rows + swizzled k-group
+#pragma unroll
+    for (int cs = 0; cs < CSW; ++cs) wbase[cs] = ((wc * CSW + cs) * 16 + l15) * 32 + ((lq ^ ((l15 >> 2) & 3)) * 8);
 
-    const int nchunks = a.CinPad / kCK;
-    load_chunk(0);
-    store_chunk();
-    __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
-        if (ch + 1 < nchunks) load_chunk((ch + 1) * kCK);                     // in flight under this chunk's MFMAs
+        const int buf = nbuf == 2 ? (ch & 1) : 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of chunk ch has landed
+        __syncthreads();                                     // ... and everybody else's; with two buffers the other one is free
+        if (nbuf == 2 && ch + 1 < nchunks) stage(ch + 1, buf ^ 1);
+        const u16* wl = w_lds + (size_t)buf * WROWS * 32;
+        const u16* al = a_lds + (size_t)buf * aunits * 8;
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
-            const int toff = (tap / KS) * a.Wp + (tap % KS);
+            const int toff = ((tap / KS) * a.Wp + (tap % KS)) * (kSlotU * 8);
             bf16x8 af[CSW], bfr[PSW];
 #pragma unroll
-            for (int cs = 0; cs < CSW; ++cs)
-                af[cs] = *reinterpret_cast<const bf16x8*>(w_lds + (tap * TC + (wc * CSW + cs) * 16 + l15) * kStr + lq * 8);
+            for (int cs = 0; cs < CSW; ++cs) af[cs] = *reinterpret_cast<const bf16x8*>(wl + tap * TC * 32 + wbase[cs]);
 #pragma unroll
-            for (int ps = 0; ps < PSW; ++ps) bfr[ps] = *reinterpret_cast<const bf16x8*>(a_lds + (abase[ps] + toff) * kStr + lq * 8);
+            for (int ps = 0; ps < PSW; ++ps) bfr[ps] = *reinterpret_cast<const bf16x8*>(al + abase[ps] + toff);
 #pragma unroll
             for (int cs = 0; cs < CSW; ++cs)
 #pragma unroll
                 for (int ps = 0; ps < PSW; ++ps) acc[cs][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cs], bfr[ps], acc[cs][ps], 0, 0, 0);
         }
-        __syncthreads();                                                       // everybody is done reading this chunk
-        if (ch + 1 < nchunks) {
-            store_chunk();
-            __syncthreads();
+        if (nbuf == 1 && ch + 1 < nchunks) {
+            __syncthreads();                                 // single buffer: everybody is done reading before it is refilled
+            stage(ch + 1, 0);
         }
     }
 
@@ -322,8 +326,9 @@ __global__ __launch_bounds__(256) void attn_pool_bf16_kernel(const u16* __restri
     }
 }
 
-size_t lds_bytes_bf16(const ConvArgs& a, int tc) {
-    return (size_t)a.ks * a.ks * tc * kStr * 2 + (size_t)a.PSTR * kStr * 2 + (size_t)a.PSTR * 4;
+size_t lds_bytes_bf16(const ConvArgs& a, int tc, int nbuf) {
+    const size_t aunits = ((size_t)a.PSTR * kSlotU + 63) & ~(size_t)63;
+    return (size_t)nbuf * ((size_t)a.ks * a.ks * tc * 64 + aunits * 16) + (size_t)a.PSTR * 4;
 }
 
 bool plan_bf16(ConvArgs& a, int tps, int tc) {
@@ -338,14 +343,15 @@ bool plan_bf16(ConvArgs& a, int tps, int tc) {
     a.PSTR = a.G * a.Rin * a.Wp;                           // patch slots
     a.gx = a.tiles_y * a.groups;
     a.gy = a.CoutPad / tc;
-    a.TC = tc;
-    const int nt = (tps == 7 && tc == 32) ? 128 : 256;     // threads of the instantiation; each stages <= MAXA (20) patch units
-    return lds_bytes_bf16(a, tc) <= 160 * 1024 && (a.PSTR * 4 + nt - 1) / nt <= 20;
+    if ((long)a.PSTR * kSlotU >= 65536) return false;
+    // chunks double-buffered when two workgroups still fit a CU that way (or nothing else fits), else single-buffered
+    a.TC = lds_bytes_bf16(a, tc, 2) <= 80 * 1024 ? 2 : (lds_bytes_bf16(a, tc, 1) <= 80 * 1024 ? 1 : (lds_bytes_bf16(a, tc, 2) <= 160 * 1024 ? 2 : 1));
+    return lds_bytes_bf16(a, tc, a.TC) <= 160 * 1024;
 }
 
 template <int KS, int S>
 hipError_t dispatch_bf16(const ConvArgs& a, int tps, int tc, hipStream_t s) {
-    const size_t lds = lds_bytes_bf16(a, tc);
+    const size_t lds = lds_bytes_bf16(a, tc, a.TC);
     const dim3 grid(a.gx * a.gy);
     if (tps == 14 && tc == 64) return launch_k(conv_bf16_nhwc<KS, S, 14, 4, 2, 2>, grid, dim3(256), lds, s, a);
     if (tps == 14 && tc == 32) return launch_k(conv_bf16_nhwc<KS, S, 14, 2, 2, 2>, grid, dim3(256), lds, s, a);
@@ -378,7 +384,8 @@ hipError_t conv_bf16_init() {
     return hipSuccess;
 }
 
-// a.in / a.out / a.w / a.add[] point at bf16 data (NHWC activations, [tap][CoutPad][CinPad] weights); a.bias is fp32.
+// a.in / a.out / a.w / a.add[] point at bf16 data (NHWC activations, [CinPad/32][tap][CoutPad][32] weights); a.bias is fp32;
+// a.zeros: >= 16 zero bytes in HBM.
 // Requirements: CinPad % 32 == 0, CoutPad % 32 == 0, in_ctot / in_coff / out_ctot / out_coff / add_ctot / add_coff multiples of 8 (4 for outputs).
 hipError_t launch_conv_bf16(ConvArgs a, hipStream_t s, int tile_hint) {
     if (!((a.ks == 1 && a.stride == 1) || (a.ks == 3 && (a.stride == 1 || a.stride == 2)))) return hipErrorInvalidValue;

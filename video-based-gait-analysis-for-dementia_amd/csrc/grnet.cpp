@@ -686,7 +686,7 @@ struct grnet {
     int pack_conv(ConvLayer& L) {
         const int cin = L.cin_w, ks = L.ks, taps = ks * ks;
         const int TC = conv_pick_tc(L.cout);
-        const bool bf = dtype == 1;                            // bf16: [tap][CoutPad][CinPad] with CinPad % 32 == 0 (one MFMA k-step)
+        const bool bf = dtype == 1;                            // bf16: [CinPad/32][tap][CoutPad][32]: a chunk's rows are contiguous for LDS-DMA
         L.cin_pad = bf ? (L.in.c + 31) / 32 * 32 : (cin + kConvCK - 1) / kConvCK * kConvCK;
         L.cout_pad = bf ? (L.cout + 31) / 32 * 32 : (L.cout + TC - 1) / TC * TC;
         std::vector<float> wp((size_t)taps * L.cin_pad * L.cout_pad, 0.f), bp(L.cout_pad, 0.f);
@@ -717,7 +717,7 @@ struct grnet {
                 bp[co0 + co] = (float)shift[co];
                 for (int ci = 0; ci < cin; ++ci)
                     for (int t = 0; t < taps; ++t)
-                        wp[bf ? ((size_t)t * L.cout_pad + co0 + co) * L.cin_pad + ci : ((size_t)t * L.cin_pad + ci) * L.cout_pad + co0 + co] =
+                        wp[bf ? ((((size_t)(ci / 32) * taps + t) * L.cout_pad + co0 + co) * 32 + ci % 32) : ((size_t)t * L.cin_pad + ci) * L.cout_pad + co0 + co] =
                             (float)((double)w->data[((size_t)co * cin + ci) * taps + t] * scale[co]);
             }
             co0 += s.cout;
@@ -1155,7 +1155,8 @@ struct grnet {
         for (int co = 0; co < cout; ++co) {
             if (bias_host) bp[co] = bias_host[co];
             for (int ci = 0; ci < cin; ++ci)
-                for (int t = 0; t < taps; ++t) wp[((size_t)t * cout_pad + co) * cin_pad + ci] = f32_to_bf16(w_host[((size_t)co * cin + ci) * taps + t]);
+                for (int t = 0; t < taps; ++t)
+                    wp[(((size_t)(ci / 32) * taps + t) * cout_pad + co) * 32 + ci % 32] = f32_to_bf16(w_host[((size_t)co * cin + ci) * taps + t]);
         }
         void *wd = nullptr, *bd = nullptr, *xin = nullptr, *xadd = nullptr, *xout = nullptr;
         const size_t in_b = (size_t)n * hgt * wid * cin8 * 2, out_b = (size_t)n * ho * wo * cout8 * 2;
