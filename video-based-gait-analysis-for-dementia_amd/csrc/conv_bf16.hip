@@ -62,7 +62,19 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_bf16_nhwc(const ConvArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp = wave / WC, wc = wave % WC, l15 = lane & 15, lq = lane >> 4;
-    const int bx = blockIdx.x % a.gx, by = blockIdx.x / a.gx;
+    // XCD-aware block order (same rule as conv_kernels.hip:xcd_block): the channel blocks of one pixel tile are consecutive
+    // blocks of ONE XCD (ids congruent mod 8) and an XCD owns a contiguous range of tiles, so the 2nd..gy-th read of an input
+    // line hits that XCD's L2; a speed heuristic only.
+    int bx, by;
+    if (a.xcd) {
+        const int id = blockIdx.x, j = id >> 3, x = id & 7, q = j / a.gy;
+        by = j - q * a.gy;
+        bx = ((x * a.gx) >> 3) + q;
+        if (bx >= (((x + 1) * a.gx) >> 3)) return;
+    } else {
+        by = blockIdx.x / a.gx;
+        bx = blockIdx.x - by * a.gx;
+    }
     const int ty = bx % a.tiles_y, grp = bx / a.tiles_y;
     const int y0 = ty * a.R, g0 = grp * a.G, co0 = by * TC;
     const int HW = a.H * a.W, RW = a.R * a.Wo, RinWp = a.Rin * a.Wp, HoWo = a.Ho * a.Wo;
@@ -344,6 +356,8 @@ bool plan_bf16(ConvArgs& a, int tps, int tc) {
     a.gx = a.tiles_y * a.groups;
     a.gy = a.CoutPad / tc;
     if ((long)a.PSTR * kSlotU >= 65536) return false;
+    a.gx8 = (a.gx + 7) / 8;
+    a.xcd = (a.gy > 1 || a.ks > 1) && a.gx >= 16;
     // chunks double-buffered when two workgroups still fit a CU that way (or nothing else fits), else single-buffered
     a.TC = lds_bytes_bf16(a, tc, 2) <= 80 * 1024 ? 2 : (lds_bytes_bf16(a, tc, 1) <= 80 * 1024 ? 1 : (lds_bytes_bf16(a, tc, 2) <= 160 * 1024 ? 2 : 1));
     return lds_bytes_bf16(a, tc, a.TC) <= 160 * 1024;
@@ -352,7 +366,7 @@ bool plan_bf16(ConvArgs& a, int tps, int tc) {
 template <int KS, int S>
 hipError_t dispatch_bf16(const ConvArgs& a, int tps, int tc, hipStream_t s) {
     const size_t lds = lds_bytes_bf16(a, tc, a.TC);
-    const dim3 grid(a.gx * a.gy);
+    const dim3 grid((a.xcd ? a.gx8 * 8 : a.gx) * a.gy);
     if (tps == 14 && tc == 64) return launch_k(conv_bf16_nhwc<KS, S, 14, 4, 2, 2>, grid, dim3(256), lds, s, a);
     if (tps == 14 && tc == 32) return launch_k(conv_bf16_nhwc<KS, S, 14, 2, 2, 2>, grid, dim3(256), lds, s, a);
     if (tps == 7 && tc == 64) return launch_k(conv_bf16_nhwc<KS, S, 7, 4, 1, 4>, grid, dim3(256), lds, s, a);
