@@ -124,3 +124,33 @@ def test_clip_runner_sequence_feeds_gru(pkg, oracle):
     ry, rph, _ = oracle.gru_forward(x.cpu().numpy(), cp.cpu().numpy(), pkg.synth.make_gru_state_dict())
     assert rel_err(y.cpu().numpy(), ry) < 1e-4 and rel_err(phase.cpu().numpy(), rph) < 1e-4
     m.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_multi_track_overlapped_preprocess_stream(pkg, dtype):
+    """BASELINE configs[4] in miniature on one GPU: 4 person tracks x 24 frames in batches of 12, crop + normalise of the next
+    batch on a side stream while the (graph-replayed) forward of the current batch runs; same numbers as the sequential loop."""
+    p = pkg.pipeline
+    m = pkg.build_synthetic_model(max_frames=12, with_gru=False, dtype=dtype)
+    m.set_option(pkg._lib.OPT_USE_GRAPH, 1)
+    rng = np.random.default_rng(11)
+    tracks = []
+    for t in range(4):
+        batches = []
+        for b in range(2):
+            raw = rng.integers(0, 256, size=(12, 180, 240, 3), dtype=np.uint8)
+            bb = np.stack([np.array([120 + 3 * t + i, 90 - 2 * b + i, 140 + i, 150 + 2 * i], np.float32) for i in range(12)])
+            batches.append((raw, bb))
+        tracks.append(batches)
+    got = p.run_tracks_overlapped(m, tracks, batch_size=12)
+    torch.cuda.synchronize()
+    assert len(got) == 4 and got[0]["verts"].shape == (24, 6890, 3) and got[3]["joints3d"].shape == (24, 29, 3)
+    for t in (0, 3):
+        for b in range(2):
+            raw, bb = tracks[t][b]
+            x = m.crop_normalise(torch.from_numpy(raw).cuda(), torch.from_numpy(bb), scale=1.1)
+            ref = m(x.unsqueeze(0))[-1]
+            torch.cuda.synchronize()
+            assert np.array_equal(got[t]["pose"][12 * b:12 * b + 12], ref["theta"][0, :, 3:75].cpu().numpy())
+            assert np.array_equal(got[t]["verts"][12 * b:12 * b + 12], ref["verts"][0].cpu().numpy())
+    m.close()

@@ -352,3 +352,16 @@ def test_tsattn_block_matches_reference_golden_and_oracle(pkg, oracle):
     with pytest.raises(pkg._lib.GrnetError):
         m2.tsattn_forward(xd[:1, :4], xsd[:1, :4])
     m2.close()
+
+
+def test_graph_cache_is_bounded(pkg):
+    """Fresh output buffers on every call (what the Python shim does) never repeat a graph key: after 16 captured forwards the
+    library launches eagerly instead of instantiating graphs without bound; results do not depend on which way a call ran."""
+    m = pkg.build_synthetic_model(max_frames=2, with_gru=False)
+    m.set_option(pkg._lib.OPT_USE_GRAPH, 1)
+    frames = torch.from_numpy(pkg.synth.make_frames(2)).cuda()
+    outs = [m(frames)[-1] for _ in range(24)]                  # all 24 results stay alive: 24 distinct sets of pointers
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o["theta"], outs[0]["theta"]) and torch.equal(o["verts"], outs[0]["verts"])
+    m.close()

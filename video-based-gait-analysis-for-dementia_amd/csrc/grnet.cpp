@@ -1198,6 +1198,10 @@ struct grnet {
         }
         GraphKey key{n, frames, o};
         auto it = graphs.find(key);
+        // a caller that passes fresh output buffers every call (the Python shim does) never repeats a key: keep at most
+        // kMaxGraphs captured forwards and launch anything else eagerly instead of instantiating graphs without bound
+        constexpr size_t kMaxGraphs = 16;
+        if (it == graphs.end() && graphs.size() >= kMaxGraphs) return enqueue(frames, n, o, s);
         if (it == graphs.end()) {
             hipGraph_t g = nullptr;
             HIP_TRY(hipGraphCreate(&g, 0));

@@ -199,6 +199,53 @@ def run_tracklet(model, batches, device="cuda"):
     return {k: torch.cat(v, 0).cpu().numpy() for k, v in acc.items()}
 
 
+def run_tracks_overlapped(model, tracks, batch_size=64, scale=1.1):
+    """BASELINE configs[4] on one GPU: several person tracks, each a list of (raw uint8 frames (n,H,W,3), boxes (n,4)) batches.
+    Upload + crop/normalise (grnet_crop_normalise, row f1) of batch k+1 run on a side HIP stream while the forward of batch k
+    (a replayed hipGraph when GRNET_OPT_USE_GRAPH is set: fixed crop buffers make the pointers repeat) runs on the current
+    stream; two crop buffers alternate and events order the hand-over.  Returns one demo-style dict per track
+    (demo.py:151-188 slicing), identical to calling crop_normalise + model() batch after batch."""
+    dev = model.device
+    main = torch.cuda.current_stream(dev)
+    side = torch.cuda.Stream(device=dev)
+    work = [(ti, raw, bb) for ti, batches in enumerate(tracks) for (raw, bb) in batches]
+    n_max = max((len(bb) for _, _, bb in work), default=0)
+    if n_max > batch_size:
+        raise ValueError("a batch is larger than batch_size")
+    bufs = [torch.empty(n_max, 3, 224, 224, dtype=torch.float32, device=dev) for _ in range(2)]
+    ready = [torch.cuda.Event() for _ in range(2)]         # crop k has landed in bufs[k % 2]
+    free = [torch.cuda.Event() for _ in range(2)]          # the forward that read bufs[k % 2] is done
+    for e in free:
+        e.record(main)
+
+    def stage(k):
+        _, raw, bb = work[k]
+        with torch.cuda.stream(side):
+            side.wait_event(free[k % 2])
+            crop = model.crop_normalise(torch.as_tensor(raw).to(dev, non_blocking=True), torch.as_tensor(bb), scale=scale)
+            bufs[k % 2][:len(bb)].copy_(crop)
+            ready[k % 2].record(side)
+
+    acc = [defaultdict(list) for _ in tracks]
+    if work:
+        stage(0)
+    for k, (ti, _, bb) in enumerate(work):
+        if k + 1 < len(work):
+            stage(k + 1)                                    # overlaps the forward below
+        main.wait_event(ready[k % 2])
+        out = model(bufs[k % 2][:len(bb)].unsqueeze(0))[-1]
+        free[k % 2].record(main)
+        t = len(bb)
+        a = acc[ti]
+        a["pred_cam"].append(out["theta"][:, :, :3].reshape(t, -1))
+        a["verts"].append(out["verts"].reshape(t, -1, 3))
+        a["pose"].append(out["theta"][:, :, 3:75].reshape(t, -1))
+        a["betas"].append(out["theta"][:, :, 75:].reshape(t, -1))
+        a["joints3d"].append(out["kp_3d"].reshape(t, -1, 3))
+        a["smpl_joints2d"].append(out["kp_2d"].reshape(t, -1, 2))
+    return [{k: torch.cat(v, 0).cpu().numpy() for k, v in a.items()} for a in acc]
+
+
 def make_demo_result(pred, bboxes, frames, orig_width, orig_height):
     """The per-person dict the demo pickles (demo.py:198-222)."""
     return {
