@@ -91,11 +91,44 @@ __global__ __launch_bounds__(256) void bilinear2x_kernel(const float* __restrict
     }
 }
 
+// Same arithmetic per element, 4 adjacent output pixels of a row per thread: one 16-byte store instead of four 4-byte ones
+// (the 256-channel 28 -> 56 launch writes 51 MB and sits on the critical path in front of the last upsample convolution).
+__global__ __launch_bounds__(256) void bilinear2x_x4_kernel(const float* __restrict__ in, float* __restrict__ out, int NC, int H, int W) {
+    const int Ho = 2 * H, Wo = 2 * W, Wq = Wo >> 2;
+    const float sy = (float)(H - 1) / (float)(Ho - 1), sx = (float)(W - 1) / (float)(Wo - 1);
+    const long total = (long)NC * Ho * Wq;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int xq = (int)(i % Wq);
+        const long t = i / Wq;
+        const int y = (int)(t % Ho);
+        const long nc = t / Ho;
+        const float fy = sy * y;
+        const int y0 = (int)fy, y1 = min(y0 + 1, H - 1);
+        const float ly = fy - y0, wy0 = 1.f - ly;
+        const float* p0 = in + nc * H * W + y0 * W;
+        const float* p1 = in + nc * H * W + y1 * W;
+        float r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = xq * 4 + k;
+            const float fx = sx * x;
+            const int x0 = (int)fx, x1 = min(x0 + 1, W - 1);
+            const float lx = fx - x0, wx0 = 1.f - lx;
+            const float top = __fmaf_rn(p0[x1], lx, __fmul_rn(p0[x0], wx0));
+            const float bot = __fmaf_rn(p1[x1], lx, __fmul_rn(p1[x0], wx0));
+            r[k] = __fmaf_rn(bot, ly, __fmul_rn(top, wy0));
+        }
+        *reinterpret_cast<float4*>(out + (nc * Ho + y) * Wo + xq * 4) = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+
 hipError_t launch_bilinear2x(const float* in, float* out, int N, int C, int H, int W, hipStream_t s) {
-    const long total = (long)N * C * 4 * H * W;
+    const bool x4 = (2 * W) % 4 == 0;
+    const long total = (long)N * C * 4 * H * W / (x4 ? 4 : 1);
     int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    GRK_TRY(launch_k(bilinear2x_kernel, dim3(blocks), dim3(256), 0, s, in, out, N * C, H, W));
+    if (blocks > 8192) blocks = 8192;
+    if (x4) GRK_TRY(launch_k(bilinear2x_x4_kernel, dim3(blocks), dim3(256), 0, s, in, out, N * C, H, W));
+    else GRK_TRY(launch_k(bilinear2x_kernel, dim3(blocks), dim3(256), 0, s, in, out, N * C, H, W));
     return hipGetLastError();
 }
 
