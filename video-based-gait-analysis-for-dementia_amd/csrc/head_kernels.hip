@@ -329,17 +329,30 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
     __shared__ float s_pose[24 * 6];
     __shared__ float s_sc[13];
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int e = tid; e < 192 * 24; e += 256) {              // add the pixel-range partials of the pooling, fixed order
-        float v = 0.f;
+    // add the pixel-range partials of the pooling in a fixed order; 6 elements x 7 partials of loads in flight per thread
+    // (one block per frame: nothing else hides the L2 latency of this kernel, which sits on the critical path)
+    static_assert((192 * 24) % (256 * 6) == 0, "partials loop");
+    for (int e0 = tid; e0 < 192 * 24; e0 += 256 * 6) {
+        float v[6][kPoolSplit];
 #pragma unroll
-        for (int sp = 0; sp < kPoolSplit; ++sp) v += part[((size_t)n * kPoolSplit + sp) * (192 * 24) + e];
-        if (e < 128 * 24) { s_plf[e] = v; plf[(size_t)n * 128 * 24 + e] = v; }
-        else { s_csf[e - 128 * 24] = v; csf[(size_t)n * 64 * 24 + e - 128 * 24] = v; }
+        for (int u = 0; u < 6; ++u)
+#pragma unroll
+            for (int sp = 0; sp < kPoolSplit; ++sp) v[u][sp] = part[((size_t)n * kPoolSplit + sp) * (192 * 24) + e0 + u * 256];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int e = e0 + u * 256;
+            float acc = 0.f;
+#pragma unroll
+            for (int sp = 0; sp < kPoolSplit; ++sp) acc += v[u][sp];
+            if (e < 128 * 24) { s_plf[e] = acc; plf[(size_t)n * 128 * 24 + e] = acc; }
+            else { s_csf[e - 128 * 24] = acc; csf[(size_t)n * 64 * 24 + e - 128 * 24] = acc; }
+        }
     }
     __syncthreads();
     if (tid < 144) {
         const int j = tid / 6, o = tid % 6;
         float acc = 0.f;
+#pragma unroll 16
         for (int c = 0; c < 128; ++c) acc += s_plf[c * 24 + j] * w.pose_w[(o * 128 + c) * 24 + j];
         s_pose[j * 6 + o] = acc;
         rot6d[(size_t)n * 144 + j * 6 + o] = acc;
