@@ -372,23 +372,11 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
 // ---------------------------------------------------------------------------------------------
 // Split-K variant for layers whose output is too small to fill 1024 SIMDs with whole-K tiles
 // (the 7x7 / 14x14 / 28x28 branches and the 32-channel 56x56 branch at 16 frames per call).
-// A workgroup owns ONE small output tile (PSW*16 pixels x CSW*16 channels); its NW waves split the
+// A workgroup owns ONE small output tile (PSW*16 pixels x CSW*16 channels); its NW (4 or 8) waves split the
 // input channels in groups of 4 (= one MFMA k-step per filter tap), round-robin.  The waves share
 // nothing but the source-offset table: each stages its OWN channel group (input patch + weight
-// slab) by LDS-DMA into its own double buffer and runs its own wait -> prefetch -> MFMA loop with
+// slab) by LDS-DMA into its own stage buffer and runs its own wait -> MFMA -> refill loop with
 // no workgroup barrier; partial accumulators are summed through LDS in a fixed order at the end.
-// s_waitcnt vmcnt(N) takes an immediate; the number of LDS-DMA instructions per stage is wave-uniform
-// but only known at run time, so pick the immediate with a scalar switch.  Waiting for FEWER outstanding
-// operations than allowed is always safe, so counts above 24 wait at 24.
-__device__ __forceinline__ void wait_vmcnt_le(int n) {
-#define GRK_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-    switch (n < 24 ? n : 24) {
-        GRK_W(0) GRK_W(1) GRK_W(2) GRK_W(3) GRK_W(4) GRK_W(5) GRK_W(6) GRK_W(7) GRK_W(8) GRK_W(9) GRK_W(10) GRK_W(11) GRK_W(12)
-        GRK_W(13) GRK_W(14) GRK_W(15) GRK_W(16) GRK_W(17) GRK_W(18) GRK_W(19) GRK_W(20) GRK_W(21) GRK_W(22) GRK_W(23) GRK_W(24)
-    }
-#undef GRK_W
-}
-
 
 // MODE: 0 = gather (source-offset table), 1 = rows (contiguous image rows), 2 = planes (the 4 channel planes of a
 // k-group of ONE whole small image are contiguous in NCHW: one 16-byte LDS-DMA per k-group; all zero padding is
@@ -857,7 +845,6 @@ hipError_t launch_conv_group(const ConvArgs* list, int n, hipStream_t s) {
     GroupArgs g{};
     g.n = n;
     size_t lds = 0;
-    long total_waves = 0;
     bool ok_all = true;
     static const int allow_csw2 = getenv("GRNET_GROUP_CSW2") ? atoi(getenv("GRNET_GROUP_CSW2")) : 1;
     // members with the longest per-wave MFMA chain first: their blocks are dispatched first and the short
@@ -906,7 +893,6 @@ hipError_t launch_conv_group(const ConvArgs* list, int n, hipStream_t s) {
         g.first_block[i + 1] = g.first_block[i] + blocks;
         const size_t l = lds_bytes(a, best);
         if (l > lds) lds = l;
-        total_waves += (long)blocks * 4;
     }
     if (!ok_all) {                                        // not groupable: separate launches, same results
         for (int i = 0; i < n; ++i) {
