@@ -30,7 +30,7 @@ def vid_sort_key(x):
         return (1, x)
 
 
-def prepare_data(fv, vid_folder, outpath, pretrained_file=None, synthetic_weights=False, max_frames=128):
+def prepare_data(fv, vid_folder, outpath, pretrained_file=None, synthetic_weights=False, max_frames=128, dtype="f32"):
     import joblib
     import torch
     pkg = importlib.import_module(PKG)
@@ -47,9 +47,9 @@ def prepare_data(fv, vid_folder, outpath, pretrained_file=None, synthetic_weight
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if synthetic_weights:
-        model = pkg.build_synthetic_model(max_frames=max_frames, device_id=local_rank, with_gru=False)
+        model = pkg.build_synthetic_model(max_frames=max_frames, device_id=local_rank, with_gru=False, dtype=dtype)
     else:
-        model = pkg.GRNet(writer=None, seqlen=100, featcorr=None, max_frames=max_frames, device_id=local_rank)
+        model = pkg.GRNet(writer=None, seqlen=100, featcorr=None, max_frames=max_frames, device_id=local_rank, dtype=dtype)
         ckpt = torch.load(pretrained_file, map_location="cpu")["gen_state_dict"]
         model.load_state_dict(ckpt, strict=True)              # batch_generation.py:218
         model.finalize()
@@ -101,6 +101,7 @@ if __name__ == "__main__":
     p.add_argument("--pretrained_file", type=str, default="checkpoint/max-grnet.pth.tar")
     p.add_argument("--synthetic_weights", action="store_true")
     p.add_argument("--max_frames", type=int, default=128)
+    p.add_argument("--dtype", choices=("f32", "bf16"), default="f32")
     a = p.parse_args()
     prepare_data(fv=a.bbox_path, vid_folder=a.vid_folder, outpath=a.outpath, pretrained_file=a.pretrained_file,
-                 synthetic_weights=a.synthetic_weights, max_frames=a.max_frames)
+                 synthetic_weights=a.synthetic_weights, max_frames=a.max_frames, dtype=a.dtype)

@@ -37,10 +37,10 @@ def load_cfg(path):
 def build_model(pkg, args, seqlen):
     import torch
     if args.synthetic_weights:
-        return pkg.build_synthetic_model(max_frames=args.max_frames, with_gru=False)
+        return pkg.build_synthetic_model(max_frames=args.max_frames, with_gru=False, dtype=args.dtype)
     if not args.ckpt:
         sys.exit("!!! Please provide a pretrained checkpoint (--ckpt) or --synthetic_weights !!!")
-    model = pkg.GRNet(writer=None, seqlen=seqlen, featcorr=None, max_frames=args.max_frames)
+    model = pkg.GRNet(writer=None, seqlen=seqlen, featcorr=None, max_frames=args.max_frames, dtype=args.dtype)
     ckpt = torch.load(args.ckpt, map_location="cpu")["gen_state_dict"]
     print(f"Load pretrained weights from '{args.ckpt}'")
     res = model.load_state_dict(ckpt, strict=False)
@@ -132,6 +132,7 @@ def parser():
     # additions of this implementation
     p.add_argument("--synthetic_weights", action="store_true", help="seed-defined weights (no checkpoint exists offline)")
     p.add_argument("--smpl_dir", type=str, default="data/smpl_data")
+    p.add_argument("--dtype", choices=("f32", "bf16"), default="f32", help="f32: the reference's precision; bf16: bf16 storage, fp32 accumulation")
     p.add_argument("--max_frames", type=int, default=64, help="frames per grnet_forward call (activation buffers are sized for it)")
     return p
 
