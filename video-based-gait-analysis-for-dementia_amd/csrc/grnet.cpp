@@ -137,6 +137,7 @@ struct grnet {
     hipStream_t capture_stream = nullptr;   // the caller's stream may be the (uncapturable) null stream
     hipStream_t side[kLanes] = {};      // lanes 1.. (lane 0 = the caller's stream)
     hipEvent_t ev_fork = nullptr, ev_join[kLanes] = {};
+    int lanes_used = 1;
     std::vector<hipEvent_t> op_events;
     int cur_lane = 0;
     bool multi_lane = true;
@@ -464,7 +465,10 @@ struct grnet {
         analyze_dependencies(ops_flat, op_events_flat);
         // streams / events of the parallel lanes are created here, never inside a stream capture
         if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return fail(GRNET_EHIP, "hipEventCreate failed");
-        for (int l = 1; l < kLanes; ++l) {
+        lanes_used = 1;                                        // only the streams the two schedules really use are created / forked / joined
+        for (const Op& op : ops) lanes_used = std::max(lanes_used, op.lane + 1);
+        for (const Op& op : ops_flat) lanes_used = std::max(lanes_used, op.lane + 1);
+        for (int l = 1; l < lanes_used; ++l) {
             if (hipStreamCreateWithFlags(&side[l], hipStreamNonBlocking) != hipSuccess) return fail(GRNET_EHIP, "hipStreamCreate failed");
             if (hipEventCreateWithFlags(&ev_join[l], hipEventDisableTiming) != hipSuccess) return fail(GRNET_EHIP, "hipEventCreate failed");
         }
@@ -1026,7 +1030,7 @@ struct grnet {
         for (int l = 0; l < kLanes; ++l) lane_stream[l] = s;
         if (lanes) {
             HIP_TRY(hipEventRecord(ev_fork, s));                 // fork: side lanes start after everything before this forward
-            for (int l = 1; l < kLanes; ++l) {
+            for (int l = 1; l < lanes_used; ++l) {
                 lane_stream[l] = side[l];
                 HIP_TRY(hipStreamWaitEvent(side[l], ev_fork, 0));
             }
@@ -1115,7 +1119,7 @@ struct grnet {
         }
         s = caller;
         if (lanes)
-            for (int l = 1; l < kLanes; ++l) {                   // join: the caller's stream continues after every lane
+            for (int l = 1; l < lanes_used; ++l) {                // join: the caller's stream continues after every lane
                 HIP_TRY(hipEventRecord(ev_join[l], side[l]));
                 HIP_TRY(hipStreamWaitEvent(s, ev_join[l], 0));
             }
