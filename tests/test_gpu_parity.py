@@ -365,3 +365,20 @@ def test_graph_cache_is_bounded(pkg):
     for o in outs[1:]:
         assert torch.equal(o["theta"], outs[0]["theta"]) and torch.equal(o["verts"], outs[0]["verts"])
     m.close()
+
+
+def test_temporal_modules_single_frame_and_long_clip(pkg, oracle):
+    """Edge sizes of the temporal modules: a one-frame clip (softmax over one key, GRU of one step) and the longest clip the
+    demo feeds (450 frames, demo.py:149)."""
+    m = pkg.build_synthetic_model(max_frames=2, with_gru=True, with_tsattn=True)
+    gsd, tsd = pkg.synth.make_gru_state_dict(), pkg.synth.make_tsattn_state_dict()
+    for (b, t) in ((1, 1), (2, 1), (1, 450)):
+        x, cp = pkg.synth.make_gru_inputs(b, t)
+        y, ph, xc = m.gru_forward(torch.from_numpy(x).cuda(), torch.from_numpy(cp).cuda())
+        ry, rph, rxc = oracle.gru_forward(x, cp, gsd)
+        assert rel_err(y.cpu().numpy(), ry) < 1e-4 and rel_err(ph.cpu().numpy(), rph) < 1e-4 and rel_err(xc.cpu().numpy(), rxc) < 1e-5, (b, t)
+    for (b, t) in ((1, 1), (3, 1), (1, 450)):
+        x, xs = pkg.synth.make_tsattn_inputs(b, t)
+        y = m.tsattn_forward(torch.from_numpy(x).cuda(), torch.from_numpy(xs).cuda())
+        assert rel_err(y.cpu().numpy(), oracle.ts_attn_block(x, xs, tsd)) < 3e-5, (b, t)
+    m.close()
