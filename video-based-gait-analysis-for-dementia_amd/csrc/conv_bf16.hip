@@ -50,14 +50,11 @@ constexpr int kSlotU = 5;      // 16-byte DMA units per patch slot: 4 of data + 
 template <int KS, int S, int TPS, int TCS, int WP, int WC>
 __global__ __launch_bounds__(WP * WC * 64) void conv_bf16_nhwc(const ConvArgs a) {
     constexpr int NT = WP * WC * 64, PSW = TPS / WP, CSW = TCS / WC, TC = TCS * 16, TAPS = KS * KS;
-    constexpr int WROWS = TAPS * TC, WUNITS = WROWS * 4;                 // weight rows of 64 B (32 channels) per chunk
     static_assert(TPS % WP == 0 && TCS % WC == 0, "wave grid must divide the tile");
-    static_assert(WUNITS % 64 == 0, "weight chunk must be whole wave-instructions");
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int aunits = (a.PSTR * kSlotU + 63) & ~63;                     // patch units per chunk, whole wave-instructions
     const int nbuf = a.TC;                                               // set by plan_bf16 for this kernel: 2 = double-buffered chunks, 1 = single
-    u16* w_lds = reinterpret_cast<u16*>(smem_raw);                       // [nbuf][WROWS][32]       part index XOR-swizzled by row
-    u16* a_lds = w_lds + (size_t)nbuf * WROWS * 32;                      // [nbuf][aunits][8]       80-byte slots
+    u16* a_lds = reinterpret_cast<u16*>(smem_raw);                       // [nbuf][aunits][8]       80-byte slots
     int* tab = reinterpret_cast<int*>(a_lds + (size_t)nbuf * aunits * 8);   // [PSTR] input pixel of each patch slot, -1 = zero
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -96,13 +93,6 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_bf16_nhwc(const ConvArgs a)
     // (the 16-byte part a lane fetches is XOR-ed with (row >> 2) & 3, the read side applies the same involution), and the
     // zero-padded input patch, 5 DMA lanes per slot.
     auto stage = [&](int chunk, int buf) {
-        u16* wdst = w_lds + (size_t)buf * WROWS * 32;
-        const u16* wsrc = wg + (size_t)chunk * TAPS * a.CoutPad * 32;
-        for (int ub = wave * 64; ub < WUNITS; ub += NT) {
-            const int u = ub + lane, row = u >> 2, part = (u & 3) ^ ((row >> 2) & 3);
-            const int tap = row / TC, co = row - tap * TC;
-            dma16(wsrc + ((size_t)tap * a.CoutPad + co0 + co) * 32 + part * 8, wdst + ub * 8);
-        }
         u16* adst = a_lds + (size_t)buf * aunits * 8;
         const int c0 = chunk * kCK;
         for (int ub = wave * 64; ub < aunits; ub += NT) {
@@ -134,29 +124,38 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_bf16_nhwc(const ConvArgs a)
         const int slot = (q < a.G * RW) ? gl * RinWp + yl * S * a.Wp + x * S : 0;     // masked pixels read slot 0, never stored
         abase[ps] = slot * (kSlotU * 8) + lq * 8;
     }
-    int wbase[CSW];                                        // row (cout) of this lane inside a tap's TC rows + swizzled k-group
+    // A operand (weights) straight from global memory: lane (cout row l15, k-group lq) of a fragment reads its 16 bytes of the packed
+    // [chunk][tap][CoutPad][32] array -- 1 KB contiguous per fragment, the same for every workgroup of a channel block (L1/L2 hits).
+    // No weight slab in LDS: more workgroups fit a CU and a chunk needs no weight DMA.
+    const u16* wlane[CSW];
 #pragma unroll
-    for (int cs = 0; cs < CSW; ++cs) wbase[cs] = ((wc * CSW + cs) * 16 + l15) * 32 + ((lq ^ ((l15 >> 2) & 3)) * 8);
+    for (int cs = 0; cs < CSW; ++cs) wlane[cs] = wg + ((size_t)co0 + (wc * CSW + cs) * 16 + l15) * 32 + lq * 8;
+    const size_t wtap = (size_t)a.CoutPad * 32;            // elements between taps
 
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = nbuf == 2 ? (ch & 1) : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of chunk ch has landed
         __syncthreads();                                     // ... and everybody else's; with two buffers the other one is free
+        // all weight fragments of the chunk first: vmcnt retires in order, so fragments requested AFTER the next chunk's
+        // DMA batch could only be consumed once that whole batch had landed
+        const size_t wchunk = (size_t)ch * TAPS * wtap;
+        bf16x8 af[TAPS][CSW];
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+            for (int cs = 0; cs < CSW; ++cs) af[tap][cs] = *reinterpret_cast<const bf16x8*>(wlane[cs] + wchunk + tap * wtap);
         if (nbuf == 2 && ch + 1 < nchunks) stage(ch + 1, buf ^ 1);
-        const u16* wl = w_lds + (size_t)buf * WROWS * 32;
         const u16* al = a_lds + (size_t)buf * aunits * 8;
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int toff = ((tap / KS) * a.Wp + (tap % KS)) * (kSlotU * 8);
-            bf16x8 af[CSW], bfr[PSW];
-#pragma unroll
-            for (int cs = 0; cs < CSW; ++cs) af[cs] = *reinterpret_cast<const bf16x8*>(wl + tap * TC * 32 + wbase[cs]);
+            bf16x8 bfr[PSW];
 #pragma unroll
             for (int ps = 0; ps < PSW; ++ps) bfr[ps] = *reinterpret_cast<const bf16x8*>(al + abase[ps] + toff);
 #pragma unroll
             for (int cs = 0; cs < CSW; ++cs)
 #pragma unroll
-                for (int ps = 0; ps < PSW; ++ps) acc[cs][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cs], bfr[ps], acc[cs][ps], 0, 0, 0);
+                for (int ps = 0; ps < PSW; ++ps) acc[cs][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tap][cs], bfr[ps], acc[cs][ps], 0, 0, 0);
         }
         if (nbuf == 1 && ch + 1 < nchunks) {
             __syncthreads();                                 // single buffer: everybody is done reading before it is refilled
@@ -340,7 +339,8 @@ __global__ __launch_bounds__(256) void attn_pool_bf16_kernel(const u16* __restri
 
 size_t lds_bytes_bf16(const ConvArgs& a, int tc, int nbuf) {
     const size_t aunits = ((size_t)a.PSTR * kSlotU + 63) & ~(size_t)63;
-    return (size_t)nbuf * ((size_t)a.ks * a.ks * tc * 64 + aunits * 16) + (size_t)a.PSTR * 4;
+    (void)tc;                                              // weights are read from global memory: only the input patch lives in LDS
+    return (size_t)nbuf * aunits * 16 + (size_t)a.PSTR * 4;
 }
 
 bool plan_bf16(ConvArgs& a, int tps, int tc) {
