@@ -37,6 +37,9 @@ __device__ __forceinline__ u16 f2bf(float f) {           // round to nearest eve
 }
 __device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float((unsigned)h << 16); }
 __device__ __forceinline__ unsigned pack2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+// q / d for 0 <= q < 2^20 through one fp32 reciprocal multiply (exact: the +0.5 keeps exact multiples off the rounding edge);
+// an integer division by a run-time value costs ~40 VALU instructions, and a tile of a 32-channel layer has only ~1000 cycles of MFMAs
+__device__ __forceinline__ int fdiv(int q, float inv_d) { return (int)(((float)q + 0.5f) * inv_d); }
 
 // LDS-DMA: lane l's 16 bytes land at lds_wave_base + 16*l; the source address is per lane.
 #define GRNET_GLOBAL_AS __attribute__((address_space(1)))
@@ -80,9 +83,10 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_bf16_nhwc(const ConvArgs a)
     const u16* wg = reinterpret_cast<const u16*>(a.w);
     const u16* zeros = reinterpret_cast<const u16*>(a.zeros);
 
+    const float inv_RinWp = 1.0f / (float)RinWp, inv_Wp = 1.0f / (float)a.Wp, inv_RW = 1.0f / (float)RW, inv_Wo = 1.0f / (float)a.Wo;
     for (int idx = tid; idx < a.PSTR; idx += NT) {
-        const int gl = idx / RinWp, rem = idx - gl * RinWp;
-        const int ry = rem / a.Wp, rx = rem - ry * a.Wp;
+        const int gl = fdiv(idx, inv_RinWp), rem = idx - gl * RinWp;
+        const int ry = fdiv(rem, inv_Wp), rx = rem - ry * a.Wp;
         const int yin = y0 * S + ry - pad, xin = rx - pad;
         const bool ok = gl < a.G && (g0 + gl) < a.N && yin >= 0 && yin < a.H && xin >= 0 && xin < a.W;
         tab[idx] = ok ? (g0 + gl) * HW + yin * a.W + xin : -1;
@@ -119,8 +123,8 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_bf16_nhwc(const ConvArgs a)
 #pragma unroll
     for (int ps = 0; ps < PSW; ++ps) {
         const int q = (wp * PSW + ps) * 16 + l15;
-        const int gl = q / RW, rem = q - gl * RW;
-        const int yl = rem / a.Wo, x = rem - yl * a.Wo;
+        const int gl = fdiv(q, inv_RW), rem = q - gl * RW;
+        const int yl = fdiv(rem, inv_Wo), x = rem - yl * a.Wo;
         const int slot = (q < a.G * RW) ? gl * RinWp + yl * S * a.Wp + x * S : 0;     // masked pixels read slot 0, never stored
         abase[ps] = slot * (kSlotU * 8) + lq * 8;
     }
@@ -170,10 +174,10 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_bf16_nhwc(const ConvArgs a)
     for (int ps = 0; ps < PSW; ++ps) {
         const int q = (wp * PSW + ps) * 16 + l15;
         if (q >= a.G * RW) continue;
-        const int gl = q / RW, rem = q - gl * RW;
+        const int gl = fdiv(q, inv_RW), rem = q - gl * RW;
         const int img = g0 + gl, pix = y0 * a.Wo + rem;
         if (img >= a.N || pix >= HoWo) continue;
-        const int y = pix / a.Wo, x = pix - y * a.Wo;
+        const int y = fdiv(pix, inv_Wo), x = pix - y * a.Wo;
 #pragma unroll
         for (int cs = 0; cs < CSW; ++cs) {
             const int co = co0 + (wc * CSW + cs) * 16 + lq * 4;
