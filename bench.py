@@ -70,12 +70,15 @@ def cpu_baseline(pkg, frames_np, budget_s=20.0):
 def parity_vs_oracle(got, ref):
     """BASELINE.json's second metric: MPJPE of kp_3d and max relative error (max|a-b| / max|b| per tensor, the 1e-3 bar of
     the north star) of the GPU path's outputs against the CPU oracle on the same frames."""
-    rel = {}
+    rel, med = {}, {}
     for k in ("theta", "kp_3d", "kp_2d", "verts", "rotmat"):
         a, b = np.asarray(got[k], np.float64), np.asarray(ref[k], np.float64).reshape(got[k].shape)
         rel[k] = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+        per_frame = np.abs(a - b).reshape(a.shape[0], -1).max(1) / max(np.abs(b).max(), 1e-30)
+        med[k] = float(np.median(per_frame))
     d = np.asarray(got["kp_3d"], np.float64) - np.asarray(ref["kp_3d"], np.float64).reshape(got["kp_3d"].shape)
     return {"mpjpe_m": float(np.linalg.norm(d, axis=-1).mean()), "max_rel_err": {k: float(f"{v:.3e}") for k, v in rel.items()},
+            "median_frame_rel_err": {k: float(f"{v:.3e}") for k, v in med.items()},
             "tolerance": 1e-3, "ok": bool(max(rel.values()) < 1e-3),
             "vs": "oracle (CPU port of the reference path) on the same frames and weights"}
 
@@ -231,8 +234,10 @@ def main():
             got.update(verts=runner.verts.cpu().numpy(), rotmat=runner.rotmat.cpu().numpy())
             line["parity"] = parity_vs_oracle(got, ref)
             if args.dtype == "bf16":                          # the 1e-3 bar is the fp32 path's; bf16 error is reported, not gated
-                line["parity"].update(tolerance=None, ok=None, note="bf16 storage: distance from the fp32 oracle is rounding noise of the size "
-                                      "the bf16-emulating oracle shows (tests/test_gpu_bf16.py)")
+                line["parity"].update(tolerance=None, ok=None, note="bf16 storage: distance from the fp32 oracle is rounding noise of the size the "
+                                      "bf16-emulating oracle shows (tests/test_gpu_bf16.py); the network's rot6d output is within ~7e-3 on every frame, "
+                                      "the maxima of rotmat / theta / verts come from frames whose two 6-D vectors are nearly collinear (ill-conditioned "
+                                      "Gram-Schmidt with random synthetic weights; the emulation moves as far on the same frames: tools/bf16_outliers.py)")
         print(json.dumps(line), flush=True)
     model.close()
     if dist is not None:
