@@ -16,6 +16,9 @@
 // operand reads fall on distinct banks.
 #include "kernels.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace grk {
 
 #define GRK_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return _e; } while (0)
@@ -47,6 +50,17 @@ __device__ __forceinline__ int fdiv(int q, float inv_d) { return (int)(((float)q
 __device__ __forceinline__ void dma16(const u16* src, u16* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const GRNET_GLOBAL_AS void*)src, (GRNET_LDS_AS void*)lds_wave_base, 16, 0, 0);
 }
+
+// Diagnostic build only (make ABLATION=1, GRNET_BF16_PHASES=1): where a workgroup of the bf16 kernel spends its life, in shader-clock
+// ticks summed over workgroups: [0] table build, [1] wait for the first chunk, [2] chunk loop (MFMAs + waits), [3] epilogue, [4] workgroups.
+#ifdef GRNET_ABLATION
+__device__ unsigned long long g_phase[8];
+#define GRK_TICK(var) const unsigned long long var = __builtin_readcyclecounter()
+#define GRK_PHASE(i, t0, t1) do { if (threadIdx.x == 0) atomicAdd(&g_phase[i], (t1) - (t0)); } while (0)
+#else
+#define GRK_TICK(var) do { } while (0)
+#define GRK_PHASE(i, t0, t1) do { } while (0)
+#endif
 
 constexpr int kSlotU = 5;      // 16-byte DMA units per patch slot: 4 of data + 1 of padding (80-byte stride: conflict-free b128 reads)
 
@@ -84,6 +98,7 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_bf16_nhwc(const ConvArgs a)
     const u16* zeros = reinterpret_cast<const u16*>(a.zeros);
 
     const float inv_RinWp = 1.0f / (float)RinWp, inv_Wp = 1.0f / (float)a.Wp, inv_RW = 1.0f / (float)RW, inv_Wo = 1.0f / (float)a.Wo;
+    GRK_TICK(t_start);
     for (int idx = tid; idx < a.PSTR; idx += NT) {
         const int gl = fdiv(idx, inv_RinWp), rem = idx - gl * RinWp;
         const int ry = fdiv(rem, inv_Wp), rx = rem - ry * a.Wp;
@@ -117,6 +132,7 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_bf16_nhwc(const ConvArgs a)
         for (int ps = 0; ps < PSW; ++ps) acc[cs][ps] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nchunks = a.CinPad / kCK;
+    GRK_TICK(t_tab);
     stage(0, 0);
 
     int abase[PSW];                                        // bf16 offset of tap (0,0) of this lane's pixel + its k-group, per pixel sub-tile
@@ -136,10 +152,16 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_bf16_nhwc(const ConvArgs a)
     for (int cs = 0; cs < CSW; ++cs) wlane[cs] = wg + ((size_t)co0 + (wc * CSW + cs) * 16 + l15) * 32 + lq * 8;
     const size_t wtap = (size_t)a.CoutPad * 32;            // elements between taps
 
+#ifdef GRNET_ABLATION
+    unsigned long long t_first = 0;
+#endif
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = nbuf == 2 ? (ch & 1) : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of chunk ch has landed
         __syncthreads();                                     // ... and everybody else's; with two buffers the other one is free
+#ifdef GRNET_ABLATION
+        if (ch == 0) t_first = __builtin_readcyclecounter();
+#endif
         // all weight fragments of the chunk first: vmcnt retires in order, so fragments requested AFTER the next chunk's
         // DMA batch could only be consumed once that whole batch had landed
         const size_t wchunk = (size_t)ch * TAPS * wtap;
@@ -167,41 +189,75 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_bf16_nhwc(const ConvArgs a)
         }
     }
 
-    // ---- epilogue: lane holds channels cbase..cbase+3 of pixel l15 of each sub-tile
+    GRK_TICK(t_loop);
+    // ---- epilogue: lane holds channels co..co+3 of pixel l15 of each sub-tile.  Every load (bias, addends) is issued before the
+    // first store: loads and stores share vmcnt on CDNA, so a load behind a store waits for that store's round trip to memory
+    // (measured with the phase ticks above: 0.75 us per tile when the bias was loaded tile by tile).
     u16* out = reinterpret_cast<u16*>(a.out);
     const int cstore = a.out_ctot - a.out_coff < a.CoutPad ? a.out_ctot - a.out_coff : a.CoutPad;
+    int img_[PSW], pix_[PSW];                              // pix_ < 0: masked pixel
 #pragma unroll
     for (int ps = 0; ps < PSW; ++ps) {
         const int q = (wp * PSW + ps) * 16 + l15;
-        if (q >= a.G * RW) continue;
         const int gl = fdiv(q, inv_RW), rem = q - gl * RW;
-        const int img = g0 + gl, pix = y0 * a.Wo + rem;
-        if (img >= a.N || pix >= HoWo) continue;
-        const int y = fdiv(pix, inv_Wo), x = pix - y * a.Wo;
+        img_[ps] = g0 + gl;
+        pix_[ps] = (q < a.G * RW && img_[ps] < a.N && y0 * a.Wo + rem < HoWo) ? y0 * a.Wo + rem : -1;
+    }
+    f32x4 biasv[CSW];
+#pragma unroll
+    for (int cs = 0; cs < CSW; ++cs) {
+        const int co = co0 + (wc * CSW + cs) * 16 + lq * 4;
+        biasv[cs] = co < cstore ? *reinterpret_cast<const f32x4*>(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxAdd; ++k) {
+        if (k >= a.n_add) break;
+        const int sh = a.add_shift[k], hs = a.Ho >> sh, ws = a.Wo >> sh;
+        u32x2 r[PSW][CSW];
+#pragma unroll
+        for (int ps = 0; ps < PSW; ++ps) {
+            const int pix = pix_[ps] < 0 ? 0 : pix_[ps], img = pix_[ps] < 0 ? 0 : img_[ps];
+            const int y = fdiv(pix, inv_Wo), x = pix - y * a.Wo;
+            const u16* ap = reinterpret_cast<const u16*>(a.add[k]) + ((size_t)(img * hs + (y >> sh)) * ws + (x >> sh)) * a.add_ctot[k] + a.add_coff[k];
+#pragma unroll
+            for (int cs = 0; cs < CSW; ++cs) {
+                const int co = co0 + (wc * CSW + cs) * 16 + lq * 4;
+                r[ps][cs] = co < cstore ? *reinterpret_cast<const u32x2*>(ap + co) : u32x2{0u, 0u};
+            }
+        }
+#pragma unroll
+        for (int ps = 0; ps < PSW; ++ps)
+#pragma unroll
+            for (int cs = 0; cs < CSW; ++cs) {
+                acc[cs][ps][0] += bf2f((u16)(r[ps][cs][0] & 0xffffu)); acc[cs][ps][1] += bf2f((u16)(r[ps][cs][0] >> 16));
+                acc[cs][ps][2] += bf2f((u16)(r[ps][cs][1] & 0xffffu)); acc[cs][ps][3] += bf2f((u16)(r[ps][cs][1] >> 16));
+            }
+    }
+#pragma unroll
+    for (int ps = 0; ps < PSW; ++ps) {
+        if (pix_[ps] < 0) continue;
 #pragma unroll
         for (int cs = 0; cs < CSW; ++cs) {
             const int co = co0 + (wc * CSW + cs) * 16 + lq * 4;
             if (co >= cstore) continue;
-            f32x4 v = acc[cs][ps];
-            const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + co);
-            v += b;
-#pragma unroll
-            for (int k = 0; k < kMaxAdd; ++k) {
-                if (k >= a.n_add) break;
-                const int sh = a.add_shift[k], hs = a.Ho >> sh, ws = a.Wo >> sh;
-                const u16* ap = reinterpret_cast<const u16*>(a.add[k]) +
-                                ((size_t)(img * hs + (y >> sh)) * ws + (x >> sh)) * a.add_ctot[k] + a.add_coff[k] + co;
-                const u32x2 r = *reinterpret_cast<const u32x2*>(ap);
-                v[0] += bf2f((u16)(r[0] & 0xffffu)); v[1] += bf2f((u16)(r[0] >> 16));
-                v[2] += bf2f((u16)(r[1] & 0xffffu)); v[3] += bf2f((u16)(r[1] >> 16));
-            }
+            f32x4 v = acc[cs][ps] + biasv[cs];
             if (a.relu) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
-            *reinterpret_cast<u32x2*>(out + ((size_t)img * HoWo + pix) * a.out_ctot + a.out_coff + co) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(out + ((size_t)img_[ps] * HoWo + pix_[ps]) * a.out_ctot + a.out_coff + co) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
         }
     }
+#ifdef GRNET_ABLATION
+    {
+        GRK_TICK(t_end);
+        GRK_PHASE(0, t_start, t_tab);
+        GRK_PHASE(1, t_tab, t_first);
+        GRK_PHASE(2, t_first, t_loop);
+        GRK_PHASE(3, t_loop, t_end);
+        if (threadIdx.x == 0) atomicAdd(&g_phase[4], 1ull);
+    }
+#endif
 }
 
 // (N,C,H,W) f32 -> (N,H,W,Cp) bf16, channels C..Cp-1 zero.  The caller's frames (C = 3 -> 8) and the test hooks.
@@ -417,8 +473,20 @@ hipError_t launch_conv_bf16(ConvArgs a, hipStream_t s, int tile_hint) {
         tps = tps == 14 ? 7 : 14;
         if (!plan_bf16(a, tps, tc)) return hipErrorInvalidValue;
     }
-    if (a.ks == 1) return dispatch_bf16<1, 1>(a, tps, tc, s);
-    return a.stride == 1 ? dispatch_bf16<3, 1>(a, tps, tc, s) : dispatch_bf16<3, 2>(a, tps, tc, s);
+    hipError_t e = a.ks == 1 ? dispatch_bf16<1, 1>(a, tps, tc, s) : (a.stride == 1 ? dispatch_bf16<3, 1>(a, tps, tc, s) : dispatch_bf16<3, 2>(a, tps, tc, s));
+#ifdef GRNET_ABLATION
+    static const bool phases = getenv("GRNET_BF16_PHASES") != nullptr;
+    if (phases && e == hipSuccess) {
+        unsigned long long h[8] = {}, z[8] = {};
+        hipStreamSynchronize(s);
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h));
+        hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z));
+        const double n = h[4] ? (double)h[4] : 1.0;
+        fprintf(stderr, "[bf16 phases] %d->%d k%d s%d %dx%d N%d tps %d tc %d nbuf %d wgs %llu: per WG ticks  table %.0f  first-wait %.0f  loop %.0f (%d chunks)  epilogue %.0f\n",
+                a.Cin, a.Cout, a.ks, a.stride, a.H, a.W, a.N, tps, tc, a.TC, h[4], h[0] / n, h[1] / n, h[2] / n, a.CinPad / kCK, h[3] / n);
+    }
+#endif
+    return e;
 }
 
 hipError_t launch_nchw_f32_to_nhwc_bf16(const float* in, void* out, int N, int C, int H, int W, int Cp, hipStream_t s) {

@@ -100,9 +100,11 @@ __device__ __forceinline__ f32x4 prefetch_add0(const ConvArgs& a, const EpiCtx& 
     if (img >= a.N || pix >= e.HoWo) return z;
     return *reinterpret_cast<const f32x4*>(a.add[0] + ((size_t)img * a.add_ctot[0] + a.add_coff[0] + co) * e.HoWo + pix);
 }
-__device__ __forceinline__ void store_tile(const ConvArgs& a, const EpiCtx& e, f32x4 v, int q, int co, f32x4 pre) {
+// `bias` is loaded by the caller BEFORE the first store of the epilogue: on CDNA loads and stores share vmcnt, so a load issued
+// after a store can only be consumed once that store has completed -- a bias load per tile serialises the tiles' stores at one
+// memory round trip each (measured in the bf16 twin of this epilogue: 0.75 us per tile).
+__device__ __forceinline__ void store_tile(const ConvArgs& a, const EpiCtx& e, f32x4 v, int q, int co, f32x4 pre, float bias) {
     if (co >= a.Cout) return;
-    const float bias = a.bias[co];
     if (e.vec_ok) {
         if (q >= e.qlimit) return;
         const int gl = fdiv(q, e.inv_RW), rem = q - gl * e.RW;
@@ -360,11 +362,17 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
 
     // ---- epilogue.  D: column (lane&15) = cout, rows (lane>>4)*4 + r = 4 consecutive pixels.
     if (GRK_DBG(a, 4)) return;
+    float biasv[CSW];
+#pragma unroll
+    for (int cs = 0; cs < CSW; ++cs) {
+        const int co = co0 + (wc * CSW + cs) * 16 + l15;
+        biasv[cs] = co < a.Cout ? a.bias[co] : 0.f;
+    }
 #pragma unroll
     for (int cs = 0; cs < CSW; ++cs) {
         const int co = co0 + (wc * CSW + cs) * 16 + l15;
 #pragma unroll
-        for (int ps = 0; ps < PSW; ++ps) store_tile(a, ec, acc[ps][cs], (wp * PSW + ps) * 16 + lq * 4, co, pre[ps][cs]);
+        for (int ps = 0; ps < PSW; ++ps) store_tile(a, ec, acc[ps][cs], (wp * PSW + ps) * 16 + lq * 4, co, pre[ps][cs], biasv[cs]);
     }
 }
 
@@ -600,6 +608,12 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
         for (int cs = 0; cs < CSW; ++cs) red[(wave * NT + ps * CSW + cs) * 64 + lane] = acc[ps][cs];
     __syncthreads();
     if (GRK_DBG(a, 4)) return;
+    float biasv[MAXT];
+#pragma unroll
+    for (int i2 = 0; i2 < MAXT; ++i2) {
+        const int t = wave + i2 * NW, co = co0 + (t % CSW) * 16 + l15;
+        biasv[i2] = (t < NT && co < a.Cout) ? a.bias[co] : 0.f;
+    }
 #pragma unroll
     for (int i2 = 0; i2 < MAXT; ++i2) {
         const int t = wave + i2 * NW;
@@ -608,7 +622,7 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
 #pragma unroll
         for (int w = 1; w < NW; ++w) v += red[(w * NT + t) * 64 + lane];
         const int ps = t / CSW, cs = t - ps * CSW;
-        store_tile(a, ec, v, ps * 16 + lq * 4, co0 + cs * 16 + l15, pre[i2]);
+        store_tile(a, ec, v, ps * 16 + lq * 4, co0 + cs * 16 + l15, pre[i2], biasv[i2]);
     }
 }
 
