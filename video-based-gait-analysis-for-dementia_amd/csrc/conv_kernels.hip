@@ -30,6 +30,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #else
 #define GRK_DBG(a, bit) false
 #endif
+// Diagnostic build only: shader-clock ticks of the phases of a split-K workgroup, summed over workgroups (wave 0 reports):
+// [0] index math up to the first stage's DMA, [1] wait for it, [2] stage loop, [3] cross-wave reduction, [4] epilogue, [5] workgroups.
+#ifdef GRNET_ABLATION
+__device__ unsigned long long g_phase_f32[8];
+#define GRK_TICK(var) const unsigned long long var = __builtin_readcyclecounter()
+#define GRK_PHASE(i, t0, t1) do { if (threadIdx.x == 0) atomicAdd(&g_phase_f32[i], (t1) - (t0)); } while (0)
+#else
+#define GRK_TICK(var) do { } while (0)
+#define GRK_PHASE(i, t0, t1) do { } while (0)
+#endif
 #define GRNET_GLOBAL_AS __attribute__((address_space(1)))
 #define GRNET_LDS_AS __attribute__((address_space(3)))
 
@@ -287,6 +297,12 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
 #pragma unroll
         for (int cs = 0; cs < CSW; ++cs)
             pre[ps][cs] = prefetch_add0(a, ec, (wp * PSW + ps) * 16 + lq * 4, co0 + (wc * CSW + cs) * 16 + l15);
+    float biasv[CSW];                                      // with the residual: nothing is loaded once the epilogue has started storing
+#pragma unroll
+    for (int cs = 0; cs < CSW; ++cs) {
+        const int co = co0 + (wc * CSW + cs) * 16 + l15;
+        biasv[cs] = co < a.Cout ? a.bias[co] : 0.f;
+    }
     // A operand: lane holds pixel (lane&15) of its sub-tile, channel (lane>>4) of the k-group.
     int abase[PSW];
     unsigned lmask = 0, rmask = 0;                         // ROWS: sub-tiles whose pixel sits on the left / right image edge
@@ -362,12 +378,6 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
 
     // ---- epilogue.  D: column (lane&15) = cout, rows (lane>>4)*4 + r = 4 consecutive pixels.
     if (GRK_DBG(a, 4)) return;
-    float biasv[CSW];
-#pragma unroll
-    for (int cs = 0; cs < CSW; ++cs) {
-        const int co = co0 + (wc * CSW + cs) * 16 + l15;
-        biasv[cs] = co < a.Cout ? a.bias[co] : 0.f;
-    }
 #pragma unroll
     for (int cs = 0; cs < CSW; ++cs) {
         const int co = co0 + (wc * CSW + cs) * 16 + l15;
@@ -394,6 +404,7 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
     constexpr int TC = CSW * 16, TAPS = KS * KS, WFL = TAPS * 4 * TC, NT = PSW * CSW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
+    GRK_TICK(t_start);
     const int stage_floats = WFL + 4 * a.PSTR;           // [weights TAPS*4 x TC | input 4 x PSTR], ONE stage per wave:
     int* tab = reinterpret_cast<int*>(smem + NW * stage_floats);   // the co-resident waves hide the DMA (a second stage per wave
     float* mine = smem + wave * stage_floats;                        // measured no faster), and a fixed buffer keeps LDS addresses loop-invariant
@@ -499,14 +510,18 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
     // One stage per wave at a time: issue -> wait -> MFMAs -> issue the next into the same buffer.
     const int ngroups = a.CinPad / 4;
     const int my_stages = ngroups > wave ? (ngroups - wave + NW - 1) / NW : 0;
+    GRK_TICK(t_issue);
     if (my_stages > 0) issue(wave, 0);
     const EpiCtx ec = make_epi_ctx(a, y0, g0);
     constexpr int MAXT = (NT + NW - 1) / NW;                 // output tiles this wave finishes after the reduction
     f32x4 pre[MAXT];
+    float biasv[MAXT];                                     // with the residual: nothing is loaded once the epilogue has started storing
 #pragma unroll
     for (int i2 = 0; i2 < MAXT; ++i2) {
         const int t = wave + i2 * NW, ps = t / CSW, cs = t - ps * CSW;
         pre[i2] = t < NT ? prefetch_add0(a, ec, ps * 16 + lq * 4, co0 + cs * 16 + l15) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const int co = co0 + cs * 16 + l15;
+        biasv[i2] = (t < NT && co < a.Cout) ? a.bias[co] : 0.f;
     }
     // (the first stages are in flight while the lane offsets and edge masks are computed)
     int abase[PSW];
@@ -550,8 +565,14 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
         for (int ky = 0; ky < KS; ++ky) arow[ps][ky] = mine + abase[ps] + ky * a.Wp;
 #pragma unroll
     for (int cs = 0; cs < CSW; ++cs) brow[cs] = mine + bbase[cs];
+#ifdef GRNET_ABLATION
+    unsigned long long t_first = 0;
+#endif
     for (int i = 0; i < my_stages; ++i) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's stage has landed
+#ifdef GRNET_ABLATION
+        if (i == 0) t_first = __builtin_readcyclecounter();
+#endif
         if (!GRK_DBG(a, 1)) {
             // software pipeline over the filter taps: the LDS reads of tap t+1 are in flight under the
             // MFMAs of tap t (one exposed LDS latency per stage instead of one per tap)
@@ -600,6 +621,7 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
     }
 
     // ---- cross-wave reduction (fixed order -> deterministic), then the shared epilogue
+    GRK_TICK(t_loop);
     __syncthreads();                                       // every wave is done with its staging buffers
     f32x4* red = reinterpret_cast<f32x4*>(smem);           // [NW][NT][64]
 #pragma unroll
@@ -608,12 +630,7 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
         for (int cs = 0; cs < CSW; ++cs) red[(wave * NT + ps * CSW + cs) * 64 + lane] = acc[ps][cs];
     __syncthreads();
     if (GRK_DBG(a, 4)) return;
-    float biasv[MAXT];
-#pragma unroll
-    for (int i2 = 0; i2 < MAXT; ++i2) {
-        const int t = wave + i2 * NW, co = co0 + (t % CSW) * 16 + l15;
-        biasv[i2] = (t < NT && co < a.Cout) ? a.bias[co] : 0.f;
-    }
+    GRK_TICK(t_red);
 #pragma unroll
     for (int i2 = 0; i2 < MAXT; ++i2) {
         const int t = wave + i2 * NW;
@@ -622,8 +639,26 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
 #pragma unroll
         for (int w = 1; w < NW; ++w) v += red[(w * NT + t) * 64 + lane];
         const int ps = t / CSW, cs = t - ps * CSW;
+#ifdef GRNET_ABLATION
+        const unsigned long long t_v = __builtin_readcyclecounter();
+        if (i2 == 0) GRK_PHASE(6, t_red, t_v);                     // bias loads + partial sums of the first tile
+#endif
         store_tile(a, ec, v, ps * 16 + lq * 4, co0 + cs * 16 + l15, pre[i2], biasv[i2]);
+#ifdef GRNET_ABLATION
+        if (i2 == 0) { const unsigned long long t_s = __builtin_readcyclecounter(); GRK_PHASE(7, t_v, t_s); }   // first tile's store_tile
+#endif
     }
+#ifdef GRNET_ABLATION
+    {
+        GRK_TICK(t_end);
+        GRK_PHASE(0, t_start, t_issue);
+        GRK_PHASE(1, t_issue, t_first);
+        GRK_PHASE(2, t_first, t_loop);
+        GRK_PHASE(3, t_loop, t_red);
+        GRK_PHASE(4, t_red, t_end);
+        if (threadIdx.x == 0) atomicAdd(&g_phase_f32[5], 1ull);
+    }
+#endif
 }
 
 template <int MODE, int KS, int S, int PSW, int CSW, int NW>
@@ -970,7 +1005,21 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s, int tile_hint) {
     plan_tile(a, best.tps, best.family);
     a.TC = best.tcs * 16;
     const size_t lds = lds_bytes(a, best);
-    return a.rows == 1 ? dispatch_ks<true>(a, best, lds, s) : dispatch_ks<false>(a, best, lds, s);
+    const hipError_t e = a.rows == 1 ? dispatch_ks<true>(a, best, lds, s) : dispatch_ks<false>(a, best, lds, s);
+#ifdef GRNET_ABLATION
+    static const bool phases = getenv("GRNET_F32_PHASES") != nullptr;
+    if (phases && e == hipSuccess && best.family == 1) {
+        unsigned long long h[8] = {}, z[8] = {};
+        hipStreamSynchronize(s);
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_f32), sizeof(h));
+        hipMemcpyToSymbol(HIP_SYMBOL(g_phase_f32), z, sizeof(z));
+        const double n = h[5] ? (double)h[5] : 1.0;
+        fprintf(stderr, "[f32 split-K phases] %d->%d k%d s%d %dx%d N%d psw %d csw %d nw %d wgs %llu: per WG ticks  index math %.0f  first wait %.0f  "
+                "stage loop %.0f  reduction %.0f  epilogue %.0f (first tile: sums %.0f, store_tile %.0f)\n", a.Cin, a.Cout, a.ks, a.stride, a.H, a.W, a.N,
+                best.tps, best.tcs, best.nw, h[5], h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[6] / n, h[7] / n);
+    }
+#endif
+    return e;
 }
 
 }  // namespace grk
