@@ -34,6 +34,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // [0] index math up to the first stage's DMA, [1] wait for it, [2] stage loop, [3] cross-wave reduction, [4] epilogue, [5] workgroups.
 #ifdef GRNET_ABLATION
 __device__ unsigned long long g_phase_f32[8];
+__device__ unsigned long long g_phase_wk[8];    // whole-K: [0] index math up to the first chunk's DMA, [1] more math + wait for it, [2] chunk loop, [3] epilogue, [4] workgroups
+#define GRK_PHASE_WK(i, t0, t1) do { if (threadIdx.x == 0) atomicAdd(&g_phase_wk[i], (t1) - (t0)); } while (0)
 #define GRK_TICK(var) const unsigned long long var = __builtin_readcyclecounter()
 #define GRK_PHASE(i, t0, t1) do { if (threadIdx.x == 0) atomicAdd(&g_phase_f32[i], (t1) - (t0)); } while (0)
 #else
@@ -198,6 +200,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
 
     int bx, by;
     if (!xcd_block(a, bx, by)) return;
+    GRK_TICK(t_start);
     const int ty = bx % a.tiles_y, grp = bx / a.tiles_y;
     const int y0 = ty * a.R, g0 = grp * a.G, co0 = by * TC;
     const int HW = a.H * a.W, RW = a.R * a.Wo, RinWp = a.Rin * a.Wp;
@@ -289,6 +292,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
         for (int cs = 0; cs < CSW; ++cs) acc[ps][cs] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nchunks = a.CinPad / CK;
+    GRK_TICK(t_issue);
     issue(0, 0);                                          // first chunk in flight while the lane offsets are computed
     const EpiCtx ec = make_epi_ctx(a, y0, g0);
     f32x4 pre[PSW][CSW];
@@ -327,10 +331,16 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
 #pragma unroll
     for (int cs = 0; cs < CSW; ++cs) bbase[cs] = lq * TC + (((wc * CSW + cs) * 16 + l15) ^ ((lq & 1) << 4));
 
+#ifdef GRNET_ABLATION
+    unsigned long long t_first = 0;
+#endif
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of chunk ch has landed
         __syncthreads();                                     // ... and everybody else's; buf^1 is free
+#ifdef GRNET_ABLATION
+        if (ch == 0) t_first = __builtin_readcyclecounter();
+#endif
         if (ch + 1 < nchunks && !GRK_DBG(a, 2)) issue(ch + 1, buf ^ 1);
         if (GRK_DBG(a, 1)) continue;
         const float* wi = w_lds + buf * WFLOATS;
@@ -378,12 +388,27 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
 
     // ---- epilogue.  D: column (lane&15) = cout, rows (lane>>4)*4 + r = 4 consecutive pixels.
     if (GRK_DBG(a, 4)) return;
+    GRK_TICK(t_loop);
 #pragma unroll
     for (int cs = 0; cs < CSW; ++cs) {
         const int co = co0 + (wc * CSW + cs) * 16 + l15;
 #pragma unroll
-        for (int ps = 0; ps < PSW; ++ps) store_tile(a, ec, acc[ps][cs], (wp * PSW + ps) * 16 + lq * 4, co, pre[ps][cs], biasv[cs]);
+        for (int ps = 0; ps < PSW; ++ps) {
+            if (GRK_DBG(a, 8) && (ps & 1)) continue;       // ablation: half of the tile stores
+            if (GRK_DBG(a, 16)) { if (acc[ps][cs][0] == 12345.678f) a.out[0] = 1.f; continue; }   // ablation: no stores at all (results kept live)
+            store_tile(a, ec, acc[ps][cs], (wp * PSW + ps) * 16 + lq * 4, co, pre[ps][cs], biasv[cs]);
+        }
     }
+#ifdef GRNET_ABLATION
+    {
+        GRK_TICK(t_end);
+        GRK_PHASE_WK(0, t_start, t_issue);
+        GRK_PHASE_WK(1, t_issue, t_first);
+        GRK_PHASE_WK(2, t_first, t_loop);
+        GRK_PHASE_WK(3, t_loop, t_end);
+        if (threadIdx.x == 0) atomicAdd(&g_phase_wk[4], 1ull);
+    }
+#endif
 }
 
 
@@ -1008,6 +1033,16 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s, int tile_hint) {
     const hipError_t e = a.rows == 1 ? dispatch_ks<true>(a, best, lds, s) : dispatch_ks<false>(a, best, lds, s);
 #ifdef GRNET_ABLATION
     static const bool phases = getenv("GRNET_F32_PHASES") != nullptr;
+    if (phases && e == hipSuccess && best.family == 0) {
+        unsigned long long h[8] = {}, z[8] = {};
+        hipStreamSynchronize(s);
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_wk), sizeof(h));
+        hipMemcpyToSymbol(HIP_SYMBOL(g_phase_wk), z, sizeof(z));
+        const double n = h[4] ? (double)h[4] : 1.0;
+        fprintf(stderr, "[f32 whole-K phases] %d->%d k%d s%d %dx%d N%d tps %d tcs %d wgs %llu: per WG ticks  index math %.0f  first wait %.0f  chunk loop %.0f "
+                "(%d chunks)  epilogue %.0f\n", a.Cin, a.Cout, a.ks, a.stride, a.H, a.W, a.N, best.tps, best.tcs, h[4], h[0] / n, h[1] / n, h[2] / n,
+                a.CinPad / (a.ks == 1 ? 32 : kConvCK), h[3] / n);
+    }
     if (phases && e == hipSuccess && best.family == 1) {
         unsigned long long h[8] = {}, z[8] = {};
         hipStreamSynchronize(s);
