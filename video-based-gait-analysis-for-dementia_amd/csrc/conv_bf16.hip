@@ -233,20 +233,36 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_bf16_nhwc(const ConvArgs a)
                 acc[cs][ps][2] += bf2f((u16)(r[ps][cs][1] & 0xffffu)); acc[cs][ps][3] += bf2f((u16)(r[ps][cs][1] >> 16));
             }
     }
+    // The finished tile goes through LDS ([pixel][TC channels], 16 B of padding per pixel) and leaves as 16 bytes per lane with the
+    // lanes walking the channels of a pixel and then the next pixel: whole 64/128-byte channel rows per request instead of sixteen
+    // 32-byte pieces per store instruction.  (Per-workgroup phase ticks: with the direct 8-byte stores the epilogue was 33-57 % of a
+    // small layer's workgroup life -- only ~4 such stores per wave are in flight for free, every further one waits for a drain.)
+    constexpr int TCP = TC + 8;                            // bf16 per pixel in LDS
+    u16* o_lds = a_lds;                                    // the patch buffers are free after the barrier below
+    __syncthreads();
 #pragma unroll
     for (int ps = 0; ps < PSW; ++ps) {
-        if (pix_[ps] < 0) continue;
+        const int pl = (wp * PSW + ps) * 16 + l15;
 #pragma unroll
         for (int cs = 0; cs < CSW; ++cs) {
-            const int co = co0 + (wc * CSW + cs) * 16 + lq * 4;
-            if (co >= cstore) continue;
             f32x4 v = acc[cs][ps] + biasv[cs];
             if (a.relu) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
-            *reinterpret_cast<u32x2*>(out + ((size_t)img_[ps] * HoWo + pix_[ps]) * a.out_ctot + a.out_coff + co) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(o_lds + pl * TCP + (wc * CSW + cs) * 16 + lq * 4) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
         }
+    }
+    __syncthreads();
+    constexpr int UPP = TC / 8;                            // 16-byte units per pixel
+    for (int u = tid; u < TPS * 16 * UPP; u += NT) {
+        const int pl = u / UPP, part = u - pl * UPP;
+        if (pl >= a.G * RW) continue;
+        const int gl = fdiv(pl, inv_RW), rem = pl - gl * RW;
+        const int img = g0 + gl, pix = y0 * a.Wo + rem;
+        if (img >= a.N || pix >= HoWo || co0 + part * 8 >= cstore) continue;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(o_lds + pl * TCP + part * 8);
+        *reinterpret_cast<u32x4*>(out + ((size_t)img * HoWo + pix) * a.out_ctot + a.out_coff + co0 + part * 8) = v;
     }
 #ifdef GRNET_ABLATION
     {
@@ -397,10 +413,11 @@ __global__ __launch_bounds__(256) void attn_pool_bf16_kernel(const u16* __restri
     }
 }
 
-size_t lds_bytes_bf16(const ConvArgs& a, int tc, int nbuf) {
+size_t lds_bytes_bf16(const ConvArgs& a, int tc, int nbuf, int tps_px) {
     const size_t aunits = ((size_t)a.PSTR * kSlotU + 63) & ~(size_t)63;
-    (void)tc;                                              // weights are read from global memory: only the input patch lives in LDS
-    return (size_t)nbuf * aunits * 16 + (size_t)a.PSTR * 4;
+    // weights are read from global memory: LDS holds the input patch and, afterwards, the output tile [pixels][tc + 8] bf16
+    const size_t patch = (size_t)nbuf * aunits * 16, tile = (size_t)tps_px * (tc + 8) * 2;
+    return (patch > tile ? patch : tile) + (size_t)a.PSTR * 4;
 }
 
 bool plan_bf16(ConvArgs& a, int tps, int tc) {
@@ -419,14 +436,14 @@ bool plan_bf16(ConvArgs& a, int tps, int tc) {
     a.gx8 = (a.gx + 7) / 8;
     a.xcd = (a.gy > 1 || a.ks > 1) && a.gx >= 16;
     // chunks double-buffered when two workgroups still fit a CU that way (or nothing else fits), else single-buffered
-    a.TC = lds_bytes_bf16(a, tc, 2) <= 80 * 1024 ? 2 : (lds_bytes_bf16(a, tc, 1) <= 80 * 1024 ? 1 : (lds_bytes_bf16(a, tc, 2) <= 160 * 1024 ? 2 : 1));
+    a.TC = lds_bytes_bf16(a, tc, 2, TP) <= 80 * 1024 ? 2 : (lds_bytes_bf16(a, tc, 1, TP) <= 80 * 1024 ? 1 : (lds_bytes_bf16(a, tc, 2, TP) <= 160 * 1024 ? 2 : 1));
     // (measured at 256 frames: double buffers at one workgroup per CU are 1.7x slower than single buffers at two)
-    return lds_bytes_bf16(a, tc, a.TC) <= 160 * 1024;
+    return lds_bytes_bf16(a, tc, a.TC, TP) <= 160 * 1024;
 }
 
 template <int KS, int S>
 hipError_t dispatch_bf16(const ConvArgs& a, int tps, int tc, hipStream_t s) {
-    const size_t lds = lds_bytes_bf16(a, tc, a.TC);
+    const size_t lds = lds_bytes_bf16(a, tc, a.TC, tps * 16);
     const dim3 grid((a.xcd ? a.gx8 * 8 : a.gx) * a.gy);
     if (tps == 14 && tc == 64) return launch_k(conv_bf16_nhwc<KS, S, 14, 4, 2, 2>, grid, dim3(256), lds, s, a);
     if (tps == 14 && tc == 32) return launch_k(conv_bf16_nhwc<KS, S, 14, 2, 2, 2>, grid, dim3(256), lds, s, a);
@@ -461,10 +478,10 @@ hipError_t conv_bf16_init() {
 
 // a.in / a.out / a.w / a.add[] point at bf16 data (NHWC activations, [CinPad/32][tap][CoutPad][32] weights); a.bias is fp32;
 // a.zeros: >= 16 zero bytes in HBM.
-// Requirements: CinPad % 32 == 0, CoutPad % 32 == 0, in_ctot / in_coff / out_ctot / out_coff / add_ctot / add_coff multiples of 8 (4 for outputs).
+// Requirements: CinPad % 32 == 0, CoutPad % 32 == 0, in_ctot / in_coff / out_ctot / out_coff multiples of 8, add_ctot / add_coff multiples of 4.
 hipError_t launch_conv_bf16(ConvArgs a, hipStream_t s, int tile_hint) {
     if (!((a.ks == 1 && a.stride == 1) || (a.ks == 3 && (a.stride == 1 || a.stride == 2)))) return hipErrorInvalidValue;
-    if (a.CinPad % kCK != 0 || a.CoutPad % 32 != 0 || a.in_ctot % 8 != 0 || a.in_coff % 8 != 0 || a.out_ctot % 4 != 0 || a.out_coff % 4 != 0)
+    if (a.CinPad % kCK != 0 || a.CoutPad % 32 != 0 || a.in_ctot % 8 != 0 || a.in_coff % 8 != 0 || a.out_ctot % 8 != 0 || a.out_coff % 8 != 0)
         return hipErrorInvalidValue;
     const int tc = a.CoutPad % 64 == 0 ? 64 : 32;          // measured at 256 frames: 32 everywhere is 1.5x slower
     // 224-pixel tiles for the 56-wide maps, 112 otherwise (measured: 224 everywhere ties at 256 frames and loses 13 % at 16; 112 everywhere loses 28 %)
