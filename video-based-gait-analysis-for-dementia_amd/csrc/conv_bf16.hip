@@ -436,8 +436,10 @@ bool plan_bf16(ConvArgs& a, int tps, int tc) {
     a.gx8 = (a.gx + 7) / 8;
     a.xcd = (a.gy > 1 || a.ks > 1) && a.gx >= 16;
     // chunks double-buffered when two workgroups still fit a CU that way (or nothing else fits), else single-buffered
+    // (thresholds of 32..80 KB for double buffering measure within 1.5 % of each other at 256 frames)
     a.TC = lds_bytes_bf16(a, tc, 2, TP) <= 80 * 1024 ? 2 : (lds_bytes_bf16(a, tc, 1, TP) <= 80 * 1024 ? 1 : (lds_bytes_bf16(a, tc, 2, TP) <= 160 * 1024 ? 2 : 1));
     // (measured at 256 frames: double buffers at one workgroup per CU are 1.7x slower than single buffers at two)
+    if (a.CinPad == kCK) a.TC = 1;                          // a single chunk has nothing to double-buffer: half the LDS, twice the workgroups per CU
     return lds_bytes_bf16(a, tc, a.TC, TP) <= 160 * 1024;
 }
 
