@@ -397,6 +397,6 @@ def test_parity_bar_holds_over_128_frames(pkg, oracle, synth_weights, synth_smpl
     for k in ("theta", "kp_3d", "kp_2d", "verts", "rotmat"):
         a, r = out[k].cpu().numpy().reshape(n, -1), np.asarray(ref[k]).reshape(n, -1)
         per_frame = np.abs(a - r).max(1) / np.abs(r).max()
-        assert per_frame.max() < TOL, (k, float(per_frame.max()), int(per_frame.argmax()))
+        assert per_frame.max() < 1e-3, (k, float(per_frame.max()), int(per_frame.argmax()))      # the bar itself
         assert np.median(per_frame) < 2e-5, k
     m.close()
