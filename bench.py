@@ -200,7 +200,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         total_frames = n * world * args.steps
         line = {
-            "metric": "frames/sec (224x224, seq=16)", "value": round(total_frames / elapsed, 2), "unit": "frames/s",
+            "metric": f"frames/sec (224x224, seq={n})", "value": round(total_frames / elapsed, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"1 clip x {n} frames x 3x224x224 per GPU, {'fp32' if args.dtype == 'f32' else 'bf16 storage / fp32 accumulation'}, MAX-GRNet per-frame path "
