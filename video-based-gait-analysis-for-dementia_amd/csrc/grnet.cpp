@@ -677,6 +677,11 @@ struct grnet {
                 for (int ci : op.group) writers[convs[ci].out.p].push_back(i);
         }
         op_events.assign(ops.size(), nullptr);
+        if (getenv("GRNET_TRACE")) {
+            size_t waits = 0, records = 0;
+            for (const Op& op : ops) { waits += op.waits.size(); records += op.record; }
+            fprintf(stderr, "[grnet] dependencies: %zu ops, %zu cross-lane waits, %zu recorded events\n", ops.size(), waits, records);
+        }
     }
 
     // ------------------------------------------------------------------ weights
