@@ -70,7 +70,7 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_bf16_nhwc(const ConvArgs a)
     static_assert(TPS % WP == 0 && TCS % WC == 0, "wave grid must divide the tile");
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int aunits = (a.PSTR * kSlotU + 63) & ~63;                     // patch units per chunk, whole wave-instructions
-    const int nbuf = a.TC;                                               // set by plan_bf16 for this kernel: 2 = double-buffered chunks, 1 = single
+    const int nbuf = a.nbuf;                                             // plan_bf16: 2 = double-buffered chunks, 1 = single
     u16* a_lds = reinterpret_cast<u16*>(smem_raw);                       // [nbuf][aunits][8]       80-byte slots
     int* tab = reinterpret_cast<int*>(a_lds + (size_t)nbuf * aunits * 8);   // [PSTR] input pixel of each patch slot, -1 = zero
 
@@ -437,15 +437,15 @@ bool plan_bf16(ConvArgs& a, int tps, int tc) {
     a.xcd = (a.gy > 1 || a.ks > 1) && a.gx >= 16;
     // chunks double-buffered when two workgroups still fit a CU that way (or nothing else fits), else single-buffered
     // (thresholds of 32..80 KB for double buffering measure within 1.5 % of each other at 256 frames)
-    a.TC = lds_bytes_bf16(a, tc, 2, TP) <= 80 * 1024 ? 2 : (lds_bytes_bf16(a, tc, 1, TP) <= 80 * 1024 ? 1 : (lds_bytes_bf16(a, tc, 2, TP) <= 160 * 1024 ? 2 : 1));
+    a.nbuf = lds_bytes_bf16(a, tc, 2, TP) <= 80 * 1024 ? 2 : (lds_bytes_bf16(a, tc, 1, TP) <= 80 * 1024 ? 1 : (lds_bytes_bf16(a, tc, 2, TP) <= 160 * 1024 ? 2 : 1));
     // (measured at 256 frames: double buffers at one workgroup per CU are 1.7x slower than single buffers at two)
-    if (a.CinPad == kCK) a.TC = 1;                          // a single chunk has nothing to double-buffer: half the LDS, twice the workgroups per CU
-    return lds_bytes_bf16(a, tc, a.TC, TP) <= 160 * 1024;
+    if (a.CinPad == kCK) a.nbuf = 1;                          // a single chunk has nothing to double-buffer: half the LDS, twice the workgroups per CU
+    return lds_bytes_bf16(a, tc, a.nbuf, TP) <= 160 * 1024;
 }
 
 template <int KS, int S>
 hipError_t dispatch_bf16(const ConvArgs& a, int tps, int tc, hipStream_t s) {
-    const size_t lds = lds_bytes_bf16(a, tc, a.TC, tps * 16);
+    const size_t lds = lds_bytes_bf16(a, tc, a.nbuf, tps * 16);
     const dim3 grid((a.xcd ? a.gx8 * 8 : a.gx) * a.gy);
     if (tps == 14 && tc == 64) return launch_k(conv_bf16_nhwc<KS, S, 14, 4, 2, 2>, grid, dim3(256), lds, s, a);
     if (tps == 14 && tc == 32) return launch_k(conv_bf16_nhwc<KS, S, 14, 2, 2, 2>, grid, dim3(256), lds, s, a);
@@ -502,7 +502,7 @@ hipError_t launch_conv_bf16(ConvArgs a, hipStream_t s, int tile_hint) {
         hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z));
         const double n = h[4] ? (double)h[4] : 1.0;
         fprintf(stderr, "[bf16 phases] %d->%d k%d s%d %dx%d N%d tps %d tc %d nbuf %d wgs %llu: per WG ticks  table %.0f  first-wait %.0f  loop %.0f (%d chunks)  epilogue %.0f\n",
-                a.Cin, a.Cout, a.ks, a.stride, a.H, a.W, a.N, tps, tc, a.TC, h[4], h[0] / n, h[1] / n, h[2] / n, a.CinPad / kCK, h[3] / n);
+                a.Cin, a.Cout, a.ks, a.stride, a.H, a.W, a.N, tps, tc, a.nbuf, h[4], h[0] / n, h[1] / n, h[2] / n, a.CinPad / kCK, h[3] / n);
     }
 #endif
     return e;
