@@ -342,7 +342,9 @@ def test_tsattn_block_matches_reference_golden_and_oracle(pkg, oracle):
     y = m.tsattn_forward(xd, xsd)
     assert rel_err(y.cpu().numpy(), oracle.ts_attn_block(x, xs, sd)) < 2e-5
     y1 = m.tsattn_forward(xd[1:2], xsd[1:2])
-    assert torch.equal(y[1:2], y1)                                        # clips are independent, bit for bit
+    # clips are independent; the GEMMs split K differently for 40 and for 120 rows, so equal up to fp32 re-association, not bit for bit
+    assert rel_err(y1.cpu().numpy(), y[1:2].cpu().numpy()) < 2e-5
+    assert torch.equal(m.tsattn_forward(xd[1:2], xsd[1:2]), y1)           # and deterministic
     yh = m.tsattn_forward(xd[1:2, :20], xsd[1:2, :20])
     assert rel_err(yh.cpu().numpy(), y[1:2, :20].cpu().numpy()) > 1e-3   # frames of a clip are coupled
     with pytest.raises(ValueError):

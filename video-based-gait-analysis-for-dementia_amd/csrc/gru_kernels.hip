@@ -19,9 +19,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // 64x64 tile, K-chunk 32, 4 waves as 2x2, each 2x2 MFMA 16x16x4 tiles.  LDS row stride 34 floats:
 // the 32 lanes of a half-wave (16 rows x 2 k) fall on 32 distinct banks (2*row + k).
 constexpr int kGemmLd = 34;
+// blockIdx.z = K slice (split-K for GEMMs with few rows: slice z covers [z*kc, (z+1)*kc) and writes its partial sums to C + z*zstride;
+// gemm_splitk_reduce adds the slices in a fixed order and the bias).  kc is a multiple of 32; one slice = the plain GEMM.
 __global__ __launch_bounds__(256) void gemm_nt_bias_f32(const float* __restrict__ A, const float* __restrict__ B,
                                                           const float* __restrict__ bias, float* __restrict__ C, int M, int N, int K,
-                                                          int ldc) {
+                                                          int ldc, int kc, size_t zstride) {
     __shared__ __align__(16) float As[64 * kGemmLd];
     __shared__ __align__(16) float Bs[64 * kGemmLd];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -33,12 +35,14 @@ __global__ __launch_bounds__(256) void gemm_nt_bias_f32(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int lr = tid >> 3, lk = (tid & 7) * 4;
-    for (int k0 = 0; k0 < K; k0 += 32) {
+    const int kbeg = blockIdx.z * kc, kend = (kbeg + kc < K) ? kbeg + kc : K;
+    C += (size_t)blockIdx.z * zstride;
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int r = lr + 32 * h;
             f32x4 va = f32x4{0.f, 0.f, 0.f, 0.f}, vb = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (k0 + lk < K) {
+            if (k0 + lk < kend) {
                 if (m0 + r < M) va = *reinterpret_cast<const f32x4*>(A + (size_t)(m0 + r) * K + k0 + lk);
                 if (n0 + r < N) vb = *reinterpret_cast<const f32x4*>(B + (size_t)(n0 + r) * K + k0 + lk);
             }
@@ -77,10 +81,44 @@ __global__ __launch_bounds__(256) void gemm_nt_bias_f32(const float* __restrict_
         }
 }
 
+// C = bias + sum_z P[z]  (fixed order: deterministic)
+__global__ __launch_bounds__(256) void gemm_splitk_reduce(const float* __restrict__ P, const float* __restrict__ bias, float* __restrict__ C, int M, int N,
+                                                            int ldc, int splits) {
+    const long total = (long)M * N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / N), n = (int)(i - (long)m * N);
+        float v = bias ? bias[n] : 0.f;
+        for (int z = 0; z < splits; ++z) v += P[(size_t)z * total + i];
+        C[(size_t)m * ldc + n] = v;
+    }
+}
+
 hipError_t launch_gemm_nt_bias(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int ldc, hipStream_t s) {
     if (K % 4 != 0) return hipErrorInvalidValue;
-    GRK_TRY(launch_k(gemm_nt_bias_f32, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, s, A, B, bias, C, M, N, K, ldc));
-    return hipGetLastError();
+    const int blocks = ((N + 63) / 64) * ((M + 63) / 64);
+    // few rows (a clip of 16 frames is ONE row block): 47 workgroups would stream a 37 MB weight matrix; split K so that >= ~512 do
+    int splits = 1;
+    if (blocks < 128 && K >= 512) {                          // (at 188 blocks -- 8 clips x 32 frames -- splitting already costs more than it saves)
+        splits = (512 + blocks - 1) / blocks;
+        if (splits > 16) splits = 16;
+        if (splits > K / 128) splits = K / 128;
+    }
+    if (splits <= 1) {
+        GRK_TRY(launch_k(gemm_nt_bias_f32, dim3((N + 63) / 64, (M + 63) / 64, 1), dim3(256), 0, s, A, B, bias, C, M, N, K, ldc, K, (size_t)0));
+        return hipGetLastError();
+    }
+    const int kc = ((K + splits - 1) / splits + 31) / 32 * 32;
+    splits = (K + kc - 1) / kc;
+    float* part = nullptr;                                  // per call: these GEMMs are not on the per-frame hot path and are not graph-captured
+    GRK_TRY(hipMallocAsync(reinterpret_cast<void**>(&part), (size_t)splits * M * N * sizeof(float), s));
+    hipError_t e = launch_k(gemm_nt_bias_f32, dim3((N + 63) / 64, (M + 63) / 64, splits), dim3(256), 0, s, A, B, static_cast<const float*>(nullptr), part, M, N, K, N, kc,
+                            (size_t)M * N);
+    if (e == hipSuccess) {
+        const long total = (long)M * N;
+        e = launch_k(gemm_splitk_reduce, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0, s, part, bias, C, M, N, ldc, splits);
+    }
+    hipFreeAsync(part, s);
+    return e != hipSuccess ? e : hipGetLastError();
 }
 
 // xc[r, c*24+j] = sum_f cp[r,f] * wc[c,f,j];  xin = x + xc   (dropout is the identity in eval)
