@@ -5,27 +5,31 @@
 
 A "step" is one pass of the hot path over one clip of 16 synthetic frames per GPU (BASELINE.json
 configs[1]: 1 clip x 16 x 224 x 224, fp32), frames already resident in HBM.  With N > 1 (one process
-per GPU, launched by torch.distributed.run) every rank owns the 16-frame shard [16r, 16r+16) of a
-16N-frame clip -- frames are independent (grnet.py:136-152), so the shards need no collective -- and
-the step ends with the one exchange the north star names: an RCCL all-gather of the per-frame pose
-results (theta, kp_3d, kp_2d, point_local_feat = the GRU input).  Weak scaling.
+per GPU) every rank owns the 16-frame shard [16r, 16r+16) of a 16N-frame clip -- frames are independent
+(grnet.py:136-152), so the shards need no collective -- and the step ends with the one exchange the north
+star names: an RCCL all-gather of the per-frame pose results (theta, kp_3d, kp_2d, point_local_feat = the
+GRU input).  Weak scaling.
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel family (conv_mfma_f32, the fp32
-MFMA implicit-GEMM convolution): algorithmic FLOPs of all conv launches of a step / their summed
-duration, measured live with HIP events on the launch stream.  `cpu_baseline` times the oracle (a
-port of the reference's CPU path; the reference itself cannot travel to the GPU box) on the host cores;
-`parity` is BASELINE.json's second metric (MPJPE / max relative error of the GPU outputs vs that oracle
-on the same 16 frames).
+Launching: under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (the driver's
+command) every process is one rank (RANK / LOCAL_RANK / WORLD_SIZE from the environment).  A bare
+`python bench.py --gpus N` with N > 1 starts that same launcher itself as a CHILD process -- before this
+process has made any GPU call -- relays rank 0's JSON line and exits with the child's code.
+
+Rank 0 prints ONE JSON line.  `roofline.achieved` follows SURVEY 8(d): frames/s per GPU x F_frame (the
+algorithmic convolution FLOPs of one frame) -- the whole step's wall time is charged to the convolutions;
+`roofline.conv_only_*` is the same FLOPs over the wall time of the conv launches alone (HIP events on the
+launch stream).  `cpu_baseline` times the oracle (a port of the reference's CPU path; the reference itself
+cannot travel to the GPU box) on the host cores; `parity` is BASELINE.json's second metric (MPJPE / max
+relative error of the GPU outputs vs that oracle on the same 16 frames).
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -33,12 +37,157 @@ PKG = "video-based-gait-analysis-for-dementia_amd"
 FRAMES_PER_GPU = 16
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA = vector peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA (the sparse headline figure is never used)
+F_FRAME_FLOP = 2 * 15441563648     # algorithmic conv FLOPs of one 224x224 frame (pinned by tests/test_gpu_parity.py)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step (default: configs[1])")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=1, help="clips in flight per GPU: 1 = strictly one clip at a time (headline); "
+                    "k > 1 alternates k independent model instances on k streams so consecutive clips overlap (throughput mode)")
+    ap.add_argument("--tune-level", type=int, default=1, help="0: cost model only, 1: per-shape measurement (~0.1 s), "
+                    "2: + in-context greedy refinement (~20 s, untimed)")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32", help="f32: the headline (BASELINE configs[1]); bf16: bf16 storage / "
+                    "fp32 accumulation on the bf16 matrix cores (configs[2] with --frames 256), errors vs the fp32 oracle reported in `parity`")
+    ap.add_argument("--tune-cache", default=None, help="tuning table file (default: the packaged table for this dtype and clip length, if any)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------- launching
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def child_command(argv, n, port, script=None):
+    """The driver's own command line for N ranks on one node (one process per GPU)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(argv, n, run=subprocess.run, script=None):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks as a CHILD process tree (never exec: this must
+    happen before any GPU call of this process, and it does -- nothing above has touched HIP), relay their output."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    proc = run(child_command(argv, n, free_port(), script), env=env)
+    return proc.returncode
+
+
+def rank_env():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_dist(world, rank, local_rank):
+    """One process per GPU; backend "nccl" is RCCL on ROCm.  GRNET_BENCH_BACKEND=gloo rehearses the N > 1 path where the ranks
+    share one GPU (or have none: CPU tests).  Returns (dist module or None, local_rank to use, device of the reduce tensor)."""
+    import torch
+    if world == 1:
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
+        return None, local_rank, "cuda"
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    backend = os.environ.get("GRNET_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return dist, local_rank, ("cuda" if backend == "nccl" else "cpu")
+
+
+def timed_steps(do_step, device_sync, steps, warmup, dist, reduce_device):
+    """W untimed steps, then EXACTLY K steps bracketed by barrier + device sync on both sides; MAX over ranks (seconds)."""
+    import torch
+
+    def sync_all():
+        device_sync()
+        if dist is not None:
+            dist.barrier()
+        device_sync()
+
+    for _ in range(warmup):
+        do_step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        do_step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+# ------------------------------------------------------------------------------------------- the JSON line
+def roofline_object(fps_per_gpu, dtype, conv_flops_per_frame, conv_ms, conv_ms_serial, n_conv, n, extra=None):
+    """achieved = frames/s per GPU x F_frame; the conv-only figure (same FLOPs / wall time of the conv launches
+    alone) and the serial per-launch average (what rocprofv3 --stats averages add up to) sit beside it."""
+    peak = PEAK_BF16_MFMA_TFLOPS if dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
+    achieved = fps_per_gpu * conv_flops_per_frame / 1e12
+    conv_flops = conv_flops_per_frame * n
+    r = {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+         "definition": "frames/s per GPU x F_frame (SURVEY 8d: 30.883 GFLOP of convolutions per frame); the whole step -- pooling, tail, "
+                       "SMPL, launch gaps -- is charged to the convolutions",
+         "traffic": None,
+         "kernel": ("conv_mfma_f32 + conv_splitk_f32 + hr_block_f32 (fp32 MFMA implicit-GEMM convolution, all launches of a step)" if dtype == "f32"
+                    else "conv_bf16_nhwc (bf16 MFMA implicit-GEMM convolution on NHWC activations, all launches of a step)"),
+         "conv_launches_per_step": n_conv, "conv_gflop_per_step": round(conv_flops / 1e9, 3),
+         "gflop_per_launch": round(conv_flops / 1e9 / max(n_conv, 1), 4)}
+    if conv_ms:
+        r.update(conv_only_ms_per_step=round(conv_ms, 4), conv_only_achieved=round(conv_flops / (conv_ms * 1e-3) / 1e12, 3),
+                 conv_only_frac=round(conv_flops / (conv_ms * 1e-3) / 1e12 / peak, 4),
+                 avg_launch_us=round(conv_ms * 1e3 / max(n_conv, 1), 3))
+    if conv_ms_serial:
+        r.update(conv_ms_per_step_serial=round(conv_ms_serial, 4), avg_launch_us_serial=round(conv_ms_serial * 1e3 / max(n_conv, 1), 3),
+                 serial_note="the same launches one after another on ONE stream: sum of per-kernel durations, what rocprofv3 --kernel-trace "
+                             "--stats averages of a GRNET_MULTI_LANE=0 run add up to (profiles/)")
+    if extra:
+        r.update(extra)
+    return r
+
+
+def stored_traffic(n, dtype):
+    """HBM bytes per step of the conv launches from the PMC passes (tools/gpu_pmc.sh -> profiles/): a static, committed
+    measurement of this same workload, not collected inside this run (counters need their own rocprofv3 passes)."""
+    if not (n == FRAMES_PER_GPU and dtype == "f32"):
+        return None
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                tj = json.load(f)
+        except OSError:
+            continue
+        return {"traffic": tj.get("hbm_bytes_per_step_conv_kernels"),
+                "traffic_calibrated": tj.get("hbm_bytes_per_step_conv_kernels_calibrated"),
+                "algorithmic_bytes": tj.get("algorithmic_bytes_per_step_conv_kernels"),
+                "traffic_source": f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this workload "
+                                  "(FETCH x2 gfx950 correction), bytes of all conv launches of one step; a stored measurement, "
+                                  "not taken inside this run"}
+    return None
 
 
 def cpu_baseline(pkg, frames_np, budget_s=20.0):
     """The oracle (port of the reference's CPU path) on the host cores, bounded sample.  oneDNN oversubscribes badly on
     a 128-thread host for 16-frame batches, so the thread count is probed first and the fastest one is used and reported.
     Returns (cpu_baseline object, the oracle's outputs for `frames_np` -- the checker for the `parity` object)."""
+    import torch
     oracle = importlib.import_module("oracle.grnet_oracle")
     sd, smpl = pkg.synth.make_state_dict(), pkg.synth.make_smpl_tables()
     oracle.grnet_forward(frames_np[:2], sd, smpl)           # warm-up (oneDNN primitive caches)
@@ -62,187 +211,156 @@ def cpu_baseline(pkg, frames_np, budget_s=20.0):
         passes += 1
     torch.set_num_threads(all_threads)
     n = frames_np.shape[0] * passes
-    return {"value": round(n / t_all, 3), "unit": "frames/s", "cores": best_t, "kind": "port",
+    return {"value": round(n / t_all, 3), "unit": "frames/s", "cores": best_t, "host_cores": os.cpu_count(), "kind": "port",
             "sample": f"{passes} passes of the oracle (torch-CPU oneDNN convs + numpy tail) over the same {frames_np.shape[0]} frames, "
-                      f"fp32, {best_t} threads (fastest of a probe over 8..{all_threads})"}, ref
+                      f"fp32, {best_t} threads used (fastest of a probe over 8..{all_threads}) on a host with {os.cpu_count()} logical cores"}, ref
 
 
 def parity_vs_oracle(got, ref):
-    """BASELINE.json's second metric: MPJPE of kp_3d and max relative error (max|a-b| / max|b| per tensor, the 1e-3 bar of
-    the north star) of the GPU path's outputs against the CPU oracle on the same frames."""
-    rel, med = {}, {}
+    """BASELINE.json's second metric: MPJPE of kp_3d and the error of the GPU path's outputs against the CPU oracle on the same
+    frames, in two forms: max|a-b| / max|b| per tensor (tensor scale) and element-wise |a-b| <= 1e-3 |b| + floor with the
+    floor at 1e-3 of the tensor's RMS (a per-element relative bar that does not blow up on entries that are ~0 by cancellation)."""
+    import numpy as np
+    rel, med, elem = {}, {}, {}
     for k in ("theta", "kp_3d", "kp_2d", "verts", "rotmat"):
         a, b = np.asarray(got[k], np.float64), np.asarray(ref[k], np.float64).reshape(got[k].shape)
         rel[k] = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
         per_frame = np.abs(a - b).reshape(a.shape[0], -1).max(1) / max(np.abs(b).max(), 1e-30)
         med[k] = float(np.median(per_frame))
+        floor = 1e-3 * float(np.sqrt(np.mean(b * b)))
+        elem[k] = float((np.abs(a - b) / (1e-3 * np.abs(b) + floor)).max())      # <= 1 passes
     d = np.asarray(got["kp_3d"], np.float64) - np.asarray(ref["kp_3d"], np.float64).reshape(got["kp_3d"].shape)
     return {"mpjpe_m": float(np.linalg.norm(d, axis=-1).mean()), "max_rel_err": {k: float(f"{v:.3e}") for k, v in rel.items()},
             "median_frame_rel_err": {k: float(f"{v:.3e}") for k, v in med.items()},
-            "tolerance": 1e-3, "ok": bool(max(rel.values()) < 1e-3),
-            "vs": "oracle (CPU port of the reference path) on the same frames and weights"}
+            "elementwise_worst_ratio": {k: float(f"{v:.3e}") for k, v in elem.items()},
+            "elementwise_form": "|a-b| <= 1e-3*|b| + 1e-3*rms(b) for every element (ratio <= 1 passes)",
+            "tolerance": 1e-3, "ok": bool(max(rel.values()) < 1e-3 and max(elem.values()) <= 1.0),
+            "vs": "oracle (CPU port of the reference path) on the same frames and weights; SMPL (smplx) and its tables are "
+                  "pinned to the published algorithm only (no smplx offline)"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step (default: configs[1])")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=1, help="clips in flight per GPU: 1 = strictly one clip at a time (headline); "
-                    "k > 1 alternates k independent model instances on k streams so consecutive clips overlap (throughput mode)")
-    ap.add_argument("--tune-level", type=int, default=1, help="0: cost model only, 1: per-shape measurement (~0.1 s), "
-                    "2: + in-context greedy refinement (~20 s, untimed)")
-    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32", help="f32: the headline (BASELINE configs[1]); bf16: bf16 storage / "
-                    "fp32 accumulation on the bf16 matrix cores (configs[2] with --frames 256), errors vs the fp32 oracle reported in `parity`")
-    ap.add_argument("--tune-cache", default=None, help="tuning table file (default: the packaged table for this clip length, if any)")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------- one rank
+class GpuWorkload:
+    """The real thing: the synthetic MAX-GRNet model of this rank + its resident 16-frame shard."""
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("GRNET_BENCH_BACKEND", "nccl")      # "gloo": rehearsal of the N > 1 path on a 1-GPU box (ranks share GPU 0)
-        if backend != "nccl":
-            local_rank = local_rank % max(1, torch.cuda.device_count())
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    def __init__(self, args, world, rank, local_rank, dist):
+        import torch
+        self.torch, self.args, self.world, self.rank, self.dist = torch, args, world, rank, dist
+        pkg = self.pkg = importlib.import_module(PKG)
+        harness = pkg.harness
+        n = self.n = args.frames
+        self.model = pkg.build_synthetic_model(max_frames=n, device_id=local_rank, with_gru=False, dtype=args.dtype)
+        self.frames_np = pkg.synth.make_frames(n, start=rank * n)
+        frames = torch.from_numpy(self.frames_np).cuda()
+        cache = args.tune_cache or os.path.join(ROOT, PKG, "tuning", f"mi355x_{args.dtype}_n{n}.txt")
+        if not (args.tune_cache or os.path.isfile(cache)):
+            cache = None
+        self.cache = cache
+        mk = lambda m: harness.ClipRunner(m, frames, use_graph=not args.no_graph, world=world, rank=rank, dist=dist,
+                                          tune_level=args.tune_level, tune_cache=cache)
+        self.runner = mk(self.model)
+        self.runners, self.streams = [self.runner], [torch.cuda.current_stream()]
+        for _ in range(1, max(1, args.inflight)):             # extra clips in flight: own buffers, own stream
+            m_k = pkg.build_synthetic_model(max_frames=n, device_id=local_rank, with_gru=False, dtype=args.dtype)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                self.runners.append(mk(m_k))
+            self.streams.append(st)
+        self.step_no = 0
+
+    def step(self):
+        k = self.step_no % len(self.runners)
+        self.step_no += 1
+        if len(self.runners) == 1:
+            self.runner.step()
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    else:
-        torch.cuda.set_device(local_rank)
+            with self.torch.cuda.stream(self.streams[k]):
+                self.runners[k].step()
 
-    pkg = importlib.import_module(PKG)
-    harness = pkg.harness
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def config(self):
+        args, model, n = self.args, self.model, self.n
+        tm = model.tuned_mode(n) or {}
+        eager = args.no_graph or tm.get("eager", False)
+        launch_desc = ("eager launches on 4 lane streams" if eager else "hipGraph replay") + \
+                      (", grouped HR-module launches" if tm.get("grouped") else ", one launch per convolution / fused block") + \
+                      (" (schedule picked by grnet_tune)" if tm else "")
+        return {"workload": f"1 clip x {n} frames x 3x224x224 per GPU, {'fp32' if args.dtype == 'f32' else 'bf16 storage / fp32 accumulation'}, "
+                            "MAX-GRNet per-frame path (HRNet-W32 + PARE head + SMPL LBS), seed-defined synthetic weights",
+                "frames_per_gpu": n, "clips_in_flight": len(self.runners), "launch": launch_desc,
+                "kernel_launches_per_step": model.num_kernel_launches(),
+                "launch_configs": ("stored table " + os.path.relpath(self.cache, ROOT)) if self.cache else f"grnet_tune level {args.tune_level}",
+                "exchange": "none (1 GPU)" if self.world == 1 else "RCCL all-gather of per-frame pose results"}
+
+    def roofline(self, fps_per_gpu):
+        model, n, pkg = self.model, self.n, self.pkg
+        conv_ms = min(model.time_convs(n) for _ in range(5))
+        model.set_option(pkg._lib.OPT_MULTI_LANE, 0)          # the same launches one after another on one stream
+        conv_ms_serial = min(model.time_convs(n) for _ in range(3))
+        model.set_option(pkg._lib.OPT_MULTI_LANE, 1)
+        return roofline_object(fps_per_gpu, self.args.dtype, model.conv_flops_per_frame(), conv_ms, conv_ms_serial,
+                               model.num_conv_launches(), n, stored_traffic(n, self.args.dtype))
+
+    def extras(self, line):
+        """cpu_baseline + parity: rank 0 at N = 1 only, after the timed region."""
+        if self.world != 1 or self.args.no_cpu_baseline:
+            return
+        line["cpu_baseline"], ref = cpu_baseline(self.pkg, self.frames_np)
+        self.runner.step()
+        self.torch.cuda.synchronize()
+        got = {k: v.cpu().numpy() for k, v in self.runner.sequence().items() if k != "point_local_feat"}
+        got.update(verts=self.runner.verts.cpu().numpy(), rotmat=self.runner.rotmat.cpu().numpy())
+        line["parity"] = parity_vs_oracle(got, ref)
+        if self.args.dtype == "bf16":                          # the 1e-3 bar is the fp32 path's; bf16 error is reported, not gated
+            line["parity"].update(tolerance=None, ok=None, note="bf16 storage: distance from the fp32 oracle is rounding noise of the size the "
+                                  "bf16-emulating oracle shows (tests/test_gpu_bf16.py); the network's rot6d output is within ~7e-3 on every frame, "
+                                  "the maxima of rotmat / theta / verts come from frames whose two 6-D vectors are nearly collinear (ill-conditioned "
+                                  "Gram-Schmidt with random synthetic weights; the emulation moves as far on the same frames: tools/bf16_outliers.py)")
+
+    def close(self):
+        for r in self.runners:
+            r.model.close()
+
+
+def run_rank(args, make_workload=GpuWorkload, out=None):
+    """Everything one rank does; returns the JSON object on rank 0 (None elsewhere).  `make_workload` is the seam the CPU
+    tests use to drive the rank logic (barrier, MAX over ranks, rank-0 line) with a stand-in workload under gloo."""
+    world, rank, local_rank = rank_env()
+    dist, local_rank, reduce_device = init_dist(world, rank, local_rank)
+    wl = make_workload(args, world, rank, local_rank, dist)
+    elapsed = timed_steps(wl.step, wl.sync, args.steps, args.warmup, dist, reduce_device)
+    line = None
     n = args.frames
-    model = pkg.build_synthetic_model(max_frames=n, device_id=local_rank, with_gru=False, dtype=args.dtype)
-    frames_np = pkg.synth.make_frames(n, start=rank * n)
-    frames = torch.from_numpy(frames_np).cuda()
-    cache = args.tune_cache or os.path.join(ROOT, PKG, "tuning", f"mi355x_f32_n{n}.txt")
-    if not (args.tune_cache or os.path.isfile(cache)):
-        cache = None
-    runner = harness.ClipRunner(model, frames, use_graph=not args.no_graph, world=world, rank=rank, dist=dist,
-                                tune_level=args.tune_level, tune_cache=cache)
-    runners, streams = [runner], [torch.cuda.current_stream()]
-    for k in range(1, max(1, args.inflight)):                 # extra clips in flight: own buffers, own stream
-        m_k = pkg.build_synthetic_model(max_frames=n, device_id=local_rank, with_gru=False, dtype=args.dtype)
-        st = torch.cuda.Stream()
-        with torch.cuda.stream(st):
-            runners.append(harness.ClipRunner(m_k, frames, use_graph=not args.no_graph, world=world, rank=rank, dist=dist,
-                                              tune_level=args.tune_level, tune_cache=cache))
-        streams.append(st)
-    step_no = [0]
-
-    def do_step():
-        k = step_no[0] % len(runners)
-        step_no[0] += 1
-        if len(runners) == 1:
-            runner.step()
-        else:
-            with torch.cuda.stream(streams[k]):
-                runners[k].step()
-
-    def sync_all():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        do_step()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        do_step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # dominant-kernel roofline: all conv launches of one step, HIP events on the launch stream
-    conv_ms = min(model.time_convs(n) for _ in range(5))
-    conv_flops = model.conv_flops_per_frame() * n
-    achieved = conv_flops / (conv_ms * 1e-3) / 1e12
-    peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
-    # the same launches one after another on one stream (no overlap): comparable with rocprofv3's per-kernel averages
-    model.set_option(pkg._lib.OPT_MULTI_LANE, 0)
-    conv_ms_serial = min(model.time_convs(n) for _ in range(3))
-    model.set_option(pkg._lib.OPT_MULTI_LANE, 1)
-    n_conv = model.num_conv_launches()                         # 316: the reference's 317 convolutions, two of them merged
-    traffic = traffic_cal = alg_bytes = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            tj = json.load(f)
-        traffic, traffic_cal = tj.get("hbm_bytes_per_step_conv_kernels"), tj.get("hbm_bytes_per_step_conv_kernels_calibrated")
-        alg_bytes = tj.get("algorithmic_bytes_per_step_conv_kernels")
-    except OSError:
-        pass
-    at_cfg = n == FRAMES_PER_GPU and args.dtype == "f32"
-
-    tm = model.tuned_mode(n) or {}
-    eager = args.no_graph or tm.get("eager", False)
-    launch_desc = ("eager launches on 4 lane streams" if eager else "hipGraph replay") + \
-                  (", grouped HR-module launches" if tm.get("grouped") else ", one launch per convolution") + \
-                  (" (schedule picked by grnet_tune)" if tm else "")
+    total_frames = n * world * args.steps
+    fps = total_frames / elapsed
+    roof = wl.roofline(fps / world)                            # every rank runs it (keeps the ranks in step), rank 0 reports
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        total_frames = n * world * args.steps
-        line = {
-            "metric": f"frames/sec (224x224, seq={n})", "value": round(total_frames / elapsed, 2), "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"1 clip x {n} frames x 3x224x224 per GPU, {'fp32' if args.dtype == 'f32' else 'bf16 storage / fp32 accumulation'}, MAX-GRNet per-frame path "
-                                   "(HRNet-W32 + PARE head + SMPL LBS), seed-defined synthetic weights",
-                       "frames_per_gpu": n, "clips_in_flight": len(runners), "launch": launch_desc,
-                       "kernel_launches_per_step": model.num_kernel_launches(),
-                       "launch_configs": ("stored table " + os.path.relpath(cache, ROOT)) if cache else f"grnet_tune level {args.tune_level}",
-                       "exchange": "none (1 GPU)" if world == 1 else "RCCL all-gather of per-frame pose results"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4),
-                         "traffic": traffic if (at_cfg and traffic) else None,
-                         "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
-                                           "FETCH x2 gfx950 correction), bytes of all conv launches of one step",
-                         "traffic_calibrated": traffic_cal if at_cfg else None,
-                         "algorithmic_bytes": alg_bytes if at_cfg else None,
-                         "traffic_note": "x2 is exact only for long 16 B/lane streams; on the conv kernels' row staging the counter reads "
-                                         "bytes x (1/2 + 128 B / staged segment) (profiles/r01_fetch_calibration.json), hence traffic_calibrated",
-                         "kernel": "conv_mfma_f32 + conv_splitk_f32 (fp32 MFMA implicit-GEMM convolution, all launches of a step)" if args.dtype == "f32"
-                                   else "conv_bf16_nhwc (bf16 MFMA implicit-GEMM convolution on NHWC activations, all launches of a step)",
-                         "conv_launches_per_step": n_conv, "conv_ms_per_step": round(conv_ms, 4),
-                         "conv_ms_per_step_serial": round(conv_ms_serial, 4),
-                         "avg_launch_us": round(conv_ms * 1e3 / n_conv, 3), "avg_launch_us_serial": round(conv_ms_serial * 1e3 / n_conv, 3),
-                         "gflop_per_launch": round(conv_flops / 1e9 / n_conv, 4),
-                         "conv_gflop_per_step": round(conv_flops / 1e9, 3)},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"], ref = cpu_baseline(pkg, frames_np)
-            runner.step()
-            torch.cuda.synchronize()
-            got = {k: v.cpu().numpy() for k, v in runner.sequence().items() if k != "point_local_feat"}
-            got.update(verts=runner.verts.cpu().numpy(), rotmat=runner.rotmat.cpu().numpy())
-            line["parity"] = parity_vs_oracle(got, ref)
-            if args.dtype == "bf16":                          # the 1e-3 bar is the fp32 path's; bf16 error is reported, not gated
-                line["parity"].update(tolerance=None, ok=None, note="bf16 storage: distance from the fp32 oracle is rounding noise of the size the "
-                                      "bf16-emulating oracle shows (tests/test_gpu_bf16.py); the network's rot6d output is within ~7e-3 on every frame, "
-                                      "the maxima of rotmat / theta / verts come from frames whose two 6-D vectors are nearly collinear (ill-conditioned "
-                                      "Gram-Schmidt with random synthetic weights; the emulation moves as far on the same frames: tools/bf16_outliers.py)")
-        print(json.dumps(line), flush=True)
-    model.close()
+        line = {"metric": f"frames/sec (224x224, seq={n})", "value": round(fps, 2), "unit": "frames/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                "config": wl.config(), "roofline": roof}
+        wl.extras(line)
+        print(json.dumps(line), file=out or sys.stdout, flush=True)
+    wl.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    return line
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if world == 0 and args.gpus > 1:                           # no launcher around us: start the ranks as children, relay, exit
+        return self_launch(argv, args.gpus)
+    if world > 1 and args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    run_rank(args)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
