@@ -139,6 +139,19 @@ int grnet_op_bilinear2x(grnet_t* h, const float* in_dev, int n, int c, int hgt, 
 int grnet_smpl_forward(grnet_t* h, const float* betas_dev, const float* rotmat_dev, const float* cam_dev, int n, float* verts_dev,
                        float* kp3d_dev, float* kp2d_dev, void* stream);
 
+/* PareHead.forward + VPRegressor.forward from GIVEN pooled features -- lib/models/pare.py:271-303 (_pare_get_final_preds :338-375:
+ * per-joint 128->6, Linear 1536->10/3, rot6d_to_rotmat) and :52-91 (SMPL, projection, rotmat -> axis-angle, theta packing).  This is
+ * the second head pass of the use_gait_feat branch (grnet.py:165,171: head(new_point_local_feat, cam_shape_feats, ...) then the
+ * regressor) and the single-op hook the tail's parity tests use.  point_local_feat (n,128,24), cam_shape_feats (n,64,24) are device
+ * INPUTS; `out` as in grnet_forward (theta, verts, kp_2d, kp_3d, rotmat, pred_rot6d; map outputs are ignored). */
+int grnet_head_forward(grnet_t* h, const float* point_local_feat_dev, const float* cam_shape_feats_dev, int n, const grnet_outputs_t* out,
+                       void* stream);
+/* rot6d_to_rotmat -- lib/utils/geometry.py:395-410: (m,6) -> (m,3,3); rotation_matrix_to_angle_axis -- geometry.py:68-97 (via
+ * quaternion :213-293,:159-210, NaN -> 0): (m,3,3) -> (m,3).  The device functions the tail kernel calls, exposed so the
+ * reference's edge-case vectors (degenerate 6-D pairs, the four quaternion branches, near-pi rotations) reach the GPU code. */
+int grnet_op_rot6d_to_rotmat(grnet_t* h, const float* rot6d_dev, int m, float* rotmat_dev, void* stream);
+int grnet_op_rotmat_to_aa(grnet_t* h, const float* rotmat_dev, int m, float* aa_dev, void* stream);
+
 /* Inference.__getitem__ -- lib/dataset/inference.py:71-87 (get_single_image_crop_demo + ToTensor + Normalize,
  * lib/data_utils/img_utils.py:252-285,355-363; rot = 0): n uint8 HWC frames (n,H,W,3) [one_image_for_all: a single
  * (H,W,3) frame shared by all boxes] and boxes (n,4) [cx,cy,w,h] -> (n,3,224,224) fp32 normalised crops, all device

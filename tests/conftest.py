@@ -47,3 +47,12 @@ def rel_err(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def elem_ratio(a, b, rtol=1e-3):
+    """Element-wise form of the 1e-3 bar: worst |a-b| / (rtol*|b| + floor) with floor = rtol * rms(b); <= 1 passes.
+    (The floor keeps entries that are ~0 by cancellation from demanding absolute accuracy below rtol of the tensor's scale.)"""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64).reshape(a.shape)
+    floor = rtol * float(np.sqrt(np.mean(b * b)))
+    return float((np.abs(a - b) / (rtol * np.abs(b) + max(floor, 1e-30))).max())

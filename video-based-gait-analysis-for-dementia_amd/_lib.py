@@ -46,6 +46,9 @@ EXPORTS = {
                                      C.c_void_p]),
     "grnet_crop_normalise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_int,
                                        C.c_void_p, C.c_void_p]),
+    "grnet_head_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Outputs), C.c_void_p]),
+    "grnet_op_rot6d_to_rotmat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "grnet_op_rotmat_to_aa": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "grnet_debug_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
     "grnet_last_error": (C.c_char_p, [C.c_void_p]),
     "grnet_version": (C.c_char_p, []),

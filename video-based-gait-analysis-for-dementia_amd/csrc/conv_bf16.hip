@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void fuse_sum_bf16_kernel(const SumArgs a) {
 // Attention pooling on NHWC bf16 maps (keypoint_attention.py:42-48): the spatial softmax of heat channel 1+j weights the
 // features.  Pass 1: per (image, joint) max and sum of exp over the P positions.  Pass 2: partial sums over a range of
 // positions, written in the fp32 path's workspace layout so head_tail_kernel finishes both paths alike.
-constexpr int kPoolSplitB = 7;
+constexpr int kPoolSplitB = kPoolSplit;   // shared with the fp32 path: both feed head_tail_kernel through softmax_pool_ws_floats()
 __global__ __launch_bounds__(256) void softmax_stats_bf16_kernel(const u16* __restrict__ heat, int hc, float* __restrict__ stats, int P) {
     __shared__ float red[256];
     const int n = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;

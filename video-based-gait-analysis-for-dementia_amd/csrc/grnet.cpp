@@ -83,6 +83,16 @@ struct Op {
 
 constexpr int kLanes = 8;            // streams available to the lane scheduler (the hand-written plan uses 4)
 
+// Every entry point runs on the handle's device whatever the caller's current device is, and leaves the caller's device as it found it.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
         hipError_t _e = (expr);                                                               \
@@ -133,7 +143,10 @@ struct grnet {
             return std::memcmp(&o, &r.o, sizeof(o)) < 0;
         }
     };
-    std::map<GraphKey, hipGraphExec_t> graphs;
+    struct GraphEntry { hipGraphExec_t exec; unsigned long long last_use; };
+    std::map<GraphKey, GraphEntry> graphs;                  // at most kMaxGraphs captured forwards, least recently used evicted
+    unsigned long long graph_clock = 0;
+    std::vector<GraphKey> seen_once;
     hipStream_t capture_stream = nullptr;   // the caller's stream may be the (uncapturable) null stream
     hipStream_t side[kLanes] = {};      // lanes 1.. (lane 0 = the caller's stream)
     hipEvent_t ev_fork = nullptr, ev_join[kLanes] = {};
@@ -147,6 +160,43 @@ struct grnet {
     int fail(int code, const std::string& msg) {
         err = msg;
         return code;
+    }
+
+    // Scratch of the temporal modules (GRU, attention block, feature corrector): owned by the handle and grown on demand, so a call
+    // with a size seen before allocates nothing (graph-capturable, no allocator traffic per call).  Growing synchronises the device.
+    float* temporal_ws = nullptr;
+    size_t temporal_ws_floats = 0;
+    int temporal_scratch(size_t floats, float** out) {
+        if (floats > temporal_ws_floats) {
+            if (temporal_ws) { (void)hipDeviceSynchronize(); (void)hipFree(temporal_ws); temporal_ws = nullptr; temporal_ws_floats = 0; }
+            const size_t want = floats + floats / 4;                 // head-room: clips of slightly different length reuse the buffer
+            void* q = nullptr;
+            if (hipMalloc(&q, want * sizeof(float)) != hipSuccess) return fail(GRNET_ENOMEM, "temporal workspace (" + std::to_string(want * 4 >> 20) + " MiB)");
+            temporal_ws = static_cast<float*>(q);
+            temporal_ws_floats = want;
+        }
+        *out = temporal_ws;
+        return 0;
+    }
+
+    // releases everything the handle owns (also the clean-up of a failed grnet_create)
+    ~grnet() {
+        for (auto& g : graphs) (void)hipGraphExecDestroy(g.second.exec);
+        if (capture_stream) (void)hipStreamDestroy(capture_stream);
+        for (int l = 1; l < kLanes; ++l) {
+            if (side[l]) (void)hipStreamDestroy(side[l]);
+            if (ev_join[l]) (void)hipEventDestroy(ev_join[l]);
+        }
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        for (hipEvent_t e : op_events) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : op_events_flat) if (e) (void)hipEventDestroy(e);
+        for (void* p : dev_allocs) (void)hipFree(p);
+        if (temporal_ws) (void)hipFree(temporal_ws);
+        if (arena) (void)hipFree(arena);
+    }
+    void drop_graphs() {
+        for (auto& g : graphs) (void)hipGraphExecDestroy(g.second.exec);
+        graphs.clear();
     }
 
     // ------------------------------------------------------------------ plan construction
@@ -864,7 +914,20 @@ struct grnet {
         if (!finalized) return fail(GRNET_ESTATE, "grnet_tune before grnet_finalize_weights");
         if (n < 1 || n > max_frames) return fail(GRNET_EINVAL, "n_frames outside [1, max_frames]");
         static const int cands[] = {0, 14, 7, 1071, 1072, 1041, 1042, 1171, 1141};
-        hipEvent_t e0, e1;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        // whatever way this function is left: events destroyed, half-built graphs dropped, the caller's schedule switches restored,
+        // and -- unless the tuning completed -- no partial entry for n left behind
+        struct Restore {
+            grnet* g; int n; bool grouping, use_graph, done = false; hipEvent_t *e0, *e1;
+            ~Restore() {
+                if (*e0) (void)hipEventDestroy(*e0);
+                if (*e1) (void)hipEventDestroy(*e1);
+                g->drop_graphs();
+                g->grouping = grouping;
+                g->use_graph = use_graph;
+                if (!done) { g->tuned_mode.erase(n); for (auto& L : g->convs) L.tuned.erase(n); }
+            }
+        } restore{this, n, grouping, use_graph, false, &e0, &e1};
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         std::map<std::tuple<int, int, int, int, int, int, int>, int> by_shape;
@@ -905,9 +968,10 @@ struct grnet {
             use_graph = (mode & 4) == 0;
             grouping = dtype != 1;
             tuned_mode[n] = mode;
-            for (auto& g : graphs) hipGraphExecDestroy(g.second);
-            graphs.clear();
-            int rc = forward(v_cat.p, n, nullptr, s);          // builds the graph, first replay
+            drop_graphs();
+            seen_once.clear();
+            int rc = forward(v_cat.p, n, nullptr, s);          // first sight of the key: eager
+            if (!rc) rc = forward(v_cat.p, n, nullptr, s);     // second: builds the graph, first replay
             if (rc) return rc;
             HIP_TRY(hipEventRecord(e0, s));
             for (int r = 0; r < 3; ++r) if ((rc = forward(v_cat.p, n, nullptr, s))) return rc;
@@ -927,9 +991,10 @@ struct grnet {
             use_graph = (best_mode & 4) == 0;
             tuned_mode[n] = best_mode | 1;                      // refine the measured table under the winning schedule
             auto time_forward = [&](float* out_ms) -> int {
-                for (auto& g : graphs) hipGraphExecDestroy(g.second);
-                graphs.clear();
+                drop_graphs();
+                seen_once.clear();
                 int rc = forward(v_cat.p, n, nullptr, s);
+                if (!rc) rc = forward(v_cat.p, n, nullptr, s);
                 if (rc) return rc;
                 float best_ms = 1e30f;
                 for (int rep2 = 0; rep2 < 2; ++rep2) {
@@ -979,10 +1044,8 @@ struct grnet {
             if (getenv("GRNET_TRACE")) fprintf(stderr, "[grnet] in-context tuning n=%d: %.3f -> %.3f ms\n", n, start_ms, cur_ms);
             use_graph = keep_graph;
         }
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        for (auto& g : graphs) hipGraphExecDestroy(g.second);
-        graphs.clear();
+        restore.done = true;
+        seen_once.clear();
         if (getenv("GRNET_TRACE"))
             fprintf(stderr, "[grnet] tuned n=%d: forward ms graph[lanes/model %.3f lanes/measured %.3f grouped/model %.3f grouped/measured %.3f] "
                     "eager[%.3f %.3f %.3f %.3f] -> mode %d\n",
@@ -1180,8 +1243,12 @@ struct grnet {
         if (hipMalloc(&wd, wp.size() * 2) != hipSuccess || hipMalloc(&bd, bp.size() * 4) != hipSuccess || hipMalloc(&xin, in_b) != hipSuccess ||
             hipMalloc(&xout, out_b) != hipSuccess || (add_dev && hipMalloc(&xadd, out_b) != hipSuccess))
             return fail(GRNET_ENOMEM, "hipMalloc failed");
-        hipMemcpy(wd, wp.data(), wp.size() * 2, hipMemcpyHostToDevice);
-        hipMemcpy(bd, bp.data(), bp.size() * 4, hipMemcpyHostToDevice);
+        if (hipMemcpy(wd, wp.data(), wp.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(bd, bp.data(), bp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            hipFree(wd); hipFree(bd); hipFree(xin); hipFree(xout);
+            if (xadd) hipFree(xadd);
+            return fail(GRNET_EHIP, "hipMemcpy of the test weights failed");
+        }
         hipError_t e = launch_nchw_f32_to_nhwc_bf16(in_dev, xin, n, cin, hgt, wid, cin8, s);
         if (e == hipSuccess && add_dev) e = launch_nchw_f32_to_nhwc_bf16(add_dev, xadd, n, cout, ho, wo, cout8, s);
         ConvArgs a{};
@@ -1202,6 +1269,21 @@ struct grnet {
         return 0;
     }
 
+    // tail + SMPL from given pooled features; outputs as in enqueue() (NULL -> internal buffer)
+    int head_from_feats(const float* plf, const float* csf, int n, const grnet_outputs_t& o, hipStream_t s) {
+        float* rot6d = o.pred_rot6d ? o.pred_rot6d : d_rot6d;
+        float* rotmat = o.rotmat ? o.rotmat : d_rotmat;
+        float* theta = o.theta ? o.theta : d_theta;
+        float* verts = o.verts ? o.verts : d_verts;
+        float* kp3d = o.kp_3d ? o.kp_3d : d_kp3d;
+        float* kp2d = o.kp_2d ? o.kp_2d : d_kp2d;
+        HIP_TRY(launch_head_tail_from_feats(plf, csf, tailw, rot6d, d_shape, d_cam, rotmat, theta, n, s));
+        HIP_TRY(launch_smpl(d_shape, rotmat, d_cam, smpl, d_A, verts, kp3d, kp2d, n, s));
+        if (o.point_local_feat && o.point_local_feat != plf) HIP_TRY(hipMemcpyAsync(o.point_local_feat, plf, (size_t)n * 3072 * 4, hipMemcpyDeviceToDevice, s));
+        if (o.cam_shape_feats && o.cam_shape_feats != csf) HIP_TRY(hipMemcpyAsync(o.cam_shape_feats, csf, (size_t)n * 1536 * 4, hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
+
     int forward(const float* frames, int n, const grnet_outputs_t* out, hipStream_t s) {
         if (!finalized) return fail(GRNET_ESTATE, "grnet_forward before grnet_finalize_weights");
         if (!frames || n < 1 || n > max_frames)
@@ -1215,10 +1297,26 @@ struct grnet {
         }
         GraphKey key{n, frames, o};
         auto it = graphs.find(key);
-        // a caller that passes fresh output buffers every call (the Python shim does) never repeats a key: keep at most
-        // kMaxGraphs captured forwards and launch anything else eagerly instead of instantiating graphs without bound
+        // A caller that passes fresh output buffers every call (the Python shim does) rarely repeats a key, so a key is only
+        // captured the SECOND time it is seen (first sight: eager launch, remembered in `seen_once`), and the cache keeps the
+        // kMaxGraphs most recently used captured forwards: a steady-state key always ends up captured, one-off keys cost nothing.
         constexpr size_t kMaxGraphs = 16;
-        if (it == graphs.end() && graphs.size() >= kMaxGraphs) return enqueue(frames, n, o, s);
+        if (it == graphs.end()) {
+            bool seen = false;
+            for (const GraphKey& k : seen_once) seen |= !(k < key) && !(key < k);
+            if (!seen) {
+                if (seen_once.size() >= 64) seen_once.erase(seen_once.begin());
+                seen_once.push_back(key);
+                return enqueue(frames, n, o, s);
+            }
+            if (graphs.size() >= kMaxGraphs) {
+                auto lru = graphs.begin();
+                for (auto g = graphs.begin(); g != graphs.end(); ++g)
+                    if (g->second.last_use < lru->second.last_use) lru = g;
+                (void)hipGraphExecDestroy(lru->second.exec);
+                graphs.erase(lru);
+            }
+        }
         if (it == graphs.end()) {
             hipGraph_t g = nullptr;
             HIP_TRY(hipGraphCreate(&g, 0));
@@ -1233,9 +1331,10 @@ struct grnet {
             e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
             hipGraphDestroy(g);
             if (e != hipSuccess) return fail(GRNET_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-            it = graphs.emplace(key, ge).first;
+            it = graphs.emplace(key, GraphEntry{ge, 0}).first;
         }
-        HIP_TRY(hipGraphLaunch(it->second, s));
+        it->second.last_use = ++graph_clock;
+        HIP_TRY(hipGraphLaunch(it->second.exec, s));
         return 0;
     }
 };
@@ -1248,7 +1347,9 @@ const char* grnet_version(void) { return "grnet_hip 0.1 (gfx950, fp32 MFMA)"; }
 int grnet_create(grnet_t** out_handle, int device_id, int dtype, int max_frames) {
     if (!out_handle || max_frames < 1 || max_frames > 2048 || (dtype != 0 && dtype != 1)) return GRNET_EINVAL;
     *out_handle = nullptr;
-    if (hipSetDevice(device_id) != hipSuccess) return GRNET_EHIP;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return GRNET_EHIP;
+    DeviceGuard guard(device_id);                          // the caller's current device is restored on return
     std::unique_ptr<grnet> h(new grnet());
     h->device = device_id;
     h->max_frames = max_frames;
@@ -1280,6 +1381,7 @@ int grnet_load_smpl(grnet_t* h, const float* v_template, const float* shapedirs,
                     const float* lbs_weights, const int32_t* parents, const float* J_regressor_extra) {
     if (!h || !v_template || !shapedirs || !posedirs || !J_regressor || !lbs_weights || !parents || !J_regressor_extra)
         return GRNET_EINVAL;
+    DeviceGuard guard(h->device);
     const int V = 6890;
     for (int i = 0; i < 24; ++i)
         if (parents[i] >= i || (i > 0 && parents[i] < 0)) return h->fail(GRNET_EINVAL, "SMPL parents must be topologically ordered");
@@ -1325,22 +1427,27 @@ int grnet_load_smpl(grnet_t* h, const float* v_template, const float* shapedirs,
     return 0;
 }
 
-int grnet_finalize_weights(grnet_t* h) { return h ? h->finalize() : GRNET_EINVAL; }
+int grnet_finalize_weights(grnet_t* h) {
+    if (!h) return GRNET_EINVAL;
+    DeviceGuard guard(h->device);
+    return h->finalize();
+}
 
 int grnet_forward(grnet_t* h, const float* frames_dev, int n_frames, const grnet_outputs_t* out, void* stream) {
     if (!h) return GRNET_EINVAL;
+    DeviceGuard guard(h->device);
     return h->forward(frames_dev, n_frames, out, static_cast<hipStream_t>(stream));
 }
 
 int grnet_gru_forward(grnet_t* h, const float* x, const float* cp, int b, int T, float* y, float* phase, float* xc, void* stream) {
     if (!h || !x || !cp || !y || !phase || b < 1 || T < 1) return GRNET_EINVAL;
     if (!h->gru_ready) return h->fail(GRNET_ESTATE, "GRU weights were not loaded (keys gru.* or pfeat_corrector.featnet.*)");
+    DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t rows = (size_t)b * T;
-    // workspace is per call (the GRU is not on the per-frame hot path and is not graph-captured)
-    float* ws = nullptr;
+    float* ws = nullptr;                                   // handle-owned scratch: no allocation once a size has been seen
     const size_t need = rows * 3072 * 2 + 2 * rows * 900 + 2 * rows * 600 + (size_t)b * 1200 + 1024;
-    if (hipMallocAsync(reinterpret_cast<void**>(&ws), need * sizeof(float), s) != hipSuccess) return h->fail(GRNET_ENOMEM, "GRU workspace");
+    if (int rc = h->temporal_scratch(need, &ws)) return rc;
     GruWorkspace w;
     w.xin = ws;
     float* xc_buf = xc ? xc : ws + rows * 3072;
@@ -1349,7 +1456,6 @@ int grnet_gru_forward(grnet_t* h, const float* x, const float* cp, int b, int T,
     w.l1 = w.l0 + rows * 600;
     w.hfin = w.l1 + rows * 600;
     hipError_t e = launch_gru(x, cp, h->gruw, w, y, phase, xc_buf, b, T, s);
-    hipFreeAsync(ws, s);
     if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("launch_gru: ") + hipGetErrorString(e));
     return 0;
 }
@@ -1358,12 +1464,11 @@ int grnet_tsattn_forward(grnet_t* h, const float* x, const float* xs, int b, int
     if (!h || !x || !xs || !y || b < 1 || n < 1 || n > 4096) return GRNET_EINVAL;
     if (!h->tsattn_ready)
         return h->fail(GRNET_ESTATE, "attention-block weights were not loaded (keys tsattn.* or pfeat_corrector.featTencoder.0.*)");
+    DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    float* ws = nullptr;                                   // per call, like the GRU: not on the per-frame hot path
-    if (hipMallocAsync(reinterpret_cast<void**>(&ws), tsattn_ws_floats(b, n) * sizeof(float), s) != hipSuccess)
-        return h->fail(GRNET_ENOMEM, "attention-block workspace");
+    float* ws = nullptr;                                   // handle-owned scratch, like the GRU's
+    if (int rc = h->temporal_scratch(tsattn_ws_floats(b, n), &ws)) return rc;
     hipError_t e = launch_tsattn(x, xs, h->tsw, ws, y, b, n, s);
-    hipFreeAsync(ws, s);
     if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("launch_tsattn: ") + hipGetErrorString(e));
     return 0;
 }
@@ -1377,27 +1482,26 @@ int grnet_set_option(grnet_t* h, int option, int value) {
         if (value != 0 && value != 7 && value != 14 && value != 1071 && value != 1072 && value != 1041 && value != 1042 && value != 1171 && value != 1141)
             return h->fail(GRNET_EINVAL, "conv tile must be 0, 7, 14 or a split-K code 1071/1072/1041/1042/1171/1141");
         h->conv_tile_hint = value;
-        for (auto& g : h->graphs) hipGraphExecDestroy(g.second);
-        h->graphs.clear();
+        h->drop_graphs();
         return 0;
     }
     if (option == GRNET_OPT_GROUPING) {
         h->grouping = value != 0;
-        for (auto& g : h->graphs) hipGraphExecDestroy(g.second);
-        h->graphs.clear();
+        h->drop_graphs();
         return 0;
     }
     if (option == GRNET_OPT_MULTI_LANE) {
         h->multi_lane = value != 0;
-        for (auto& g : h->graphs) hipGraphExecDestroy(g.second);
-        h->graphs.clear();
+        h->drop_graphs();
         return 0;
     }
     return h->fail(GRNET_EINVAL, "unknown option");
 }
 
 int grnet_tune(grnet_t* h, int n_frames, void* stream, int level) {
-    return h ? h->tune(n_frames, static_cast<hipStream_t>(stream), level) : GRNET_EINVAL;
+    if (!h) return GRNET_EINVAL;
+    DeviceGuard guard(h->device);
+    return h->tune(n_frames, static_cast<hipStream_t>(stream), level);
 }
 
 // Tuned table <-> text ("mode" line + one line per convolution: index hint), so a table measured once on a GPU
@@ -1428,8 +1532,7 @@ int grnet_set_tuning(grnet_t* h, int n_frames, const char* text) {
         p += used;
     }
     h->tuned_mode[n_frames] = mode;
-    for (auto& g : h->graphs) hipGraphExecDestroy(g.second);
-    h->graphs.clear();
+    h->drop_graphs();
     return 0;
 }
 
@@ -1464,6 +1567,7 @@ int grnet_describe_conv(grnet_t* h, int pos, int32_t* info, char* name, int name
 
 int grnet_time_convs(grnet_t* h, int n_frames, void* stream, float* ms_out) {
     if (!h || !ms_out || !h->finalized) return GRNET_EINVAL;
+    DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return GRNET_EHIP;
@@ -1482,6 +1586,7 @@ int grnet_time_convs(grnet_t* h, int n_frames, void* stream, float* ms_out) {
 int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, int wid, const float* w_host, const float* bias_host,
                     int cout, int ks, int stride, int relu, const float* add_dev, float* out_dev, int tile_hint, void* stream) {
     if (!h || !in_dev || !w_host || !out_dev) return GRNET_EINVAL;
+    DeviceGuard guard(h->device);
     if (h->dtype == 1) return h->op_conv2d_bf16(in_dev, n, cin, hgt, wid, w_host, bias_host, cout, ks, stride, relu, add_dev, out_dev, tile_hint,
                                                 static_cast<hipStream_t>(stream));
     const int taps = ks * ks, TC = conv_pick_tc(cout);
@@ -1495,8 +1600,11 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
     float *wd = nullptr, *bd = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&wd), wp.size() * 4) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&bd), bp.size() * 4) != hipSuccess)
         return h->fail(GRNET_ENOMEM, "hipMalloc failed");
-    hipMemcpy(wd, wp.data(), wp.size() * 4, hipMemcpyHostToDevice);
-    hipMemcpy(bd, bp.data(), bp.size() * 4, hipMemcpyHostToDevice);
+    if (hipMemcpy(wd, wp.data(), wp.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(bd, bp.data(), bp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        hipFree(wd); hipFree(bd);
+        return h->fail(GRNET_EHIP, "hipMemcpy of the test weights failed");
+    }
     const int pad = ks / 2;
     ConvArgs a{};
     a.in = in_dev; a.in_ctot = cin; a.in_coff = 0; a.N = n; a.Cin = cin; a.H = hgt; a.W = wid;
@@ -1532,6 +1640,7 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
 
 int grnet_op_bilinear2x(grnet_t* h, const float* in_dev, int n, int c, int hgt, int wid, float* out_dev, void* stream) {
     if (!h || !in_dev || !out_dev) return GRNET_EINVAL;
+    DeviceGuard guard(h->device);
     hipError_t e = launch_bilinear2x(in_dev, out_dev, n, c, hgt, wid, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("bilinear2x: ") + hipGetErrorString(e));
     return 0;
@@ -1539,6 +1648,7 @@ int grnet_op_bilinear2x(grnet_t* h, const float* in_dev, int n, int c, int hgt, 
 
 int grnet_debug_tensor(grnet_t* h, const char* name, int n_frames, float* out_dev, int64_t* shape_out, void* stream) {
     if (!h || !name) return GRNET_EINVAL;
+    DeviceGuard guard(h->device);
     for (auto& nv : h->named) {
         if (nv.first != name) continue;
         const View& v = nv.second;
@@ -1563,6 +1673,7 @@ int grnet_smpl_forward(grnet_t* h, const float* betas_dev, const float* rotmat_d
     if (!h || !betas_dev || !rotmat_dev || !verts_dev || !kp3d_dev || n < 1) return GRNET_EINVAL;
     if (!h->smpl_loaded) return h->fail(GRNET_ESTATE, "SMPL tables were not loaded");
     if (n > h->max_frames) return h->fail(GRNET_EINVAL, "n exceeds max_frames (the skinning-matrix workspace is sized for it)");
+    DeviceGuard guard(h->device);
     hipError_t e = launch_smpl(betas_dev, rotmat_dev, cam_dev, h->smpl, h->d_A, verts_dev, kp3d_dev, kp2d_dev, n,
                                static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("smpl: ") + hipGetErrorString(e));
@@ -1572,6 +1683,7 @@ int grnet_smpl_forward(grnet_t* h, const float* betas_dev, const float* rotmat_d
 int grnet_crop_normalise(grnet_t* h, const unsigned char* images_dev, int n, int height, int width, int one_image_for_all,
                          const float* bboxes_dev, float scale, int bgr, float* out_dev, void* stream) {
     if (!h || !images_dev || !bboxes_dev || !out_dev || n < 1 || height < 1 || width < 1 || !(scale > 0.f)) return GRNET_EINVAL;
+    DeviceGuard guard(h->device);
     hipError_t e = launch_crop_normalise(images_dev, height, width, one_image_for_all ? 0 : 1, bboxes_dev, scale, bgr, out_dev, n,
                                          static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("crop_normalise: ") + hipGetErrorString(e));
@@ -1582,18 +1694,34 @@ const char* grnet_last_error(grnet_t* h) { return h ? h->err.c_str() : "null han
 
 void grnet_destroy(grnet_t* h) {
     if (!h) return;
-    for (auto& g : h->graphs) hipGraphExecDestroy(g.second);
-    if (h->capture_stream) hipStreamDestroy(h->capture_stream);
-    for (int l = 1; l < kLanes; ++l) {
-        if (h->side[l]) hipStreamDestroy(h->side[l]);
-        if (h->ev_join[l]) hipEventDestroy(h->ev_join[l]);
-    }
-    if (h->ev_fork) hipEventDestroy(h->ev_fork);
-    for (hipEvent_t e : h->op_events) if (e) hipEventDestroy(e);
-    for (hipEvent_t e : h->op_events_flat) if (e) hipEventDestroy(e);
-    for (void* p : h->dev_allocs) hipFree(p);
-    if (h->arena) hipFree(h->arena);
-    delete h;
+    DeviceGuard guard(h->device);
+    delete h;                                              // ~grnet releases graphs, streams, events and device memory
+}
+
+// PareHead.forward + VPRegressor.forward from given pooled features -- lib/models/pare.py:271-303,52-91: the second head pass of the
+// use_gait_feat branch (grnet.py:165,171) and the single-op parity hook of the tail.
+int grnet_head_forward(grnet_t* h, const float* plf_dev, const float* csf_dev, int n, const grnet_outputs_t* out, void* stream) {
+    if (!h || !plf_dev || !csf_dev || !out || n < 1) return GRNET_EINVAL;
+    if (!h->finalized) return h->fail(GRNET_ESTATE, "grnet_head_forward before grnet_finalize_weights");
+    if (n > h->max_frames) return h->fail(GRNET_EINVAL, "n exceeds max_frames");
+    DeviceGuard guard(h->device);
+    return h->head_from_feats(plf_dev, csf_dev, n, *out, static_cast<hipStream_t>(stream));
+}
+
+int grnet_op_rot6d_to_rotmat(grnet_t* h, const float* rot6d_dev, int m, float* rotmat_dev, void* stream) {
+    if (!h || !rot6d_dev || !rotmat_dev || m < 1) return GRNET_EINVAL;
+    DeviceGuard guard(h->device);
+    hipError_t e = launch_rot6d_to_rotmat(rot6d_dev, rotmat_dev, m, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("rot6d_to_rotmat: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int grnet_op_rotmat_to_aa(grnet_t* h, const float* rotmat_dev, int m, float* aa_dev, void* stream) {
+    if (!h || !rotmat_dev || !aa_dev || m < 1) return GRNET_EINVAL;
+    DeviceGuard guard(h->device);
+    hipError_t e = launch_rotmat_to_aa(rotmat_dev, aa_dev, m, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("rotmat_to_aa: ") + hipGetErrorString(e));
+    return 0;
 }
 
 }  // extern "C"

@@ -205,7 +205,6 @@ __global__ __launch_bounds__(256) void softmax_stats_kernel(const float* __restr
 // 256 threads = 16 channel pairs x 4 joint groups of 6 x 4 pixel phases; pixel tiles of 64 staged in
 // LDS.  Each block writes a partial sum; head_tail_kernel adds the kPoolSplit partials in a fixed order.
 constexpr int kPoolPT = 64;
-constexpr int kPoolSplit = 7;                                // 3136 pixels = 7 x 448
 __global__ __launch_bounds__(256) void attn_pool_kernel(const float* __restrict__ heat, int heat_ctot, const float* __restrict__ stats,
                                                           const float* __restrict__ featA, int CA, const float* __restrict__ featB,
                                                           int CB, float* __restrict__ part, int P) {
@@ -320,6 +319,9 @@ __device__ __forceinline__ void rotmat_to_aa_dev(const float* R, float* aa) {
     aa[2] = isnan(a2) ? 0.f : a2;
 }
 
+// FROM_PARTS: plf / csf are produced here from the pooling partials (first head pass); otherwise they are INPUTS (the second
+// head pass of the use_gait_feat branch, grnet.py:165, and the single-op parity hook).
+template <bool FROM_PARTS>
 __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict__ part, float* __restrict__ plf, float* __restrict__ csf, TailWeights w,
                                                           float* __restrict__ rot6d, float* __restrict__ shape,
                                                           float* __restrict__ cam, float* __restrict__ rotmat,
@@ -332,6 +334,10 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
     // add the pixel-range partials of the pooling in a fixed order; 6 elements x 7 partials of loads in flight per thread
     // (one block per frame: nothing else hides the L2 latency of this kernel, which sits on the critical path)
     static_assert((192 * 24) % (256 * 6) == 0, "partials loop");
+    if constexpr (!FROM_PARTS) {
+        for (int e = tid; e < 128 * 24; e += 256) s_plf[e] = plf[(size_t)n * 128 * 24 + e];
+        for (int e = tid; e < 64 * 24; e += 256) s_csf[e] = csf[(size_t)n * 64 * 24 + e];
+    } else
     for (int e0 = tid; e0 < 192 * 24; e0 += 256 * 6) {
         float v[6][kPoolSplit];
 #pragma unroll
@@ -389,7 +395,44 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
 
 hipError_t launch_head_tail(const float* pool_ws, float* plf, float* csf, TailWeights w, float* rot6d, float* shape, float* cam,
                             float* rotmat, float* theta, int N, hipStream_t s) {
-    GRK_TRY(launch_k(head_tail_kernel, dim3(N), dim3(256), 0, s, pool_ws + (size_t)N * 48, plf, csf, w, rot6d, shape, cam, rotmat, theta));
+    GRK_TRY(launch_k(head_tail_kernel<true>, dim3(N), dim3(256), 0, s, pool_ws + (size_t)N * 48, plf, csf, w, rot6d, shape, cam, rotmat, theta));
+    return hipGetLastError();
+}
+
+hipError_t launch_head_tail_from_feats(const float* plf, const float* csf, TailWeights w, float* rot6d, float* shape, float* cam, float* rotmat,
+                                       float* theta, int N, hipStream_t s) {
+    GRK_TRY(launch_k(head_tail_kernel<false>, dim3(N), dim3(256), 0, s, (const float*)nullptr, const_cast<float*>(plf), const_cast<float*>(csf), w,
+                     rot6d, shape, cam, rotmat, theta));
+    return hipGetLastError();
+}
+
+// Single-op hooks of the geometry tail (parity tests feed the reference's edge-case goldens straight to the device functions).
+__global__ __launch_bounds__(256) void rot6d_to_rotmat_kernel(const float* __restrict__ x, float* __restrict__ R, int m) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    float xi[6], r[9];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) xi[k] = x[(size_t)i * 6 + k];
+    rot6d_to_rotmat_dev(xi, r);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[(size_t)i * 9 + k] = r[k];
+}
+__global__ __launch_bounds__(256) void rotmat_to_aa_kernel(const float* __restrict__ R, float* __restrict__ aa, int m) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    float r[9], a[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r[k] = R[(size_t)i * 9 + k];
+    rotmat_to_aa_dev(r, a);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) aa[(size_t)i * 3 + k] = a[k];
+}
+hipError_t launch_rot6d_to_rotmat(const float* x, float* R, int m, hipStream_t s) {
+    GRK_TRY(launch_k(rot6d_to_rotmat_kernel, dim3((m + 255) / 256), dim3(256), 0, s, x, R, m));
+    return hipGetLastError();
+}
+hipError_t launch_rotmat_to_aa(const float* R, float* aa, int m, hipStream_t s) {
+    GRK_TRY(launch_k(rotmat_to_aa_kernel, dim3((m + 255) / 256), dim3(256), 0, s, R, aa, m));
     return hipGetLastError();
 }
 

@@ -125,7 +125,13 @@ struct TailWeights {
 // pool_ws: the workspace launch_softmax_pool filled (per-range partial sums); plf / csf are WRITTEN here
 hipError_t launch_head_tail(const float* pool_ws, float* plf, float* csf, TailWeights w, float* rot6d, float* shape, float* cam,
                             float* rotmat, float* theta, int N, hipStream_t s);
+// the same tail from given features (second head pass of the use_gait_feat branch, grnet.py:165; plf / csf are inputs)
+hipError_t launch_head_tail_from_feats(const float* plf, const float* csf, TailWeights w, float* rot6d, float* shape, float* cam, float* rotmat,
+                                       float* theta, int N, hipStream_t s);
+hipError_t launch_rot6d_to_rotmat(const float* x, float* R, int m, hipStream_t s);      // geometry.py:395-410
+hipError_t launch_rotmat_to_aa(const float* R, float* aa, int m, hipStream_t s);        // geometry.py:68-97,159-293
 size_t softmax_pool_ws_floats(int N);
+constexpr int kPoolSplit = 7;                 // pixel ranges of the attention pooling (3136 = 7 x 448): ONE constant for the fp32 and bf16 paths
 
 struct SmplTables {
     const float* v_template;   // (6890,3)

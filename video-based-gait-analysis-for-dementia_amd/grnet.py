@@ -169,6 +169,8 @@ class GRNet:
             raise NotImplementedError("J_regressor override (evaluation-only, pare.py:70-76) is outside the inference path")
         if not features.is_cuda:
             raise RuntimeError("frames must live in HBM (features.to('cuda')); the HIP path has no CPU fallback")
+        if features.device != self.device:
+            raise RuntimeError(f"frames live on {features.device} but this model's handle is bound to {self.device}")
         self.finalize()
         x = features.to(torch.float32).contiguous()
         n = x.shape[0]
@@ -337,6 +339,45 @@ class GRNet:
         rc = self._lib.grnet_tsattn_forward(self._h, x.data_ptr(), xs.data_ptr(), b, n, y.data_ptr(), stream)
         _lib.check(self._lib, self._h, rc, "grnet_tsattn_forward")
         return y
+
+    def head_forward(self, point_local_feat, cam_shape_feats):
+        """PareHead.forward + VPRegressor.forward from given pooled features (pare.py:271-303,52-91): (n,128,24), (n,64,24) ->
+        dict(theta (n,85), verts, kp_2d, kp_3d, rotmat, pred_rot6d).  The second head pass of the use_gait_feat branch."""
+        self.finalize()
+        n = point_local_feat.shape[0]
+        if tuple(point_local_feat.shape) != (n, 128, 24) or tuple(cam_shape_feats.shape) != (n, 64, 24):
+            raise ValueError("point_local_feat must be (n,128,24) and cam_shape_feats (n,64,24)")
+        dev = self.device
+        plf = point_local_feat.to(dev, torch.float32).contiguous()
+        csf = cam_shape_feats.to(dev, torch.float32).contiguous()
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        out = {"theta": new(n, 85), "verts": new(n, 6890, 3), "kp_2d": new(n, 29, 2), "kp_3d": new(n, 29, 3),
+               "rotmat": new(n, 24, 3, 3), "pred_rot6d": new(n, 24, 6)}
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        for s0 in range(0, n, self.max_frames):
+            m = min(self.max_frames, n - s0)
+            o = _lib.Outputs()
+            for k, t in out.items():
+                setattr(o, k, t[s0:s0 + m].data_ptr())
+            rc = self._lib.grnet_head_forward(self._h, plf[s0:].data_ptr(), csf[s0:].data_ptr(), m, C.byref(o), stream)
+            _lib.check(self._lib, self._h, rc, "grnet_head_forward")
+        return out
+
+    def op_rot6d_to_rotmat(self, x):
+        x = x.to(self.device, torch.float32).reshape(-1, 6).contiguous()
+        out = torch.empty(x.shape[0], 3, 3, dtype=torch.float32, device=self.device)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self._lib, self._h, self._lib.grnet_op_rot6d_to_rotmat(self._h, x.data_ptr(), x.shape[0], out.data_ptr(), stream),
+                   "grnet_op_rot6d_to_rotmat")
+        return out
+
+    def op_rotmat_to_aa(self, R):
+        R = R.to(self.device, torch.float32).reshape(-1, 9).contiguous()
+        out = torch.empty(R.shape[0], 3, dtype=torch.float32, device=self.device)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self._lib, self._h, self._lib.grnet_op_rotmat_to_aa(self._h, R.data_ptr(), R.shape[0], out.data_ptr(), stream),
+                   "grnet_op_rotmat_to_aa")
+        return out
 
     # single-op hooks for kernel parity tests
     def op_conv2d(self, x, w, bias=None, stride=1, relu=False, add=None, tile_hint=0):
