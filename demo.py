@@ -93,6 +93,17 @@ def main(args):
                 model, pred["pose"], pred["betas"], min_cutoff=args.smooth_min_cutoff, beta=args.smooth_beta,
                 smpl_tables=smpl_tables)
         results[pid] = pipe.make_demo_result(pred, ds.bboxes, ds.frames, w, h)
+        if args.joint_type != "spin":                          # demo.py:224-229
+            # the reference converts with src='spin' (49 joints); without --smooth the path emits the 29 'spin2' joints, on which
+            # the reference's call raises IndexError -- here the source skeleton is the one the arrays really are
+            src = "spin" if results[pid]["joints3d"].shape[1] == 49 else "spin2"
+            try:
+                results[pid]["joints3d"] = pipe.convert_kps(results[pid]["joints3d"], src, args.joint_type)
+                j2 = results[pid]["joints2d"]
+                j2 = np.concatenate([j2, np.zeros_like(j2[..., :1])], -1)      # convert_kps writes 3 columns; the third stays 0
+                results[pid]["joints2d"] = pipe.convert_kps(j2, "spin2", args.joint_type)[..., :2]
+            except NameError:
+                print(f"Unknown skeleton type: {args.joint_type}.")
         n_frames += len(ds)
     dt = time.time() - t0
     print(f"GRNet FPS: {n_frames / max(dt, 1e-9):.2f}")
@@ -142,4 +153,8 @@ if __name__ == "__main__":
     for flag in ("mesh_render", "display", "save_obj"):
         if getattr(a, flag):
             sys.exit(f"--{flag} belongs to steps outside the per-frame path (SURVEY 8f) and is not implemented")
+    d = parser().parse_args([])
+    for flag in ("detector", "yolo_img_size", "tracker_batch_size", "wireframe", "sideview", "save_vid"):
+        if getattr(a, flag) != getattr(d, flag):
+            print(f"warning: --{flag} configures a step outside the per-frame path (tracker / renderer, SURVEY 8f) and has no effect here")
     main(a)

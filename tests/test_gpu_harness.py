@@ -54,6 +54,15 @@ def test_demo_entry_point(pkg, tmp_path):
     # a second run must not overwrite the first (demo.py:258-266)
     out2 = demo.main(args)
     assert out2.endswith("synthetic1.pkl")
+    # --joint_type (demo.py:224-229): joints re-ordered into the requested skeleton; an unknown one is reported and left as is
+    args_k = demo.parser().parse_args(["--img_folder", img_dir, "--tracking_path", tp, "--output_folder", str(tmp_path / "out"),
+                                       "--synthetic_weights", "--grnet_batch_size", "16", "--max_frames", "16", "--joint_type", "kinectv2"])
+    rk = joblib.load(demo.main(args_k))[1]
+    assert rk["joints3d"].shape == (30, 25, 3) and rk["joints2d"].shape == (30, 25, 2)
+    assert np.array_equal(rk["joints3d"], pkg.pipeline.spin2_to_kinectv2(r["joints3d"]))
+    args_u = demo.parser().parse_args(["--img_folder", img_dir, "--tracking_path", tp, "--output_folder", str(tmp_path / "out"),
+                                       "--synthetic_weights", "--grnet_batch_size", "16", "--max_frames", "16", "--joint_type", "nonsense"])
+    assert joblib.load(demo.main(args_u))[1]["joints3d"].shape == (30, 29, 3)
 
 
 def test_batch_generation_entry_point(pkg, tmp_path):
@@ -74,6 +83,10 @@ def test_batch_generation_entry_point(pkg, tmp_path):
     assert db["vid_name"].shape == (11,) and db["bbox"].shape == (11, 4) and db["joints3D"].shape == (11, 25, 3)
     assert list(db["vid_name"][:6]) == ["S001C001P001R001A001"] * 6            # sorted by the digits of the name
     assert db["joints3D"].dtype == np.float32 and np.isfinite(db["joints3D"]).all()
+    # the reference stores the boxes AFTER Inference scaled w,h by 1.1 in place (inference.py:48, batch_generation.py:265)
+    assert db["bbox"].dtype == np.float32
+    assert np.array_equal(db["bbox"], np.tile(np.array([[112.0, 112.0, 200.0, 200.0]], np.float32) * np.array([1, 1, 1.1, 1.1], np.float32), (11, 1)))
+    assert np.array_equal(annos[names[0]][:, 2], np.full(5, 200.0, np.float32))          # the caller's annotations are not touched
     # kinectv2 joint 0 is spin2 joint 0 (pelvis), joint 20 is the thorax (index 28)
     m = pkg.build_synthetic_model(max_frames=8, with_gru=False)
     f = torch.from_numpy(pkg.synth.make_frames(6, start=100)).cuda()

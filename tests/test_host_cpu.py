@@ -200,3 +200,86 @@ def test_header_is_plain_c_and_links_against_the_library(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-Wno-cast-function-type", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
                            "-L", lib_dir, "-lgrnet_hip", f"-Wl,-rpath,{lib_dir}", "-Wl,--allow-shlib-undefined"])
     assert len(names) >= 24
+
+
+# ----------------------------------------------------------------------------- round 2: work items, convert_kps, db windows
+def test_plan_work_items_balances_and_keeps_short_clips_whole(pkg):
+    h = pkg.harness
+    lengths = [10000]
+    items = h.plan_work_items(lengths, 8, 128)
+    assert [(lo, hi) for _, lo, hi, _ in items][:2] == [(0, 128), (128, 256)] and items[-1][2] == 10000
+    load = [sum(hi - lo for _, lo, hi, r in items if r == k) for k in range(8)]
+    assert sum(load) == 10000 and max(load) - min(load) <= 128
+    # a directory of short clips: no clip is split, ranks get whole clips, loads stay within one clip of each other
+    lengths = [37, 90, 12, 64, 128, 5, 77, 101, 33, 48, 19, 120]
+    items = h.plan_work_items(lengths, 4, 128)
+    assert [(vi, lo, hi) for vi, lo, hi, _ in items] == [(i, 0, n) for i, n in enumerate(lengths)]
+    load = [sum(hi - lo for _, lo, hi, r in items if r == k) for k in range(4)]
+    assert sum(load) == sum(lengths) and max(load) - min(load) <= max(lengths)
+    assert h.plan_work_items(lengths, 4, 128) == items                       # deterministic: every rank derives the same plan
+    assert h.plan_work_items([], 4, 128) == [] and h.plan_work_items([0, 3], 2, 128) == [(1, 0, 3, 0)]
+
+
+def _items_worker(rank, world, port, lengths, chunk, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    h = importlib.import_module(PKG_NAME).harness
+    items = h.plan_work_items(lengths, world, chunk)
+    rows = [torch.arange(lo, hi, dtype=torch.float32)[:, None] + 1000.0 * vi + torch.arange(75)[None] / 100.0
+            for vi, lo, hi, r in items if r == rank]
+    local = torch.cat(rows, 0) if rows else torch.zeros(0, 75)
+    per_video = h.gather_work_items(items, local, 75, world, rank, dist, torch.device("cpu"))
+    ok = set(per_video) == {i for i, n in enumerate(lengths) if n > 0}
+    for vi, n in enumerate(lengths):
+        if n:
+            want = torch.arange(n, dtype=torch.float32)[:, None] + 1000.0 * vi + torch.arange(75)[None] / 100.0
+            ok = ok and torch.equal(per_video[vi], want)
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("lengths,chunk", [([300, 17, 128, 129, 1], 128), ([5, 5], 128), ([9], 4)])
+def test_work_items_gather_once_world2(lengths, chunk):
+    """The window-wide exchange of batch_generation.py: ONE all-gather reassembles every video of the window in frame order
+    on every rank (here with one rank possibly holding nothing)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_items_worker, args=(r, 2, port, lengths, chunk, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res
+
+
+def test_flush_windows_follow_the_reference_rule():
+    import sys
+    sys.path.insert(0, ROOT)
+    bg = importlib.import_module("batch_generation")
+    assert bg.flush_windows(7, 50) == [(0, 7)]
+    assert bg.flush_windows(120, 50) == [(0, 50), (50, 100), (100, 120)]
+    assert bg.flush_windows(105, 50) == [(0, 50), (50, 105)]                  # at idx 100 only 5 remain: no flush (<= 10)
+    assert bg.flush_windows(0, 50) == []
+
+
+def test_convert_kps_matches_reference_for_every_skeleton(pkg):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "kps.npz"))
+    pipe = pkg.pipeline
+    dsts = sorted(k[len("spin_to_"):] for k in g.files if k.startswith("spin_to_"))
+    assert len(dsts) >= 20 and "kinectv2" in dsts and "common" in dsts
+    for dst in dsts:
+        a = pipe.convert_kps(g["j49"], "spin", dst)
+        b = pipe.convert_kps(g["j29"], "spin2", dst)
+        assert a.dtype == np.float64 and np.array_equal(a, g[f"spin_to_{dst}"]), dst
+        assert np.array_equal(b, g[f"spin2_to_{dst}"]), dst
+    assert np.array_equal(pipe.convert_kps(g["j29"], "spin2", "kinectv2"), pipe.spin2_to_kinectv2(g["j29"]))
+    with pytest.raises(NameError):
+        pipe.convert_kps(g["j29"], "spin2", "no_such_skeleton")
+    with pytest.raises(IndexError):
+        pipe.convert_kps(g["j29"], "spin", "common")                          # 29 joints passed as the 49-joint layout: as the reference

@@ -25,6 +25,47 @@ def shard_range(n_total, world, rank):
     return lo, min(lo + per, n_total)
 
 
+def plan_work_items(lengths, world, chunk=128):
+    """Work items of a directory of videos for ``world`` ranks: every video is cut into runs of <= ``chunk`` consecutive frames
+    (a short clip is ONE item: it is never split below the size at which the kernels run efficiently), and the items go, in
+    order, to the rank with the fewest frames so far (ties: lowest rank).  Deterministic, so every rank computes the same plan
+    and nobody communicates it.  Returns [(video index, lo, hi, rank)] in (video, lo) order."""
+    load = [0] * world
+    items = []
+    for vi, n in enumerate(lengths):
+        for lo in range(0, n, chunk):
+            hi = min(n, lo + chunk)
+            r = min(range(world), key=lambda k: (load[k], k))
+            load[r] += hi - lo
+            items.append((vi, lo, hi, r))
+    return items
+
+
+def gather_work_items(items, local_rows, row_floats, world, rank, dist, device):
+    """ONE all-gather for a whole window of videos: every rank contributes the rows (frames) of its items, concatenated in item
+    order and padded to the largest per-rank count; returns {video index: (n_frames_of_the_video, row_floats) tensor} in frame
+    order (on every rank).  ``local_rows``: (count_of_this_rank, row_floats) tensor on ``device``."""
+    counts = [0] * world
+    for _, lo, hi, r in items:
+        counts[r] += hi - lo
+    assert local_rows.shape[0] == counts[rank], (local_rows.shape, counts, rank)
+    cap = max(max(counts), 1)
+    send = torch.zeros(cap, row_floats, dtype=torch.float32, device=device)
+    send[:counts[rank]] = local_rows
+    if world == 1:
+        recv = send.unsqueeze(0)
+    else:
+        flat = torch.empty(world * cap, row_floats, dtype=torch.float32, device=device)
+        dist.all_gather_into_tensor(flat, send)
+        recv = flat.view(world, cap, row_floats)
+    cursor = [0] * world
+    per_video = {}
+    for vi, lo, hi, r in items:
+        per_video.setdefault(vi, []).append(recv[r, cursor[r]:cursor[r] + hi - lo])
+        cursor[r] += hi - lo
+    return {vi: torch.cat(parts, 0) for vi, parts in per_video.items()}
+
+
 def pack_layout(n_local):
     """Offsets (in floats) of each field inside one rank's packed block: field-major, frame-minor."""
     off, layout = 0, {}

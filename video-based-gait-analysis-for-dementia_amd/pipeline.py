@@ -47,6 +47,37 @@ def convert_crop_coords_to_orig_img(bbox, keypoints, crop_size=224):
     return kp
 
 
+_KPS = None
+
+
+def _kps_tables():
+    global _KPS
+    if _KPS is None:
+        import json
+        with open(osp.join(osp.dirname(osp.abspath(__file__)), "kps_tables.json")) as f:
+            _KPS = json.load(f)
+    return _KPS
+
+
+def convert_kps(joints, src, dst):
+    """convert_kps (kp_utils.py:26-36): (n,J_src,3) joints of skeleton ``src`` -> (n,J_dst,3) float64 in skeleton ``dst``; joints
+    ``dst`` names that ``src`` lacks stay 0.  ``src`` is 'spin' (49) or 'spin2' (29) -- the two layouts the path emits; the index
+    tables are derived by running the reference's joint-name functions (tools/make_kps_tables.py).  An unknown ``dst`` raises
+    NameError, as the reference's eval() does (demo.py:227 catches exactly that)."""
+    t = _kps_tables()
+    if src not in ("spin", "spin2"):
+        raise NameError(f"name 'get_{src}_joint_names' is not defined")
+    if dst not in t["sizes"]:
+        raise NameError(f"name 'get_{dst}_joint_names' is not defined")
+    joints = np.asarray(joints)
+    idx = t["from_" + src][dst]
+    out = np.zeros((joints.shape[0], len(idx), 3))
+    for k, i in enumerate(idx):
+        if i >= 0:
+            out[:, k] = joints[:, i]                          # IndexError / shape error on a wrong-sized input, like the reference
+    return out
+
+
 def spin2_to_kinectv2(joints):
     """(n,29,3) spin2 joints -> (n,25,3) kinectv2 joints (convert_kps(src='spin2', dst='kinectv2'))."""
     joints = np.asarray(joints)
@@ -261,16 +292,18 @@ def make_demo_result(pred, bboxes, frames, orig_width, orig_height):
     }
 
 
-def run_on_frames(model, image_folder, frames, bboxes, device="cuda"):
-    """batch_generation.py:289-371: one batch per video (batch_size = max(n_frames, 400)), kp_3d -> kinectv2."""
+def run_on_frames(model, image_folder, frames, bboxes, device="cuda", batch_size=None):
+    """batch_generation.py:289-371: one batch per video (batch_size = max(n_frames, 400)), kp_3d -> kinectv2.  ``bboxes`` is scaled
+    by 1.1 IN PLACE, as the reference's Inference.__init__ does to the caller's array (inference.py:48).  Image files are cropped
+    and normalised by the HIP kernel (grnet_crop_normalise, row f1); .npy files hold ready crops."""
     ds = InferenceFrames(image_folder, frames, bboxes, scale=1.1)
     joints = []
-    for batch in ds.batches(max(len(frames), MAX_SEQLEN)):
+    for batch in ds.batches(batch_size or max(len(frames), MAX_SEQLEN), model=model):
         x = torch.as_tensor(batch, dtype=torch.float32).unsqueeze(0).to(device)
         out = model(x)[-1]
         j = out["kp_3d"].detach().cpu().squeeze(0).numpy()
         joints.append(spin2_to_kinectv2(j).astype(np.float32))
-    return {"kp_3d": np.concatenate(joints, 0)}
+    return {"kp_3d": np.concatenate(joints, 0) if joints else np.zeros((0, 25, 3), np.float32)}
 
 
 class BatchDb:
