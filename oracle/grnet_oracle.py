@@ -562,3 +562,73 @@ def ts_attn_block(x, xs, sd, p="", num_heads=4, num_token=24):
     y = x.reshape(b, n, -1) + multi_attention(x, xs, sd, p + "mulattn.", num_heads)
     y = layer_normalization(y, sd[p + "norm1.gamma"], sd[p + "norm1.beta"])
     return layer_normalization(joint_wise_ffn(y, sd, p + "ffn.", num_token) + y, sd[p + "norm2.gamma"], sd[p + "norm2.beta"])
+
+
+# ----------------------------------------------------------------------------- pose-feature corrector (row f2)
+def feat_corrector(x, cparams, sd, p="pfeat_corrector."):
+    """FeatCorrector.forward (feature_correction.py:104-157), eval, in the configuration GRNet builds (grnet.py:69-79 with
+    configs/config_grnet.yaml: one layer, 4 heads, h_size 1024 -> 1000, use_jwff).  The reference class cannot be constructed as
+    shipped (undefined names); the names are bound as DESIGN.md records: use_leff = leff_smpl_feats = False (their
+    branch only unpacks shapes), `N` (:144) = n, everything else is stored and never read in forward.  Composition of the
+    separately pinned module restatements: gru_forward (gait_feat_encoder.py:79-104) and ts_attn_block (attention_utils.py:261-270).
+
+    x (b,n,3072) index c*24+j, cparams (b,n,3) -> y (b*n,128,24), pred_avg (b,3), pred_phase (b,n,4).
+    """
+    x = np.asarray(x, np.float32)
+    b, n, _ = x.shape
+    gsd = {k[len(p + "featnet."):]: v for k, v in sd.items() if k.startswith(p + "featnet.")}
+    pred_avg, pred_phase, _ = gru_forward(x, cparams, gsd)
+    n1 = np.linalg.norm(pred_phase[:, :, :2], axis=-1, keepdims=True)
+    n2 = np.linalg.norm(pred_phase[:, :, 2:], axis=-1, keepdims=True)
+    phase = pred_phase / np.concatenate([n1, n1, n2, n2], -1)
+    raw = np.concatenate([np.broadcast_to(pred_avg[:, None, :], (b, n, pred_avg.shape[-1])), phase], -1).astype(np.float32)
+
+    def mlp(name):
+        h = raw @ sd[f"{p}{name}.0.weight"].T + sd[f"{p}{name}.0.bias"]
+        h = np.where(h > 0, h, np.float32(0.05) * h)                        # LeakyReLU(0.05); Dropout = identity in eval
+        return (h @ sd[f"{p}{name}.3.weight"].T + sd[f"{p}{name}.3.bias"]).astype(np.float32)
+
+    def bn1d(z, name):                                                      # BatchNorm1d over the feature axis, running statistics
+        g, be = sd[f"{p}{name}.weight"], sd[f"{p}{name}.bias"]
+        m, v = sd[f"{p}{name}.running_mean"], sd[f"{p}{name}.running_var"]
+        return ((z - m) / np.sqrt(v + np.float32(1e-5)) * g + be).astype(np.float32)
+
+    x_wgf = x + mlp("gfeat_mpl_t")
+    x_wgf_s = np.concatenate([x, mlp("gfeat_mpl_s")], -1)
+    y = bn1d(x_wgf, "bn_in")
+    y_s = bn1d(x_wgf_s, "bn_in_s")
+    tsd = {k[len(p + "featTencoder.0."):]: v for k, v in sd.items() if k.startswith(p + "featTencoder.0.")}
+    y = ts_attn_block(y.reshape(b, n, 128, -1), y_s.reshape(b, n, 128, -1), tsd)
+    y = y[:, :n, :3072]
+    return (y + x).reshape(b * n, -1, 24).astype(np.float32), pred_avg, pred_phase
+
+
+def gait_cparams(pred_cam, bbox, cimg):
+    """grnet.py:156-160: camera parameters in the full image from the crop camera and the box."""
+    cam = np.asarray(pred_cam, np.float32).reshape(-1, 3)
+    bbox, cimg = np.asarray(bbox, np.float32), np.asarray(cimg, np.float32)
+    bs = bbox[..., 2] / np.float32(224.0)
+    t_bb = bbox[..., :2] - cimg
+    scale = bs.reshape(-1, 1) * cam[:, 0:1]
+    return np.concatenate([scale, t_bb.reshape(-1, 2) / scale / np.float32(112.0) + cam[:, 1:]], -1).astype(np.float32)
+
+
+def grnet_forward_gait(frames, bbox, cimg, sd, smpl):
+    """GRNet.forward with use_gait_feat=True (grnet.py:129-175): first head pass, cparams from the predicted camera and the box,
+    FeatCorrector, SECOND head pass on the corrected pose features, regressor.  frames (b,T,3,224,224), bbox (b,T,4), cimg (b,T,2)."""
+    frames = np.asarray(frames, np.float32)
+    b, t = frames.shape[:2]
+    first = grnet_forward(frames, sd, smpl, return_intermediates=True)
+    cparams = gait_cparams(first["pred_cam"], bbox, cimg)
+    plf, csf = first["point_local_feat"], first["cam_shape_feats"]
+    new_plf, pred_avg, pred_phase = feat_corrector(plf.reshape(b, t, -1), cparams.reshape(b, t, 3), sd)
+    rot6d, shape, cam = head_tail(new_plf, csf, sd)
+    rotmat = rot6d_to_rotmat(rot6d).reshape(-1, 24, 3, 3)
+    verts, j24 = smpl_lbs(shape, rotmat, smpl)
+    kp3d = smpl_joints29(verts, j24, smpl)
+    kp2d = project(kp3d, cam)
+    aa = rotmat_to_aa(rotmat.reshape(-1, 3, 3)).reshape(-1, 72)
+    theta = np.concatenate([cam, aa, shape], 1)
+    return {"theta": theta.reshape(b, t, 85), "verts": verts.reshape(b, t, -1, 3), "kp_2d": kp2d.reshape(b, t, -1, 2),
+            "kp_3d": kp3d.reshape(b, t, -1, 3), "rotmat": rotmat.reshape(b, t, 24, 3, 3), "pred_avg": pred_avg,
+            "pred_phase": pred_phase, "pred_cparam": cparams, "point_local_feat": new_plf, "first_pass": first}

@@ -155,3 +155,38 @@ def test_layer_normalization_is_the_reference_variant(oracle):
     ref = torch.nn.functional.layer_norm(torch.from_numpy(z), (3072,), eps=0.0).numpy() * np.sqrt(3071.0 / 3072.0)
     assert rel_err(out, ref) < 1e-5
     assert abs(out.std(-1, ddof=1).mean() - 1.0) < 1e-4
+
+
+def test_feat_corrector_matches_reference(pkg, oracle):
+    """Row f2: oracle.feat_corrector vs outputs of the reference's FeatCorrector.forward run with its undefined names bound
+    (tools/make_goldens_featcorr.py)."""
+    import os
+    from .conftest import ROOT
+    g = np.load(os.path.join(ROOT, "tests", "golden", "featcorr.npz"))
+    sd = pkg.synth.make_featcorr_state_dict()
+    for (b, n) in ((2, 8), (1, 16)):
+        x, cp = pkg.synth.make_featcorr_inputs(b, n)
+        y, avg, ph = oracle.feat_corrector(x, cp, sd)
+        assert y.shape == (b * n, 128, 24)
+        assert rel_err(y, g[f"y_{b}_{n}"]) < 2e-5, rel_err(y, g[f"y_{b}_{n}"])
+        assert rel_err(avg, g[f"avg_{b}_{n}"]) < 1e-5 and rel_err(ph, g[f"phase_{b}_{n}"]) < 1e-5
+
+
+def test_gait_branch_matches_reference(pkg, oracle, synth_weights, synth_smpl):
+    """GRNet.forward with use_gait_feat=True (grnet.py:154-173) on 4 frames: cparams, second head pass, regressor."""
+    import os
+    from .conftest import ROOT
+    g = np.load(os.path.join(ROOT, "tests", "golden", "featcorr.npz"))
+    sd = dict(synth_weights)
+    sd.update(pkg.synth.make_featcorr_state_dict())
+    frames = pkg.synth.make_frames(4).reshape(1, 4, 3, 224, 224)
+    bbox, cimg = pkg.synth.make_gait_boxes(1, 4)
+    out = oracle.grnet_forward_gait(frames, bbox, cimg, sd, synth_smpl)
+    assert rel_err(out["pred_cparam"], g["gait_pred_cparam"]) < 1e-5
+    assert rel_err(out["pred_avg"], g["gait_pred_avg"]) < 1e-4 and rel_err(out["pred_phase"], g["gait_pred_phase"]) < 1e-4
+    for k in ("theta", "kp_3d", "kp_2d", "rotmat"):
+        assert rel_err(out[k], g["gait_" + k]) < 1e-4, (k, rel_err(out[k], g["gait_" + k]))
+    assert rel_err(out["verts"][:, :, ::5], g["gait_verts_s5"]) < 1e-4
+    # the corrector does change the pose: the branch is not a no-op on these weights
+    first = out["first_pass"]
+    assert rel_err(out["theta"][..., 3:75], first["theta"][..., 3:75]) > 1e-2

@@ -196,6 +196,28 @@ def tsattn_spec(prefix=""):
     return s
 
 
+def featcorr_spec(prefix="pfeat_corrector."):
+    """FeatCorrector(x_size=128, num_avg_gfeat=3, estim_phase=True, num_layers=1, h_size=1024 -> 1000, num_joints=24,
+    num_transformer_head=4, use_jwff=True) tensors in state_dict order (feature_correction.py:44-101; the configuration of
+    configs/config_grnet.yaml FEAT_CORR as GRNet passes it, grnet.py:69-79): the GRU gait encoder `featnet`, the two gait-token
+    MLPs, the two input BatchNorm1d and the one TSAttnBlock."""
+    s = OrderedDict()
+    p, D, G = prefix, 128 * NUM_JOINTS, 128
+    s.update(gru_spec(p + "featnet."))
+    s[p + "gfeat_mpl_t.0.weight"] = ((D // 2, 7), "linear_w")
+    s[p + "gfeat_mpl_t.0.bias"] = ((D // 2,), "bias")
+    s[p + "gfeat_mpl_t.3.weight"] = ((D, D // 2), "linear_w")
+    s[p + "gfeat_mpl_t.3.bias"] = ((D,), "bias")
+    s[p + "gfeat_mpl_s.0.weight"] = ((G // 2, 7), "linear_w")
+    s[p + "gfeat_mpl_s.0.bias"] = ((G // 2,), "bias")
+    s[p + "gfeat_mpl_s.3.weight"] = ((G, G // 2), "linear_w")
+    s[p + "gfeat_mpl_s.3.bias"] = ((G,), "bias")
+    _bn(s, p + "bn_in_s", D + G)
+    _bn(s, p + "bn_in", D)
+    s.update(tsattn_spec(p + "featTencoder.0."))
+    return s
+
+
 def grnet_spec():
     """backbone.* + head.* in the order of the reference's gen_state_dict."""
     s = OrderedDict()

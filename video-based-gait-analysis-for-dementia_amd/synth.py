@@ -94,6 +94,29 @@ def make_tsattn_state_dict(seed=WEIGHT_SEED):
     return make_state_dict(netspec.tsattn_spec(), seed)
 
 
+def make_featcorr_state_dict(seed=WEIGHT_SEED, prefix="pfeat_corrector."):
+    """FeatCorrector weights under the reference's keys (netspec.featcorr_spec)."""
+    return make_state_dict(netspec.featcorr_spec(prefix), seed)
+
+
+def make_featcorr_inputs(b, n, seed=FRAME_SEED):
+    """x (b,n,3072): pooled pose features in the c*24+j layout (grnet.py:163); cparams (b,n,3) as grnet.py:157-160 forms them."""
+    g = _rng(seed, f"featcorr_in_{b}_{n}")
+    x = (g.standard_normal((b, n, 3072)) * 0.5).astype(np.float32)
+    cp = np.concatenate([g.uniform(0.6, 1.2, (b, n, 1)), g.standard_normal((b, n, 2)) * 0.3], -1)
+    return x, cp.astype(np.float32)
+
+
+def make_gait_boxes(b, n, seed=FRAME_SEED, width=1920, height=1080):
+    """bbox (b,n,4) [cx,cy,w,h] in image pixels and cimg (b,n,2) = half the image size, as Inference.__getitem__ returns them
+    with use_gait_feat=True (inference.py:84-85)."""
+    g = _rng(seed, f"gait_boxes_{b}_{n}")
+    side = g.uniform(180, 420, (b, n, 1))
+    bbox = np.concatenate([g.uniform(400, 1500, (b, n, 1)), g.uniform(300, 800, (b, n, 1)), side, side], -1).astype(np.float32)
+    cimg = np.broadcast_to(np.array([width * 0.5, height * 0.5], np.float32), (b, n, 2)).copy()
+    return bbox, cimg
+
+
 def make_tsattn_inputs(b, n, seed=FRAME_SEED):
     """x (b,n,128,24): per-joint pose features; xs (b,n,128,25): the same plus the gait-feature token
     (feature_correction.py:137-148 builds them as batch-normalised features, i.e. roughly unit variance)."""
