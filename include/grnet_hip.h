@@ -146,6 +146,25 @@ int grnet_smpl_forward(grnet_t* h, const float* betas_dev, const float* rotmat_d
  * INPUTS; `out` as in grnet_forward (theta, verts, kp_2d, kp_3d, rotmat, pred_rot6d; map outputs are ignored). */
 int grnet_head_forward(grnet_t* h, const float* point_local_feat_dev, const float* cam_shape_feats_dev, int n, const grnet_outputs_t* out,
                        void* stream);
+/* The use_gait_feat branch of GRNet.forward AFTER the first head pass -- lib/models/grnet.py:154-173: camera parameters in the
+ * full image from the crop camera and the box (:156-160), FeatCorrector.forward (lib/models/layers/feature_correction.py:104-157:
+ * GRU gait encoder, gait-token MLPs, BatchNorm1d, one TSAttnBlock, residual), the SECOND head pass on the corrected pose features
+ * (:165) and the regressor (:171).  The reference class reads names that are defined nowhere (it cannot be constructed as shipped);
+ * they are bound as DESIGN.md records and tests/golden/featcorr.npz pins the result to the reference's own code run with those
+ * bindings.  Inputs are the FIRST pass's results for the whole clip(s) (the temporal modules need every frame, so on several GPUs
+ * this runs after the all-gather): point_local_feat (b*T,128,24), cam_shape_feats (b*T,64,24), cam = pred_cam rows [s,tx,ty] with a
+ * row stride of cam_ld floats (3, or 85 to pass theta), bbox (b*T,4) [cx,cy,w,h], cimg (b*T,2) = half the image size
+ * (lib/dataset/inference.py:84-85).  `out` as in grnet_head_forward for all b*T frames; `gait` may be NULL. */
+typedef struct grnet_gait_outputs {
+    float* pred_avg;          /* (b,3)      gait parameters, gait_feat_encoder.py:100-101 */
+    float* pred_phase;        /* (b,T,4)    gait_feat_encoder.py:102                      */
+    float* pred_cparam;       /* (b*T,3)    grnet.py:160,173                              */
+    float* point_local_feat;  /* (b*T,128,24) corrected pose features, feature_correction.py:150 */
+} grnet_gait_outputs_t;
+int grnet_gait_correct(grnet_t* h, const float* point_local_feat_dev, const float* cam_shape_feats_dev, const float* cam_dev, int cam_ld,
+                       const float* bbox_dev, const float* cimg_dev, int b, int T, const grnet_outputs_t* out,
+                       const grnet_gait_outputs_t* gait, void* stream);
+
 /* rot6d_to_rotmat -- lib/utils/geometry.py:395-410: (m,6) -> (m,3,3); rotation_matrix_to_angle_axis -- geometry.py:68-97 (via
  * quaternion :213-293,:159-210, NaN -> 0): (m,3,3) -> (m,3).  The device functions the tail kernel calls, exposed so the
  * reference's edge-case vectors (degenerate 6-D pairs, the four quaternion branches, near-pi rotations) reach the GPU code. */

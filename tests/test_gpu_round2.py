@@ -189,3 +189,49 @@ def test_config5_four_tracks_of_64_frames_bf16(pkg, oracle, synth_weights, synth
     d = got[2]["joints3d"][pick] - np.asarray(ref["kp_3d"]).reshape(4, 29, 3)
     assert np.linalg.norm(d, axis=-1).mean() < 0.02                       # MPJPE vs fp32 in metres: bf16 storage noise
     m.close()
+
+
+def test_feature_corrector_and_gait_branch_match_reference_golden(pkg, oracle, synth_weights, synth_smpl):
+    """Row f2 end to end on the GPU: GRNet(use_gait_feat=True) -- first head pass, cparams (grnet.py:156-160), FeatCorrector
+    (feature_correction.py:104-157), second head pass, regressor -- against the outputs of the reference's own code run with its
+    undefined names bound (tests/golden/featcorr.npz), and the corrector alone against its module golden and the oracle."""
+    import os
+    from .conftest import ROOT
+    g = np.load(os.path.join(ROOT, "tests", "golden", "featcorr.npz"))
+    m = pkg.build_synthetic_model(max_frames=3, use_gait_feat=True)          # 4 frames > max_frames: both passes chunk
+    frames = torch.from_numpy(pkg.synth.make_frames(4)).cuda().reshape(1, 4, 3, 224, 224)
+    bbox, cimg = pkg.synth.make_gait_boxes(1, 4)
+    out = m(frames, bbox=torch.from_numpy(bbox).cuda(), cimg=torch.from_numpy(cimg).cuda())[-1]
+    torch.cuda.synchronize()
+    assert rel_err(out["pred_cparam"].cpu().numpy(), g["gait_pred_cparam"]) < 1e-5
+    assert rel_err(out["pred_avg"].cpu().numpy(), g["gait_pred_avg"]) < 1e-4
+    assert rel_err(out["pred_phase"].cpu().numpy(), g["gait_pred_phase"]) < 1e-4
+    for k in ("theta", "kp_3d", "kp_2d", "rotmat"):
+        assert out[k].shape == g["gait_" + k].shape, k
+        assert rel_err(out[k].cpu().numpy(), g["gait_" + k]) < 1e-4, (k, rel_err(out[k].cpu().numpy(), g["gait_" + k]))
+    assert rel_err(out["verts"].cpu().numpy()[:, :, ::5], g["gait_verts_s5"]) < 1e-4
+    # the corrector alone on the module golden's inputs (features in, corrected features out)
+    sd = pkg.synth.make_featcorr_state_dict()
+    for (b, n) in ((2, 8), (1, 16), (1, 1)):
+        x, cp = pkg.synth.make_featcorr_inputs(b, n)
+        # gait_correct derives cparams from (cam, bbox, cimg): choose them so that cparams == cp exactly
+        # (bbox w = 224 -> bs = 1, cam = [s, tx, ty] = cp, bbox centre == cimg -> no translation term)
+        bb = np.zeros((b, n, 4), np.float32); bb[..., 2:] = 224.0
+        ci = np.zeros((b, n, 2), np.float32)
+        csf = np.zeros((b * n, 64, 24), np.float32)
+        r = m.gait_correct(torch.from_numpy(x).reshape(b * n, 128, 24), torch.from_numpy(csf), torch.from_numpy(cp).reshape(b * n, 3),
+                           torch.from_numpy(bb), torch.from_numpy(ci), b, n)
+        torch.cuda.synchronize()
+        assert np.array_equal(r["pred_cparam"].cpu().numpy(), cp.reshape(-1, 3))
+        ry, ravg, rph = oracle.feat_corrector(x, cp, sd)
+        assert rel_err(r["point_local_feat"].cpu().numpy(), ry) < 3e-5, (b, n)
+        assert rel_err(r["pred_avg"].cpu().numpy(), ravg) < 1e-4 and rel_err(r["pred_phase"].cpu().numpy(), rph) < 1e-4
+        if f"y_{b}_{n}" in g.files:
+            assert rel_err(r["point_local_feat"].cpu().numpy(), g[f"y_{b}_{n}"]) < 3e-5, (b, n)
+    m.close()
+    m2 = pkg.build_synthetic_model(max_frames=2, with_gru=True)               # corrector weights absent: loud
+    with pytest.raises(pkg._lib.GrnetError):
+        m2.gait_correct(torch.zeros(2, 128, 24), torch.zeros(2, 64, 24), torch.ones(2, 3), torch.ones(1, 2, 4), torch.zeros(1, 2, 2), 1, 2)
+    m2.close()
+    with pytest.raises(ValueError):
+        pkg.GRNet(max_frames=1, use_gait_feat=True, featcorr=dict(AVG_DIM=3, ESTIM_PHASE=True, NUM_LAYERS=2, H_SIZE=1024, NUM_HEADS=4, USE_JWFF=True))

@@ -21,6 +21,11 @@ class Outputs(C.Structure):
         "features", "part_attn", "smpl_feats")]
 
 
+class GaitOutputs(C.Structure):
+    """grnet_gait_outputs_t"""
+    _fields_ = [(n, C.c_void_p) for n in ("pred_avg", "pred_phase", "pred_cparam", "point_local_feat")]
+
+
 EXPORTS = {
     "grnet_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
     "grnet_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_int]),
@@ -47,6 +52,8 @@ EXPORTS = {
     "grnet_crop_normalise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_int,
                                        C.c_void_p, C.c_void_p]),
     "grnet_head_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Outputs), C.c_void_p]),
+    "grnet_gait_correct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                     C.POINTER(Outputs), C.POINTER(GaitOutputs), C.c_void_p]),
     "grnet_op_rot6d_to_rotmat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "grnet_op_rotmat_to_aa": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "grnet_debug_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),

@@ -105,8 +105,9 @@ struct grnet {
     int device = 0, max_frames = 0;
     int dtype = 0;               // 0: fp32 NCHW activations, 1: bf16 NHWC activations (conv_bf16.hip), fp32 tail either way
     View v_in8;                  // bf16: the caller's frames converted to NHWC bf16 with 8 channels (3 real)
-    bool finalized = false, smpl_loaded = false, gru_ready = false, tsattn_ready = false;
+    bool finalized = false, smpl_loaded = false, gru_ready = false, tsattn_ready = false, featcorr_ready = false;
     TsAttnWeights tsw{};
+    FeatCorrWeights fcw{};
     bool use_graph = false;
     int conv_tile_hint = 0;
     std::string err;
@@ -875,6 +876,44 @@ struct grnet {
         return 0;
     }
 
+    // The rest of the pose-feature corrector (feature_correction.py:66-91): the two gait-token MLPs and the two input BatchNorm1d
+    // (eval: folded to scale / shift in fp64).  Optional, under the keys of a MAX-GRNet checkpoint.
+    int finalize_featcorr() {
+        const std::string pre = "pfeat_corrector.";
+        if (!find(pre + "gfeat_mpl_t.0.weight")) return 0;
+        int rc;
+        if ((rc = upload_key(pre + "gfeat_mpl_t.0.weight", 1536 * 7, &fcw.t0_w))) return rc;
+        if ((rc = upload_key(pre + "gfeat_mpl_t.0.bias", 1536, &fcw.t0_b))) return rc;
+        if ((rc = upload_key(pre + "gfeat_mpl_t.3.weight", (size_t)3072 * 1536, &fcw.t3_w))) return rc;
+        if ((rc = upload_key(pre + "gfeat_mpl_t.3.bias", 3072, &fcw.t3_b))) return rc;
+        if ((rc = upload_key(pre + "gfeat_mpl_s.0.weight", 64 * 7, &fcw.s0_w))) return rc;
+        if ((rc = upload_key(pre + "gfeat_mpl_s.0.bias", 64, &fcw.s0_b))) return rc;
+        if ((rc = upload_key(pre + "gfeat_mpl_s.3.weight", 128 * 64, &fcw.s3_w))) return rc;
+        if ((rc = upload_key(pre + "gfeat_mpl_s.3.bias", 128, &fcw.s3_b))) return rc;
+        struct { const char* name; size_t c; const float** scale; const float** shift; } bns[2] = {
+            {"bn_in", 3072, &fcw.bn_scale, &fcw.bn_shift}, {"bn_in_s", 3200, &fcw.bns_scale, &fcw.bns_shift}};
+        for (auto& bn : bns) {
+            const HostTensor *g = find(pre + bn.name + ".weight"), *be = find(pre + bn.name + ".bias"),
+                             *m = find(pre + bn.name + ".running_mean"), *v = find(pre + bn.name + ".running_var");
+            if (!g || !be || !m || !v) return fail(GRNET_ENOENT, "missing BatchNorm1d tensors " + pre + bn.name + ".*");
+            if (g->numel() != bn.c || be->numel() != bn.c || m->numel() != bn.c || v->numel() != bn.c)
+                return fail(GRNET_EINVAL, "bad BatchNorm1d size " + pre + bn.name);
+            std::vector<float> sc(bn.c), sh(bn.c);
+            for (size_t c = 0; c < bn.c; ++c) {
+                const double k = (double)g->data[c] / std::sqrt((double)v->data[c] + kBnEps);
+                sc[c] = (float)k;
+                sh[c] = (float)((double)be->data[c] - (double)m->data[c] * k);
+            }
+            float* p = nullptr;
+            if ((rc = upload(sc, &p))) return rc;
+            *bn.scale = p;
+            if ((rc = upload(sh, &p))) return rc;
+            *bn.shift = p;
+        }
+        featcorr_ready = true;
+        return 0;
+    }
+
     int finalize() {
         if (finalized) return fail(GRNET_ESTATE, "weights already finalized");
         for (auto& L : convs) {
@@ -889,6 +928,7 @@ struct grnet {
         if ((rc = upload_key("head.cam_mlp.bias", 3, &tailw.cam_b))) return rc;
         if ((rc = finalize_gru())) return rc;
         if ((rc = finalize_tsattn())) return rc;
+        if ((rc = finalize_featcorr())) return rc;
         if (!smpl_loaded) return fail(GRNET_ESTATE, "grnet_load_smpl must be called before grnet_finalize_weights");
         tensors.clear();                                    // host copies no longer needed
         finalized = true;
@@ -1284,6 +1324,49 @@ struct grnet {
         return 0;
     }
 
+    // The use_gait_feat branch of GRNet.forward after the first head pass (grnet.py:154-173): cparams, FeatCorrector, second head pass,
+    // regressor.  plf (b*T,128,24), csf (b*T,64,24), cam (b*T rows of stride cam_ld: pred_cam, or theta with cam_ld = 85) are the first
+    // pass's results for the WHOLE clip(s); the second head pass runs in chunks of max_frames.
+    int gait_correct(const float* plf, const float* csf, const float* cam, int cam_ld, const float* bbox, const float* cimg, int b, int T,
+                     const grnet_outputs_t& o, const grnet_gait_outputs_t& g, hipStream_t s) {
+        const size_t M = (size_t)b * T;
+        const size_t gru_need = M * 3072 * 2 + 2 * M * 900 + 2 * M * 600 + (size_t)b * 1200 + (size_t)b * 2400 + 1024;
+        const size_t own = M * 3 + (size_t)b * 3 + M * 4 + M * 3072 + 64;
+        float* ws = nullptr;
+        if (int rc = temporal_scratch(kGemmWsFloats + gru_need + featcorr_ws_floats(b, T) + own, &ws)) return rc;
+        set_gemm_workspace(ws, kGemmWsFloats);
+        float* p = ws + kGemmWsFloats;
+        float* cparams = g.pred_cparam ? g.pred_cparam : p;   p += M * 3;
+        float* avg = g.pred_avg ? g.pred_avg : p;             p += (size_t)b * 3;
+        float* phase = g.pred_phase ? g.pred_phase : p;       p += M * 4;
+        float* new_plf = g.point_local_feat ? g.point_local_feat : p;   p += M * 3072;
+        GruWorkspace w;
+        w.xin = p;
+        float* xc_buf = p + M * 3072;
+        w.gi = p + M * 3072 * 2;
+        w.l0 = w.gi + 2 * M * 900;
+        w.l1 = w.l0 + M * 600;
+        w.hfin = w.l1 + M * 600;
+        w.xbuf = reinterpret_cast<unsigned long long*>(w.hfin + (((size_t)b * 1200 + 63) & ~(size_t)63));
+        float* fws = p + gru_need;
+        HIP_TRY(launch_gait_cparams(cam, cam_ld, bbox, cimg, cparams, (int)M, s));
+        HIP_TRY(launch_gru(plf, cparams, gruw, w, avg, phase, xc_buf, b, T, s));
+        HIP_TRY(launch_featcorr(plf, avg, phase, fcw, tsw, fws, new_plf, b, T, s));
+        set_gemm_workspace(nullptr, 0);
+        for (size_t s0 = 0; s0 < M; s0 += (size_t)max_frames) {
+            const int m = (int)std::min<size_t>((size_t)max_frames, M - s0);
+            grnet_outputs_t oc{};
+            oc.theta = o.theta ? o.theta + s0 * 85 : nullptr;
+            oc.verts = o.verts ? o.verts + s0 * 6890 * 3 : nullptr;
+            oc.kp_2d = o.kp_2d ? o.kp_2d + s0 * 58 : nullptr;
+            oc.kp_3d = o.kp_3d ? o.kp_3d + s0 * 87 : nullptr;
+            oc.rotmat = o.rotmat ? o.rotmat + s0 * 216 : nullptr;
+            oc.pred_rot6d = o.pred_rot6d ? o.pred_rot6d + s0 * 144 : nullptr;
+            if (int rc = head_from_feats(new_plf + s0 * 3072, csf + s0 * 1536, m, oc, s)) return rc;
+        }
+        return 0;
+    }
+
     int forward(const float* frames, int n, const grnet_outputs_t* out, hipStream_t s) {
         if (!finalized) return fail(GRNET_ESTATE, "grnet_forward before grnet_finalize_weights");
         if (!frames || n < 1 || n > max_frames)
@@ -1446,8 +1529,10 @@ int grnet_gru_forward(grnet_t* h, const float* x, const float* cp, int b, int T,
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t rows = (size_t)b * T;
     float* ws = nullptr;                                   // handle-owned scratch: no allocation once a size has been seen
-    const size_t need = rows * 3072 * 2 + 2 * rows * 900 + 2 * rows * 600 + (size_t)b * 1200 + 1024;
-    if (int rc = h->temporal_scratch(need, &ws)) return rc;
+    const size_t need = rows * 3072 * 2 + 2 * rows * 900 + 2 * rows * 600 + (size_t)b * 1200 + (size_t)b * 2400 + 1024;
+    if (int rc = h->temporal_scratch(kGemmWsFloats + need, &ws)) return rc;
+    set_gemm_workspace(ws, kGemmWsFloats);
+    ws += kGemmWsFloats;
     GruWorkspace w;
     w.xin = ws;
     float* xc_buf = xc ? xc : ws + rows * 3072;
@@ -1455,7 +1540,9 @@ int grnet_gru_forward(grnet_t* h, const float* x, const float* cp, int b, int T,
     w.l0 = w.gi + 2 * rows * 900;
     w.l1 = w.l0 + rows * 600;
     w.hfin = w.l1 + rows * 600;
+    w.xbuf = reinterpret_cast<unsigned long long*>(w.hfin + (((size_t)b * 1200 + 63) & ~(size_t)63));
     hipError_t e = launch_gru(x, cp, h->gruw, w, y, phase, xc_buf, b, T, s);
+    set_gemm_workspace(nullptr, 0);
     if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("launch_gru: ") + hipGetErrorString(e));
     return 0;
 }
@@ -1467,8 +1554,10 @@ int grnet_tsattn_forward(grnet_t* h, const float* x, const float* xs, int b, int
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* ws = nullptr;                                   // handle-owned scratch, like the GRU's
-    if (int rc = h->temporal_scratch(tsattn_ws_floats(b, n), &ws)) return rc;
-    hipError_t e = launch_tsattn(x, xs, h->tsw, ws, y, b, n, s);
+    if (int rc = h->temporal_scratch(kGemmWsFloats + tsattn_ws_floats(b, n), &ws)) return rc;
+    set_gemm_workspace(ws, kGemmWsFloats);
+    hipError_t e = launch_tsattn(x, xs, h->tsw, ws + kGemmWsFloats, y, b, n, s);
+    set_gemm_workspace(nullptr, 0);
     if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("launch_tsattn: ") + hipGetErrorString(e));
     return 0;
 }
@@ -1706,6 +1795,19 @@ int grnet_head_forward(grnet_t* h, const float* plf_dev, const float* csf_dev, i
     if (n > h->max_frames) return h->fail(GRNET_EINVAL, "n exceeds max_frames");
     DeviceGuard guard(h->device);
     return h->head_from_feats(plf_dev, csf_dev, n, *out, static_cast<hipStream_t>(stream));
+}
+
+int grnet_gait_correct(grnet_t* h, const float* plf_dev, const float* csf_dev, const float* cam_dev, int cam_ld, const float* bbox_dev,
+                       const float* cimg_dev, int b, int T, const grnet_outputs_t* out, const grnet_gait_outputs_t* gait, void* stream) {
+    if (!h || !plf_dev || !csf_dev || !cam_dev || !bbox_dev || !cimg_dev || !out || b < 1 || T < 1 || cam_ld < 3) return GRNET_EINVAL;
+    if (!h->finalized) return h->fail(GRNET_ESTATE, "grnet_gait_correct before grnet_finalize_weights");
+    if (!h->gru_ready || !h->tsattn_ready || !h->featcorr_ready)
+        return h->fail(GRNET_ESTATE, "pose-feature corrector weights were not loaded (keys pfeat_corrector.*)");
+    if ((long)b * T > 65536) return h->fail(GRNET_EINVAL, "b*T exceeds 65536 frames");
+    DeviceGuard guard(h->device);
+    grnet_gait_outputs_t g{};
+    if (gait) g = *gait;
+    return h->gait_correct(plf_dev, csf_dev, cam_dev, cam_ld, bbox_dev, cimg_dev, b, T, *out, g, static_cast<hipStream_t>(stream));
 }
 
 int grnet_op_rot6d_to_rotmat(grnet_t* h, const float* rot6d_dev, int m, float* rotmat_dev, void* stream) {

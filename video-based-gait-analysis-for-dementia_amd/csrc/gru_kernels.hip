@@ -8,6 +8,8 @@
 //   5. heads: speed/step MLPs on the final hidden states, phase MLP + tanh on the layer-1 outputs
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace grk {
 
 #define GRK_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return _e; } while (0)
@@ -93,6 +95,10 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(const float* __restric
     }
 }
 
+thread_local float* g_gemm_ws = nullptr;       // split-K partial sums: scratch lent by the caller (the handle), see set_gemm_workspace
+thread_local size_t g_gemm_ws_floats = 0;
+void set_gemm_workspace(float* ws, size_t floats) { g_gemm_ws = ws; g_gemm_ws_floats = floats; }
+
 hipError_t launch_gemm_nt_bias(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int ldc, hipStream_t s) {
     if (K % 4 != 0) return hipErrorInvalidValue;
     const int blocks = ((N + 63) / 64) * ((M + 63) / 64);
@@ -109,15 +115,18 @@ hipError_t launch_gemm_nt_bias(const float* A, const float* B, const float* bias
     }
     const int kc = ((K + splits - 1) / splits + 31) / 32 * 32;
     splits = (K + kc - 1) / kc;
-    float* part = nullptr;                                  // per call: these GEMMs are not on the per-frame hot path and are not graph-captured
-    GRK_TRY(hipMallocAsync(reinterpret_cast<void**>(&part), (size_t)splits * M * N * sizeof(float), s));
+    float* part = nullptr;
+    const size_t need = (size_t)splits * M * N;
+    const bool lent = g_gemm_ws && need <= g_gemm_ws_floats;  // the handle's scratch: no allocation in the call (graph-capturable);
+    if (lent) part = g_gemm_ws;                               // the launches of one stream run one after another, so one region serves them all
+    else GRK_TRY(hipMallocAsync(reinterpret_cast<void**>(&part), need * sizeof(float), s));
     hipError_t e = launch_k(gemm_nt_bias_f32, dim3((N + 63) / 64, (M + 63) / 64, splits), dim3(256), 0, s, A, B, static_cast<const float*>(nullptr), part, M, N, K, N, kc,
                             (size_t)M * N);
     if (e == hipSuccess) {
         const long total = (long)M * N;
         e = launch_k(gemm_splitk_reduce, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0, s, part, bias, C, M, N, ldc, splits);
     }
-    hipFreeAsync(part, s);
+    if (!lent) hipFreeAsync(part, s);
     return e != hipSuccess ? e : hipGetLastError();
 }
 
@@ -173,6 +182,112 @@ __global__ __launch_bounds__(1024) void gru_recurrent_kernel(const float* __rest
     if (tid < kH) hfin[(size_t)seq * (4 * kH) + hfin_off + dir * kH + tid] = h[tid];
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Recurrence with W_hh RESIDENT for the whole sequence (long clips: BASELINE configs[3] reassembles 10 000 frames before the GRU).
+// The kernel above pulls the 1.08 MB of W_hh from L2 every step (~10 us per step).  Here the 900 x 300 matrix of one (sequence,
+// direction) is split over kGruSlices workgroups: slice s owns the hidden units [s*38, s*38+38) = 114 gate rows, kept in REGISTERS
+// for all T steps (lane l holds rows l and l+64, wave w the 38 columns [w*38, w*38+38): 76 weights per lane).  A step is
+//   1. every workgroup collects the 300 values of h_{t-1}: its own slice from LDS, the others from the exchange buffer, where each
+//      value travels as ONE 8-byte granule {value, step tag} written with a device-scope (sc1) store and polled with device-scope
+//      loads -- no flag, no fence, placement-independent (guide: handoff-1to1);
+//   2. per wave: its 38 h values are broadcast lane by lane (v_readlane -> scalar operand), 76 FMAs per lane, no cross-lane
+//      reduction; the 8 column-slices are added through LDS in a fixed order (deterministic);
+//   3. the 38 owners of a hidden unit apply the gate equations and publish h_t.
+// Two granule buffers alternate by step parity: a workgroup can be at most one step ahead of its peers (it cannot finish step t+1
+// without their h_t), so a buffer is never overwritten while somebody still reads it.  The buffer is zeroed before the launch and
+// tags are step+1, so no stale tag can match.  The kGruSlices workgroups of a group are all resident for sure when the grid is
+// <= one workgroup per CU (b <= 16 here); larger batches use the kernel above (they have sequences to run in parallel instead).
+constexpr int kGruSlices = 8, kGruUnits = 38, kGruCols = 38;      // 8 x 38 = 304 >= 300
+__global__ __launch_bounds__(512) void gru_recurrent_split_kernel(const float* __restrict__ gi, const float* __restrict__ w_hhT_f,
+                                                                    const float* __restrict__ w_hhT_b, const float* __restrict__ b_hh_f,
+                                                                    const float* __restrict__ b_hh_b, float* __restrict__ out,
+                                                                    float* __restrict__ hfin, int hfin_off, int b, int T,
+                                                                    unsigned long long* __restrict__ xbuf) {
+    __shared__ float h[kGruSlices * kGruCols];                 // 304: columns >= 300 stay 0
+    __shared__ float part[kGruSlices][128];
+    // block id = slice*8 + (group % 8) + 64*(group / 8): the 8 slices of a group have ids congruent mod 8 -> one XCD (speed only)
+    const int slot = blockIdx.x & 7, slice = (blockIdx.x >> 3) & 7, group = (blockIdx.x >> 6) * 8 + slot;
+    if (group >= 2 * b) return;
+    const int seq = group >> 1, dir = group & 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* wT = dir ? w_hhT_b : w_hhT_f;
+    const float* bh = dir ? b_hh_b : b_hh_f;
+    const float* gid = gi + (size_t)dir * b * T * 900;
+    const int u0 = slice * kGruUnits, nu = min(kGruUnits, kH - u0);          // hidden units of this slice
+    const int c0 = wave * kGruCols;                                           // columns of this wave
+    // local row lr in [0, 114): gate lr / 38, unit u0 + lr % 38
+    float W0[kGruCols], W1[kGruCols];
+    {
+        const int lr0 = lane, lr1 = lane + 64;
+        const int g0 = lr0 / kGruUnits, j0 = lr0 - g0 * kGruUnits, g1 = lr1 / kGruUnits, j1 = lr1 - g1 * kGruUnits;
+        const bool v0 = j0 < nu, v1 = lr1 < 3 * kGruUnits && j1 < nu;
+#pragma unroll
+        for (int k = 0; k < kGruCols; ++k) {
+            const int c = c0 + k;
+            W0[k] = (v0 && c < kH) ? wT[(size_t)c * 900 + g0 * kH + u0 + j0] : 0.f;
+            W1[k] = (v1 && c < kH) ? wT[(size_t)c * 900 + g1 * kH + u0 + j1] : 0.f;
+        }
+    }
+    float bias3[3] = {0.f, 0.f, 0.f};
+    if (tid < nu) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) bias3[g] = bh[g * kH + u0 + tid];
+    }
+    if (tid < kGruSlices * kGruCols) h[tid] = 0.f;
+    unsigned long long* xb = xbuf + (size_t)group * 2 * kH;                 // [parity][300] granules of this (sequence, direction)
+    float h_own = 0.f;                                                      // h of the unit this thread owns (tid < nu)
+    __syncthreads();
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? T - 1 - step : step;
+        float g3[3] = {0.f, 0.f, 0.f};
+        if (tid < nu) {                                                     // this step's input projections: in flight under the exchange
+            const float* g = gid + ((size_t)seq * T + t) * 900 + u0 + tid;
+            g3[0] = g[0]; g3[1] = g[kH]; g3[2] = g[2 * kH];
+        }
+        if (step > 0 && tid < kH && (tid < u0 || tid >= u0 + nu)) {          // collect h_{t-1} of the other slices
+            const unsigned long long* src = xb + (size_t)((step - 1) & 1) * kH + tid;
+            unsigned long long v;
+            do {
+                v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } while ((unsigned)(v >> 32) != (unsigned)step);                // tag of step-1's result = (step-1)+1
+            h[tid] = __uint_as_float((unsigned)v);
+        }
+        __syncthreads();
+        const float hv = (lane < kGruCols) ? h[c0 + lane] : 0.f;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < kGruCols; ++k) {
+            const float hk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hv), k));
+            a0 = fmaf(W0[k], hk, a0);
+            a1 = fmaf(W1[k], hk, a1);
+        }
+        part[wave][lane] = a0;
+        part[wave][lane + 64] = a1;
+        __syncthreads();
+        if (tid < nu) {
+            float gh[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                float acc = bias3[g];
+#pragma unroll
+                for (int w = 0; w < kGruSlices; ++w) acc += part[w][g * kGruUnits + tid];
+                gh[g] = acc;
+            }
+            const float r = 1.f / (1.f + expf(-(g3[0] + gh[0])));
+            const float z = 1.f / (1.f + expf(-(g3[1] + gh[1])));
+            const float nn = tanhf(g3[2] + r * gh[2]);
+            const float hn = (1.f - z) * nn + z * h_own;
+            h_own = hn;
+            h[u0 + tid] = hn;                                               // read again only after the next barrier
+            out[((size_t)seq * T + t) * (2 * kH) + dir * kH + u0 + tid] = hn;
+            const unsigned long long granule = ((unsigned long long)(unsigned)(step + 1) << 32) | (unsigned long long)__float_as_uint(hn);
+            __hip_atomic_store(xb + (size_t)(step & 1) * kH + u0 + tid, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // no barrier here: the next step's collect writes h[] entries of OTHER slices only, and its barrier orders h[own] and part[]
+    }
+    if (tid < nu) hfin[(size_t)seq * (4 * kH) + hfin_off + dir * kH + u0 + tid] = h_own;
+}
+
 // hidden (rows,100) -> LeakyReLU(0.05) -> Linear(100 -> nout) [-> tanh]
 __global__ __launch_bounds__(64) void mlp_out_kernel(const float* __restrict__ hidden, const float* __restrict__ w2,
                                                        const float* __restrict__ b2, float* __restrict__ out, int nout, int ld_out,
@@ -212,8 +327,17 @@ hipError_t launch_gru(const float* x, const float* cparams, GruWeights w, GruWor
             e = launch_gemm_nt_bias(layer_in, w.w_ih[layer][d], w.b_ih[layer][d], ws.gi + (size_t)d * rows * 900, (int)rows, 900, in_size, 900, s);
             if (e != hipSuccess) return e;
         }
-        GRK_TRY(launch_k(gru_recurrent_kernel, dim3(b, 2), dim3(1024), 0, s, ws.gi, w.w_hh[layer][0], w.w_hh[layer][1],
-                           w.b_hh[layer][0], w.b_hh[layer][1], layer_out[layer], ws.hfin, layer * 600, b, T));
+        static const int split_env = getenv("GRNET_GRU_SPLIT") ? atoi(getenv("GRNET_GRU_SPLIT")) : 1;     // A/B: 0 = one workgroup per (sequence, direction)
+        if (split_env && ws.xbuf && b <= 16 && T >= 8) {
+            // W_hh resident in registers, split over 8 workgroups per (sequence, direction); the exchange buffer starts zeroed
+            GRK_TRY(hipMemsetAsync(ws.xbuf, 0, (size_t)b * 2 * 2 * kH * sizeof(unsigned long long), s));
+            const int ngroups = 2 * b;
+            GRK_TRY(launch_k(gru_recurrent_split_kernel, dim3(64 * ((ngroups + 7) / 8)), dim3(512), 0, s, (const float*)ws.gi, w.w_hh[layer][0], w.w_hh[layer][1],
+                             w.b_hh[layer][0], w.b_hh[layer][1], layer_out[layer], ws.hfin, layer * 600, b, T, ws.xbuf));
+        } else {
+            GRK_TRY(launch_k(gru_recurrent_kernel, dim3(b, 2), dim3(1024), 0, s, ws.gi, w.w_hh[layer][0], w.w_hh[layer][1],
+                             w.b_hh[layer][0], w.b_hh[layer][1], layer_out[layer], ws.hfin, layer * 600, b, T));
+        }
         layer_in = layer_out[layer];
         in_size = 600;
     }

@@ -161,6 +161,7 @@ struct GruWorkspace {
     float* l0;       // (b*T, 600)
     float* l1;       // (b*T, 600)
     float* hfin;     // (b, 1200)
+    unsigned long long* xbuf = nullptr;   // (b, 2 dirs, 2 parities, 300) 8-byte {h value, step tag} granules of the split recurrence (may be null)
 };
 // bf16 path (conv_bf16.hip): NHWC bf16 activations, fp32 accumulation on the bf16 matrix cores ----------------------
 hipError_t conv_bf16_init();
@@ -173,6 +174,10 @@ hipError_t launch_softmax_pool_bf16(const void* heat, int hc, const void* featA,
                                     int P, hipStream_t s);
 
 // C[M][N] = A[M][K] . B[N][K]^T + bias[N] on the fp32 matrix cores (row-major, K % 4 == 0, 16-byte aligned rows).
+// split-K partial sums of few-row GEMMs live in scratch lent by the caller (kGemmWsFloats floats are always enough: a GEMM only splits
+// while M*N < 128 tiles of 64x64, and into at most 16 slices); without it the launcher falls back to hipMallocAsync.
+constexpr size_t kGemmWsFloats = (size_t)16 * 128 * 4096;
+void set_gemm_workspace(float* ws, size_t floats);
 hipError_t launch_gemm_nt_bias(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int ldc, hipStream_t s);
 
 // TSAttnBlock (attention_utils.py:219-270) weights, reference layouts: Linear weights (out, in); jw1 (64,128,24), jw2 (128,64,24).
@@ -184,6 +189,18 @@ struct TsAttnWeights {
 size_t tsattn_ws_floats(int b, int n);
 // x (b,n,3072) index c*24+j, xs (b,n,3200) index c*25+t -> y (b,n,3072); ws: tsattn_ws_floats(b, n) floats of scratch.
 hipError_t launch_tsattn(const float* x, const float* xs, const TsAttnWeights& w, float* ws, float* y, int b, int n, hipStream_t s);
+
+// FeatCorrector (feature_correction.py:104-157) pieces around the GRU and the attention block; BatchNorm1d folded to scale / shift at load.
+struct FeatCorrWeights {
+    const float *t0_w, *t0_b, *t3_w, *t3_b;      // gfeat_mpl_t: (1536,7), (1536), (3072,1536), (3072)
+    const float *s0_w, *s0_b, *s3_w, *s3_b;      // gfeat_mpl_s: (64,7), (64), (128,64), (128)
+    const float *bn_scale, *bn_shift;            // bn_in   (3072)
+    const float *bns_scale, *bns_shift;          // bn_in_s (3200)
+};
+size_t featcorr_ws_floats(int b, int n);
+hipError_t launch_gait_cparams(const float* cam, int cam_ld, const float* bbox, const float* cimg, float* cparams, int M, hipStream_t s);
+hipError_t launch_featcorr(const float* x, const float* avg, const float* phase, const FeatCorrWeights& w, const TsAttnWeights& tw, float* ws, float* out,
+                           int b, int n, hipStream_t s);
 
 hipError_t launch_gru(const float* x, const float* cparams, GruWeights w, GruWorkspace ws, float* y, float* phase,
                       float* xc, int b, int T, hipStream_t s);

@@ -7,9 +7,10 @@ in libgrnet_hip.so on the MI355X.  PyTorch is used only as the tensor container 
 for the current HIP stream and for reading checkpoints.
 
 Differences from the reference that are deliberate: no ``sys.exit`` on a missing PARE
-checkpoint (weights arrive through ``load_state_dict`` / ``load_pare_dict``), ``torch.load`` uses
-``map_location='cpu'``, and ``use_gait_feat=True`` raises (the reference's FeatCorrector cannot be
-constructed as shipped, feature_correction.py:40-62).
+checkpoint (weights arrive through ``load_state_dict`` / ``load_pare_dict``) and ``torch.load`` uses
+``map_location='cpu'``.  ``use_gait_feat=True`` runs the temporal branch of ``grnet.py:154-173`` with the
+names the reference's FeatCorrector leaves undefined bound as DESIGN.md records (feature_correction.py:40-62,144);
+``featcorr`` must describe the one configuration the class can run in (configs/config_grnet.yaml).
 """
 import ctypes as C
 import logging
@@ -46,9 +47,14 @@ class GRNet:
                 or backbone != 'hrnet_w32' or focal_length != 5000. or img_res != 224:
             raise ValueError("the HIP path implements the reference's fixed configuration "
                              "(24 joints, hrnet_w32 -> 480 features, PARE 128/64, f=5000, 224 px)")
-        if use_gait_feat:
-            raise NotImplementedError("use_gait_feat=True: the reference's FeatCorrector is not constructible "
-                                      "(feature_correction.py:40-62); use BidirectionalModel for the GRU")
+        self.use_gait_feat = bool(use_gait_feat)
+        if use_gait_feat and featcorr is not None:
+            want = dict(AVG_DIM=3, ESTIM_PHASE=True, NUM_LAYERS=1, H_SIZE=1024, NUM_HEADS=4, USE_JWFF=True)
+            get = (lambda k: featcorr[k]) if isinstance(featcorr, dict) else (lambda k: getattr(featcorr, k))
+            got = {k: get(k) for k in want}
+            if got != want:
+                raise ValueError(f"MODEL.FEAT_CORR {got}: the HIP path implements configs/config_grnet.yaml's {want} -- the only "
+                                 "configuration in which FeatCorrector's reshapes are consistent (feature_correction.py:92,144)")
         self._lib = _lib.load()
         self.max_frames = int(max_frames)
         self.device = torch.device("cuda", device_id)
@@ -112,7 +118,7 @@ class GRNet:
                     smpl[name] = v
                 elif name not in _TOLERATED_SMPL_KEYS:
                     unexpected.append(k)
-            elif k in spec or k.startswith(("pfeat_corrector.featnet.", "gru.", "pfeat_corrector.featTencoder.0.", "tsattn.")):
+            elif k in spec or k.startswith(("pfeat_corrector.", "gru.", "tsattn.")):
                 want = spec.get(k)
                 if want is not None and tuple(np.shape(v)) != tuple(want[0]):
                     raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(np.shape(v))} vs model {tuple(want[0])}")
@@ -167,6 +173,13 @@ class GRNet:
             raise ValueError(f"expected frames of shape (3,224,224), got {(nc, h, w)}")
         if J_regressor is not None:
             raise NotImplementedError("J_regressor override (evaluation-only, pare.py:70-76) is outside the inference path")
+        if self.use_gait_feat:
+            assert (bbox is not None) and (cimg is not None)                     # grnet.py:133
+            if bbox.dim() == 2:
+                bbox = bbox.unsqueeze(0)
+            if cimg.dim() == 2:
+                cimg = cimg.unsqueeze(0)
+            extras = tuple(extras) + tuple(k for k in ("point_local_feat", "cam_shape_feats") if k not in extras)
         if not features.is_cuda:
             raise RuntimeError("frames must live in HBM (features.to('cuda')); the HIP path has no CPU fallback")
         if features.device != self.device:
@@ -197,9 +210,41 @@ class GRNet:
                "rotmat": out["rotmat"].reshape(batch_size, seqlen, 24, 3, 3)}
         for k in extras:
             res[k] = out[k]
+        if self.use_gait_feat:                                 # grnet.py:154-173: FeatCorrector, second head pass, regressor
+            g = self.gait_correct(out["point_local_feat"], out["cam_shape_feats"], out["theta"], bbox, cimg, batch_size, seqlen)
+            for k in ("theta", "verts", "kp_2d", "kp_3d", "rotmat"):
+                res[k] = g[k].reshape(res[k].shape)
+            res["pred_avg"], res["pred_phase"] = g["pred_avg"], g["pred_phase"]
+            res["pred_cparam"] = g["pred_cparam"]
+            res["point_local_feat"] = g["point_local_feat"]
         return [res]
 
     __call__ = forward
+
+    def gait_correct(self, point_local_feat, cam_shape_feats, theta_or_cam, bbox, cimg, b, t):
+        """grnet.py:154-173 on the first pass's results for whole clips: (b*t,128,24), (b*t,64,24), theta (b*t,85) or pred_cam
+        (b*t,3), bbox (b,t,4), cimg (b,t,2) -> dict(theta, verts, kp_2d, kp_3d, rotmat, pred_avg (b,3), pred_phase (b,t,4),
+        pred_cparam (b*t,3), point_local_feat (b*t,128,24) corrected)."""
+        self.finalize()
+        dev, m = self.device, b * t
+        f = lambda x, *shape: x.to(dev, torch.float32).reshape(*shape).contiguous()
+        plf, csf = f(point_local_feat, m, 128, 24), f(cam_shape_feats, m, 64, 24)
+        cam = f(theta_or_cam, m, -1)
+        bb, ci = f(bbox, m, 4), f(cimg, m, 2)
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        out = {"theta": new(m, 85), "verts": new(m, 6890, 3), "kp_2d": new(m, 29, 2), "kp_3d": new(m, 29, 3), "rotmat": new(m, 24, 3, 3)}
+        gait = {"pred_avg": new(b, 3), "pred_phase": new(b, t, 4), "pred_cparam": new(m, 3), "point_local_feat": new(m, 128, 24)}
+        o, g = _lib.Outputs(), _lib.GaitOutputs()
+        for k, v in out.items():
+            setattr(o, k, v.data_ptr())
+        for k, v in gait.items():
+            setattr(g, k, v.data_ptr())
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        rc = self._lib.grnet_gait_correct(self._h, plf.data_ptr(), csf.data_ptr(), cam.data_ptr(), cam.shape[1], bb.data_ptr(), ci.data_ptr(),
+                                          b, t, C.byref(o), C.byref(g), stream)
+        _lib.check(self._lib, self._h, rc, "grnet_gait_correct")
+        out.update(gait)
+        return out
 
     def tune(self, n_frames, level=1, cache=None):
         """Measure-and-pick launch configurations for calls of ``n_frames`` frames (see grnet_tune).
@@ -416,11 +461,16 @@ class GRNet:
             pass
 
 
-def build_synthetic_model(max_frames=64, device_id=0, with_gru=True, with_tsattn=False, dtype="f32"):
-    """GRNet with the seed-defined weights / SMPL tables of synth.py (no checkpoint exists offline)."""
+def build_synthetic_model(max_frames=64, device_id=0, with_gru=True, with_tsattn=False, dtype="f32", use_gait_feat=False):
+    """GRNet with the seed-defined weights / SMPL tables of synth.py (no checkpoint exists offline).  use_gait_feat: the whole
+    pose-feature corrector under its checkpoint keys (pfeat_corrector.*: GRU, gait-token MLPs, BatchNorm1d, attention block)."""
     from . import synth
-    m = GRNet(max_frames=max_frames, device_id=device_id, dtype=dtype)
+    m = GRNet(max_frames=max_frames, device_id=device_id, dtype=dtype, use_gait_feat=use_gait_feat,
+              featcorr=dict(AVG_DIM=3, ESTIM_PHASE=True, NUM_LAYERS=1, H_SIZE=1024, NUM_HEADS=4, USE_JWFF=True) if use_gait_feat else None)
     sd = synth.make_state_dict()
+    if use_gait_feat:
+        sd.update(synth.make_featcorr_state_dict())
+        with_gru = with_tsattn = False
     if with_gru:
         sd.update({"gru." + k: v for k, v in synth.make_gru_state_dict().items()})
     if with_tsattn:
