@@ -1331,15 +1331,16 @@ struct grnet {
                      const grnet_outputs_t& o, const grnet_gait_outputs_t& g, hipStream_t s) {
         const size_t M = (size_t)b * T;
         const size_t gru_need = M * 3072 * 2 + 2 * M * 900 + 2 * M * 600 + (size_t)b * 1200 + (size_t)b * 2400 + 1024;
-        const size_t own = M * 3 + (size_t)b * 3 + M * 4 + M * 3072 + 64;
+        auto al = [](size_t f) { return (f + 63) & ~(size_t)63; };         // every sub-buffer starts 256-byte aligned (16-byte vector loads, 8-byte granules)
+        const size_t own = al(M * 3) + al((size_t)b * 3) + al(M * 4) + al(M * 3072);
         float* ws = nullptr;
         if (int rc = temporal_scratch(kGemmWsFloats + gru_need + featcorr_ws_floats(b, T) + own, &ws)) return rc;
         set_gemm_workspace(ws, kGemmWsFloats);
         float* p = ws + kGemmWsFloats;
-        float* cparams = g.pred_cparam ? g.pred_cparam : p;   p += M * 3;
-        float* avg = g.pred_avg ? g.pred_avg : p;             p += (size_t)b * 3;
-        float* phase = g.pred_phase ? g.pred_phase : p;       p += M * 4;
-        float* new_plf = g.point_local_feat ? g.point_local_feat : p;   p += M * 3072;
+        float* cparams = g.pred_cparam ? g.pred_cparam : p;   p += al(M * 3);
+        float* avg = g.pred_avg ? g.pred_avg : p;             p += al((size_t)b * 3);
+        float* phase = g.pred_phase ? g.pred_phase : p;       p += al(M * 4);
+        float* new_plf = g.point_local_feat ? g.point_local_feat : p;   p += al(M * 3072);
         GruWorkspace w;
         w.xin = p;
         float* xc_buf = p + M * 3072;
