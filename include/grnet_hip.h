@@ -178,6 +178,17 @@ int grnet_op_rotmat_to_aa(grnet_t* h, const float* rotmat_dev, int m, float* aa_
 int grnet_crop_normalise(grnet_t* h, const unsigned char* images_dev, int n, int height, int width, int one_image_for_all,
                          const float* bboxes_dev, float scale, int bgr, float* out_dev, void* stream);
 
+/* The same step with OpenCV's OWN arithmetic -- cv2.warpAffine(img, trans, (224,224), INTER_LINEAR, BORDER_CONSTANT) as
+ * generate_patch_image_cv calls it (lib/data_utils/img_utils.py:90-113): positions in 1/32-pixel fixed point from the inverse
+ * affine map (AB_BITS 10, INTER_BITS 5, round half to even), 15-bit blending weights, taps outside the image 0, then ToTensor +
+ * Normalize (:355-363).  inv_affine_dev: (n,6) float64, the inverse of `trans` per frame, which the HOST computes the way
+ * gen_trans_from_patch_cv (:54-88: float32 triangle points), cv2.getAffineTransform (6x6 solve in double) and warpAffine's own
+ * inversion do -- pipeline.cv_inverse_affine.  This is the default crop of demo.py / batch_generation.py; grnet_crop_normalise
+ * (exact bilinear in float) stays for A/B.  cv2 is absent offline: agreement with a real OpenCV build is argued from its source
+ * (DESIGN.md), the uint8 patch is bit-identical to the oracle's restatement of the same arithmetic. */
+int grnet_crop_normalise_cv(grnet_t* h, const unsigned char* images_dev, int n, int height, int width, int one_image_for_all,
+                            const double* inv_affine_dev, int bgr, float* out_dev, void* stream);
+
 /* Copy a named intermediate of the LAST forward (first n_frames images) into out_dev as a dense
  * (n,C,H,W) tensor; shape_out[3] receives C,H,W (out_dev may be NULL to query the shape).  Names:
  * stem_conv1, stem_conv2, layer1, stage{2,3,4}.{branch}, up{2,3,4}.{layer}.{bilinear,conv}.

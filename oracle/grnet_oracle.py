@@ -497,6 +497,48 @@ def crop_normalise(img_u8, bbox, scale=1.0, crop=224):
     return np.ascontiguousarray(((val - IMAGENET_MEAN) / IMAGENET_STD).transpose(2, 0, 1)).astype(np.float32)
 
 
+def cv_round(v):
+    """cvRound / saturate_cast<int>(double): round half to even (lrint in the default rounding mode)."""
+    return np.rint(np.asarray(v, np.float64)).astype(np.int64)
+
+
+def warp_affine_u8(img_u8, inv_m, size=224):
+    """cv2.warpAffine(img, M, (size,size), flags=INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=0) for an 8-bit image, given
+    the INVERSE map `inv_m` (6 doubles) that warpAffine derives from M.  OpenCV 4.1.2 imgwarp.cpp restated (third-party source, absent
+    offline -- restated from its published algorithm): WarpAffineInvoker computes 1/32-pixel fixed-point positions (AB_BITS = 10,
+    INTER_BITS = 5, round_delta = 16), remapBilinear blends the four taps with the 15-bit table of initInterTab2D and
+    FixedPtCast<int, uchar, 15>.  Returns the uint8 patch (size,size,C)."""
+    img = np.asarray(img_u8)
+    H, W = img.shape[:2]
+    m0, m1, m2, m3, m4, m5 = [float(v) for v in inv_m]
+    x = np.arange(size)
+    adelta, bdelta = cv_round(m0 * x * 1024.0), cv_round(m3 * x * 1024.0)
+    X0 = cv_round((m1 * x + m2) * 1024.0) + 16               # indexed by the row y
+    Y0 = cv_round((m4 * x + m5) * 1024.0) + 16
+    X = (X0[:, None] + adelta[None, :]) >> 5
+    Y = (Y0[:, None] + bdelta[None, :]) >> 5
+    sx, sy = np.clip(X >> 5, -32768, 32767), np.clip(Y >> 5, -32768, 32767)
+    ax, ay = X & 31, Y & 31
+    pad = np.zeros((H + 2, W + 2) + img.shape[2:], np.int64)
+    pad[1:-1, 1:-1] = img
+
+    def tap(yy, xx):
+        ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)
+        v = pad[np.clip(yy + 1, 0, H + 1), np.clip(xx + 1, 0, W + 1)]
+        return v * ok[..., None]
+
+    w = [(32 - ax) * (32 - ay), ax * (32 - ay), (32 - ax) * ay, ax * ay]
+    acc = (tap(sy, sx) * w[0][..., None] + tap(sy, sx + 1) * w[1][..., None] + tap(sy + 1, sx) * w[2][..., None] +
+           tap(sy + 1, sx + 1) * w[3][..., None])
+    return ((acc * 32 + 16384) >> 15).astype(np.uint8)
+
+
+def crop_normalise_cv(img_u8, inv_m, crop=224):
+    """warp_affine_u8 + ToTensor + Normalize (img_utils.py:355-363): (3,crop,crop) float32."""
+    val = warp_affine_u8(img_u8, inv_m, crop).astype(np.float32) / np.float32(255.0)
+    return np.ascontiguousarray(((val - IMAGENET_MEAN) / IMAGENET_STD).transpose(2, 0, 1)).astype(np.float32)
+
+
 # ----------------------------------------------------------------------------- temporal/spatial attention block (row f2)
 def layer_normalization(z, gamma, beta, eps=1e-6):
     """The reference's own LayerNormalization (attention_utils.py:10-27): UNBIASED std and (std + eps), not nn.LayerNorm."""

@@ -247,13 +247,37 @@ def test_schedules_and_tuning_agree(pkg):
     m.close()
 
 
+def test_crop_normalise_cv_kernel_is_bit_exact(model, oracle, pkg):
+    """Row f1 with OpenCV's fixed-point warpAffine arithmetic (the default crop): integer arithmetic end to end, so the GPU patch
+    equals the oracle's restatement BIT FOR BIT -- boxes inside, across and outside the image, sub-pixel centres, odd sizes."""
+    g = np.random.Generator(np.random.Philox(key=[4, 4]))
+    imgs = g.integers(0, 256, (5, 270, 480, 3), dtype=np.uint8)
+    boxes = np.array([[240.0, 135.0, 200.0, 200.0], [20.5, 30.25, 150.0, 150.0], [470.3, 260.9, 90.0, 90.0],
+                      [233.33, 101.77, 333.3, 333.3], [-40.0, 400.0, 120.0, 120.0]], np.float32)
+    for scale in (1.0, 1.1):
+        got = model.crop_normalise(torch.from_numpy(imgs).cuda(), torch.from_numpy(boxes), scale=scale).cpu().numpy()
+        inv = pkg.pipeline.cv_inverse_affine(boxes, scale)
+        for i in range(5):
+            ref = oracle.crop_normalise_cv(imgs[i], inv[i])
+            assert np.array_equal(got[i], ref), (scale, i, np.abs(got[i] - ref).max())
+    assert np.all(got[4] == got[4][:, :1, :1])                                  # entirely outside the image: the normalised zero border
+    one = model.crop_normalise(torch.from_numpy(imgs[2]).cuda(), torch.from_numpy(boxes), scale=1.1).cpu().numpy()
+    for i in range(5):
+        assert np.array_equal(one[i], oracle.crop_normalise_cv(imgs[2], inv[i]))
+    bgr = model.crop_normalise(torch.from_numpy(imgs[:1, :, :, ::-1].copy()).cuda(), torch.from_numpy(boxes[:1]), scale=1.1, bgr=True).cpu().numpy()
+    assert np.array_equal(bgr[0], got[0])
+    # the two crops (OpenCV's fixed point vs exact bilinear) differ by position quantisation only: a few grey levels at most
+    ideal = model.crop_normalise(torch.from_numpy(imgs).cuda(), torch.from_numpy(boxes), scale=1.1, mode="ideal").cpu().numpy()
+    assert np.abs(ideal[:4] - got[:4]).max() < 12.0 / 255 / 0.224 and np.abs(ideal[:4] - got[:4]).mean() < 1.5 / 255 / 0.224
+
+
 def test_crop_normalise_kernel(model, oracle):
     """Row f1: uint8 frame + box -> normalised 224x224 crop on the GPU vs the numpy restatement."""
     g = np.random.Generator(np.random.Philox(key=[3, 3]))
     imgs = g.integers(0, 256, (3, 180, 320, 3), dtype=np.uint8)
     boxes = np.array([[160.0, 90.0, 150.0, 150.0], [20.5, 30.25, 200.0, 120.0], [300.0, 170.0, 90.0, 260.0]], np.float32)
-    got = model.crop_normalise(torch.from_numpy(imgs).cuda(), torch.from_numpy(boxes), scale=1.1).cpu().numpy()
-    one = model.crop_normalise(torch.from_numpy(imgs[0]).cuda(), torch.from_numpy(boxes), scale=1.1).cpu().numpy()
+    got = model.crop_normalise(torch.from_numpy(imgs).cuda(), torch.from_numpy(boxes), scale=1.1, mode="ideal").cpu().numpy()
+    one = model.crop_normalise(torch.from_numpy(imgs[0]).cuda(), torch.from_numpy(boxes), scale=1.1, mode="ideal").cpu().numpy()
     lsb = 1.0 / 255 / 0.224                                      # one grey level after normalisation
     for i in range(3):
         ref = oracle.crop_normalise(imgs[i], boxes[i], scale=1.1)
@@ -262,7 +286,7 @@ def test_crop_normalise_kernel(model, oracle):
         ref0 = oracle.crop_normalise(imgs[0], boxes[i], scale=1.1)
         assert np.abs(one[i] - ref0).max() <= lsb * 1.01
     bgr = model.crop_normalise(torch.from_numpy(imgs[:1, :, :, ::-1].copy()).cuda(), torch.from_numpy(boxes[:1]), scale=1.1,
-                               bgr=True).cpu().numpy()
+                               bgr=True, mode="ideal").cpu().numpy()
     assert np.array_equal(bgr[0], got[0])
 
 

@@ -190,3 +190,58 @@ def test_gait_branch_matches_reference(pkg, oracle, synth_weights, synth_smpl):
     # the corrector does change the pose: the branch is not a no-op on these weights
     first = out["first_pass"]
     assert rel_err(out["theta"][..., 3:75], first["theta"][..., 3:75]) > 1e-2
+
+
+# ----------------------------------------------------------------------------- row f1: OpenCV's warpAffine arithmetic, known answers
+def _cv_crop(oracle, pkg, img, box, scale=1.0):
+    inv = pkg.pipeline.cv_inverse_affine(np.asarray([box]), scale)[0]
+    return oracle.warp_affine_u8(img, inv), inv
+
+
+def test_cv_crop_known_answers(oracle, pkg):
+    """The restated cv2.warpAffine(INTER_LINEAR, BORDER_CONSTANT) on cases whose result is known without running OpenCV: the
+    identity, integer translations (with the zero border), exact 2:1 decimation, the half-pixel blend (S0 + S1 + 1) >> 1 of the
+    15-bit table, and the snap of positions to the nearest 1/32 pixel."""
+    g = np.random.Generator(np.random.Philox(key=[41, 41]))
+    img = g.integers(0, 256, (224, 224, 3), dtype=np.uint8)
+    out, inv = _cv_crop(oracle, pkg, img, [112.0, 112.0, 224.0, 224.0])
+    assert np.allclose(inv, [1, 0, 0, 0, 1, 0], atol=1e-12) and np.array_equal(out, img)
+    big = g.integers(0, 256, (300, 400, 3), dtype=np.uint8)
+    out, _ = _cv_crop(oracle, pkg, big, [150.0, 120.0, 224.0, 224.0])
+    assert np.array_equal(out, big[8:232, 38:262])
+    out, _ = _cv_crop(oracle, pkg, big, [10.0, 290.0, 224.0, 224.0])              # mostly outside: constant border 0
+    want = np.zeros((224, 224, 3), np.uint8)
+    want[:122, 102:] = big[178:300, 0:122]
+    assert np.array_equal(out, want)
+    out, _ = _cv_crop(oracle, pkg, big, [200.0, 150.0, 448.0, 448.0])             # x_src = 2 (x - 112) + 200: pure picks, zero outside
+    ys, xs = 2 * (np.arange(224) - 112) + 150, 2 * (np.arange(224) - 112) + 200
+    want = np.zeros((224, 224, 3), np.uint8)
+    oky, okx = (ys >= 0) & (ys < 300), (xs >= 0) & (xs < 400)
+    want[np.ix_(oky, okx)] = big[np.ix_(ys[oky], xs[okx])]
+    assert np.array_equal(out, want)
+    out, _ = _cv_crop(oracle, pkg, big, [200.0, 150.0, 112.0, 112.0])             # x_src = (x - 112)/2 + 200: odd x sits on .5
+    a = big[150 + (np.arange(0, 224, 2) - 112) // 2][:, 200 + (np.arange(1, 224, 2) - 113) // 2].astype(np.int32)
+    b = big[150 + (np.arange(0, 224, 2) - 112) // 2][:, 201 + (np.arange(1, 224, 2) - 113) // 2].astype(np.int32)
+    assert np.array_equal(out[0::2, 1::2], ((a + b + 1) >> 1).astype(np.uint8))
+    # positions snap to 1/32 pixel: a shift of 0.01 px is the integer translation, 0.02 px is 1/32 of the way to the neighbour
+    base, _ = _cv_crop(oracle, pkg, big, [150.0, 120.0, 224.0, 224.0])
+    out, _ = _cv_crop(oracle, pkg, big, [150.01, 120.0, 224.0, 224.0])
+    assert np.array_equal(out, base)
+    out, _ = _cv_crop(oracle, pkg, big, [150.02, 120.0, 224.0, 224.0])
+    s0, s1 = big[8:232, 38:262].astype(np.int64), big[8:232, 39:263].astype(np.int64)
+    assert np.array_equal(out, (((s0 * 31 * 32 + s1 * 32) * 32 + 16384) >> 15).astype(np.uint8))
+
+
+def test_cv_inverse_affine_follows_the_reference_steps(pkg):
+    """float32 triangle points, double solve, warpAffine's inversion: for a square box the inverse map is the scale w*s/224 about
+    the centre, up to the float32 rounding of the points (that rounding is part of the reference's arithmetic and is kept)."""
+    boxes = np.array([[412.3, 233.7, 187.4, 187.4], [100.0, 50.0, 300.0, 300.0]], np.float64)
+    inv = pkg.pipeline.cv_inverse_affine(boxes, 1.1)
+    for (cx, cy, w, h), m in zip(boxes, inv):
+        a = w * 1.1 / 224.0
+        assert abs(m[0] - a) < 1e-6 * a and abs(m[4] - a) < 1e-6 * a and abs(m[1]) < 1e-9 and abs(m[3]) < 1e-9
+        assert abs(m[2] - (cx - 112 * a)) < 1e-4 and abs(m[5] - (cy - 112 * a)) < 1e-4
+    # float32 input boxes are used as float32 values (no hidden re-rounding of the centre)
+    b32 = boxes.astype(np.float32)
+    inv32 = pkg.pipeline.cv_inverse_affine(b32, 1.1)
+    assert np.allclose(inv32, pkg.pipeline.cv_inverse_affine(b32.astype(np.float64), 1.1), rtol=0, atol=0)

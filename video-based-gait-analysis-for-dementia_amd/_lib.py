@@ -51,6 +51,8 @@ EXPORTS = {
                                      C.c_void_p]),
     "grnet_crop_normalise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_int,
                                        C.c_void_p, C.c_void_p]),
+    "grnet_crop_normalise_cv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                          C.c_void_p]),
     "grnet_head_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Outputs), C.c_void_p]),
     "grnet_gait_correct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                      C.POINTER(Outputs), C.POINTER(GaitOutputs), C.c_void_p]),

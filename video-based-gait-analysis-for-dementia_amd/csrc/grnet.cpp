@@ -1780,6 +1780,16 @@ int grnet_crop_normalise(grnet_t* h, const unsigned char* images_dev, int n, int
     return 0;
 }
 
+int grnet_crop_normalise_cv(grnet_t* h, const unsigned char* images_dev, int n, int height, int width, int one_image_for_all,
+                            const double* inv_affine_dev, int bgr, float* out_dev, void* stream) {
+    if (!h || !images_dev || !inv_affine_dev || !out_dev || n < 1 || height < 1 || width < 1) return GRNET_EINVAL;
+    DeviceGuard guard(h->device);
+    hipError_t e = launch_crop_normalise_cv(images_dev, height, width, one_image_for_all ? 0 : 1, inv_affine_dev, bgr, out_dev, n,
+                                            static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("crop_normalise_cv: ") + hipGetErrorString(e));
+    return 0;
+}
+
 const char* grnet_last_error(grnet_t* h) { return h ? h->err.c_str() : "null handle"; }
 
 void grnet_destroy(grnet_t* h) {

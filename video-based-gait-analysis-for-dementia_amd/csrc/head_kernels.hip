@@ -167,6 +167,51 @@ __global__ __launch_bounds__(256) void crop_normalise_kernel(const unsigned char
     }
 }
 
+// The same crop with OpenCV's own arithmetic (cv2.warpAffine, INTER_LINEAR, BORDER_CONSTANT 0, 8-bit source; OpenCV 4.1.2,
+// requirements.txt:8): the INVERSE affine map M (6 doubles per frame, computed on the host exactly as generate_patch_image_cv /
+// getAffineTransform / warpAffine's own inversion do) is evaluated in FIXED POINT --
+//   adelta[x] = cvRound(M0*x*1024), bdelta[x] = cvRound(M3*x*1024)                 (AB_BITS = 10, cvRound = round half to even)
+//   X0 = cvRound((M1*y + M2)*1024) + 16,  Y0 = cvRound((M4*y + M5)*1024) + 16       (round_delta = 1024/32/2)
+//   X = (X0 + adelta[x]) >> 5, Y = (Y0 + bdelta[x]) >> 5                            (INTER_BITS = 5: 1/32-pixel positions)
+//   sx = X >> 5, sy = Y >> 5 (saturated to int16), ax = X & 31, ay = Y & 31
+// -- and the four taps are blended with the 15-bit table weights 32*(32-ax)(32-ay) ... (they add up to 32768 exactly; the one
+// entry OpenCV patches, ax = ay = 0, yields the pixel itself either way), result = (sum + 16384) >> 15; taps outside the image are 0.
+// Integer arithmetic end to end: the uint8 patch is bit-identical to the oracle's.  cv2 itself is absent offline, so agreement
+// with a real OpenCV build is argued from its source, not measured.
+__device__ __forceinline__ int cv_round(double v) { return (int)__builtin_rint(v); }
+__global__ __launch_bounds__(256) void crop_normalise_cv_kernel(const unsigned char* __restrict__ img, int H, int W, int per_image,
+                                                                const double* __restrict__ inv_m, int bgr, float* __restrict__ out) {
+    const int n = blockIdx.y;
+    const unsigned char* src = img + (size_t)(per_image ? n : 0) * H * W * 3;
+    const double m0 = inv_m[n * 6 + 0], m1 = inv_m[n * 6 + 1], m2 = inv_m[n * 6 + 2];
+    const double m3 = inv_m[n * 6 + 3], m4 = inv_m[n * 6 + 4], m5 = inv_m[n * 6 + 5];
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 224 * 224; i += gridDim.x * 256) {
+        const int y = i / 224, x = i - y * 224;
+        const int X0 = cv_round((m1 * y + m2) * 1024.0) + 16, Y0 = cv_round((m4 * y + m5) * 1024.0) + 16;
+        const int X = (X0 + cv_round(m0 * x * 1024.0)) >> 5, Y = (Y0 + cv_round(m3 * x * 1024.0)) >> 5;
+        const int sx = min(max(X >> 5, -32768), 32767), sy = min(max(Y >> 5, -32768), 32767);
+        const int ax = X & 31, ay = Y & 31;
+        const int w00 = (32 - ax) * (32 - ay), w01 = ax * (32 - ay), w10 = (32 - ax) * ay, w11 = ax * ay;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int cs = bgr ? 2 - c : c;
+            auto px = [&](int yy, int xx) -> int {
+                return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (int)src[((size_t)yy * W + xx) * 3 + cs] : 0;
+            };
+            const int sum = px(sy, sx) * w00 + px(sy, sx + 1) * w01 + px(sy + 1, sx) * w10 + px(sy + 1, sx + 1) * w11;
+            const int val = (sum * 32 + 16384) >> 15;
+            out[((size_t)n * 3 + c) * (224 * 224) + i] = ((float)val / 255.f - mean[c]) / stdv[c];
+        }
+    }
+}
+
+hipError_t launch_crop_normalise_cv(const unsigned char* img, int H, int W, int per_image, const double* inv_m, int bgr, float* out, int N,
+                                    hipStream_t s) {
+    GRK_TRY(launch_k(crop_normalise_cv_kernel, dim3(49, N), dim3(256), 0, s, img, H, W, per_image, inv_m, bgr, out));
+    return hipSuccess;
+}
+
 hipError_t launch_crop_normalise(const unsigned char* img, int H, int W, int per_image, const float* bbox, float scale, int bgr,
                                  float* out, int N, hipStream_t s) {
     GRK_TRY(launch_k(crop_normalise_kernel, dim3(49, N), dim3(256), 0, s, img, H, W, per_image, bbox, scale, bgr, out));

@@ -108,6 +108,10 @@ hipError_t launch_bilinear2x(const float* in, float* out, int N, int C, int H, i
 hipError_t launch_crop_normalise(const unsigned char* img, int H, int W, int per_image, const float* bbox, float scale, int bgr,
                                  float* out, int N, hipStream_t s);
 
+// the same with OpenCV's fixed-point warpAffine arithmetic; inv_m: (N,6) doubles, the inverse affine map of each frame
+hipError_t launch_crop_normalise_cv(const unsigned char* img, int H, int W, int per_image, const double* inv_m, int bgr, float* out, int N,
+                                    hipStream_t s);
+
 // PARE head tail ---------------------------------------------------------------------------
 // softmax over H*W of heat[:,1+j] and attention pooling of feat channels (keypoint_attention.py:42-48)
 // heat: (N,25,P) with channel 0 = background; featA (N,CA,P) -> outA (N,CA,24); featB (N,CB,P) -> outB (N,CB,24)

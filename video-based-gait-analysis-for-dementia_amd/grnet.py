@@ -324,19 +324,32 @@ class GRNet:
             _lib.check(self._lib, self._h, rc, "grnet_smpl_forward")
         return verts, kp3d, kp2d
 
-    def crop_normalise(self, images, bboxes, scale=1.0, bgr=False):
-        """uint8 frames (n,H,W,3) [or one (H,W,3) frame] + boxes (n,4) -> (n,3,224,224) normalised crops, on the GPU."""
+    def crop_normalise(self, images, bboxes, scale=1.0, bgr=False, mode="cv2"):
+        """uint8 frames (n,H,W,3) [or one (H,W,3) frame] + boxes (n,4) -> (n,3,224,224) normalised crops, on the GPU.
+        mode "cv2" (default): OpenCV's fixed-point warpAffine arithmetic (grnet_crop_normalise_cv; the inverse affine maps are
+        computed on the host as the reference's gen_trans_from_patch_cv / getAffineTransform / warpAffine do);
+        mode "ideal": exact bilinear sampling in float (grnet_crop_normalise), kept for A/B."""
         shared = images.dim() == 3
         if images.dtype != torch.uint8 or images.shape[-1] != 3 or not images.is_cuda:
             raise ValueError("images must be a uint8 CUDA tensor (n,H,W,3) or (H,W,3)")
         images = images.contiguous()
-        bb = bboxes.to(device=images.device, dtype=torch.float32).contiguous()
-        n = bb.shape[0]
-        if bb.shape != (n, 4) or (not shared and images.shape[0] != n):
+        bb_host = bboxes.detach().cpu().numpy() if torch.is_tensor(bboxes) else np.asarray(bboxes)
+        n = bb_host.shape[0]
+        if bb_host.shape != (n, 4) or (not shared and images.shape[0] != n):
             raise ValueError("bboxes must be (n,4) and match the number of frames")
         hgt, wid = images.shape[-3], images.shape[-2]
         out = torch.empty(n, 3, 224, 224, dtype=torch.float32, device=images.device)
         stream = C.c_void_p(torch.cuda.current_stream(images.device).cuda_stream)
+        if mode == "cv2":
+            from .pipeline import cv_inverse_affine
+            inv = torch.from_numpy(cv_inverse_affine(bb_host, scale)).to(images.device, non_blocking=True)
+            rc = self._lib.grnet_crop_normalise_cv(self._h, images.data_ptr(), n, hgt, wid, int(shared), inv.data_ptr(), int(bgr),
+                                                   out.data_ptr(), stream)
+            _lib.check(self._lib, self._h, rc, "grnet_crop_normalise_cv")
+            return out
+        if mode != "ideal":
+            raise ValueError("mode must be 'cv2' or 'ideal'")
+        bb = torch.as_tensor(bb_host).to(device=images.device, dtype=torch.float32).contiguous()
         rc = self._lib.grnet_crop_normalise(self._h, images.data_ptr(), n, hgt, wid, int(shared), bb.data_ptr(), float(scale),
                                             int(bgr), out.data_ptr(), stream)
         _lib.check(self._lib, self._h, rc, "grnet_crop_normalise")

@@ -142,6 +142,42 @@ def smooth_pose(model, pred_pose, pred_betas, min_cutoff=0.004, beta=0.7, kinect
     return verts, pose_hat.reshape(T, 72), joints
 
 
+# ----------------------------------------------------------------------------- the crop's affine map, as the reference forms it
+def cv_inverse_affine(bboxes, scale=1.0, crop_size=224):
+    """(n,4) boxes [cx,cy,w,h] -> (n,6) float64: the INVERSE affine map cv2.warpAffine evaluates for the crop of
+    get_single_image_crop_demo (img_utils.py:252-285 -> generate_patch_image_cv :90-113 with bb_width == bb_height handled like any
+    box: the reference's own boxes are square -> gen_trans_from_patch_cv :54-88, rot = 0).  Steps restated:
+      * src_w = w*scale, src_h = h*scale in double (numpy 1.18 promotes float32-scalar * Python float to float64);
+      * the two triangles as FLOAT32 points: centre, centre + (0, src_h/2), centre + (src_w/2, 0) and (112,112), (112,224), (224,112);
+      * cv2.getAffineTransform: the 6x6 system of the three point pairs solved in double (LU with partial pivoting);
+      * warpAffine (no WARP_INVERSE_MAP) inverts the 2x3 matrix in double: D = 1/(M0*M4 - M1*M3), ...
+    The LU's last-bit rounding can differ between LAPACK and OpenCV; it matters only where cvRound(x*1024) sits on an exact tie."""
+    bboxes = np.asarray(bboxes)
+    out = np.empty((bboxes.shape[0], 6), np.float64)
+    half = np.float32(crop_size * 0.5)
+    dst = np.array([[half, half], [half, half + half], [half + half, half]], np.float32)
+    for i, (cx, cy, w, h) in enumerate(bboxes):
+        src_w, src_h = float(w) * float(scale), float(h) * float(scale)
+        centre = np.array([cx, cy], np.float64)
+        src = np.zeros((3, 2), np.float32)
+        src[0] = centre
+        src[1] = centre + np.array([0, src_h * 0.5], np.float32)
+        src[2] = centre + np.array([src_w * 0.5, 0], np.float32)
+        a = np.zeros((6, 6), np.float64)
+        b = np.zeros(6, np.float64)
+        for k in range(3):
+            a[2 * k, 0:2], a[2 * k, 2] = src[k], 1.0
+            a[2 * k + 1, 3:5], a[2 * k + 1, 5] = src[k], 1.0
+            b[2 * k], b[2 * k + 1] = dst[k]
+        m = np.linalg.solve(a, b)                              # [M0 M1 M2 M3 M4 M5]
+        d = m[0] * m[4] - m[1] * m[3]
+        d = 1.0 / d if d != 0 else 0.0
+        a11, a22 = m[4] * d, m[0] * d
+        m0, m1, m3, m4 = a11, m[1] * -d, m[3] * -d, a22
+        out[i] = (m0, m1, -m0 * m[2] - m1 * m[5], m3, m4, -m3 * m[2] - m4 * m[5])
+    return out
+
+
 # ----------------------------------------------------------------------------- frame sources
 def crop_and_normalise(img_rgb_u8, bbox, scale=1.0, crop_size=224):
     """One frame: uint8 HxWx3 RGB + [cx,cy,w,h] -> float32 (3,224,224), ImageNet-normalised.
