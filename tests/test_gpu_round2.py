@@ -235,3 +235,38 @@ def test_feature_corrector_and_gait_branch_match_reference_golden(pkg, oracle, s
     m2.close()
     with pytest.raises(ValueError):
         pkg.GRNet(max_frames=1, use_gait_feat=True, featcorr=dict(AVG_DIM=3, ESTIM_PHASE=True, NUM_LAYERS=2, H_SIZE=1024, NUM_HEADS=4, USE_JWFF=True))
+
+
+def test_frame_shards_gather_then_temporal_branch_equals_one_process(pkg):
+    """BASELINE configs[3]'s data flow on one GPU: 3 'ranks' run the per-frame path on their shard_range() of a 2-clip batch, the
+    packed records (theta, kp, point_local_feat, cam_shape_feats) are reassembled exactly as the all-gather delivers them, and the
+    temporal branch runs on the whole sequence -- same result as GRNet(use_gait_feat=True) in one process."""
+    h = pkg.harness
+    b, t, world = 1, 14, 3
+    n_total = b * t
+    m = pkg.build_synthetic_model(max_frames=8, use_gait_feat=True)
+    frames = torch.from_numpy(pkg.synth.make_frames(n_total)).cuda()
+    bbox, cimg = pkg.synth.make_gait_boxes(b, t)
+    bbox, cimg = torch.from_numpy(bbox).cuda(), torch.from_numpy(cimg).cuda()
+    whole = m(frames.reshape(b, t, 3, 224, 224), bbox=bbox, cimg=cimg)[-1]
+    per = -(-n_total // world)
+    blocks = []
+    m.use_gait_feat = False                                   # the ranks run the per-frame path only
+    for rank in range(world):
+        lo, hi = h.shard_range(n_total, world, rank)
+        pad = torch.zeros(per, 3, 224, 224, device="cuda")
+        pad[:hi - lo] = frames[lo:hi]
+        runner = h.ClipRunner(m, pad, use_graph=False, tune_level=0, record=h.POSE_RECORD_GAIT)
+        runner.step()
+        torch.cuda.synchronize()
+        blocks.append(runner.packed.clone())
+    m.use_gait_feat = True
+    gathered = torch.stack(blocks)                            # what all_gather_into_tensor(...).view(world, block) holds on every rank
+    seq = h.unpack_sequence(gathered, per, n_total, h.POSE_RECORD_GAIT)
+    assert seq["cam_shape_feats"].shape == (n_total, 64, 24)
+    got = h.temporal_after_gather(m, seq, bbox, cimg, b, t)
+    torch.cuda.synchronize()
+    for k in ("theta", "kp_3d", "verts", "rotmat"):
+        assert rel_err(got[k].cpu().numpy().reshape(whole[k].shape), whole[k].cpu().numpy()) < 2e-5, k
+    assert rel_err(got["pred_phase"].cpu().numpy(), whole["pred_phase"].cpu().numpy()) < 2e-5
+    m.close()

@@ -735,6 +735,136 @@ __global__ __launch_bounds__(256) void conv_group_f32(const GroupArgs g) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Persistent per-XCD dataflow kernel for the HR stages (see kernels.h).  256 threads = the 4 split-K waves of splitk_body.
+__device__ __forceinline__ int xcc_id() {
+    int v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 7;
+}
+
+// fuse output 0 of an HR module: out = relu(x0 + up2(t1) + up4(t2) + up8(t3)) (hrnet.py:258-265) for R rows of one image
+__device__ __forceinline__ void df_sum_tile(const ConvArgs& a, int img, int ty) {
+    const int HW = a.Ho * a.Wo, pix0 = ty * a.R * a.Wo, npx = min(a.R * a.Wo, HW - pix0);
+    const int units = a.Cout * (npx >> 2);
+    for (int u = threadIdx.x; u < units; u += 256) {
+        const int c = u / (npx >> 2), pix = pix0 + 4 * (u - c * (npx >> 2));
+        f32x4 v = *reinterpret_cast<const f32x4*>(a.in + ((size_t)img * a.in_ctot + a.in_coff + c) * HW + pix);
+#pragma unroll
+        for (int k = 0; k < kMaxAdd; ++k) {
+            if (k >= a.n_add) break;
+            const int sh = a.add_shift[k], hs = a.Ho >> sh, ws = a.Wo >> sh;
+            const float* ap = a.add[k] + ((size_t)img * a.add_ctot[k] + a.add_coff[k] + c) * (hs * ws);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int y = (pix + r) / a.Wo, x = (pix + r) - y * a.Wo;
+                v[r] += ap[(y >> sh) * ws + (x >> sh)];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        *reinterpret_cast<f32x4*>(a.out + ((size_t)img * a.out_ctot + a.out_coff + c) * HW + pix) = v;
+    }
+}
+
+__device__ __forceinline__ void df_run_conv(const ConvArgs& a, int variant, int bx, int by, float* smem) {
+    switch (variant) {                                       // (ks, stride) x {rows 7x1, rows 4x1, planes 4x1}
+        case 0: splitk_body<1, 3, 1, 7, 1, 4>(a, bx, by, smem); break;
+        case 1: splitk_body<1, 3, 1, 4, 1, 4>(a, bx, by, smem); break;
+        case 2: splitk_body<2, 3, 1, 4, 1, 4>(a, bx, by, smem); break;
+        case 3: splitk_body<1, 3, 2, 7, 1, 4>(a, bx, by, smem); break;
+        case 4: splitk_body<1, 3, 2, 4, 1, 4>(a, bx, by, smem); break;
+        case 5: splitk_body<2, 3, 2, 4, 1, 4>(a, bx, by, smem); break;
+        case 6: splitk_body<1, 1, 1, 7, 1, 4>(a, bx, by, smem); break;
+        case 7: splitk_body<1, 1, 1, 4, 1, 4>(a, bx, by, smem); break;
+        default: splitk_body<2, 1, 1, 4, 1, 4>(a, bx, by, smem); break;
+    }
+}
+
+// Run the queue of XCD `q`.  fence = true when this workgroup may sit on another XCD than the queue's producers / consumers.
+__device__ __forceinline__ void df_run_queue(const DfParams& p, int q, bool fence, float* smem, int* s_task) {
+    unsigned* ctr = p.counters + (size_t)q * p.ctr_stride;
+    unsigned* done = ctr + 16;
+    const int first_img = q * p.ipx, img_end = min(p.n, first_img + p.ipx), nimg = img_end - first_img;
+    if (nimg <= 0) return;
+    const int nblk = (nimg + p.B - 1) / p.B, total = nblk * p.tasks_per_blk;
+    for (;;) {
+        if (threadIdx.x == 0) *s_task = (int)atomicAdd(&ctr[0], 1u);
+        __syncthreads();
+        const int t = __builtin_amdgcn_readfirstlane(*s_task);
+        if (t >= total) break;
+        const int blk = t / p.tasks_per_blk, ti = t - blk * p.tasks_per_blk;
+        const DfTask task = p.tasks[ti];
+        const int ci = __builtin_amdgcn_readfirstlane((int)task.conv);
+        const int il = __builtin_amdgcn_readfirstlane((int)task.img);
+        const int img = first_img + blk * p.B + il;
+        if (img < img_end) {
+            const DfConv& c = p.convs[ci];
+            if ((int)threadIdx.x < c.ndeps) {                  // wait for the producers of this image (they are earlier in the queue: already popped)
+                const unsigned* d = done + ((size_t)blk * p.nconv + c.dep[threadIdx.x]) * p.B + il;
+                const unsigned need = (unsigned)c.need[threadIdx.x];
+                while (__hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(1);
+                if (fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            const int ty = __builtin_amdgcn_readfirstlane((int)task.ty), by = __builtin_amdgcn_readfirstlane((int)task.by);
+            if (c.variant < 0) df_sum_tile(c.a, img, ty);
+            else df_run_conv(c.a, c.variant, img * c.a.tiles_y + ty, by, smem);
+            // every wave's stores have left (vmcnt 0) before the workgroup's barrier; then ONE increment publishes the task.  The
+            // consumers are on this XCD: its L2 is the coherence point (a CU's L1 holds no line of a tensor before that tensor is complete)
+            if (fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(done + ((size_t)blk * p.nconv + ci) * p.B + il, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __syncthreads();                                   // s_task is re-written right away: keep the barrier count equal on both paths
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void hr_dataflow_f32(const DfParams p) {
+    extern __shared__ __align__(16) float smem[];
+    __shared__ int s_task;
+    __shared__ int s_flag;
+    const int xcd = xcc_id();
+    // census + handshake (sequentially consistent device-scope read-modify-writes): an own worker registers, THEN reads the queue's
+    // "foreign workers present" flag; a foreign worker raises the flag, THEN re-reads the census.  At least one sees the other, so a
+    // queue is never run by unfenced own workers and fenced foreign workers that do not know of each other.
+    if (threadIdx.x == 0) {
+        unsigned* ctr = p.counters + (size_t)xcd * p.ctr_stride;
+        atomicAdd(&ctr[1], 1u);
+        s_flag = (int)atomicOr(&ctr[2], 0u);
+    }
+    __syncthreads();
+    const bool own_fenced = p.fence != 0 || s_flag != 0;
+    __syncthreads();
+    df_run_queue(p, xcd, own_fenced, smem, &s_task);
+    // Placement independence: an XCD that received no workgroup of this launch (the dispatcher promises nothing) still has a queue.
+    // Workgroups that finished their own queue take over queues whose census is still zero, with device-scope fences (correct from
+    // any XCD).  On the observed round-robin dispatch this loop finds nothing to do.
+    for (int q = 0; q < 8; ++q) {
+        if (q == xcd) continue;
+        if (threadIdx.x == 0) {
+            unsigned* ctr = p.counters + (size_t)q * p.ctr_stride;
+            int take = 0;
+            if (__hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                atomicOr(&ctr[2], 1u);
+                take = atomicAdd(&ctr[1], 0u) == 0u;
+            }
+            s_flag = take;
+        }
+        __syncthreads();
+        const bool take = s_flag != 0;
+        __syncthreads();
+        if (take) df_run_queue(p, q, true, smem, &s_task);
+    }
+}
+
+__global__ void df_probe_kernel(int* out) {
+    if (threadIdx.x == 0) atomicAdd(&out[xcc_id()], 1);
+}
+
 // ---------------------------------------------------------------------------------------------
 int conv_pick_tc(int Cout) { return Cout >= 64 ? 64 : 32; }
 
@@ -979,6 +1109,65 @@ hipError_t launch_conv_group(const ConvArgs* list, int n, hipStream_t s) {
     if (list[0].ks == 1) return launch_k(conv_group_f32<1, 1>, grid, dim3(256), lds, s, g);
     return list[0].stride == 1 ? launch_k(conv_group_f32<3, 1>, grid, dim3(256), lds, s, g)
                                : launch_k(conv_group_f32<3, 2>, grid, dim3(256), lds, s, g);
+}
+
+
+// ---- host side of the dataflow kernel ------------------------------------------------------------------------------------------
+int df_plan_conv(ConvArgs& a, size_t* lds_out) {
+    if (a.CoutPad % 16 != 0 || a.CinPad % kConvCK != 0) return -1;
+    int ksid;
+    if (a.ks == 3 && a.stride == 1) ksid = 0;
+    else if (a.ks == 3 && a.stride == 2) ksid = 1;
+    else if (a.ks == 1 && a.stride == 1) ksid = 2;
+    else return -1;
+    const int tps_cands[2] = {7, 4};
+    for (int tps : tps_cands) {
+        if (a.Wo > tps * 16) continue;
+        ConvArgs t = a;
+        plan_tile(t, tps, 1);
+        if (t.R < 1 || t.G != 1) continue;                     // a tile never spans two images: dependencies are per image
+        if (t.rows == 0) continue;                             // gather staging has no variant here
+        if (t.rows == 2 && tps != 4) continue;                 // planes mode exists for 4x1 tiles
+        if (tps == 4 && t.rows == 1 && a.Ho * a.Wo > 64 * 8 && false) continue;
+        const Cfg c{1, tps, 1, 4};
+        const size_t lds = lds_bytes(t, c);
+        if (lds > kMaxLds) continue;
+        // prefer 7x1 rows where the map is wide enough to fill it (56 and 28 pixel rows), 4x1 otherwise
+        if (tps == 7 && t.rows == 1 && (t.R * t.Wo) * 10 < 112 * 8) continue;      // < 80 % of the 112-pixel tile used
+        a = t;
+        a.TC = 16;
+        a.gx = a.tiles_y * a.groups;
+        a.gy = a.CoutPad / 16;
+        a.xcd = 0;
+        *lds_out = lds;
+        return ksid * 3 + (t.rows == 2 ? 2 : (tps == 7 ? 0 : 1));
+    }
+    return -1;
+}
+
+hipError_t launch_hr_dataflow(const DfParams& p, size_t lds, int wgs_per_xcd, hipStream_t s) {
+    static bool lds_set = false;
+    if (!lds_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hr_dataflow_f32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+        if (e != hipSuccess) return e;
+        lds_set = true;
+    }
+    return launch_k(hr_dataflow_f32, dim3(8 * wgs_per_xcd), dim3(256), lds, s, p);
+}
+
+hipError_t df_probe_xcc(int wgs_per_xcd, int* ok, hipStream_t s) {
+    int* d = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d), 8 * sizeof(int));
+    if (e != hipSuccess) return e;
+    int h[8] = {};
+    e = hipMemsetAsync(d, 0, sizeof(h), s);
+    if (e == hipSuccess) { hipLaunchKernelGGL(df_probe_kernel, dim3(8 * wgs_per_xcd), dim3(256), 0, s, d); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    hipFree(d);
+    *ok = 1;
+    for (int x = 0; x < 8; ++x) if (h[x] != wgs_per_xcd) *ok = 0;
+    return e;
 }
 
 const char* conv_dominant_kernel_name() { return "conv_mfma_f32 / conv_splitk_f32"; }

@@ -540,7 +540,7 @@ struct grnet {
         if ((rc = dev_alloc(&d_cam, n * 3))) return rc;
         if ((rc = dev_alloc(&d_rotmat, n * 216))) return rc;
         if ((rc = dev_alloc(&d_theta, n * 85))) return rc;
-        if ((rc = dev_alloc(&d_A, n * 288))) return rc;
+        if ((rc = dev_alloc(&d_A, n * kSmplWsFloatsPerFrame))) return rc;
         if ((rc = dev_alloc(&d_verts, n * 6890 * 3))) return rc;
         if ((rc = dev_alloc(&d_kp3d, n * 87))) return rc;
         if ((rc = dev_alloc(&d_kp2d, n * 58))) return rc;
@@ -1219,7 +1219,7 @@ struct grnet {
                     break;
                 case Op::SMPL:
                     HIP_TRY(launch_smpl(d_shape, rotmat, d_cam, smpl, d_A, verts, kp3d, kp2d, n, s));
-                    launches += 3;
+                    launches += 4;
                     break;
             }
             if (lanes && op.record) HIP_TRY(hipEventRecord(op_events[oi], s));
@@ -1477,11 +1477,57 @@ int grnet_load_smpl(grnet_t* h, const float* v_template, const float* shapedirs,
         return rc;
     };
     int rc;
-    if ((rc = up(v_template, (size_t)V * 3, &h->smpl.v_template))) return rc;
-    if ((rc = up(shapedirs, (size_t)V * 30, &h->smpl.shapedirs))) return rc;
-    if ((rc = up(posedirs, (size_t)207 * V * 3, &h->smpl.posedirs))) return rc;
+    {   // blend-shape table of the MFMA GEMM: [posedirs (207 rows) ; shapedirs^T (10) ; v_template (1) ; 0 0], row-major (220, 20670)
+        const size_t C = (size_t)V * 3;
+        std::vector<float> blend((size_t)kBlendK * C, 0.f);
+        memcpy(blend.data(), posedirs, (size_t)207 * C * sizeof(float));
+        for (size_t c = 0; c < C; ++c) {
+            for (int l = 0; l < 10; ++l) blend[(size_t)(207 + l) * C + c] = shapedirs[c * 10 + l];
+            blend[(size_t)217 * C + c] = v_template[c];
+        }
+        float* p = nullptr;
+        if ((rc = h->upload(blend, &p))) return rc;
+        h->smpl.blend = p;
+    }
+    {   // skinning weights as a padded (joint, weight) list per vertex: non-zero entries in ascending joint order
+        int kmax = 1;
+        for (int v = 0; v < V; ++v) {
+            int c = 0;
+            for (int j = 0; j < 24; ++j) c += lbs_weights[(size_t)v * 24 + j] != 0.f;
+            kmax = std::max(kmax, c);
+        }
+        std::vector<float> w((size_t)V * kmax, 0.f), idx_f((size_t)V * kmax);
+        int32_t* idx = reinterpret_cast<int32_t*>(idx_f.data());
+        for (int v = 0; v < V; ++v) {
+            int c = 0;
+            for (int j = 0; j < 24; ++j) {
+                const float wj = lbs_weights[(size_t)v * 24 + j];
+                if (wj != 0.f) { idx[(size_t)v * kmax + c] = j; w[(size_t)v * kmax + c] = wj; ++c; }
+            }
+            for (; c < kmax; ++c) idx[(size_t)v * kmax + c] = -1;
+        }
+        float* p = nullptr;
+        if ((rc = h->upload(w, &p))) return rc;
+        h->smpl.skin_w = p;
+        if ((rc = h->upload(idx_f, &p))) return rc;          // int32 payload moved as raw 4-byte words
+        h->smpl.skin_idx = reinterpret_cast<const int*>(p);
+        h->smpl.skin_k = kmax;
+    }
     if ((rc = up(lbs_weights, (size_t)V * 24, &h->smpl.lbs_weights))) return rc;
-    if ((rc = up(J_regressor_extra, (size_t)9 * V, &h->smpl.J_extra))) return rc;
+    {   // the one extra joint the path uses (smpl.py:117: JOINT_MAP 'Thorax (MPII)' = 50 -> row 5): sparse row
+        std::vector<float> w, idx_f;
+        for (int v = 0; v < V; ++v) {
+            const float x = J_regressor_extra[(size_t)5 * V + v];
+            if (x != 0.f) { w.push_back(x); int32_t i = v; float f; memcpy(&f, &i, 4); idx_f.push_back(f); }
+        }
+        h->smpl.thorax_n = (int)w.size();
+        if (w.empty()) { w.push_back(0.f); idx_f.push_back(0.f); }
+        float* p = nullptr;
+        if ((rc = h->upload(w, &p))) return rc;
+        h->smpl.thorax_w = p;
+        if ((rc = h->upload(idx_f, &p))) return rc;
+        h->smpl.thorax_idx = reinterpret_cast<const int*>(p);
+    }
     // the joint regressor is linear: apply it to the tables once, in fp64
     std::vector<float> Jt(72), Js(720);
     for (int j = 0; j < 24; ++j)

@@ -9,6 +9,7 @@ namespace grk {
 #define GRK_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return _e; } while (0)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -483,16 +484,22 @@ hipError_t launch_rotmat_to_aa(const float* R, float* aa, int m, hipStream_t s) 
 
 // ---------------------------------------------------------------------------------------------
 // SMPL linear blend skinning (published algorithm as implemented by smplx 0.1.26, SURVEY A.7;
-// reference call sites lib/models/smpl.py:108-130,157-162).
+// reference call sites lib/models/smpl.py:108-130,157-162), batched over the frames of a call.
 //   kernel 1 (one wave per frame): rest joints J = J_template + J_shapedirs.betas (the joint
 //     regressor is linear, so it is applied to the tables once at load), the 24-joint kinematic
-//     chain, skinning matrices A_j = G_j - [0 | G_j.J_j] as 3x4 rows, posed joints.
-//   kernel 2 (vertices): v_shaped, pose blend shapes, T_v = sum_j w_vj A_j, verts.
-//   kernel 3 (one block per frame): the 29 "spin2" joints (smpl.py:113-118) incl. the thorax row
+//     chain, skinning matrices A_j = G_j - [0 | G_j.J_j] as 3x4 rows, posed joints; and the frame's
+//     row of the blend-shape GEMM: [ (R_1..23 - I) (207) | betas (10) | 1 | 0 0 ].
+//   kernel 2 (fp32 matrix cores): v_posed (N x 20670) = rows (N x 220) . blend (220 x 20670), where
+//     blend = [posedirs ; shapedirs^T ; v_template ; 0] is assembled once at load -- pose blend shapes,
+//     shape blend shapes and the template in ONE GEMM that reads the 18 MB table once per call
+//     (the per-vertex loop it replaces re-streamed posedirs for every frame).
+//   kernel 3 (vertices): T_v = sum_j w_vj A_j over the vertex's non-zero skinning weights (a padded
+//     (joint, weight) list built at load: 4 entries for a real SMPL model), verts = T_v . [v_posed; 1], in place.
+//   kernel 4 (one block per frame): the 29 "spin2" joints (smpl.py:113-118) incl. the thorax row
 //     of J_regressor_extra, weak-perspective -> perspective camera, projection / 112
 //     (geometry.py:427-479, smpl.py:172-186).
 __global__ __launch_bounds__(64) void smpl_chain_kernel(const float* __restrict__ betas, const float* __restrict__ rotmat, SmplTables t,
-                                                          float* __restrict__ A_ws, float* __restrict__ kp3d) {
+                                                          float* __restrict__ A_ws, float* __restrict__ kp3d, float* __restrict__ feat) {
     __shared__ float J[24][3];
     __shared__ float G[24][12];
     const int n = blockIdx.x, tid = threadIdx.x;
@@ -501,6 +508,13 @@ __global__ __launch_bounds__(64) void smpl_chain_kernel(const float* __restrict_
 #pragma unroll
         for (int l = 0; l < 10; ++l) v += t.J_shapedirs[e * 10 + l] * betas[(size_t)n * 10 + l];
         J[e / 3][e % 3] = v;
+    }
+    for (int e = tid; e < kBlendK; e += 64) {                    // this frame's row of the blend-shape GEMM
+        float v = 0.f;
+        if (e < 207) v = rotmat[(size_t)n * 216 + 9 + e] - ((e % 9 == 0 || e % 9 == 4 || e % 9 == 8) ? 1.f : 0.f);   // (R[1:] - I).flatten
+        else if (e < 217) v = betas[(size_t)n * 10 + e - 207];
+        else if (e == 217) v = 1.f;
+        feat[(size_t)n * kBlendK + e] = v;
     }
     __syncthreads();
     if (tid == 0) {
@@ -542,53 +556,104 @@ __global__ __launch_bounds__(64) void smpl_chain_kernel(const float* __restrict_
 }
 
 constexpr int kNumVerts = 6890;
-__global__ __launch_bounds__(256) void smpl_verts_kernel(const float* __restrict__ betas, const float* __restrict__ rotmat, SmplTables t,
-                                                           const float* __restrict__ A_ws, float* __restrict__ verts) {
+constexpr int kBlendCols = kNumVerts * 3;
+
+// v_posed[f][c] = sum_k feat[f][k] * blend[k][c].  A workgroup owns 64 columns (one 16-column MFMA tile per wave) for ALL frames:
+// each lane pulls its 55 table values (its column, the k rows of its quarter) into registers with 55 independent loads in flight
+// -- the 18 MB table is read from memory exactly once per call, whatever the number of frames -- then walks the frames in passes of
+// 64 (4 MFMA row tiles), the pass's rows (<= 64 x 220 floats) staged in LDS.  fp32 MFMA 16x16x4: an exact fp32 fma chain per element.
+template <int MT>
+__device__ __forceinline__ void blend_pass(const float* __restrict__ As, const float (&bv)[kBlendK / 4], float* __restrict__ Cs, int l15, int lq, int wave) {
+    constexpr int LD = kBlendK + 1, KS = kBlendK / 4;
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* a0 = As + l15 * LD + lq;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[m * 16 * LD + 4 * ks], bv[ks], acc[m], 0, 0, 0);
+    // the tile leaves through LDS as whole 256-byte rows (64 columns of one frame are contiguous in the output)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cs[(m * 16 + lq * 4 + r) * 64 + wave * 16 + l15] = acc[m][r];
+}
+
+__global__ __launch_bounds__(256, 2) void smpl_blend_mfma_kernel(const float* __restrict__ feat, const float* __restrict__ blend, float* __restrict__ vposed,
+                                                               int N) {
+    constexpr int LD = kBlendK + 1, KS = kBlendK / 4;          // odd row stride: the 16 frames of an A fragment fall on distinct banks
+    __shared__ float As[64 * LD];
+    __shared__ __align__(16) float Cs[64 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+    const int col = blockIdx.x * 64 + wave * 16 + l15;
+    const bool cok = col < kBlendCols;
+    const float* bp = blend + (cok ? col : 0) + (size_t)lq * kBlendCols;
+    float bv[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) bv[ks] = bp[(size_t)(4 * ks) * kBlendCols];       // 16 lanes read 64 contiguous bytes of a table row
+    for (int f0 = 0; f0 < N; f0 += 64) {
+        const int nf = min(64, N - f0), mtiles = (nf + 15) >> 4;
+        __syncthreads();                                       // the previous pass is done with As
+        {   // 64 rows x 55 16-byte units, 14 independent loads per thread in flight (a row is 880 bytes: units stay 16-byte aligned)
+            constexpr int UPR = kBlendK / 4, NU = (64 * UPR + 255) / 256;
+            f32x4 v[NU];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                const int u = tid + 256 * i, f = u / UPR;
+                v[i] = (u < mtiles * 16 * UPR && f < nf) ? *reinterpret_cast<const f32x4*>(feat + (size_t)(f0 + f) * kBlendK + 4 * (u - f * UPR))
+                                                           : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                const int u = tid + 256 * i, f = u / UPR, k = 4 * (u - f * UPR);
+                if (u < mtiles * 16 * UPR) {
+                    As[f * LD + k] = v[i][0]; As[f * LD + k + 1] = v[i][1]; As[f * LD + k + 2] = v[i][2]; As[f * LD + k + 3] = v[i][3];
+                }
+            }
+        }
+        __syncthreads();
+        // straight-line MFMA chains (the row-tile count is a template argument: no branch between matrix instructions, so the
+        // LDS reads of later k-steps are issued ahead of the chain instead of one exposed LDS latency per MFMA)
+        switch (mtiles) {
+            case 1: blend_pass<1>(As, bv, Cs, l15, lq, wave); break;
+            case 2: blend_pass<2>(As, bv, Cs, l15, lq, wave); break;
+            case 3: blend_pass<3>(As, bv, Cs, l15, lq, wave); break;
+            default: blend_pass<4>(As, bv, Cs, l15, lq, wave); break;
+        }
+        __syncthreads();
+        const int cbase = blockIdx.x * 64;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {                          // 8 bytes per lane (a frame's row of 20670 floats is 8-byte aligned, not 16)
+            const int row = (tid >> 5) + 8 * i, c2 = (tid & 31) * 2;
+            if (row < nf && cbase + c2 < kBlendCols)
+                *reinterpret_cast<f32x2*>(vposed + (size_t)(f0 + row) * kBlendCols + cbase + c2) = *reinterpret_cast<const f32x2*>(Cs + row * 64 + c2);
+        }
+    }
+}
+
+// in place: verts[n][v] = T_v . [v_posed; 1] with T_v = sum over the vertex's non-zero weights of w * A_joint
+__global__ __launch_bounds__(256) void smpl_skin_kernel(SmplTables t, const float* __restrict__ A_ws, float* __restrict__ verts) {
     __shared__ float sA[288];
-    __shared__ float pf[208];
-    __shared__ float sb[10];
     const int n = blockIdx.y, tid = threadIdx.x;
     for (int e = tid; e < 288; e += 256) sA[e] = A_ws[(size_t)n * 288 + e];
-    if (tid < 207) {
-        const int k = tid % 9;
-        pf[tid] = rotmat[(size_t)n * 216 + 9 + tid] - ((k == 0 || k == 4 || k == 8) ? 1.f : 0.f);   // (R[1:] - I).flatten
-    }
-    if (tid < 10) sb[tid] = betas[(size_t)n * 10 + tid];
     __syncthreads();
     const int v = blockIdx.x * 256 + tid;
     if (v >= kNumVerts) return;
-    float p[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        float acc = t.v_template[v * 3 + d];
-#pragma unroll
-        for (int l = 0; l < 10; ++l) acc += t.shapedirs[(v * 3 + d) * 10 + l] * sb[l];
-        p[d] = acc;
-    }
-    const float* pd = t.posedirs + (size_t)v * 3;
-    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-#pragma unroll 9
-    for (int k = 0; k < 207; ++k) {
-        const float f = pf[k];
-        o0 += f * pd[(size_t)k * (kNumVerts * 3) + 0];
-        o1 += f * pd[(size_t)k * (kNumVerts * 3) + 1];
-        o2 += f * pd[(size_t)k * (kNumVerts * 3) + 2];
-    }
-    p[0] += o0; p[1] += o1; p[2] += o2;
+    float* pv = verts + ((size_t)n * kNumVerts + v) * 3;
+    const float p0 = pv[0], p1 = pv[1], p2 = pv[2];
     float T[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) T[e] = 0.f;
-    const float* wv = t.lbs_weights + (size_t)v * 24;
-    for (int j = 0; j < 24; ++j) {
-        const float wj = wv[j];
-        if (wj != 0.f) {
+    for (int k = 0; k < t.skin_k; ++k) {                       // ascending joint index, zero weights skipped: the dense sum's order
+        const int j = t.skin_idx[(size_t)v * t.skin_k + k];
+        const float wj = t.skin_w[(size_t)v * t.skin_k + k];
+        if (j < 0) break;
 #pragma unroll
-            for (int e = 0; e < 12; ++e) T[e] += wj * sA[j * 12 + e];
-        }
+        for (int e = 0; e < 12; ++e) T[e] += wj * sA[j * 12 + e];
     }
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
-        verts[((size_t)n * kNumVerts + v) * 3 + r] = T[r * 4 + 0] * p[0] + T[r * 4 + 1] * p[1] + T[r * 4 + 2] * p[2] + T[r * 4 + 3];
+    for (int r = 0; r < 3; ++r) pv[r] = T[r * 4 + 0] * p0 + T[r * 4 + 1] * p1 + T[r * 4 + 2] * p2 + T[r * 4 + 3];
 }
 
 __global__ __launch_bounds__(256) void smpl_joints_kernel(const float* __restrict__ verts, const float* __restrict__ cam, SmplTables t,
@@ -597,11 +662,12 @@ __global__ __launch_bounds__(256) void smpl_joints_kernel(const float* __restric
     __shared__ float sj[29][3];
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* vn = verts + (size_t)n * kNumVerts * 3;
-    const float* je = t.J_extra + (size_t)5 * kNumVerts;          // 'Thorax (MPII)' = row 50-45 (smpl.py:117)
+    // 'Thorax (MPII)' = row 50-45 of J_regressor_extra (smpl.py:117): its non-zero entries as a (vertex, weight) list built at load
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int v = tid; v < kNumVerts; v += 256) {
-        const float w = je[v];
-        if (w != 0.f) { a0 += w * vn[v * 3]; a1 += w * vn[v * 3 + 1]; a2 += w * vn[v * 3 + 2]; }
+    for (int k = tid; k < t.thorax_n; k += 256) {
+        const int v = t.thorax_idx[k];
+        const float w = t.thorax_w[k];
+        a0 += w * vn[v * 3]; a1 += w * vn[v * 3 + 1]; a2 += w * vn[v * 3 + 2];
     }
     a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
     if (lane == 0) { red[wave][0] = a0; red[wave][1] = a1; red[wave][2] = a2; }
@@ -627,8 +693,10 @@ __global__ __launch_bounds__(256) void smpl_joints_kernel(const float* __restric
 
 hipError_t launch_smpl(const float* betas, const float* rotmat, const float* cam, SmplTables t, float* A_ws, float* verts,
                        float* kp3d, float* kp2d, int N, hipStream_t s) {
-    GRK_TRY(launch_k(smpl_chain_kernel, dim3(N), dim3(64), 0, s, betas, rotmat, t, A_ws, kp3d));
-    GRK_TRY(launch_k(smpl_verts_kernel, dim3((kNumVerts + 255) / 256, N), dim3(256), 0, s, betas, rotmat, t, A_ws, verts));
+    float* feat = A_ws + (size_t)N * 288;                    // the workspace holds (N,288) skinning matrices + (N,220) GEMM rows
+    GRK_TRY(launch_k(smpl_chain_kernel, dim3(N), dim3(64), 0, s, betas, rotmat, t, A_ws, kp3d, feat));
+    GRK_TRY(launch_k(smpl_blend_mfma_kernel, dim3((kBlendCols + 63) / 64), dim3(256), 0, s, (const float*)feat, t.blend, verts, N));
+    GRK_TRY(launch_k(smpl_skin_kernel, dim3((kNumVerts + 255) / 256, N), dim3(256), 0, s, t, (const float*)A_ws, verts));
     GRK_TRY(launch_k(smpl_joints_kernel, dim3(N), dim3(256), 0, s, verts, cam, t, kp3d, kp2d));
     return hipGetLastError();
 }

@@ -93,6 +93,30 @@ int conv_pick_tc(int Cout);                 // cout tile (32 or 64) -> defines C
 hipError_t conv_init();                     // sets max dynamic LDS on every instantiation
 const char* conv_dominant_kernel_name();
 
+// ---- per-XCD dataflow execution of the HR stages (conv_kernels.hip: hr_dataflow_f32) -------------------------------------------
+// One persistent launch runs every convolution of transition1 .. stage 4 (~270 launches otherwise).  Frames are independent and
+// the 8 XCDs have private L2s, so XCD x takes the images [x*ipx, (x+1)*ipx) through the WHOLE section on its own: its workgroups pop
+// tile tasks from the XCD's queue (a static, topologically ordered list, the same for every block of B images) and a task waits only
+// for the (producer convolution, same image) counters it reads from.  Producer and consumer of every byte sit on the same XCD -- the
+// one read from the hardware register XCC_ID, not inferred from the block id -- so hand-offs go through that XCD's L2 and need no
+// cache write-back or invalidate; nothing depends on how the dispatcher places workgroups (an XCD that received none is served by a
+// second phase in which the remaining workgroups take over its queue with device-scope fences).
+struct DfTask { unsigned short conv, img, ty, by; };          // convolution (index into DfConv[]), image within the block, pixel tile, channel block
+struct DfConv {
+    ConvArgs a;                 // tile plan filled (plan_tile): N = frames of the call, image selected through bx
+    int variant;                // (ks,stride) x tile variant, see hr_dataflow_f32; -1: fuse sum (a.in = identity term, a.add = upsampled terms)
+    int ndeps, dep[4], need[4]; // producers inside the section and their task count per image
+};
+struct DfParams {
+    const DfConv* convs; const DfTask* tasks;
+    int tasks_per_blk, nconv, n, ipx, B;
+    unsigned* counters; int ctr_stride;   // per XCD: [0] queue head, [1] arrived workgroups, [16 + (blk*nconv + conv)*B + img] finished tasks
+    int fence;                  // 1: device-scope release/acquire around every hand-off (validation / foreign-queue phase)
+};
+int df_plan_conv(ConvArgs& a, size_t* lds_bytes);              // picks the tile variant, fills the plan; -1 if the shape has none
+hipError_t launch_hr_dataflow(const DfParams& p, size_t lds, int wgs_per_xcd, hipStream_t s);
+hipError_t df_probe_xcc(int wgs_per_xcd, int* ok, hipStream_t s);   // does a grid of this shape reach all 8 XCDs evenly?
+
 // out = relu?( sum_k nearest_up(add_k) ), 1..4 addends, out and every addend are Views.
 struct SumArgs {
     float* out; int out_ctot, out_coff;
@@ -137,14 +161,19 @@ hipError_t launch_rotmat_to_aa(const float* R, float* aa, int m, hipStream_t s);
 size_t softmax_pool_ws_floats(int N);
 constexpr int kPoolSplit = 7;                 // pixel ranges of the attention pooling (3136 = 7 x 448): ONE constant for the fp32 and bf16 paths
 
+constexpr int kBlendK = 220;       // rows of the blend-shape table: 207 pose + 10 shape + 1 template + 2 of padding (k-steps of 4)
+constexpr int kSmplWsFloatsPerFrame = 288 + kBlendK;   // skinning matrices + the frame's row of the blend-shape GEMM
 struct SmplTables {
-    const float* v_template;   // (6890,3)
-    const float* shapedirs;    // (6890*3,10)
-    const float* posedirs;     // (207,20670)
+    const float* blend;        // (220,20670) = [posedirs ; shapedirs^T ; v_template ; 0 0], assembled at load
+    const int* skin_idx;       // (6890,skin_k) joints with a non-zero skinning weight, ascending, padded with -1
+    const float* skin_w;       // (6890,skin_k)
+    int skin_k;                // max non-zero weights per vertex (4 for a real SMPL model)
     const float* J_template;   // (24,3)   = J_regressor . v_template           (precomputed at load)
     const float* J_shapedirs;  // (24*3,10) = J_regressor . shapedirs             (precomputed at load)
     const float* lbs_weights;  // (6890,24)
-    const float* J_extra;      // (9,6890)
+    const int* thorax_idx;     // non-zero entries of row 5 ('Thorax (MPII)') of J_regressor_extra (9,6890): vertex ids ...
+    const float* thorax_w;     // ... and weights
+    int thorax_n;
     const int* parents;        // (24)
 };
 // betas (N,10), rotmat (N,24,9), cam (N,3) -> verts (N,6890,3), kp3d (N,29,3), kp2d (N,29,2)

@@ -16,6 +16,8 @@ from . import _lib
 # per-frame pose record gathered across ranks: name -> floats per frame
 POSE_RECORD = (("theta", 85), ("kp_3d", 87), ("kp_2d", 58), ("point_local_feat", 3072))
 POSE_RECORD_FLOATS = sum(s for _, s in POSE_RECORD)
+# with the temporal branch (use_gait_feat, grnet.py:154-173) the second head pass also needs the first pass's cam_shape_feats
+POSE_RECORD_GAIT = POSE_RECORD + (("cam_shape_feats", 1536),)
 
 
 def shard_range(n_total, world, rank):
@@ -66,10 +68,10 @@ def gather_work_items(items, local_rows, row_floats, world, rank, dist, device):
     return {vi: torch.cat(parts, 0) for vi, parts in per_video.items()}
 
 
-def pack_layout(n_local):
+def pack_layout(n_local, record=POSE_RECORD):
     """Offsets (in floats) of each field inside one rank's packed block: field-major, frame-minor."""
     off, layout = 0, {}
-    for name, sz in POSE_RECORD:
+    for name, sz in record:
         layout[name] = (off, sz)
         off += sz * n_local
     return layout, off
@@ -91,9 +93,9 @@ def gather_pose_records(packed_local, n_local, world, dist, out=None):
     return out.view(world, block)
 
 
-def unpack_sequence(gathered, n_local, n_total):
+def unpack_sequence(gathered, n_local, n_total, record=POSE_RECORD):
     """(world, block) -> dict of whole-sequence tensors (n_total, ...) in frame order."""
-    layout, _ = pack_layout(n_local)
+    layout, _ = pack_layout(n_local, record)
     world = gathered.shape[0]
     seq = {}
     for name, (off, sz) in layout.items():
@@ -102,7 +104,17 @@ def unpack_sequence(gathered, n_local, n_total):
     seq["kp_3d"] = seq["kp_3d"].reshape(-1, 29, 3)
     seq["kp_2d"] = seq["kp_2d"].reshape(-1, 29, 2)
     seq["point_local_feat"] = seq["point_local_feat"].reshape(-1, 128, 24)
+    if "cam_shape_feats" in seq:
+        seq["cam_shape_feats"] = seq["cam_shape_feats"].reshape(-1, 64, 24)
     return seq
+
+
+def temporal_after_gather(model, seq, bbox, cimg, b, t):
+    """BASELINE configs[3]: after the all-gather every rank holds the whole sequence's first-pass records; the temporal branch
+    (cparams, GRU gait encoder, attention block, second head pass -- grnet.py:154-173) needs all frames of a clip at once, so it runs
+    here, on the reassembled sequence (replicated: ~0.04 s for 10 000 frames against ~0.4 s of per-frame work per GPU).
+    ``seq``: unpack_sequence(..., record=POSE_RECORD_GAIT); bbox (b,t,4), cimg (b,t,2)."""
+    return model.gait_correct(seq["point_local_feat"], seq["cam_shape_feats"], seq["theta"], bbox, cimg, b, t)
 
 
 class ClipRunner:
@@ -113,11 +125,12 @@ class ClipRunner:
     the exchange needs no packing kernel.  ``verts`` / ``rotmat`` stay sharded (rank-local).
     """
 
-    def __init__(self, model, frames, use_graph=True, world=1, rank=0, dist=None, tune_level=1, tune_cache=None):
+    def __init__(self, model, frames, use_graph=True, world=1, rank=0, dist=None, tune_level=1, tune_cache=None, record=POSE_RECORD):
         self.model, self.frames, self.world, self.rank, self.dist = model, frames.contiguous(), world, rank, dist
         self.n = n = frames.shape[0]
+        self.record = record
         dev = frames.device
-        layout, block = pack_layout(n)
+        layout, block = pack_layout(n, record)
         self.packed = torch.zeros(block, dtype=torch.float32, device=dev)
         self.verts = torch.empty(n, 6890, 3, dtype=torch.float32, device=dev)
         self.rotmat = torch.empty(n, 24, 3, 3, dtype=torch.float32, device=dev)
@@ -145,4 +158,4 @@ class ClipRunner:
     def sequence(self, n_total=None):
         """Whole-clip results in frame order (after step())."""
         g = self.gathered.view(self.world, -1) if self.world > 1 else self.packed.view(1, -1)
-        return unpack_sequence(g, self.n, n_total if n_total is not None else self.n * self.world)
+        return unpack_sequence(g, self.n, n_total if n_total is not None else self.n * self.world, self.record)
