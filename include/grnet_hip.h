@@ -102,6 +102,10 @@ int grnet_tsattn_forward(grnet_t* h, const float* x_dev, const float* xs_dev, in
 #define GRNET_OPT_CONV_TILE 2     /* 0 = cost model; 7 / 14 = whole-K tiles; 1071/1072/1041/1042 = split-K (psw,csw) (tests / tuning) */
 #define GRNET_OPT_MULTI_LANE 3    /* 1 (default): independent HR-module branches run on parallel streams / graph branches */
 #define GRNET_OPT_GROUPING 4      /* 1 (default): same-depth convolutions of an HR module are one grouped launch */
+#define GRNET_OPT_DATAFLOW 5      /* HR section (transition1 .. stage 4) as ONE persistent per-XCD dataflow launch: 0 never (default: it is
+                                   * correct but measured slower than the per-convolution launches this round), 1 wherever a plan exists,
+                                   * 2 where grnet_tune measured it faster */
+#define GRNET_OPT_DATAFLOW_FENCE 6 /* 1: device-scope release/acquire around every hand-off inside that launch (validation; slower) */
 int grnet_set_option(grnet_t* h, int option, int value);
 
 /* Optional, once per distinct n_frames after grnet_finalize_weights: times every launch configuration of every

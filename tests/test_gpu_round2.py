@@ -270,3 +270,56 @@ def test_frame_shards_gather_then_temporal_branch_equals_one_process(pkg):
         assert rel_err(got[k].cpu().numpy().reshape(whole[k].shape), whole[k].cpu().numpy()) < 2e-5, k
     assert rel_err(got["pred_phase"].cpu().numpy(), whole["pred_phase"].cpu().numpy()) < 2e-5
     m.close()
+
+
+def test_dataflow_hr_section_parity_and_determinism(pkg, golden):
+    """The HR section (transition1 .. stage 4) as ONE persistent per-XCD dataflow launch (GRNET_OPT_DATAFLOW = 1): same results as
+    the per-convolution launches (different split-K variants: fp32 re-association noise), the reference goldens, bit-identical
+    between runs, bit-identical with device-scope fences around every hand-off (the fences change visibility, not arithmetic),
+    for frame counts that fill the 8 XCDs evenly, unevenly and not at all."""
+    lib = pkg._lib
+    m = pkg.build_synthetic_model(max_frames=40, with_gru=False)
+    frames = torch.from_numpy(pkg.synth.make_frames(40)).cuda()
+    keys = ("theta", "kp_3d", "kp_2d", "verts", "rotmat")
+    for n in (16, 4, 1, 11, 40):
+        x = frames[:n]
+        m.set_option(lib.OPT_DATAFLOW, 0)
+        base = {k: v.clone() for k, v in m(x, extras=("features",))[-1].items()}
+        launches_lanes = m.num_kernel_launches()
+        m.set_option(lib.OPT_DATAFLOW, 1)
+        a = {k: v.clone() for k, v in m(x, extras=("features",))[-1].items()}
+        assert m.num_kernel_launches() < launches_lanes - 250, (n, m.num_kernel_launches(), launches_lanes)   # the plan exists and was used
+        b = {k: v.clone() for k, v in m(x, extras=("features",))[-1].items()}
+        m.set_option(lib.OPT_DATAFLOW_FENCE, 1)
+        c = {k: v.clone() for k, v in m(x, extras=("features",))[-1].items()}
+        m.set_option(lib.OPT_DATAFLOW_FENCE, 0)
+        torch.cuda.synchronize()
+        for k in keys + ("features",):
+            assert rel_err(a[k].cpu().numpy(), base[k].cpu().numpy()) < 5e-5, (n, k, rel_err(a[k].cpu().numpy(), base[k].cpu().numpy()))
+            assert torch.equal(a[k], b[k]), (n, k, "run-to-run")
+            assert torch.equal(a[k], c[k]), (n, k, "fenced vs unfenced")
+        if n == 4:
+            g = golden["grnet_n4"]
+            for k in ("theta", "kp_3d", "kp_2d"):
+                assert rel_err(a[k].cpu().numpy().reshape(g[k].shape), g[k]) < 1e-4, k
+            assert rel_err(a["features"].cpu().numpy()[..., ::4, ::4], g["features_s4"]) < 1e-4
+    # stage taps still readable (the section writes the same buffers)
+    m(frames[:4])
+    t = m.debug_tensor("stage3.2", 4).cpu().numpy()
+    assert rel_err(t, golden["grnet_n4"]["stage3_2"]) < 1e-4
+    # graph replay of the dataflow schedule
+    m.set_option(lib.OPT_USE_GRAPH, 1)
+    outs = [m(frames[:16])[-1]["theta"].clone() for _ in range(1)]
+    import ctypes as C
+    fixed = {k: torch.empty(16, *s, device="cuda") for k, s in (("theta", (85,)), ("verts", (6890, 3)))}
+    o = lib.Outputs()
+    for k, v in fixed.items():
+        setattr(o, k, v.data_ptr())
+    x16 = frames[:16].contiguous()
+    for _ in range(3):                                        # eager, capture, replay
+        rc = m._lib.grnet_forward(m._h, C.c_void_p(x16.data_ptr()), 16, C.byref(o), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, m._lib.grnet_last_error(m._h)
+    torch.cuda.synchronize()
+    assert torch.equal(fixed["theta"], outs[0].reshape(16, 85))
+    m.set_option(lib.OPT_USE_GRAPH, 0)
+    m.close()

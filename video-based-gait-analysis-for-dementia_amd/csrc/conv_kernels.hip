@@ -424,10 +424,12 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
 // MODE: 0 = gather (source-offset table), 1 = rows (contiguous image rows), 2 = planes (the 4 channel planes of a
 // k-group of ONE whole small image are contiguous in NCHW: one 16-byte LDS-DMA per k-group; all zero padding is
 // applied through a per-lane 9-bit tap-validity mask when the A operand is read).
+// tid_in: the thread index as the caller wants the body to see it (the persistent dataflow kernel passes it through an opaque
+// register copy per task, so that no lane-derived value of any body variant is loop-invariant across tasks and kept live in registers)
 template <int MODE, int KS, int S, int PSW, int CSW, int NW>
-__device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, const int by, float* smem) {
+__device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, const int by, float* smem, const int tid_in = -1) {
     constexpr int TC = CSW * 16, TAPS = KS * KS, WFL = TAPS * 4 * TC, NT = PSW * CSW;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     GRK_TICK(t_start);
     const int stage_floats = WFL + 4 * a.PSTR;           // [weights TAPS*4 x TC | input 4 x PSTR], ONE stage per wave:
@@ -768,29 +770,64 @@ __device__ __forceinline__ void df_sum_tile(const ConvArgs& a, int img, int ty) 
     }
 }
 
-__device__ __forceinline__ void df_run_conv(const ConvArgs& a, int variant, int bx, int by, float* smem) {
-    switch (variant) {                                       // (ks, stride) x {rows 7x1, rows 4x1, planes 4x1}
-        case 0: splitk_body<1, 3, 1, 7, 1, 4>(a, bx, by, smem); break;
-        case 1: splitk_body<1, 3, 1, 4, 1, 4>(a, bx, by, smem); break;
-        case 2: splitk_body<2, 3, 1, 4, 1, 4>(a, bx, by, smem); break;
-        case 3: splitk_body<1, 3, 2, 7, 1, 4>(a, bx, by, smem); break;
-        case 4: splitk_body<1, 3, 2, 4, 1, 4>(a, bx, by, smem); break;
-        case 5: splitk_body<2, 3, 2, 4, 1, 4>(a, bx, by, smem); break;
-        case 6: splitk_body<1, 1, 1, 7, 1, 4>(a, bx, by, smem); break;
-        case 7: splitk_body<1, 1, 1, 4, 1, 4>(a, bx, by, smem); break;
-        default: splitk_body<2, 1, 1, 4, 1, 4>(a, bx, by, smem); break;
+// Each body variant is a SEPARATE (non-inlined) device function with its own register allocation: inlined into one switch, the nine
+// bodies made the kernel need 350-512 registers (block-invariant and task-invariant index math of every variant hoisted and kept
+// live at once; with an occupancy bound the allocator spilled 500-1500 VGPRs instead).  Arguments arrive in VGPRs by the ABI and are
+// made wave-uniform again with readfirstlane; the LDS base comes as an address-space-3 pointer so the body's accesses stay ds_* / LDS-DMA.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <int MODE, int KS, int S, int PSW>
+__device__ __attribute__((noinline)) void df_body(const DfConv* cg, int bx, int by0, int by1, GRNET_LDS_AS float* smem_lds) {
+    const unsigned long long pu = ((unsigned long long)(unsigned)uni((int)((unsigned long long)cg >> 32)) << 32) | (unsigned)uni((int)(unsigned long long)cg);
+    const DfConv* c = reinterpret_cast<const DfConv*>(pu);
+    const ConvArgs a = c->a;                                 // uniform address: scalar loads
+    float* smem = (float*)smem_lds;
+    bx = uni(bx); by0 = uni(by0); by1 = uni(by1);
+    for (int b2 = by0; b2 < by1; ++b2) {
+        if (b2 != by0) __syncthreads();                       // the previous block's cross-wave reduction is done with the staging area
+        splitk_body<MODE, KS, S, PSW, 1, 4>(a, bx, b2, smem);
     }
+}
+__device__ __forceinline__ void df_run_conv(const DfConv* c, int variant, int bx, int by0, int by1, GRNET_LDS_AS float* smem) {
+    switch (variant) {                                       // (ks, stride) x {rows 7x1, rows 4x1, planes 4x1}
+        case 0: df_body<1, 3, 1, 7>(c, bx, by0, by1, smem); break;
+#ifndef GRNET_DF_ONE
+        case 1: df_body<1, 3, 1, 4>(c, bx, by0, by1, smem); break;
+        case 2: df_body<2, 3, 1, 4>(c, bx, by0, by1, smem); break;
+        case 3: df_body<1, 3, 2, 7>(c, bx, by0, by1, smem); break;
+        case 4: df_body<1, 3, 2, 4>(c, bx, by0, by1, smem); break;
+        case 5: df_body<2, 3, 2, 4>(c, bx, by0, by1, smem); break;
+        case 6: df_body<1, 1, 1, 7>(c, bx, by0, by1, smem); break;
+        case 7: df_body<1, 1, 1, 4>(c, bx, by0, by1, smem); break;
+        case 8: df_body<2, 1, 1, 4>(c, bx, by0, by1, smem); break;
+#endif
+        default: break;
+    }
+}
+__device__ __attribute__((noinline)) void df_sum_body(const DfConv* cg, int img, int ty) {
+    const unsigned long long pu = ((unsigned long long)(unsigned)uni((int)((unsigned long long)cg >> 32)) << 32) | (unsigned)uni((int)(unsigned long long)cg);
+    const ConvArgs a = reinterpret_cast<const DfConv*>(pu)->a;
+    df_sum_tile(a, uni(img), uni(ty));
 }
 
 // Run the queue of XCD `q`.  fence = true when this workgroup may sit on another XCD than the queue's producers / consumers.
+// Control flow around the barriers is kept WAVE-UNIFORM on purpose (conditions on SGPR values: the wave index through readfirstlane,
+// loaded words through readfirstlane): a lane-divergent `if (threadIdx.x == 0)` at the head of this loop made the compiler's CFG
+// structuriser split the loop so that waves met different numbers of s_barrier per iteration (the kernel hung on its second task).
+// Where one lane must act (queue pop, counter increment) the whole wave executes the atomic with an addend of 1 in lane 0 and 0 elsewhere.
 __device__ __forceinline__ void df_run_queue(const DfParams& p, int q, bool fence, float* smem, int* s_task) {
     unsigned* ctr = p.counters + (size_t)q * p.ctr_stride;
     unsigned* done = ctr + 16;
     const int first_img = q * p.ipx, img_end = min(p.n, first_img + p.ipx), nimg = img_end - first_img;
     if (nimg <= 0) return;
     const int nblk = (nimg + p.B - 1) / p.B, total = nblk * p.tasks_per_blk;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned one = (threadIdx.x & 63) == 0 ? 1u : 0u;
+    int last_ci = -1, last_il = -1, last_blk = -1;
     for (;;) {
-        if (threadIdx.x == 0) *s_task = (int)atomicAdd(&ctr[0], 1u);
+        if (wave == 0) {
+            const unsigned old = atomicAdd(&ctr[0], one);       // one hardware atomic per wave (lane 0 receives the old head)
+            *s_task = __builtin_amdgcn_readfirstlane((int)old);
+        }
         __syncthreads();
         const int t = __builtin_amdgcn_readfirstlane(*s_task);
         if (t >= total) break;
@@ -798,46 +835,81 @@ __device__ __forceinline__ void df_run_queue(const DfParams& p, int q, bool fenc
         const DfTask task = p.tasks[ti];
         const int ci = __builtin_amdgcn_readfirstlane((int)task.conv);
         const int il = __builtin_amdgcn_readfirstlane((int)task.img);
+        const int ty = __builtin_amdgcn_readfirstlane((int)task.ty), by = __builtin_amdgcn_readfirstlane((int)task.by);
         const int img = first_img + blk * p.B + il;
         if (img < img_end) {
-            const DfConv& c = p.convs[ci];
-            if ((int)threadIdx.x < c.ndeps) {                  // wait for the producers of this image (they are earlier in the queue: already popped)
-                const unsigned* d = done + ((size_t)blk * p.nconv + c.dep[threadIdx.x]) * p.B + il;
-                const unsigned need = (unsigned)c.need[threadIdx.x];
-                while (__hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(1);
+            const DfConv* c = p.convs + ci;
+            if (wave == 0 && !(ci == last_ci && il == last_il && blk == last_blk)) {   // (the same convolution of the same image again: already satisfied)
+                // wait for the producers of this image (earlier in the queue: already popped); the <= 4 counters are read together
+                const int ndeps = __builtin_amdgcn_readfirstlane(c->ndeps);
+                unsigned spins = 0;
+                for (;;) {
+                    unsigned missing = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (k < ndeps) {
+                            const int dep = __builtin_amdgcn_readfirstlane(c->dep[k]);
+                            const unsigned* d = done + ((size_t)blk * p.nconv + dep) * p.B + il;
+                            missing |= __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)c->need[k] ? 1u << k : 0u;
+                        }
+                    }
+                    const int m = __builtin_amdgcn_readfirstlane((int)missing);
+                    if (m == 0) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    // bounded: a hand-off that never arrives (a bug, not a placement) ends the wait, is counted in ctr[3] with the
+                    // waiting task in ctr[4..6], and the launch completes with wrong data instead of hanging the GPU
+                    if (++spins > (1u << 18)) {
+                        const unsigned first = atomicAdd(&ctr[3], one);
+                        if (__builtin_amdgcn_readfirstlane((int)first) == 0) { ctr[4] = (unsigned)t; ctr[5] = (unsigned)ci; ctr[6] = (unsigned)m; }
+                        break;
+                    }
+                }
                 if (fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
+            last_ci = ci; last_il = il; last_blk = blk;
             __syncthreads();
-            const int ty = __builtin_amdgcn_readfirstlane((int)task.ty), by = __builtin_amdgcn_readfirstlane((int)task.by);
-            if (c.variant < 0) df_sum_tile(c.a, img, ty);
-            else df_run_conv(c.a, c.variant, img * c.a.tiles_y + ty, by, smem);
+            {
+                const int variant = __builtin_amdgcn_readfirstlane(c->variant);
+                const int tiles_y = __builtin_amdgcn_readfirstlane(c->a.tiles_y), gy = __builtin_amdgcn_readfirstlane(c->a.gy);
+                const int bchunk = __builtin_amdgcn_readfirstlane(c->bchunk);
+                GRNET_LDS_AS float* lds = (GRNET_LDS_AS float*)smem;
+                // one task = one pixel tile x `bchunk` output-channel blocks (the plan picks bchunk so that a convolution of one image
+                // still splits into >= ~16 tasks: the pop, the wait and the descriptor are shared by the blocks of a task)
+                if (p.fence >= 2) {                            // diagnostic: queue and hand-offs only (2), or only one family of bodies (3: sums, 4+v: variant v)
+                    if (p.fence == 3 && variant < 0) df_sum_body(c, img, ty);
+                    if (p.fence >= 4 && variant == p.fence - 4) df_run_conv(c, variant, img * tiles_y + ty, by, by + 1, lds);
+                } else if (variant < 0) df_sum_body(c, img, ty);
+                else df_run_conv(c, variant, img * tiles_y + ty, by, min(gy, by + bchunk), lds);
+            }
             // every wave's stores have left (vmcnt 0) before the workgroup's barrier; then ONE increment publishes the task.  The
             // consumers are on this XCD: its L2 is the coherence point (a CU's L1 holds no line of a tensor before that tensor is complete)
             if (fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_fetch_add(done + ((size_t)blk * p.nconv + ci) * p.B + il, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (wave == 0) __hip_atomic_fetch_add(done + ((size_t)blk * p.nconv + ci) * p.B + il, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             __syncthreads();                                   // s_task is re-written right away: keep the barrier count equal on both paths
         }
     }
 }
 
-__global__ __launch_bounds__(256) void hr_dataflow_f32(const DfParams p) {
+__global__ __launch_bounds__(256, 2) void hr_dataflow_f32(const DfParams p) {
     extern __shared__ __align__(16) float smem[];
     __shared__ int s_task;
     __shared__ int s_flag;
     const int xcd = xcc_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned one = (threadIdx.x & 63) == 0 ? 1u : 0u;
     // census + handshake (sequentially consistent device-scope read-modify-writes): an own worker registers, THEN reads the queue's
     // "foreign workers present" flag; a foreign worker raises the flag, THEN re-reads the census.  At least one sees the other, so a
     // queue is never run by unfenced own workers and fenced foreign workers that do not know of each other.
-    if (threadIdx.x == 0) {
+    if (wave == 0) {
         unsigned* ctr = p.counters + (size_t)xcd * p.ctr_stride;
-        atomicAdd(&ctr[1], 1u);
-        s_flag = (int)atomicOr(&ctr[2], 0u);
+        atomicAdd(&ctr[1], one);
+        s_flag = __builtin_amdgcn_readfirstlane((int)atomicAdd(&ctr[2], 0u));
     }
     __syncthreads();
-    const bool own_fenced = p.fence != 0 || s_flag != 0;
+    const bool own_fenced = p.fence == 1 || __builtin_amdgcn_readfirstlane(s_flag) != 0;
     __syncthreads();
     df_run_queue(p, xcd, own_fenced, smem, &s_task);
     // Placement independence: an XCD that received no workgroup of this launch (the dispatcher promises nothing) still has a queue.
@@ -845,17 +917,17 @@ __global__ __launch_bounds__(256) void hr_dataflow_f32(const DfParams p) {
     // any XCD).  On the observed round-robin dispatch this loop finds nothing to do.
     for (int q = 0; q < 8; ++q) {
         if (q == xcd) continue;
-        if (threadIdx.x == 0) {
+        if (wave == 0) {
             unsigned* ctr = p.counters + (size_t)q * p.ctr_stride;
             int take = 0;
-            if (__hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
                 atomicOr(&ctr[2], 1u);
-                take = atomicAdd(&ctr[1], 0u) == 0u;
+                take = __builtin_amdgcn_readfirstlane((int)atomicAdd(&ctr[1], 0u)) == 0;
             }
             s_flag = take;
         }
         __syncthreads();
-        const bool take = s_flag != 0;
+        const bool take = __builtin_amdgcn_readfirstlane(s_flag) != 0;
         __syncthreads();
         if (take) df_run_queue(p, q, true, smem, &s_task);
     }
@@ -1148,7 +1220,7 @@ int df_plan_conv(ConvArgs& a, size_t* lds_out) {
 hipError_t launch_hr_dataflow(const DfParams& p, size_t lds, int wgs_per_xcd, hipStream_t s) {
     static bool lds_set = false;
     if (!lds_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hr_dataflow_f32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hr_dataflow_f32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds - 1024);   // the kernel also has a few static LDS words
         if (e != hipSuccess) return e;
         lds_set = true;
     }

@@ -57,6 +57,7 @@ struct ConvLayer {
     View in, out;
     std::vector<ConvSeg> segs;
     int cout = 0, ks = 1, stride = 1, relu = 0;
+    bool hr = false;            // inside the HR section (transition1 .. stage 4) that the dataflow kernel can run as ONE persistent launch
     bool solo = false;          // runs with no other launch beside it (stem, layer1, PARE head): isolated timings predict it well
     int cin_w = 0;              // input channels of the weight tensor (< in.c only for the bf16 stem: 3 of the 8 stored)
     std::vector<AddRef> adds;
@@ -69,7 +70,8 @@ struct ConvLayer {
 };
 
 struct Op {
-    enum Kind { CONV, GROUP, SUM, BILINEAR, POOL, TAIL, SMPL, CONVERT } kind;
+    enum Kind { CONV, GROUP, SUM, BILINEAR, POOL, TAIL, SMPL, CONVERT, DATAFLOW } kind;
+    bool hr = false;          // member of the HR section (see ConvLayer::hr)
     int conv_idx = -1;
     std::vector<int> group;   // GROUP: indices into convs[] launched together (independent, same ks/stride)
     SumArgs sum{};
@@ -117,6 +119,20 @@ struct grnet {
     std::vector<Op> ops;        // schedule A: grouped launches (GROUP ops) on lane 0 + lanes for the heads
     std::vector<Op> ops_flat;   // schedule B: every GROUP expanded into per-member launches on the members' lanes
     std::vector<hipEvent_t> op_events_flat;
+    // schedule C: the HR section of schedule B replaced by ONE Op::DATAFLOW (hr_dataflow_f32), the rest on the lane streams
+    std::vector<Op> ops_df;
+    std::vector<hipEvent_t> op_events_df;
+    std::vector<const float*> df_reads, df_writes;   // buffers the section reads from outside / writes
+    struct DfPlan {
+        std::vector<DfConv> convs; std::vector<DfTask> tasks;
+        DfConv* d_convs = nullptr; DfTask* d_tasks = nullptr; unsigned* d_counters = nullptr;
+        int tasks_per_blk = 0, nconv = 0, B = 2, ipx = 0, ctr_stride = 0; size_t lds = 0, ctr_bytes = 0; bool ok = false;
+    };
+    std::map<int, DfPlan> df_plans;                  // per frames-per-call
+    int df_mode = 0;                                 // GRNET_OPT_DATAFLOW: 0 never (default: measured slower than the lane streams this round), 1 wherever a plan exists, 2 where grnet_tune measured it faster
+    int df_probe = -1;                               // -1 not probed yet, 0 the dispatcher does not spread this grid over the 8 XCDs evenly, 1 it does
+    int df_wgs_per_xcd = 96;                         // 32 CUs x 3 resident workgroups
+    int df_fence = 0;                                // validation: device-scope fences around every hand-off
 
     // planned buffers: (pointer slot, floats per image)
     std::vector<std::pair<float**, size_t>> pending;   // pointers patched after the arena exists
@@ -191,6 +207,7 @@ struct grnet {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         for (hipEvent_t e : op_events) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : op_events_flat) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : op_events_df) if (e) (void)hipEventDestroy(e);
         for (void* p : dev_allocs) (void)hipFree(p);
         if (temporal_ws) (void)hipFree(temporal_ws);
         if (arena) (void)hipFree(arena);
@@ -238,6 +255,7 @@ struct grnet {
         L.macs_per_frame = (double)ho * wo * cout * L.cin_w * ks * ks;
         L.lane_hint = cur_lane;
         L.solo = solo_region;
+        L.hr = hr_region;
         convs.push_back(L);
         if (group_open) {
             open_group.push_back((int)convs.size() - 1);
@@ -247,12 +265,14 @@ struct grnet {
         op.kind = Op::CONV;
         op.conv_idx = (int)convs.size() - 1;
         op.lane = cur_lane;
+        op.hr = hr_region;
         ops.push_back(op);
         return convs.back().out;
     }
     // Convolutions added between begin_group() and end_group() are independent of each other and have
     // the same kernel size / stride: they become ONE grouped launch.
     bool solo_region = false;   // build_plan: convolutions added now are part of a chain nothing else overlaps
+    bool hr_region = false;     // build_plan: ops added now belong to the HR section
     bool group_open = false;
     std::vector<int> open_group;
     void begin_group() { group_open = true; open_group.clear(); }
@@ -260,6 +280,7 @@ struct grnet {
         group_open = false;
         if (open_group.empty()) return;
         Op op;
+        op.hr = hr_region;
         op.lane = 0;                                         // a grouped launch runs on lane 0; its members keep their own lane hints
         if (open_group.size() == 1) {
             op.lane = convs[open_group[0]].lane_hint;
@@ -328,6 +349,7 @@ struct grnet {
             Op op;
             op.kind = Op::SUM;
             op.lane = 0;
+            op.hr = hr_region;
             SumArgs& sa = op.sum;
             sa.C = kBranchCh[0]; sa.H = xs[0].h; sa.W = xs[0].w; sa.relu = 1;
             sa.n_add = nb;
@@ -399,6 +421,7 @@ struct grnet {
         }
         name_view("layer1", x);
         solo_region = false;
+        hr_region = true;                                   // transition1 .. stage 4: one persistent dataflow launch when enabled
         std::vector<View> xs;
         xs.push_back(conv_bn(x, b + "transition1.0.0.weight", b + "transition1.0.1", 32, 3, 1, true));
         cur_lane = 1;
@@ -420,6 +443,7 @@ struct grnet {
             xs = hr_module(xs, b + "stage4." + std::to_string(m) + ".", m == 2 ? &o0 : nullptr);
         }
         for (size_t i = 0; i < xs.size(); ++i) name_view("stage4." + std::to_string(i), xs[i]);
+        hr_region = false;
         int coff = 32;
         for (int idx = 2; idx <= 4; ++idx) {                // upsample heads (hrnet.py:440-453,521-523)
             const int br = idx - 1, c = kBranchCh[br], n_layers = idx - 1;
@@ -507,18 +531,42 @@ struct grnet {
                 m.kind = Op::CONV;
                 m.conv_idx = ci;
                 m.lane = convs[ci].lane_hint;
+                m.hr = convs[ci].hr;
                 ops_flat.push_back(m);
             }
         }
         static const int sched_env = getenv("GRNET_LANE_SCHED") ? atoi(getenv("GRNET_LANE_SCHED")) : 1;   // 0: lanes as written in the plan
         if (sched_env) schedule_lanes(ops_flat, max_frames);
+        {   // schedule C
+            std::map<const float*, int> wr, rd;
+            bool placed = false;
+            for (const Op& op : ops_flat) {
+                if (!op.hr) { ops_df.push_back(op); ops_df.back().waits.clear(); ops_df.back().record = false; continue; }
+                if (!placed) {
+                    Op d;
+                    d.kind = Op::DATAFLOW;
+                    d.lane = 0;
+                    ops_df.push_back(d);
+                    placed = true;
+                }
+                std::vector<const float*> r;
+                op_reads(op, r);
+                for (const float* b : r) rd[b] = 1;
+                if (const float* o = op_writes(op)) wr[o] = 1;
+            }
+            for (auto& kv : wr) df_writes.push_back(kv.first);
+            for (auto& kv : rd) if (!wr.count(kv.first)) df_reads.push_back(kv.first);
+            if (sched_env) schedule_lanes(ops_df, max_frames);
+        }
         analyze_dependencies(ops, op_events);
         analyze_dependencies(ops_flat, op_events_flat);
+        analyze_dependencies(ops_df, op_events_df);
         // streams / events of the parallel lanes are created here, never inside a stream capture
         if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return fail(GRNET_EHIP, "hipEventCreate failed");
         lanes_used = 1;                                        // only the streams the two schedules really use are created / forked / joined
         for (const Op& op : ops) lanes_used = std::max(lanes_used, op.lane + 1);
         for (const Op& op : ops_flat) lanes_used = std::max(lanes_used, op.lane + 1);
+        for (const Op& op : ops_df) lanes_used = std::max(lanes_used, op.lane + 1);
         for (int l = 1; l < lanes_used; ++l) {
             if (hipStreamCreateWithFlags(&side[l], hipStreamNonBlocking) != hipSuccess) return fail(GRNET_EHIP, "hipStreamCreate failed");
             if (hipEventCreateWithFlags(&ev_join[l], hipEventDisableTiming) != hipSuccess) return fail(GRNET_EHIP, "hipEventCreate failed");
@@ -528,6 +576,9 @@ struct grnet {
                 return fail(GRNET_EHIP, "hipEventCreate failed");
         for (size_t i = 0; i < ops_flat.size(); ++i)
             if (ops_flat[i].record && hipEventCreateWithFlags(&op_events_flat[i], hipEventDisableTiming) != hipSuccess)
+                return fail(GRNET_EHIP, "hipEventCreate failed");
+        for (size_t i = 0; i < ops_df.size(); ++i)
+            if (ops_df[i].record && hipEventCreateWithFlags(&op_events_df[i], hipEventDisableTiming) != hipSuccess)
                 return fail(GRNET_EHIP, "hipEventCreate failed");
         if (hipStreamCreateWithFlags(&capture_stream, hipStreamNonBlocking) != hipSuccess) return fail(GRNET_EHIP, "hipStreamCreate failed");
         const size_t n = max_frames;
@@ -565,6 +616,7 @@ struct grnet {
                 break;
             case Op::BILINEAR: r.push_back(op.bin.p); break;
             case Op::POOL: r.push_back(v_heat.p); r.push_back(v_smpl_feats.p); r.push_back(v_csmap.p); break;
+            case Op::DATAFLOW: r = df_reads; break;
             default: break;
         }
     }
@@ -600,6 +652,7 @@ struct grnet {
                     est[i] = fix_us + gf / (gf > 20 ? 0.105 : gf > 3 ? 0.085 : 0.060);     // us; GFLOP per us = TFLOP/s / 1000
                     break;
                 }
+                case Op::DATAFLOW: est[i] = 2500; break;
                 case Op::POOL: est[i] = 50; break;
                 case Op::TAIL: est[i] = 50; break;
                 case Op::SMPL: est[i] = 60; break;
@@ -617,6 +670,8 @@ struct grnet {
                 prev_tail = i;
             }
             if (const float* o = op_writes(op)) writers[o].push_back(i);
+            if (op.kind == Op::DATAFLOW)
+                for (const float* o : df_writes) writers[o].push_back(i);
         }
         for (int i = 0; i < m; ++i)
             for (int d : deps[i]) users[d].push_back(i);
@@ -641,7 +696,7 @@ struct grnet {
                 int from = -1;
                 for (int d : deps[i])
                     if (finish[d] >= ready) { ready = finish[d]; from = d; }
-                const bool pinned = list[i].kind == Op::POOL || list[i].kind == Op::TAIL || list[i].kind == Op::SMPL;
+                const bool pinned = list[i].kind == Op::POOL || list[i].kind == Op::TAIL || list[i].kind == Op::SMPL || list[i].kind == Op::DATAFLOW;
                 int lane = 0;
                 double start = std::max(ready, lane_free[0]);
                 if (!pinned) {
@@ -700,6 +755,7 @@ struct grnet {
                     break;
                 case Op::BILINEAR: r.push_back(op.bin.p); break;
                 case Op::POOL: r.push_back(v_heat.p); r.push_back(v_smpl_feats.p); r.push_back(v_csmap.p); break;
+                case Op::DATAFLOW: r = df_reads; break;
                 default: break;                                 // TAIL / SMPL follow POOL on lane 0
             }
         };
@@ -726,6 +782,8 @@ struct grnet {
             if (out) writers[out].push_back(i);
             if (op.kind == Op::GROUP)
                 for (int ci : op.group) writers[convs[ci].out.p].push_back(i);
+            if (op.kind == Op::DATAFLOW)
+                for (const float* o : df_writes) writers[o].push_back(i);
         }
         op_events.assign(ops.size(), nullptr);
         if (getenv("GRNET_TRACE")) {
@@ -1000,11 +1058,17 @@ struct grnet {
         // schedule: {parallel lanes, grouped launches} x {cost model, measured table} x {replayed hipGraph, eager launches
         // on the four lane streams} -- the graph executor of ROCm 7.2 maps parallel branches to fewer hardware queues
         // than explicit streams do, so eager multi-stream launching can win although it costs CPU time per launch
-        float t_mode[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        // bit 3: the HR section as ONE persistent per-XCD dataflow launch (hr_dataflow_f32) instead of ~270 launches
+        float t_mode[16];
+        for (float& t : t_mode) t = 1e30f;
         const bool keep = grouping, keep_graph = use_graph;
-        for (int mode = 0; mode < 8; ++mode) {
-            if ((mode & 4) == 0 && !keep_graph) { t_mode[mode] = 1e30f; continue; }   // graphs not enabled by the caller
-            if (dtype == 1 && (mode & 3)) { t_mode[mode] = 1e30f; continue; }          // bf16: no per-shape table, no grouped launches
+        const int keep_df = df_mode;
+        for (int mode = 0; mode < 16; ++mode) {
+            if ((mode & 4) == 0 && !keep_graph) continue;                               // graphs not enabled by the caller
+            if (dtype == 1 && (mode & 11)) continue;                                    // bf16: no per-shape table, no grouped launches, no dataflow
+            if ((mode & 8) && ((mode & 2) || keep_df == 0)) continue;                   // dataflow replaces grouping; switched off by the caller
+            if (!(mode & 8) && keep_df == 1 && dtype == 0) continue;                    // dataflow forced by the caller
+            if (mode & 8) { tuned_mode[n] = mode; df_mode = 1; if (!dataflow_for(n)) { df_mode = keep_df; continue; } df_mode = keep_df; }
             use_graph = (mode & 4) == 0;
             grouping = dtype != 1;
             tuned_mode[n] = mode;
@@ -1022,8 +1086,9 @@ struct grnet {
         grouping = keep;
         use_graph = keep_graph;
         int best_mode = 0;
-        for (int mode = 1; mode < 8; ++mode)
+        for (int mode = 1; mode < 16; ++mode)
             if (t_mode[mode] < t_mode[best_mode]) best_mode = mode;
+        if (t_mode[best_mode] >= 1e30f) return fail(GRNET_ESTATE, "no schedule could be timed");
         tuned_mode[n] = best_mode;
         // in-context refinement (level 2): greedy coordinate descent on the time of the whole replayed forward --
         // a configuration that wins alone can lose when four lanes share the CUs.  Shapes in order of their FLOP share.
@@ -1088,14 +1153,142 @@ struct grnet {
         seen_once.clear();
         if (getenv("GRNET_TRACE"))
             fprintf(stderr, "[grnet] tuned n=%d: forward ms graph[lanes/model %.3f lanes/measured %.3f grouped/model %.3f grouped/measured %.3f] "
-                    "eager[%.3f %.3f %.3f %.3f] -> mode %d\n",
-                    n, t_mode[0] / 3, t_mode[1] / 3, t_mode[2] / 3, t_mode[3] / 3, t_mode[4] / 3, t_mode[5] / 3, t_mode[6] / 3, t_mode[7] / 3, best_mode);
+                    "eager[%.3f %.3f %.3f %.3f] dataflow graph[%.3f %.3f] eager[%.3f %.3f] -> mode %d\n",
+                    n, t_mode[0] / 3, t_mode[1] / 3, t_mode[2] / 3, t_mode[3] / 3, t_mode[4] / 3, t_mode[5] / 3, t_mode[6] / 3, t_mode[7] / 3,
+                    t_mode[8] / 3, t_mode[9] / 3, t_mode[12] / 3, t_mode[13] / 3, best_mode);
         return 0;
     }
     bool grouping_for(int n) const {
         if (conv_tile_hint || !grouping) return false;
         auto it = tuned_mode.find(n);
         return it == tuned_mode.end() ? false : (it->second & 2) != 0;
+    }
+
+    // ------------------------------------------------------------------ dataflow plan of the HR section
+    // Tile variant, task list and dependency table for calls of n frames (cached).  Images are dealt to the XCDs in contiguous ranges
+    // of ipx = ceil(n / 8); the task list covers one block of B images and repeats for every block of an XCD's range.
+    int build_df_plan(int n, DfPlan& pl) {
+        pl.ok = false;
+        if (dtype != 0) return 0;
+        std::map<const float*, int> producer;                  // buffer -> index in pl.convs of the section op that writes it
+        std::vector<int> need;                                 // tasks per image of each section op
+        struct Item { int conv; int tiles_y, gy, bchunk; };
+        static const int min_tasks = getenv("GRNET_DF_MINTASKS") ? atoi(getenv("GRNET_DF_MINTASKS")) : 16;
+        std::vector<Item> items;
+        pl.convs.clear(); pl.tasks.clear(); pl.lds = 0;
+        for (const Op& op : ops_flat) {
+            if (!op.hr) continue;
+            DfConv c{};
+            std::vector<const float*> reads;
+            const float* out = nullptr;
+            int tiles_y = 0, gy = 1;
+            if (op.kind == Op::CONV) {
+                const ConvLayer& L = convs[op.conv_idx];
+                c.a = conv_args(L, nullptr, n);
+                size_t lds = 0;
+                c.variant = df_plan_conv(c.a, &lds);
+                if (c.variant < 0) return 0;                   // a shape without a dataflow variant: the section stays on the lane streams
+                pl.lds = std::max(pl.lds, lds);
+                tiles_y = c.a.tiles_y; gy = c.a.gy;
+                reads.push_back(L.in.p);
+                for (auto& a : L.adds) reads.push_back(a.v.p);
+                out = L.out.p;
+            } else if (op.kind == Op::SUM) {
+                const auto& sv = sum_views[op.conv_idx];
+                if ((int)sv.second.size() < 2 || (int)sv.second.size() > 1 + kMaxAdd || sv.second[0].shift != 0) return 0;
+                c.variant = -1;
+                ConvArgs& a = c.a;
+                a.N = n; a.Cout = sv.first.c; a.Ho = sv.first.h; a.Wo = sv.first.w; a.relu = 1;
+                a.out = sv.first.p; a.out_ctot = sv.first.ctot; a.out_coff = sv.first.coff;
+                a.in = sv.second[0].v.p; a.in_ctot = sv.second[0].v.ctot; a.in_coff = sv.second[0].v.coff;
+                a.n_add = (int)sv.second.size() - 1;
+                for (int k = 0; k < a.n_add; ++k) {
+                    a.add[k] = sv.second[k + 1].v.p; a.add_ctot[k] = sv.second[k + 1].v.ctot; a.add_coff[k] = sv.second[k + 1].v.coff;
+                    a.add_shift[k] = sv.second[k + 1].shift;
+                }
+                a.R = 8;                                       // 8 rows per task
+                if ((a.R * a.Wo) % 4 != 0) return 0;
+                a.tiles_y = (a.Ho + a.R - 1) / a.R;
+                tiles_y = a.tiles_y;
+                for (auto& r : sv.second) reads.push_back(r.v.p);
+                out = sv.first.p;
+            } else {
+                return 0;
+            }
+            for (const float* b : reads) {
+                auto it = producer.find(b);
+                if (it == producer.end()) continue;            // written before the section (layer1)
+                bool dup = false;
+                for (int k = 0; k < c.ndeps; ++k) dup |= c.dep[k] == it->second;
+                if (dup) continue;
+                if (c.ndeps >= 4) return 0;
+                c.dep[c.ndeps] = it->second;
+                c.need[c.ndeps] = need[it->second];
+                ++c.ndeps;
+            }
+            const int idx = (int)pl.convs.size();
+            if (producer.count(out)) return 0;                 // two writers of one buffer inside the section: not expressible per image
+            producer[out] = idx;
+            c.bchunk = std::max(1, std::min(gy, tiles_y * gy / std::max(1, min_tasks)));      // >= ~min_tasks tasks per (convolution, image)
+            const int by_tasks = (gy + c.bchunk - 1) / c.bchunk;
+            need.push_back(tiles_y * by_tasks);
+            pl.convs.push_back(c);
+            items.push_back({idx, tiles_y, gy, c.bchunk});
+        }
+        if (pl.convs.empty() || pl.convs.size() > 65535) return 0;
+        pl.nconv = (int)pl.convs.size();
+        pl.ipx = (n + 7) / 8;
+        // all images of an XCD form ONE block: the queue is convolution-major across them, so the ready work of an XCD is
+        // (images per XCD) x (branches) x (tiles of a convolution), not two images' worth
+        pl.B = pl.ipx;
+        for (const Item& it : items)
+            for (int img = 0; img < pl.B; ++img)
+                for (int ty = 0; ty < it.tiles_y; ++ty)
+                    for (int by = 0; by < it.gy; by += it.bchunk)      // channel-block chunks of one pixel tile are neighbours in the queue: they share its input patch
+                        pl.tasks.push_back(DfTask{(unsigned short)it.conv, (unsigned short)img, (unsigned short)ty, (unsigned short)by});
+        pl.tasks_per_blk = (int)pl.tasks.size();
+        const int nblk = (pl.ipx + pl.B - 1) / pl.B;
+        pl.ctr_stride = (16 + nblk * pl.nconv * pl.B + 63) / 64 * 64;
+        pl.ctr_bytes = (size_t)8 * pl.ctr_stride * sizeof(unsigned);
+        void* q = nullptr;
+        if (hipMalloc(&q, pl.convs.size() * sizeof(DfConv)) != hipSuccess) return fail(GRNET_ENOMEM, "dataflow tables");
+        dev_allocs.push_back(q);
+        pl.d_convs = static_cast<DfConv*>(q);
+        HIP_TRY(hipMemcpy(q, pl.convs.data(), pl.convs.size() * sizeof(DfConv), hipMemcpyHostToDevice));
+        if (hipMalloc(&q, pl.tasks.size() * sizeof(DfTask)) != hipSuccess) return fail(GRNET_ENOMEM, "dataflow tables");
+        dev_allocs.push_back(q);
+        pl.d_tasks = static_cast<DfTask*>(q);
+        HIP_TRY(hipMemcpy(q, pl.tasks.data(), pl.tasks.size() * sizeof(DfTask), hipMemcpyHostToDevice));
+        if (hipMalloc(&q, pl.ctr_bytes) != hipSuccess) return fail(GRNET_ENOMEM, "dataflow counters");
+        dev_allocs.push_back(q);
+        pl.d_counters = static_cast<unsigned*>(q);
+        pl.ok = true;
+        if (getenv("GRNET_TRACE"))
+            fprintf(stderr, "[grnet] dataflow plan n=%d: %d ops, %d tasks per block of %d images, %d images per XCD, LDS %zu B\n", n, pl.nconv,
+                    pl.tasks_per_blk, pl.B, pl.ipx, pl.lds);
+        return 0;
+    }
+    // Is the HR section of an n-frame call run by the dataflow kernel?  (Builds and caches the plan on first use; never inside a capture.)
+    bool dataflow_for(int n) {
+        if (dtype != 0 || conv_tile_hint || df_mode == 0 || !finalized) return false;
+        if (df_mode == 2) {
+            auto it = tuned_mode.find(n);
+            if (it == tuned_mode.end() || !(it->second & 8)) return false;
+        }
+        if (df_probe < 0) {
+            int ok = 0;
+            if (df_probe_xcc(df_wgs_per_xcd, &ok, nullptr) != hipSuccess) ok = 0;
+            df_probe = ok;
+            if (getenv("GRNET_TRACE")) fprintf(stderr, "[grnet] XCC probe: a %d-workgroup grid %s all 8 XCDs evenly\n", 8 * df_wgs_per_xcd, ok ? "reaches" : "does NOT reach");
+        }
+        if (!df_probe) return false;
+        auto it = df_plans.find(n);
+        if (it == df_plans.end()) {
+            DfPlan pl;
+            if (build_df_plan(n, pl) != 0) pl.ok = false;
+            it = df_plans.emplace(n, std::move(pl)).first;
+        }
+        return it->second.ok;
     }
 
     // ------------------------------------------------------------------ execution
@@ -1128,9 +1321,10 @@ struct grnet {
         float* verts = o.verts ? o.verts : d_verts;
         float* kp3d = o.kp_3d ? o.kp_3d : d_kp3d;
         float* kp2d = o.kp_2d ? o.kp_2d : d_kp2d;
-        const bool group_now = grouping_for(n);
-        const std::vector<Op>& ops = group_now ? this->ops : ops_flat;
-        const std::vector<hipEvent_t>& op_events = group_now ? this->op_events : op_events_flat;
+        const bool df_now = dataflow_for(n);
+        const bool group_now = !df_now && grouping_for(n);
+        const std::vector<Op>& ops = df_now ? ops_df : group_now ? this->ops : ops_flat;
+        const std::vector<hipEvent_t>& op_events = df_now ? op_events_df : group_now ? this->op_events : op_events_flat;
         GraphRecorder* rec = g_recorder;                          // non-null: build graph nodes instead of launching
         const bool lanes = multi_lane && !rec;
         std::vector<hipGraphNode_t> lane_last(kLanes, nullptr), op_node(rec ? ops.size() : 0, nullptr);
@@ -1146,7 +1340,7 @@ struct grnet {
         hipStream_t caller = s;
         for (size_t oi = 0; oi < ops.size(); ++oi) {
             const Op& op = ops[oi];
-            if (convs_only && op.kind != Op::CONV && op.kind != Op::GROUP) continue;
+            if (convs_only && op.kind != Op::CONV && op.kind != Op::GROUP && op.kind != Op::DATAFLOW) continue;
             s = lane_stream[op.lane];
             const int lane = multi_lane ? op.lane : 0;
             if (lanes)
@@ -1183,6 +1377,34 @@ struct grnet {
                             else HIP_TRY(launch_conv(list[gi], s, hint_for(convs[op.group[gi]], n)));
                         }
                         launches += cnt;
+                    }
+                    break;
+                }
+                case Op::DATAFLOW: {
+                    DfPlan& pl = df_plans[n];                // built by dataflow_for(n)
+                    DfParams dp{};
+                    dp.convs = pl.d_convs; dp.tasks = pl.d_tasks; dp.tasks_per_blk = pl.tasks_per_blk; dp.nconv = pl.nconv;
+                    dp.n = n; dp.ipx = pl.ipx; dp.B = pl.B; dp.counters = pl.d_counters; dp.ctr_stride = pl.ctr_stride; dp.fence = df_fence;
+                    if (const char* lim = getenv("GRNET_DF_LIMIT")) dp.tasks_per_blk = std::min(dp.tasks_per_blk, atoi(lim));   // diagnostic: run a prefix of the queue
+                    if (rec) {                                // graph: a memset node in front of the kernel node
+                        hipMemsetParams mp{};
+                        mp.dst = pl.d_counters; mp.value = 0; mp.elementSize = 4; mp.width = pl.ctr_bytes / 4; mp.height = 1; mp.pitch = pl.ctr_bytes;
+                        hipGraphNode_t mnode = nullptr;
+                        HIP_TRY(hipGraphAddMemsetNode(&mnode, rec->graph, rec->deps.data(), rec->deps.size(), &mp));
+                        rec->deps.assign(1, mnode);
+                    } else {
+                        HIP_TRY(hipMemsetAsync(pl.d_counters, 0, pl.ctr_bytes, s));
+                    }
+                    HIP_TRY(launch_hr_dataflow(dp, pl.lds, df_wgs_per_xcd, s));
+                    ++launches;
+                    if (!rec && getenv("GRNET_DF_DEBUG")) {     // diagnostic: queue heads, census and timed-out waits per XCD
+                        HIP_TRY(hipStreamSynchronize(s));
+                        for (int x = 0; x < 8; ++x) {
+                            unsigned c8[8];
+                            HIP_TRY(hipMemcpy(c8, pl.d_counters + (size_t)x * pl.ctr_stride, sizeof(c8), hipMemcpyDeviceToHost));
+                            fprintf(stderr, "[grnet] dataflow xcd %d: head %u of %d, workers %u, foreign %u, timeouts %u (first: task %u conv %u waits for conv %u, has %u)\n",
+                                    x, c8[0], pl.tasks_per_blk * ((std::min(n, (x + 1) * pl.ipx) - x * pl.ipx + pl.B - 1) / pl.B), c8[1], c8[2], c8[3], c8[4], c8[5], c8[6], c8[7]);
+                        }
                     }
                     break;
                 }
@@ -1440,6 +1662,9 @@ int grnet_create(grnet_t** out_handle, int device_id, int dtype, int max_frames)
     h->dtype = dtype;
     if (dtype == 1) h->grouping = false;                   // grouped launches exist for the fp32 split-K kernels only
     if (const char* ml = getenv("GRNET_MULTI_LANE")) h->multi_lane = atoi(ml) != 0;   // profiling: per-kernel times without overlap
+    if (const char* df = getenv("GRNET_DATAFLOW")) h->df_mode = std::max(0, std::min(2, atoi(df)));
+    if (const char* df = getenv("GRNET_DF_WGS")) h->df_wgs_per_xcd = std::max(8, std::min(256, atoi(df)));
+    if (const char* df = getenv("GRNET_DF_FENCE")) h->df_fence = atoi(df);
     h->build_plan();
     int rc = h->allocate();
     if (rc) { fprintf(stderr, "grnet_create: %s\n", h->err.c_str()); return rc; }
@@ -1626,6 +1851,13 @@ int grnet_set_option(grnet_t* h, int option, int value) {
         h->drop_graphs();
         return 0;
     }
+    if (option == GRNET_OPT_DATAFLOW) {
+        if (value < 0 || value > 2) return h->fail(GRNET_EINVAL, "dataflow option must be 0 (never), 1 (wherever possible) or 2 (where tuned faster)");
+        h->df_mode = value;
+        h->drop_graphs();
+        return 0;
+    }
+    if (option == GRNET_OPT_DATAFLOW_FENCE) { h->df_fence = value != 0; h->drop_graphs(); return 0; }
     if (option == GRNET_OPT_MULTI_LANE) {
         h->multi_lane = value != 0;
         h->drop_graphs();

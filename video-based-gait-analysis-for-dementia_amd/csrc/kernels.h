@@ -105,6 +105,7 @@ struct DfTask { unsigned short conv, img, ty, by; };          // convolution (in
 struct DfConv {
     ConvArgs a;                 // tile plan filled (plan_tile): N = frames of the call, image selected through bx
     int variant;                // (ks,stride) x tile variant, see hr_dataflow_f32; -1: fuse sum (a.in = identity term, a.add = upsampled terms)
+    int bchunk;                 // output-channel blocks per task
     int ndeps, dep[4], need[4]; // producers inside the section and their task count per image
 };
 struct DfParams {

@@ -273,7 +273,7 @@ class GRNet:
         if self._lib.grnet_get_tuning(self._h, int(n_frames), buf, len(buf)) <= 0:
             return None
         mode = int(buf.value.decode().split("\n", 1)[0].split()[1])
-        return {"measured_table": bool(mode & 1), "grouped": bool(mode & 2), "eager": bool(mode & 4)}
+        return {"measured_table": bool(mode & 1), "grouped": bool(mode & 2), "eager": bool(mode & 4), "dataflow": bool(mode & 8)}
 
     # ------------------------------------------------------------------ introspection (bench / tests)
     def num_kernel_launches(self):
