@@ -70,10 +70,45 @@ if out:
         out["note"] = ("memory-side (fabric) requests of the L2: Infinity-Cache hits are counted, so this is an upper bound on HBM "
                        "bytes; the 16-frame working set (~1.7 GB of activations) does not fit the 256 MiB cache")
     lt = os.path.join(dst, f"{rnd}_layer_traffic.json")          # tools/layer_table.py: the same counters joined per launch + calibration
+    lt_rnd = rnd
+    if not os.path.isfile(lt):                                    # the per-launch table was not re-taken this round: the convolution
+        lt, lt_rnd = os.path.join(dst, "r01_layer_traffic.json"), "r01"   # kernels and the workload are unchanged, so round 1's calibration still applies
     if os.path.isfile(lt):
         t = json.load(open(lt))
         out["algorithmic_bytes_per_step_conv_kernels"] = t["algorithmic_read_bytes"] + t["algorithmic_write_bytes"]
         out["hbm_bytes_per_step_conv_kernels_calibrated"] = t["fetch_calibrated_bytes"] + t["write_size_bytes"]
-        out["calibration"] = t["calibration"] + f" (profiles/{rnd}_fetch_calibration.json, profiles/{rnd}_layer_table.md)"
+        out["calibration"] = t["calibration"] + f" (profiles/{lt_rnd}_fetch_calibration.json, profiles/{lt_rnd}_layer_table.md)"
     json.dump(out, open(os.path.join(dst, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if not isinstance(v, dict)}, indent=1))
+
+
+# SQ counters per kernel (tools/gpu_pmc_sq.sh / gpu_profile_r02.sh: GRNET_MULTI_LANE=0, one pass): MFMA pipe busy and wait shares
+sq = os.path.join(src, "pmc_sq", "sq_counter_collection.csv")
+if os.path.isfile(sq):
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(set)
+    for r in csv.DictReader(open(sq)):
+        n = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("grk::", "")
+        per[n][r["Counter_Name"]] += float(r["Counter_Value"])
+        disp[n].add(r["Dispatch_Id"])
+    lines = ["kernel,dispatches,mfma_busy_frac,wait_any_frac,wait_inst_frac,active_inst_frac,valu_inst_frac,lds_inst_frac,busy_cu_cycles_per_dispatch"]
+    tot = collections.defaultdict(float)
+    for n, c in sorted(per.items(), key=lambda kv: -kv[1].get("SQ_BUSY_CU_CYCLES", 0)):
+        w, b = max(c.get("SQ_WAVE_CYCLES", 0), 1.0), max(c.get("SQ_BUSY_CU_CYCLES", 0), 1.0)
+        lines.append(f'"{n}",{len(disp[n])},{c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (4 * b):.4f},{c.get("SQ_WAIT_ANY", 0) / w:.4f},'
+                     f'{c.get("SQ_WAIT_INST_ANY", 0) / w:.4f},{c.get("SQ_ACTIVE_INST_ANY", 0) / w:.4f},{c.get("SQ_ACTIVE_INST_VALU", 0) / w:.4f},'
+                     f'{c.get("SQ_ACTIVE_INST_LDS", 0) / w:.4f},{b / len(disp[n]):.0f}')
+        for k, v in c.items():
+            tot[k] += v
+    lines.append(f'"ALL KERNELS",{sum(len(d) for d in disp.values())},{tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * max(tot["SQ_BUSY_CU_CYCLES"], 1)):.4f},'
+                 f'{tot["SQ_WAIT_ANY"] / max(tot["SQ_WAVE_CYCLES"], 1):.4f},{tot["SQ_WAIT_INST_ANY"] / max(tot["SQ_WAVE_CYCLES"], 1):.4f},'
+                 f'{tot["SQ_ACTIVE_INST_ANY"] / max(tot["SQ_WAVE_CYCLES"], 1):.4f},{tot["SQ_ACTIVE_INST_VALU"] / max(tot["SQ_WAVE_CYCLES"], 1):.4f},'
+                 f'{tot["SQ_ACTIVE_INST_LDS"] / max(tot["SQ_WAVE_CYCLES"], 1):.4f},')
+    open(os.path.join(dst, f"{rnd}_sq_summary.csv"), "w").write("\n".join(lines) + "\n")
+    print("SQ summary:", lines[-1])
+
+g2 = os.path.join(src, "bench_gpus2_gloo.log")
+if os.path.isfile(g2):
+    for line in open(g2):
+        if line.startswith("{"):
+            open(os.path.join(dst, f"{rnd}_bench_gpus2_selflaunch_gloo.json"), "w").write(line)
