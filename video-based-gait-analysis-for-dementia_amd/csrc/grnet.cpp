@@ -979,7 +979,19 @@ struct grnet {
             if (rc) return rc;
         }
         int rc;
-        if ((rc = upload_key("head.pose_mlp.weight", 6 * 128 * 24, &tailw.pose_w))) return rc;
+        {   // per-joint 128 -> 6 weights (locallyconnected2d.py:43-46), stored (6,128,24) = [o][c][j]; the tail kernel walks c with one
+            // thread per (j, o): re-order to [c][j][o] so every step reads 144 contiguous floats instead of 144 lines
+            const HostTensor* t = find("head.pose_mlp.weight");
+            if (!t) return fail(GRNET_ENOENT, "missing tensor head.pose_mlp.weight");
+            if (t->numel() != 6 * 128 * 24) return fail(GRNET_EINVAL, "bad size for head.pose_mlp.weight");
+            std::vector<float> tr(6 * 128 * 24);
+            for (int o = 0; o < 6; ++o)
+                for (int c = 0; c < 128; ++c)
+                    for (int j = 0; j < 24; ++j) tr[(size_t)c * 144 + j * 6 + o] = t->data[((size_t)o * 128 + c) * 24 + j];
+            float* p = nullptr;
+            if ((rc = upload(tr, &p))) return rc;
+            tailw.pose_w = p;
+        }
         if ((rc = upload_key("head.shape_mlp.weight", 10 * 1536, &tailw.shape_w))) return rc;
         if ((rc = upload_key("head.shape_mlp.bias", 10, &tailw.shape_b))) return rc;
         if ((rc = upload_key("head.cam_mlp.weight", 3 * 1536, &tailw.cam_w))) return rc;

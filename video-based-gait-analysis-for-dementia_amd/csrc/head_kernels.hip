@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void softmax_stats_kernel(const float* __restr
 // block = (frame n, 32 channels of the stacked [featA | featB] map, one of kPoolSplit pixel ranges);
 // 256 threads = 16 channel pairs x 4 joint groups of 6 x 4 pixel phases; pixel tiles of 64 staged in
 // LDS.  Each block writes a partial sum; head_tail_kernel adds the kPoolSplit partials in a fixed order.
-constexpr int kPoolPT = 64;
+constexpr int kPoolPT = 64;                                // pixels per staged tile (224-pixel tiles measured slower: 80 vs 44 us -- fewer, fatter workgroups hide less latency)
 __global__ __launch_bounds__(256) void attn_pool_kernel(const float* __restrict__ heat, int heat_ctot, const float* __restrict__ stats,
                                                           const float* __restrict__ featA, int CA, const float* __restrict__ featB,
                                                           int CB, float* __restrict__ part, int P) {
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
         const int j = tid / 6, o = tid % 6;
         float acc = 0.f;
 #pragma unroll 16
-        for (int c = 0; c < 128; ++c) acc += s_plf[c * 24 + j] * w.pose_w[(o * 128 + c) * 24 + j];
+        for (int c = 0; c < 128; ++c) acc += s_plf[c * 24 + j] * w.pose_w[c * 144 + tid];      // [c][j][o]: the 144 threads read one contiguous row per c
         s_pose[j * 6 + o] = acc;
         rot6d[(size_t)n * 144 + j * 6 + o] = acc;
     }

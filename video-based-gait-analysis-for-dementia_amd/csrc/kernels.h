@@ -144,7 +144,7 @@ hipError_t launch_softmax_pool(const float* heat, int heat_ctot, const float* fe
                                float* outA, float* outB, float* prob_ws, int N, int P, hipStream_t s);
 
 struct TailWeights {
-    const float* pose_w;    // (6,128,24)
+    const float* pose_w;    // (128,24,6): head.pose_mlp.weight (1,6,128,24,1,1) re-ordered at load so a channel's 144 weights are contiguous
     const float* shape_w;   // (10,1536)
     const float* shape_b;
     const float* cam_w;     // (3,1536)
