@@ -568,13 +568,7 @@ struct grnet {
         for (const Op& op : ops_flat) lanes_used = std::max(lanes_used, op.lane + 1);
         for (const Op& op : ops_df) lanes_used = std::max(lanes_used, op.lane + 1);
         for (int l = 1; l < lanes_used; ++l) {
-            // GRNET_PRIO=1 (experiment): lane 1 is a high-priority queue and the lane scheduler puts the critical chain on it
-            static const int prio_env = getenv("GRNET_PRIO") ? atoi(getenv("GRNET_PRIO")) : 0;
-            int least = 0, greatest = 0;
-            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-            const int prio = (prio_env && l == 1) ? greatest : (prio_env == 2 ? least : 0);
-            if (hipStreamCreateWithPriority(&side[l], hipStreamNonBlocking, prio) != hipSuccess) return fail(GRNET_EHIP, "hipStreamCreate failed");
-            if (getenv("GRNET_TRACE") && l == 1) fprintf(stderr, "[grnet] stream priorities: range [%d, %d], lane 1 at %d\n", least, greatest, prio);
+            if (hipStreamCreateWithFlags(&side[l], hipStreamNonBlocking) != hipSuccess) return fail(GRNET_EHIP, "hipStreamCreate failed");
             if (hipEventCreateWithFlags(&ev_join[l], hipEventDisableTiming) != hipSuccess) return fail(GRNET_EHIP, "hipEventCreate failed");
         }
         for (size_t i = 0; i < ops.size(); ++i)
@@ -686,26 +680,6 @@ struct grnet {
             for (int u : users[i]) b = std::max(b, blevel[u]);
             blevel[i] = b + est[i];
         }
-        // GRNET_PRIO: the critical chain (largest remaining path at every step) of the multi-lane region goes to lane 1 (a high-priority
-        // queue), everything else to the other lanes
-        static const int prio_env = getenv("GRNET_PRIO") ? atoi(getenv("GRNET_PRIO")) : 0;
-        std::vector<char> critical(m, 0);
-        if (prio_env) {
-            int cur = -1;
-            double best_b = -1;
-            for (int i = 0; i < m; ++i)
-                if (deps[i].empty() && blevel[i] > best_b) { best_b = blevel[i]; cur = i; }
-            while (cur >= 0) {
-                const bool pinned = list[cur].kind == Op::POOL || list[cur].kind == Op::TAIL || list[cur].kind == Op::SMPL || list[cur].kind == Op::DATAFLOW;
-                const bool solo = list[cur].kind == Op::CONV && convs[list[cur].conv_idx].solo;
-                if (!pinned && !solo) critical[cur] = 1;
-                int nxt = -1;
-                double b = -1;
-                for (int u : users[cur])
-                    if (blevel[u] > b) { b = blevel[u]; nxt = u; }
-                cur = nxt;
-            }
-        }
         std::vector<int> pending(m), lane_of(m, 0), order;
         std::vector<double> finish(m, 0.0);
         std::vector<char> done(m, 0);
@@ -725,16 +699,11 @@ struct grnet {
                 const bool pinned = list[i].kind == Op::POOL || list[i].kind == Op::TAIL || list[i].kind == Op::SMPL || list[i].kind == Op::DATAFLOW;
                 int lane = 0;
                 double start = std::max(ready, lane_free[0]);
-                if (!pinned && prio_env && critical[i]) {
-                    lane = 1;
-                    start = std::max(ready, lane_free[1]);
-                } else if (!pinned) {
-                    int pref = from >= 0 ? lane_of[from] : 0;
-                    if (prio_env && pref == 1) pref = 0;
+                if (!pinned) {
+                    const int pref = from >= 0 ? lane_of[from] : 0;
                     lane = pref;
                     start = std::max(ready, lane_free[pref]);
                     for (int l = 0; l < n_lanes; ++l) {
-                        if (prio_env && l == 1) continue;             // lane 1 is reserved for the critical chain
                         const double st = std::max(ready, lane_free[l]);
                         if (st + hop_us < start) { start = st; lane = l; }   // a cross-lane hop costs an event
                     }
