@@ -99,12 +99,16 @@ int grnet_gru_forward(grnet_t* h, const float* x_dev, const float* cparams_dev, 
 int grnet_tsattn_forward(grnet_t* h, const float* x_dev, const float* xs_dev, int b, int n, float* y_dev, void* stream);
 
 #define GRNET_OPT_USE_GRAPH 1     /* 1: capture each distinct (n, pointers) forward into a hipGraph and replay it */
-#define GRNET_OPT_CONV_TILE 2     /* 0 = cost model; 7 / 14 = whole-K tiles; 1071/1072/1041/1042 = split-K (psw,csw) (tests / tuning) */
+#define GRNET_OPT_CONV_TILE 2     /* 0 = cost model; 7 / 14 = whole-K tiles; 1071/1072/1041/1042 = split-K (psw,csw) (tests / tuning); any forced tile also
+                                   * switches the Winograd layers back to the direct kernel; grnet_op_conv2d: 2000 = the Winograd kernel */
 #define GRNET_OPT_MULTI_LANE 3    /* 1 (default): independent HR-module branches run on parallel streams / graph branches */
 #define GRNET_OPT_GROUPING 4      /* 1 (default): same-depth convolutions of an HR module are one grouped launch */
 #define GRNET_OPT_DATAFLOW 5      /* HR section (transition1 .. stage 4) as ONE persistent per-XCD dataflow launch: 0 never (default: it is
                                    * correct but measured slower than the per-convolution launches this round), 1 wherever a plan exists,
                                    * 2 where grnet_tune measured it faster */
+#define GRNET_OPT_WINOGRAD 7       /* 1 (default): the 3x3 stride-1 layers with >= 64 channels on 56x56 maps (upsample heads, PARE head) run as Winograd
+                                    * F(2x2,3x3) on the fp32 matrix cores (2.25x fewer multiplies, fp32 throughout, sums re-associated: ~1e-6 of the output
+                                    * scale from the direct kernel); 0: every convolution is the direct implicit GEMM */
 #define GRNET_OPT_DATAFLOW_FENCE 6 /* 1: device-scope release/acquire around every hand-off inside that launch (validation; slower) */
 int grnet_set_option(grnet_t* h, int option, int value);
 

@@ -323,3 +323,48 @@ def test_dataflow_hr_section_parity_and_determinism(pkg, golden):
     assert torch.equal(fixed["theta"], outs[0].reshape(16, 85))
     m.set_option(lib.OPT_USE_GRAPH, 0)
     m.close()
+
+
+WINO_CASES = [(64, 64), (128, 128), (256, 256), (480, 256), (128, 64), (72, 192)]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_winograd_conv_kernel(model, oracle, case):
+    """conv_wino_f32 (Winograd F(2x2,3x3) on the fp32 matrix cores) on single convolutions vs the oracle's direct convolution: every
+    eligible channel shape of the path plus odd ones (Cin not a multiple of the MFMA K, Cout = 3 channel blocks), 1 and 3 images
+    (first / last tile-row groups carry the zero padding), bias + ReLU epilogue."""
+    cin, cout = case
+    g = np.random.Generator(np.random.Philox(key=[77, cin * 1000 + cout]))
+    for n in (1, 3):
+        x = g.standard_normal((n, cin, 56, 56)).astype(np.float32)
+        w = (g.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (cin * 9))).astype(np.float32)
+        b = (g.standard_normal((cout,)) * 0.1).astype(np.float32)
+        ref = torch.relu(oracle.conv2d(x, w, stride=1, bias=b)).numpy()
+        got = model.op_conv2d(torch.from_numpy(x).cuda(), w, b, stride=1, relu=True, tile_hint=2000).cpu().numpy()
+        assert got.shape == ref.shape
+        assert rel_err(got, ref) < 2e-5, (case, n, rel_err(got, ref))
+        ref_lin = oracle.conv2d(x, w, stride=1).numpy()                     # no bias, no ReLU: borders and signs exposed
+        got_lin = model.op_conv2d(torch.from_numpy(x).cuda(), w, None, stride=1, relu=False, tile_hint=2000).cpu().numpy()
+        assert rel_err(got_lin, ref_lin) < 2e-5, (case, n)
+        assert rel_err(got_lin[:, :, [0, 55]], ref_lin[:, :, [0, 55]]) < 2e-5 and rel_err(got_lin[..., [0, 55]], ref_lin[..., [0, 55]]) < 2e-5
+    with pytest.raises(Exception):
+        model.op_conv2d(torch.zeros(1, 64, 28, 28).cuda(), np.zeros((64, 64, 3, 3), np.float32), tile_hint=2000)   # not a 56x56 map: refused, no fallback
+
+
+def test_winograd_layers_match_direct_layers(pkg, golden):
+    """The whole forward with the eligible layers as Winograd (default) vs all-direct (GRNET_OPT_WINOGRAD = 0): same outputs to fp32
+    re-association noise, both within the bar of the reference goldens."""
+    m = pkg.build_synthetic_model(max_frames=16, with_gru=False)
+    frames = torch.from_numpy(pkg.synth.make_frames(16)).cuda()
+    m.set_option(pkg._lib.OPT_WINOGRAD, 1)
+    a = {k: v.clone() for k, v in m(frames, extras=("features", "smpl_feats"))[-1].items()}
+    m.set_option(pkg._lib.OPT_WINOGRAD, 0)
+    b = {k: v.clone() for k, v in m(frames, extras=("features", "smpl_feats"))[-1].items()}
+    torch.cuda.synchronize()
+    assert not torch.equal(a["features"], b["features"])                    # the switch does select another kernel
+    for k in ("features", "smpl_feats", "theta", "kp_3d", "kp_2d", "verts", "rotmat"):
+        assert rel_err(a[k].cpu().numpy(), b[k].cpu().numpy()) < 5e-5, (k, rel_err(a[k].cpu().numpy(), b[k].cpu().numpy()))
+    g = golden["grnet_n4"]
+    for k in ("theta", "kp_3d", "kp_2d"):
+        assert rel_err(a[k][0, :4].cpu().numpy().reshape(g[k].shape), g[k]) < 1e-4, k
+    m.close()

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libgrnet_hip.so")
 
 OK, EINVAL, ENOENT, ENOMEM, EHIP, ESTATE = 0, -22, -2, -12, -5, -1
 DTYPE_F32, DTYPE_I64 = 0, 1
-OPT_USE_GRAPH, OPT_CONV_TILE, OPT_MULTI_LANE, OPT_GROUPING, OPT_DATAFLOW, OPT_DATAFLOW_FENCE = 1, 2, 3, 4, 5, 6
+OPT_USE_GRAPH, OPT_CONV_TILE, OPT_MULTI_LANE, OPT_GROUPING, OPT_DATAFLOW, OPT_DATAFLOW_FENCE, OPT_WINOGRAD = 1, 2, 3, 4, 5, 6, 7
 
 
 class Outputs(C.Structure):

@@ -63,6 +63,7 @@ struct ConvLayer {
     std::vector<AddRef> adds;
     float* w_dev = nullptr;
     float* b_dev = nullptr;
+    float* wino_dev = nullptr;  // transformed weights [16][cin_pad][cout_pad] of the Winograd F(2x2,3x3) kernel (eligible fp32 layers only)
     int cin_pad = 0, cout_pad = 0;
     double macs_per_frame = 0;
     int lane_hint = 0;          // lane of this convolution when it is launched on its own (not as a group member)
@@ -133,6 +134,7 @@ struct grnet {
     int df_probe = -1;                               // -1 not probed yet, 0 the dispatcher does not spread this grid over the 8 XCDs evenly, 1 it does
     int df_wgs_per_xcd = 96;                         // 32 CUs x 3 resident workgroups
     int df_fence = 0;                                // validation: device-scope fences around every hand-off
+    int wino_mode = 1;                               // GRNET_OPT_WINOGRAD: 1 = the eligible 3x3 layers on 56x56 maps run the Winograd kernel
 
     // planned buffers: (pointer slot, floats per image)
     std::vector<std::pair<float**, size_t>> pending;   // pointers patched after the arena exists
@@ -815,6 +817,8 @@ struct grnet {
         L.cin_pad = bf ? (L.in.c + 31) / 32 * 32 : (cin + kConvCK - 1) / kConvCK * kConvCK;
         L.cout_pad = bf ? (L.cout + 31) / 32 * 32 : (L.cout + TC - 1) / TC * TC;
         std::vector<float> wp((size_t)taps * L.cin_pad * L.cout_pad, 0.f), bp(L.cout_pad, 0.f);
+        const bool wino = !bf && conv_wino_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size()) && L.cin_pad % 8 == 0 && L.cout_pad % 64 == 0;
+        std::vector<double> wfold(wino ? (size_t)L.cout * cin * 9 : 0);     // BN-folded weights (cout, cin, 3, 3) for the filter transform
         int co0 = 0;
         for (auto& s : L.segs) {
             const HostTensor* w = find(s.wkey);
@@ -841,9 +845,11 @@ struct grnet {
             for (int co = 0; co < s.cout; ++co) {
                 bp[co0 + co] = (float)shift[co];
                 for (int ci = 0; ci < cin; ++ci)
-                    for (int t = 0; t < taps; ++t)
-                        wp[bf ? ((((size_t)(ci / 32) * taps + t) * L.cout_pad + co0 + co) * 32 + ci % 32) : ((size_t)t * L.cin_pad + ci) * L.cout_pad + co0 + co] =
-                            (float)((double)w->data[((size_t)co * cin + ci) * taps + t] * scale[co]);
+                    for (int t = 0; t < taps; ++t) {
+                        const double wv = (double)w->data[((size_t)co * cin + ci) * taps + t] * scale[co];
+                        wp[bf ? ((((size_t)(ci / 32) * taps + t) * L.cout_pad + co0 + co) * 32 + ci % 32) : ((size_t)t * L.cin_pad + ci) * L.cout_pad + co0 + co] = (float)wv;
+                        if (wino) wfold[((size_t)(co0 + co) * cin + ci) * 9 + t] = wv;
+                    }
             }
             co0 += s.cout;
         }
@@ -857,6 +863,11 @@ struct grnet {
             return rc;
         }
         if ((rc = upload(bp, &L.b_dev))) return rc;
+        if (wino) {                                            // U = G g G^T of the folded filter, fp64 -> fp32
+            std::vector<float> uw((size_t)16 * L.cin_pad * L.cout_pad);
+            pack_wino_weights(wfold.data(), L.cout, cin, L.cin_pad, L.cout_pad, uw.data());
+            if ((rc = upload(uw, &L.wino_dev))) return rc;
+        }
         return 0;
     }
 
@@ -1372,7 +1383,11 @@ struct grnet {
                 case Op::CONV: {
                     const ConvLayer& L = convs[op.conv_idx];
                     if (dtype == 1) HIP_TRY(launch_conv_bf16(conv_args(L, frames, n), s, hint_for(L, n)));
-                    else HIP_TRY(launch_conv(conv_args(L, frames, n), s, hint_for(L, n)));
+                    else if (L.wino_dev && wino_mode && !conv_tile_hint) {
+                        ConvArgs wa = conv_args(L, frames, n);
+                        wa.w = L.wino_dev;
+                        HIP_TRY(launch_conv_wino(wa, s));
+                    } else HIP_TRY(launch_conv(conv_args(L, frames, n), s, hint_for(L, n)));
                     ++launches;
                     break;
                 }
@@ -1674,6 +1689,7 @@ int grnet_create(grnet_t** out_handle, int device_id, int dtype, int max_frames)
     h->dtype = dtype;
     if (dtype == 1) h->grouping = false;                   // grouped launches exist for the fp32 split-K kernels only
     if (const char* ml = getenv("GRNET_MULTI_LANE")) h->multi_lane = atoi(ml) != 0;   // profiling: per-kernel times without overlap
+    if (const char* wn = getenv("GRNET_WINO")) h->wino_mode = atoi(wn) != 0;
     if (const char* df = getenv("GRNET_DATAFLOW")) h->df_mode = std::max(0, std::min(2, atoi(df)));
     if (const char* df = getenv("GRNET_DF_WGS")) h->df_wgs_per_xcd = std::max(8, std::min(256, atoi(df)));
     if (const char* df = getenv("GRNET_DF_FENCE")) h->df_fence = atoi(df);
@@ -1869,6 +1885,7 @@ int grnet_set_option(grnet_t* h, int option, int value) {
         h->drop_graphs();
         return 0;
     }
+    if (option == GRNET_OPT_WINOGRAD) { h->wino_mode = value != 0; h->drop_graphs(); return 0; }
     if (option == GRNET_OPT_DATAFLOW_FENCE) { h->df_fence = value != 0; h->drop_graphs(); return 0; }
     if (option == GRNET_OPT_MULTI_LANE) {
         h->multi_lane = value != 0;
@@ -1995,13 +2012,29 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
     a.zeros = h->zeros;
     if (const char* d = getenv("GRNET_CONV_DBG")) a.dbg = atoi(d);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = launch_conv(a, s, tile_hint);
+    float* ud = nullptr;
+    if (tile_hint == 2000) {                                   // the Winograd kernel on this one convolution
+        if (!conv_wino_eligible(cin, cout, ks, stride, hgt, wid, add_dev ? 1 : 0) || cin_pad % 8 != 0 || cout_pad % 64 != 0) {
+            hipFree(wd); hipFree(bd);
+            return h->fail(GRNET_EINVAL, "shape not eligible for the Winograd kernel");
+        }
+        std::vector<double> wf((size_t)cout * cin * 9);
+        for (size_t i = 0; i < wf.size(); ++i) wf[i] = w_host[i];
+        std::vector<float> uw((size_t)16 * cin_pad * cout_pad);
+        pack_wino_weights(wf.data(), cout, cin, cin_pad, cout_pad, uw.data());
+        if (hipMalloc(reinterpret_cast<void**>(&ud), uw.size() * 4) != hipSuccess || hipMemcpy(ud, uw.data(), uw.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            hipFree(wd); hipFree(bd); if (ud) hipFree(ud);
+            return h->fail(GRNET_ENOMEM, "Winograd test weights");
+        }
+        a.w = ud;
+    }
+    hipError_t e = tile_hint == 2000 ? launch_conv_wino(a, s) : launch_conv(a, s, tile_hint);
     if (const char* r = getenv("GRNET_CONV_REPS")) {           // timing loop for tools/conv_micro.py
         const int reps = atoi(r);
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0, s);
-        for (int i = 0; i < reps; ++i) e = launch_conv(a, s, tile_hint);
+        for (int i = 0; i < reps; ++i) e = tile_hint == 2000 ? launch_conv_wino(a, s) : launch_conv(a, s, tile_hint);
         hipEventRecord(e1, s);
         hipEventSynchronize(e1);
         float ms = 0;
@@ -2013,6 +2046,7 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
     hipError_t e2 = hipStreamSynchronize(s);
     hipFree(wd);
     hipFree(bd);
+    if (ud) hipFree(ud);
     if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("launch_conv: ") + hipGetErrorString(e));
     if (e2 != hipSuccess) return h->fail(GRNET_EHIP, std::string("conv kernel: ") + hipGetErrorString(e2));
     return 0;

@@ -93,6 +93,11 @@ int conv_pick_tc(int Cout);                 // cout tile (32 or 64) -> defines C
 hipError_t conv_init();                     // sets max dynamic LDS on every instantiation
 const char* conv_dominant_kernel_name();
 
+// ---- Winograd F(2x2,3x3) for the wide 3x3 stride-1 layers on 56x56 maps (conv_wino.hip) -------------------------------------------
+bool conv_wino_eligible(int cin, int cout, int ks, int stride, int h, int w, int n_add);
+hipError_t launch_conv_wino(ConvArgs a, hipStream_t s);      // a.w = transformed weights [16][CinPad][CoutPad]
+void pack_wino_weights(const double* w_folded /* (cout,cin,3,3) */, int cout, int cin, int cin_pad, int cout_pad, float* out);
+
 // ---- per-XCD dataflow execution of the HR stages (conv_kernels.hip: hr_dataflow_f32) -------------------------------------------
 // One persistent launch runs every convolution of transition1 .. stage 4 (~270 launches otherwise).  Frames are independent and
 // the 8 XCDs have private L2s, so XCD x takes the images [x*ipx, (x+1)*ipx) through the WHOLE section on its own: its workgroups pop
