@@ -143,10 +143,12 @@ def roofline_object(fps_per_gpu, dtype, conv_flops_per_frame, conv_ms, conv_ms_s
     achieved = fps_per_gpu * conv_flops_per_frame / 1e12
     conv_flops = conv_flops_per_frame * n
     r = {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-         "definition": "frames/s per GPU x F_frame (SURVEY 8d: 30.883 GFLOP of convolutions per frame); the whole step -- pooling, tail, "
-                       "SMPL, launch gaps -- is charged to the convolutions",
+         "definition": "frames/s per GPU x F_frame (SURVEY 8d: 30.883 GFLOP of convolutions per frame = the ALGORITHMIC, direct-convolution "
+                       "count); the whole step -- pooling, tail, SMPL, launch gaps -- is charged to the convolutions.  On the fp32 path the Winograd "
+                       "layers (42 % of F_frame) execute 2.25x fewer multiplies than counted here, in fp32 throughout",
          "traffic": None,
-         "kernel": ("conv_mfma_f32 + conv_splitk_f32 + hr_block_f32 (fp32 MFMA implicit-GEMM convolution, all launches of a step)" if dtype == "f32"
+         "kernel": ("conv_mfma_f32 + conv_splitk_f32 (fp32 MFMA implicit-GEMM convolution) + conv_wino_f32 (Winograd F(2x2,3x3) on the fp32 matrix cores "
+                    "for the 3x3 layers with >= 64 channels on 56x56 maps), all launches of a step" if dtype == "f32"
                     else "conv_bf16_nhwc (bf16 MFMA implicit-GEMM convolution on NHWC activations, all launches of a step)"),
          "conv_launches_per_step": n_conv, "conv_gflop_per_step": round(conv_flops / 1e9, 3),
          "gflop_per_launch": round(conv_flops / 1e9 / max(n_conv, 1), 4)}

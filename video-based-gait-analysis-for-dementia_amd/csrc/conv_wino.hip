@@ -184,6 +184,11 @@ __global__ __launch_bounds__(256) void conv_wino_f32(const ConvArgs a) {
         float d[4][6], e[4][6];
 #pragma unroll
         for (int part = 0; part < 8; ++part) load_group(buf, 0, 0, part);
+        if (with_transform) {                                                // the DMA requests of the coming chunks go out under the LDS latency
+            issue_u(next, buf ^ 1);                                          // of the first operand reads (nothing else can cover it: the barrier
+            if (next + 1 < nchunks) issue_raw(next + 1);                     // above is where V of this chunk became complete)
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
 #pragma unroll
@@ -224,9 +229,7 @@ __global__ __launch_bounds__(256) void conv_wino_f32(const ConvArgs a) {
         const int buf = ch & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // this wave's shares of U(ch) and raw(ch+1) have landed
         __syncthreads();                                                     // ... everybody's; everybody is past MFMA(ch-1) and transform(ch)
-        issue_u(ch + 1, buf ^ 1);
-        if (ch + 2 < nchunks) issue_raw(ch + 2);                             // into raw[ch&1], which transform(ch) has finished reading
-        chunk(buf, true, ch + 1);
+        chunk(buf, true, ch + 1);                                            // requests U(ch+1) and raw(ch+2) [into raw[ch&1], which transform(ch) has finished reading]
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
