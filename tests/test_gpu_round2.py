@@ -325,7 +325,7 @@ def test_dataflow_hr_section_parity_and_determinism(pkg, golden):
     m.close()
 
 
-WINO_CASES = [(64, 64), (128, 128), (256, 256), (480, 256), (128, 64), (72, 192)]
+WINO_CASES = [(64, 64), (128, 128), (256, 256), (480, 256), (128, 64), (72, 192), (32, 32), (256, 32), (40, 96)]
 
 
 @pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "x".join(map(str, c)))
@@ -343,6 +343,10 @@ def test_winograd_conv_kernel(model, oracle, case):
         got = model.op_conv2d(torch.from_numpy(x).cuda(), w, b, stride=1, relu=True, tile_hint=2000).cpu().numpy()
         assert got.shape == ref.shape
         assert rel_err(got, ref) < 2e-5, (case, n, rel_err(got, ref))
+        res = g.standard_normal((n, cout, 56, 56)).astype(np.float32)         # the BasicBlock form: + residual, then ReLU (hrnet.py:54-57)
+        ref_res = torch.relu(oracle.conv2d(x, w, stride=1, bias=b) + torch.from_numpy(res)).numpy()
+        got_res = model.op_conv2d(torch.from_numpy(x).cuda(), w, b, stride=1, relu=True, add=torch.from_numpy(res).cuda(), tile_hint=2000).cpu().numpy()
+        assert rel_err(got_res, ref_res) < 2e-5, (case, n, "residual")
         ref_lin = oracle.conv2d(x, w, stride=1).numpy()                     # no bias, no ReLU: borders and signs exposed
         got_lin = model.op_conv2d(torch.from_numpy(x).cuda(), w, None, stride=1, relu=False, tile_hint=2000).cpu().numpy()
         assert rel_err(got_lin, ref_lin) < 2e-5, (case, n)

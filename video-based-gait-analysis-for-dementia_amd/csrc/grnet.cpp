@@ -817,7 +817,13 @@ struct grnet {
         L.cin_pad = bf ? (L.in.c + 31) / 32 * 32 : (cin + kConvCK - 1) / kConvCK * kConvCK;
         L.cout_pad = bf ? (L.cout + 31) / 32 * 32 : (L.cout + TC - 1) / TC * TC;
         std::vector<float> wp((size_t)taps * L.cin_pad * L.cout_pad, 0.f), bp(L.cout_pad, 0.f);
-        const bool wino = !bf && conv_wino_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size()) && L.cin_pad % 8 == 0 && L.cout_pad % 64 == 0;
+        // Which eligible layers take the Winograd kernel: the wide ones (>= 64 output channels, >= 64 input channels: layer1, upsample heads,
+        // PARE head) and transition1's 256 -> 32.  NOT the 32 -> 32 convolutions of the 56x56 HR branch, although the kernel is faster on
+        // them in isolation (14.2 vs 19.0 us): a Winograd workgroup owns a CU's LDS, and those launches live on overlapping with the
+        // other branches' launches (measured in context: 2 758 frames/s with them, 2 800 without).
+        const bool wino = !bf && conv_wino_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size()) && L.cin_pad % 8 == 0 &&
+                          L.cout_pad % (L.cout % 64 == 0 ? 64 : 32) == 0 && (L.adds.empty() || L.adds[0].shift == 0) &&
+                          ((L.cout % 64 == 0 && L.in.c >= 64) || L.in.c >= 128);
         std::vector<double> wfold(wino ? (size_t)L.cout * cin * 9 : 0);     // BN-folded weights (cout, cin, 3, 3) for the filter transform
         int co0 = 0;
         for (auto& s : L.segs) {
@@ -2014,7 +2020,7 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* ud = nullptr;
     if (tile_hint == 2000) {                                   // the Winograd kernel on this one convolution
-        if (!conv_wino_eligible(cin, cout, ks, stride, hgt, wid, add_dev ? 1 : 0) || cin_pad % 8 != 0 || cout_pad % 64 != 0) {
+        if (!conv_wino_eligible(cin, cout, ks, stride, hgt, wid, add_dev ? 1 : 0) || cin_pad % 8 != 0 || cout_pad % (cout % 64 == 0 ? 64 : 32) != 0) {
             hipFree(wd); hipFree(bd);
             return h->fail(GRNET_EINVAL, "shape not eligible for the Winograd kernel");
         }
