@@ -50,7 +50,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     rows = list(csv.DictReader(open(f)))
     per_kernel = collections.defaultdict(lambda: [0.0, 0])
     for r in rows:
-        n = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        n = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         per_kernel[n][0] += float(r["Counter_Value"])
         per_kernel[n][1] += 1
     conv_launches_total = sum(v[1] for k, v in per_kernel.items() if "conv_" in k)
@@ -88,7 +88,7 @@ if os.path.isfile(sq):
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     disp = collections.defaultdict(set)
     for r in csv.DictReader(open(sq)):
-        n = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("grk::", "")
+        n = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("grk::", "")
         per[n][r["Counter_Name"]] += float(r["Counter_Value"])
         disp[n].add(r["Dispatch_Id"])
     lines = ["kernel,dispatches,mfma_busy_frac,wait_any_frac,wait_inst_frac,active_inst_frac,valu_inst_frac,lds_inst_frac,busy_cu_cycles_per_dispatch"]
