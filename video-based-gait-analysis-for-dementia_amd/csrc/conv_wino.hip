@@ -28,26 +28,26 @@ namespace {
 
 constexpr int kWCK = 8;                 // input channels per chunk
 constexpr int kWTiles = 56;             // real tiles per workgroup (2 tile rows of 28)
-constexpr int kWVT = 72;                // V row stride (tiles): 72 % 32 = 8 -> the four k-rows of an A fragment fall on disjoint bank pairs
 constexpr int kWRaw = 6 * 56;           // raw floats per channel: 6 input rows
-template <int NB> constexpr int kWUf = 16 * kWCK * NB * 16;     // floats of one transformed-weight chunk (NB 16-channel blocks per workgroup)
-constexpr int kWV = 16 * kWCK * kWVT;
+constexpr int kWV = 16 * kWCK * 64;      // V[point][channel][64 tile slots]
 constexpr int kWMrow = 17;              // epilogue: [point][tile][16 channels + 1]
-template <int NB> constexpr size_t kWinoLdsB = sizeof(float) * (2 * kWCK * kWRaw + 2 * kWUf<NB> + 2 * kWV);     // NB = 4: 160 768 B of the 160 KB
-static_assert(sizeof(float) * 16 * 64 * kWMrow <= kWinoLdsB<2>, "the epilogue tile reuses the staging area");
+constexpr size_t kWinoLdsB = sizeof(float) * (2 * kWCK * kWRaw + 2 * kWV);     // 87 040 B
+static_assert(sizeof(float) * 16 * 64 * kWMrow <= kWinoLdsB, "the epilogue tile reuses the staging area");
 
-__device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const GRNET_GLOBAL_AS void*)src, (GRNET_LDS_AS void*)lds_wave_base, 16, 0, 0);
-}
+// a use of x the compiler cannot move: its wait for the LDS read that produces x lands here (a "v" constraint is a device-side
+// thing: inside the __global__ template itself the host pass rejects it and silently drops the kernel's stub)
+template <typename T>
+__device__ __forceinline__ void landed(T& x) { asm volatile("" : "+v"(x)); }
 
 // NB: 16-channel blocks per workgroup -- 4 (64 output channels) or 2 (the 32-channel layers: 56x56 branch of the HR modules, transition1)
-template <int NB>
-__global__ __launch_bounds__(256) void conv_wino_f32(const ConvArgs a) {
-    constexpr int TC = NB * 16, kWU = kWUf<NB>, UPR = TC / 4, NUI = (128 * UPR) / 256;
+// (the body is a __device__ function: the host pass type-checks the body of a __global__ template, rejects device-only constructs
+// in it without a diagnostic and then emits no launch stub -- the library fails to load with an undefined kernel symbol)
+template <int NB, int ABL>
+__device__ __forceinline__ void conv_wino_body(const ConvArgs& a) {
+    constexpr int TC = NB * 16;
     extern __shared__ __align__(16) float smem[];
     float* raw = smem;                                  // [2][8][336]
-    float* U = raw + 2 * kWCK * kWRaw;                  // [2][16][8][64]   (16-byte units XOR-swizzled by channel parity)
-    float* V = U + 2 * kWU;                             // [2][16][8][72]
+    float* V = raw + 2 * kWCK * kWRaw;                  // [2][16][8][16][4]   (a lane's four tile blocks contiguous)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
 
     // block -> (image, tile-row group, channel block); XCD-aware like conv_kernels.hip: the channel blocks of one input tile are
@@ -68,68 +68,80 @@ __global__ __launch_bounds__(256) void conv_wino_f32(const ConvArgs a) {
     const float* inb = a.in + ((size_t)img * a.in_ctot + a.in_coff) * HW;
     const int g0 = (4 * r - 1) * 56;                     // plane index of raw[.][0]
 
-    // chunk-invariant DMA source offsets
-    int uoff[NUI];                                       // transformed weights: 128 rows of UPR 16-byte units per chunk, NUI per thread
-#pragma unroll
-    for (int i = 0; i < NUI; ++i) {
-        const int u = i * 256 + tid, row = u / UPR, j = u - row * UPR, p = row >> 3, ch = row & 7;
-        uoff[i] = (p * a.CinPad + ch) * a.CoutPad + co0 + 4 * (j ^ ((ch & 1) << 2));
-    }
-    int roff[3];                                         // raw rows: 672 units per chunk; -1 = no unit, -2 = outside the image (zeros)
+    // ---- LDS-DMA through buffer descriptors: per-lane byte offsets are chunk-invariant (a VGPR each), the chunk moves the scalar
+    // offset -- no vector-ALU address arithmetic in the loop (on gfx950 every vector-ALU instruction is matrix-pipe time, see below)
+    const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, 16 * a.CinPad * a.CoutPad * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, a.Cin * HW * 4, 0x00020000);
+    // transformed weights: a wave's MFMA B fragments are ITS four points' rows -- no other wave reads them, so they go from L2 straight
+    // into registers (one 16-byte load per lane and MFMA group, requested a whole chunk ahead), not through the LDS
+    typedef float bfrag __attribute__((ext_vector_type(NB)));
+    const int ub = ((wave * 4 * a.CinPad + lq) * a.CoutPad + co0 + l15 * NB) * 4;
+    const int u_point = a.CinPad * a.CoutPad * 4, u_kstep = 4 * a.CoutPad * 4, u_chunk = kWCK * a.CoutPad * 4;
+    auto load_u = [&](int chunk, int g) -> bfrag {                           // group g = (point wave*4 + g/2, k-step g%2)
+        const int soff = chunk * u_chunk + (g >> 1) * u_point + (g & 1) * u_kstep;
+        if constexpr (NB == 4) return __builtin_bit_cast(bfrag, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, ub, soff, 0));
+        else return __builtin_bit_cast(bfrag, __builtin_amdgcn_raw_buffer_load_b64(u_rsrc, ub, soff, 0));
+    };
+    int roff[3];                                         // raw rows: 672 units per chunk; -1 = no unit or a row outside the image
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int u = i * 256 + tid, ch = u / 84, k = u - ch * 84, gi = g0 + 4 * k;
-        roff[i] = u < kWCK * 84 ? ((gi >= 0 && gi < HW) ? ch * HW + gi : -2) : -1;
+        const bool unit = u < kWCK * 84, inside = gi >= 0 && gi < HW;
+        roff[i] = unit && inside ? (ch * HW + gi) * 4 : -1;
+        if (unit && !inside) {                           // rows -1 / 56 of the image: zero once in both buffers, the DMA never writes there
+            *reinterpret_cast<f32x4*>(raw + u * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(raw + kWCK * kWRaw + u * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
-    auto issue_u = [&](int chunk, int buf) {
-        const float* src = a.w + (size_t)chunk * kWCK * a.CoutPad;
-        float* dst = U + buf * kWU;
-#pragma unroll
-        for (int i = 0; i < NUI; ++i) dma16(src + uoff[i], dst + (i * 256 + wave * 64) * 4);
-    };
     auto issue_raw = [&](int chunk) {
-        const float* src = inb + (size_t)chunk * kWCK * HW;
+        const int soff = chunk * (kWCK * 4) * HW;
         float* dst = raw + (chunk & 1) * (kWCK * kWRaw);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            if (roff[i] != -1) dma16(roff[i] >= 0 ? src + roff[i] : a.zeros, dst + (i * 256 + wave * 64) * 4);
+            if (roff[i] >= 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (GRNET_LDS_AS void*)(dst + (i * 256 + wave * 64) * 4), 16, roff[i], soff, 0, 0);
+        asm volatile("" ::: "memory");                   // later loads stay behind these requests: the vmcnt(8) waits below count on the order
     };
-    // input transform of chunk c (raw[c & 1] -> V[c & 1]): V[p][ch][t] = (B^T d B)[p], thread -> (tile t, channel ch) pairs tid and tid + 256
-    auto transform = [&](int c) {
-        const float* rawc = raw + (c & 1) * (kWCK * kWRaw);
-        float* Vc = V + (c & 1) * kWV;
+
+    // ---- input transform.  A thread owns TWO horizontally adjacent tiles of one channel.  The 256 threads are 16 rows of 16 lanes:
+    // row = (channel 0..7, tile row 0..1), lane = tile pair 0..13 (lanes 14, 15 idle: they fill the four padding pairs of V).  The
+    // pair's four own input columns 4x .. 4x+3 come as ONE aligned 16-byte LDS read per input row; column 4x-1 is the left neighbour's
+    // last column and 4x+4 the right neighbour's first: two DPP row shifts, whose out-of-row zero (bound_ctrl) IS the image's zero
+    // padding on the left, an idle lane's zero on the right.  V[point][channel][pair & 15][2 * (pair >> 4) + half]: the MFMA row tile m
+    // of a tile is 2 * (pair >> 4) + (tile & 1), its row pair & 15 -- so the four A fragments of a lane are 16 contiguous bytes, and a
+    // thread's two results per point one 8-byte write.
+    const int row16 = tid >> 4, px = tid & 15, chn = row16 >> 1, ty2t = row16 & 1;
+    const bool real = px < 14;
+    const int pairt = real ? 14 * ty2t + px : 28 + 2 * ty2t + (px - 14);
+    const int rpos = chn * kWRaw + (2 * ty2t) * 56 + 4 * (real ? px : 13);
+    const int vpos = chn * 64 + (pairt & 15) * 4 + 2 * (pairt >> 4);
+    struct Tf { float d[4][6]; float e[4][6]; };
+    auto tf_read = [&](Tf& t, const float* rp) {        // 4 LDS reads
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            // branch-free (the second round has 192 real pairs): lanes without a pair redo pair 0 and write into the padding tiles 56..71
-            // of V, so the whole transform is straight-line code the scheduler can interleave with the MFMAs of the current chunk
-            const int pr0 = it * 256 + tid;
-            const bool real = pr0 < kWTiles * kWCK;
-            const int pr = real ? pr0 : 0;
-            const int ch = pr / kWTiles, t = pr - ch * kWTiles, ty2 = t >= 28 ? 1 : 0, tx = t - 28 * ty2;
-            const float* rp = rawc + ch * kWRaw + (2 * ty2) * 56 + 2 * tx - 1;
-            float d[4][4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) d[i][j] = rp[i * 56 + j];
-                d[i][0] = tx == 0 ? 0.f : d[i][0];       // column -1 / 56: the zero padding (the flat rows have no column halo)
-                d[i][3] = tx == 27 ? 0.f : d[i][3];
-            }
-            float e[4][4];                               // B^T d : rows (d0-d2, d1+d2, d2-d1, d1-d3)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                e[0][j] = d[0][j] - d[2][j]; e[1][j] = d[1][j] + d[2][j];
-                e[2][j] = d[2][j] - d[1][j]; e[3][j] = d[1][j] - d[3][j];
-            }
-            float* vp = Vc + ch * kWVT + (real ? t : kWTiles + (lane & 15));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {                // (B^T d) B : columns (e0-e2, e1+e2, e2-e1, e1-e3)
-                vp[(i * 4 + 0) * (kWCK * kWVT)] = e[i][0] - e[i][2];
-                vp[(i * 4 + 1) * (kWCK * kWVT)] = e[i][1] + e[i][2];
-                vp[(i * 4 + 2) * (kWCK * kWVT)] = e[i][2] - e[i][1];
-                vp[(i * 4 + 3) * (kWCK * kWVT)] = e[i][1] - e[i][3];
-            }
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rp + i * 56);
+            t.d[i][1] = v[0]; t.d[i][2] = v[1]; t.d[i][3] = v[2]; t.d[i][4] = v[3];
         }
+    };
+    auto tf_halo = [&](Tf& t) {                         // 12 vector-ALU instructions
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            t.d[i][0] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t.d[i][4]), 0x111, 0xf, 0xf, true));                 // row_shr:1
+            t.d[i][5] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(real ? t.d[i][1] : 0.f), 0x101, 0xf, 0xf, true));    // row_shl:1
+        }
+    };
+    auto tf_rows = [&](Tf& t) {                         // B^T d per column: rows (d0-d2, d1+d2, d2-d1, d1-d3); 24
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            t.e[0][j] = t.d[0][j] - t.d[2][j]; t.e[1][j] = t.d[1][j] + t.d[2][j];
+            t.e[2][j] = t.d[2][j] - t.d[1][j]; t.e[3][j] = t.d[1][j] - t.d[3][j];
+        }
+    };
+    auto tf_cols = [&](Tf& t, int i, float* vp) {       // (B^T d) B, row i, both tiles of the pair: 8 + 4 LDS writes
+        const float* e = t.e[i];
+        *reinterpret_cast<f32x2*>(vp + (i * 4 + 0) * 512) = f32x2{e[0] - e[2], e[2] - e[4]};
+        *reinterpret_cast<f32x2*>(vp + (i * 4 + 1) * 512) = f32x2{e[1] + e[2], e[3] + e[4]};
+        *reinterpret_cast<f32x2*>(vp + (i * 4 + 2) * 512) = f32x2{e[2] - e[1], e[4] - e[3]};
+        *reinterpret_cast<f32x2*>(vp + (i * 4 + 3) * 512) = f32x2{e[1] - e[3], e[3] - e[5]};
     };
 
     f32x4 acc[4][4][NB];                                 // [point of this wave][tile block][channel block]
@@ -141,102 +153,77 @@ __global__ __launch_bounds__(256) void conv_wino_f32(const ConvArgs a) {
             for (int n = 0; n < NB; ++n) acc[p][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nchunks = a.CinPad / kWCK;
+    bfrag bq[8];                                                             // B fragments of the 8 MFMA groups; each is re-requested for the
+                                                                             // next chunk right behind the group that consumed it
     issue_raw(0);
-    issue_u(0, 0);
     if (nchunks > 1) issue_raw(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    transform(0);
-    const int va = lq * kWVT + l15;                                         // + (p*8 + 4*ks) * kWVT + mt*16
-    int ubn[NB];                                                            // the 16-float block of channel block n in this lane's (swizzled) row
 #pragma unroll
-    for (int n = 0; n < NB; ++n) ubn[n] = lq * TC + ((n ^ (lq & 1)) * 16) + l15;
-    // One barrier per chunk.  At the top of iteration ch: V[ch&1] is complete, U[ch&1] and raw[(ch+1)&1] have landed.  The next chunk's
-    // weights and the raw rows of the chunk after it are requested first, then the next chunk is transformed (VALU + LDS) and this
-    // chunk's 128 MFMAs per wave run -- the DMA has the whole iteration to land.
-    // ---- the chunk loop, scheduled by hand.  One wave per SIMD (316 registers) has nobody to hide its LDS latency or its vector ALU
-    // work behind, and a wave issues in order: an instruction overlaps the matrix pipe only if it sits BETWEEN two MFMAs in program
-    // order.  So the 128 MFMAs of chunk ch carry, one micro-step behind each: the 8 operand reads of the next MFMA group (two register
-    // sets alternate) and the input transform of chunk ch+1 cut into 96 micro-steps (16 patch reads, 16 + 16 adds, 16 V writes, for each of
-    // the thread's two (tile, channel) pairs).  sched_barrier(0) after every pair pins that order (the compiler's own scheduler clusters
-    // the MFMAs; a sched_group_barrier pipeline description moved the operand reads but left the transform behind the MFMA section).
-    // Transform work item of a thread: TWO horizontally adjacent tiles of one channel (14 pairs x 2 tile rows x 8 channels = 224 threads;
-    // the other 32 redo pair 0 and write into the padding tiles of V).  The pair's six input columns are read as b32 | b64 | b64 | b32 per
-    // row (the 64-bit reads sit on even columns: aligned) and its 16 x 2 outputs leave as 64-bit writes -- 32 LDS instructions per chunk
-    // instead of 64, so that with the 8 operand reads of an MFMA group at most 12 LDS operations are pending at any wait and the
-    // compiler's s_waitcnt can name a count instead of draining the queue (lgkmcnt is a 4-bit, in-order counter).
-    struct Patch { const float* rp; float* vp; bool left, right; };
-    auto patch_of = [&](int c) {
-        const bool real = tid < 28 * kWCK;
-        const int pr = real ? tid : 0;
-        const int chn = pr / 28, pair = pr - chn * 28, ty2 = pair >= 14 ? 1 : 0, tx = 2 * (pair - 14 * ty2);
-        Patch q;
-        q.rp = raw + (c & 1) * (kWCK * kWRaw) + chn * kWRaw + (2 * ty2) * 56 + 2 * tx;           // column 2*tx of the pair's first row
-        q.vp = V + (c & 1) * kWV + chn * kWVT + (real ? 28 * ty2 + tx : kWTiles + 2 * (lane & 7));
-        q.left = tx == 0; q.right = tx == 26;
-        return q;
-    };
-    float av[2][4], bv[2][NB];
-    constexpr int NOP = 4 + NB, NMF = 4 * NB;                               // operand reads / MFMAs per group
-    auto load_group = [&](int buf, int g, int set, int part) {              // part 0..7: one of the 8 operand reads of MFMA group g = (pi, ks)
+    for (int g = 0; g < 8; ++g) bq[g] = load_u(0, g);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                        // the raw rows (requested before the 8 weight loads) have landed
+    __syncthreads();
+    {
+        Tf t;
+        tf_read(t, raw + rpos);
+        tf_halo(t);
+        tf_rows(t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tf_cols(t, i, V + vpos);
+    }
+    // ---- the chunk loop.  One barrier per chunk: at the top of iteration ch, V[ch&1] is complete and raw[(ch+1)&1] has landed.
+    // On gfx950 the fp32 MFMA runs on the SIMD's FP32 lanes (its 64 FLOP/clk/SIMD IS the vector rate): nothing a wave issues between
+    // two fp32 MFMAs is free -- tools/micro/mfma_interleave.hip: one v_add_f32 behind every MFMA 33 -> 47 cycles per MFMA, one ds_read_b32
+    // 33 -> 43.5, each further vector instruction +4..6, and a second wave per SIMD recovers only part of it (39.6 / 39.7).  The first
+    // non-MFMA instruction after an MFMA is the expensive one.  So this loop (a) has few instructions besides its 128 MFMAs per chunk --
+    // operand fragments as 16-byte loads (2 per 16 MFMAs), addresses in scalar registers, the transform's halo by DPP -- and (b) keeps
+    // them in ONE cluster in front of each group of 16 MFMAs, which then issue back to back.  A cluster consumes only LDS data requested
+    // one cluster earlier (a whole MFMA group, 512+ cycles, ago): its single lgkmcnt(0) wait finds the queue empty.
+    f32x4 av[2];
+    auto load_a = [&](int buf, int g, int set) {                             // A fragments of MFMA group g = (point pi, k-step ks): one LDS read
         const int p = wave * 4 + (g >> 1), ks = g & 1;
-        if (part < 4) av[set][part] = V[buf * kWV + va + (p * kWCK + 4 * ks) * kWVT + part * 16];
-        else bv[set][part - 4] = U[buf * kWU + (p * kWCK + 4 * ks) * TC + ubn[part - 4]];
+        av[set] = *reinterpret_cast<const f32x4*>(V + buf * kWV + p * 512 + (ks * 4 + lq) * 64 + l15 * 4);
     };
     auto chunk = [&](int buf, bool with_transform, int next) {
-        const Patch q = patch_of(next);
-        float d[4][6], e[4][6];
-#pragma unroll
-        for (int part = 0; part < NOP; ++part) load_group(buf, 0, 0, part);
-        if (with_transform) {                                                // the DMA requests of the coming chunks go out under the LDS latency
-            issue_u(next, buf ^ 1);                                          // of the first operand reads (nothing else can cover it: the barrier
-            if (next + 1 < nchunks) issue_raw(next + 1);                     // above is where V of this chunk became complete)
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        Tf t;
+        const float* rp = raw + (next & 1) * (kWCK * kWRaw) + rpos;
+        float* vp = V + (next & 1) * kWV + vpos;
+        if (ABL != 3 && ABL != 5) load_a(buf, 0, 0);
+        if (with_transform && ABL != 1 && ABL != 5 && next + 1 < nchunks) issue_raw(next + 1);     // under the latency of that first read
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-#pragma unroll
-            for (int k = 0; k < NMF; ++k) {
-                const int m = k / NB, n = k % NB, pi = g >> 1;
-                acc[pi][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][m], bv[g & 1][n], acc[pi][m][n], 0, 0, 0);
-                if (g < 7 && k < NOP) load_group(buf, g + 1, (g + 1) & 1, k);
-                // hipcc drains the whole LDS queue (lgkmcnt(0)) in front of every MFMA group, whatever is pending: all LDS traffic of a group
-                // -- the next group's 8 operand reads and 7 transform micro-steps (7 x 8 = the 56 of a chunk) -- therefore sits in the
-                // group's FIRST eight slots, and the eight MFMAs behind them (256 cycles) let it land before the next drain
-                if (with_transform && k < 7) {
-                    const int st = g * 7 + k;
-                    if (st < 16) {                                           // loads: row i = st / 4, piece st % 4 of (c-1 | c0 c1 | c2 c3 | c4)
-                        const int i = st >> 2, pc = st & 3;
-                        const float* r = q.rp + i * 56;
-                        if (pc == 0) d[i][0] = r[-1];
-                        else if (pc == 1) { const f32x2 v = *reinterpret_cast<const f32x2*>(r); d[i][1] = v[0]; d[i][2] = v[1]; }
-                        else if (pc == 2) { const f32x2 v = *reinterpret_cast<const f32x2*>(r + 2); d[i][3] = v[0]; d[i][4] = v[1]; }
-                        else d[i][5] = r[4];
-                    } else if (st < 40) {                                    // B^T d per column: rows (d0-d2, d1+d2, d2-d1, d1-d3); the padding
-                        const int kk = st - 16, j = kk >> 2, i = kk & 3;       // columns -1 / 56 are zeroed here (the row transform is linear)
-                        float ev = i == 0 ? d[0][j] - d[2][j] : i == 1 ? d[1][j] + d[2][j] : i == 2 ? d[2][j] - d[1][j] : d[1][j] - d[3][j];
-                        if (j == 0) ev = q.left ? 0.f : ev;
-                        if (j == 5) ev = q.right ? 0.f : ev;
-                        e[i][j] = ev;
-                    } else if (st < 56) {                                    // (B^T d) B for both tiles of the pair, one 64-bit write per point
-                        const int kk = st - 40, i = kk >> 2, j = kk & 3;
-                        const float vl = j == 0 ? e[i][0] - e[i][2] : j == 1 ? e[i][1] + e[i][2] : j == 2 ? e[i][2] - e[i][1] : e[i][1] - e[i][3];
-                        const float vr = j == 0 ? e[i][2] - e[i][4] : j == 1 ? e[i][3] + e[i][4] : j == 2 ? e[i][4] - e[i][3] : e[i][3] - e[i][5];
-                        *reinterpret_cast<f32x2*>(q.vp + (i * 4 + j) * (kWCK * kWVT)) = f32x2{vl, vr};
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            // cluster g: (1) everything requested one cluster ago has landed
+            landed(av[g & 1]);
+            if (with_transform && ABL != 2 && ABL != 5) {
+                if (g == 1) tf_halo(t);
+                if (g == 2) tf_rows(t);
+                if (g >= 3 && g < 7) tf_cols(t, g - 3, vp);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            // (2) requests: the next group's A fragments, the next chunk's B fragments of the previous group, the next chunk's input rows
+            if (g < 7 && ABL != 3 && ABL != 5) load_a(buf, g + 1, (g + 1) & 1);
+            if (with_transform && ABL != 1 && ABL != 5 && g > 0) bq[g - 1] = load_u(next, g - 1);
+            if (with_transform && ABL != 2 && ABL != 5 && g == 0) tf_read(t, rp);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 4 * NB; ++k) {
+                const int m = k / NB, n = k % NB, pi = g >> 1;
+                acc[pi][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][m], bq[g][n], acc[pi][m][n], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (with_transform && ABL != 1 && ABL != 5) bq[7] = load_u(next, 7);
+    };
+    auto meet = [&](bool last) {
+        if (ABL == 4 || ABL == 5) return;
+        // this wave's share of raw(ch+1) has landed: it was requested before the 8 weight loads of the previous iteration, which may stay
+        // in flight (loads return in order)
+        if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __syncthreads();                                                     // ... everybody's; everybody is past MFMA(ch-1) and transform(ch)
     };
     for (int ch = 0; ch + 1 < nchunks; ++ch) {
-        const int buf = ch & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // this wave's shares of U(ch) and raw(ch+1) have landed
-        __syncthreads();                                                     // ... everybody's; everybody is past MFMA(ch-1) and transform(ch)
-        chunk(buf, true, ch + 1);                                            // requests U(ch+1) and raw(ch+2) [into raw[ch&1], which transform(ch) has finished reading]
+        meet(false);
+        chunk(ch & 1, true, ch + 1);                                         // requests raw(ch+2) [into raw[ch&1], which transform(ch) has finished reading]
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    meet(nchunks > 1);
     chunk((nchunks - 1) & 1, false, 0);
 
     // ---- epilogue: inverse transform, + bias, ReLU, store; 16 output channels per pass
@@ -261,8 +248,9 @@ __global__ __launch_bounds__(256) void conv_wino_f32(const ConvArgs a) {
             const int co = co0 + nt * 16 + c;
             if (co >= a.Cout) continue;
             float m[16];
+            const int pairo = t >> 1, ri = (2 * (pairo >> 4) + (t & 1)) * 16 + (pairo & 15);     // the tile's MFMA row (see the V layout)
 #pragma unroll
-            for (int p = 0; p < 16; ++p) m[p] = Mx[(p * 64 + t) * kWMrow + c];
+            for (int p = 0; p < 16; ++p) m[p] = Mx[(p * 64 + ri) * kWMrow + c];
             float s[4], q[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) { s[j] = m[j] + m[4 + j] + m[8 + j]; q[j] = m[4 + j] - m[8 + j] - m[12 + j]; }
@@ -281,6 +269,9 @@ __global__ __launch_bounds__(256) void conv_wino_f32(const ConvArgs a) {
     }
 }
 
+template <int NB, int ABL = 0>                         // ABL: timing-only ablations (GRNET_ABLATION builds, tools/wino_micro.py); 0 in the product
+__global__ __launch_bounds__(256) void conv_wino_f32(const ConvArgs a) { conv_wino_body<NB, ABL>(a); }
+
 }  // namespace
 
 bool conv_wino_eligible(int cin, int cout, int ks, int stride, int h, int w, int n_add) {
@@ -291,8 +282,8 @@ bool conv_wino_eligible(int cin, int cout, int ks, int stride, int h, int w, int
 hipError_t launch_conv_wino(ConvArgs a, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_f32<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLdsB<4>);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_f32<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLdsB<2>);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_f32<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLdsB);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_f32<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLdsB);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -304,16 +295,29 @@ hipError_t launch_conv_wino(ConvArgs a, hipStream_t s) {
     a.gx8 = (a.gx + 7) / 8;
     a.xcd = a.gx >= 16 ? 1 : 0;
     const dim3 grid((a.xcd ? a.gx8 * 8 : a.gx) * a.gy);
-    if (nb == 4) return launch_k(conv_wino_f32<4>, grid, dim3(256), kWinoLdsB<4>, s, a);
-    return launch_k(conv_wino_f32<2>, grid, dim3(256), kWinoLdsB<2>, s, a);
+#ifdef GRNET_ABLATION
+    if (nb == 4 && a.dbg) {
+        auto go = [&](auto kern) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLdsB); return launch_k(kern, grid, dim3(256), kWinoLdsB, s, a); };
+        if (a.dbg == 1) return go(conv_wino_f32<4, 1>);
+        if (a.dbg == 2) return go(conv_wino_f32<4, 2>);
+        if (a.dbg == 3) return go(conv_wino_f32<4, 3>);
+        if (a.dbg == 4) return go(conv_wino_f32<4, 4>);
+        if (a.dbg == 5) return go(conv_wino_f32<4, 5>);
+    }
+#endif
+    if (nb == 4) return launch_k(conv_wino_f32<4>, grid, dim3(256), kWinoLdsB, s, a);
+    return launch_k(conv_wino_f32<2>, grid, dim3(256), kWinoLdsB, s, a);
 }
 
 // U = G g G^T per (cout, cin) in fp64 -> [16][cin_pad][cout_pad] fp32; w: (cout, cin, 3, 3) folded weights (double)
 void pack_wino_weights(const double* w, int cout, int cin, int cin_pad, int cout_pad, float* out) {
     static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     for (size_t i = 0; i < (size_t)16 * cin_pad * cout_pad; ++i) out[i] = 0.f;
+    const int nb = cout % 64 == 0 ? 4 : 2, tc = nb * 16;                    // the kernel variant launch_conv_wino picks for this layer
     for (int co = 0; co < cout; ++co)
         for (int ci = 0; ci < cin; ++ci) {
+            // within a workgroup's tc channels, channel n*16 + l sits at l*nb + n: lane l's nb MFMA B fragments are one LDS read
+            const int cpos = (co / tc) * tc + (co % 16) * nb + (co % tc) / 16;
             const double* g = w + ((size_t)co * cin + ci) * 9;
             double t[4][3];
             for (int i = 0; i < 4; ++i)
@@ -321,7 +325,7 @@ void pack_wino_weights(const double* w, int cout, int cin, int cin_pad, int cout
             for (int i = 0; i < 4; ++i)
                 for (int j = 0; j < 4; ++j) {
                     const double u = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
-                    out[((size_t)(i * 4 + j) * cin_pad + ci) * cout_pad + co] = (float)u;
+                    out[((size_t)(i * 4 + j) * cin_pad + ci) * cout_pad + cpos] = (float)u;
                 }
         }
 }
