@@ -193,9 +193,11 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a) {
             // cluster g: (1) everything requested one cluster ago has landed
             landed(av[g & 1]);
             if (with_transform && ABL != 2 && ABL != 5) {
-                if (g == 1) tf_halo(t);
+                if (g == 1 && ABL != 7) tf_halo(t);
+                if (g == 1 && ABL == 7) { for (int i = 0; i < 4; ++i) { t.d[i][0] = t.d[i][2]; t.d[i][5] = t.d[i][3]; } }
                 if (g == 2) tf_rows(t);
-                if (g >= 3 && g < 7) tf_cols(t, g - 3, vp);
+                if (g >= 3 && g < 7 && ABL != 6) tf_cols(t, g - 3, vp);
+                if (g >= 3 && g < 7 && ABL == 6) { float sk = 0.f; for (int j = 0; j < 6; ++j) sk += t.e[g - 3][j]; if (sk == 12345.f) vp[0] = sk; }
             }
             __builtin_amdgcn_sched_barrier(0);
             // (2) requests: the next group's A fragments, the next chunk's B fragments of the previous group, the next chunk's input rows
@@ -303,6 +305,8 @@ hipError_t launch_conv_wino(ConvArgs a, hipStream_t s) {
         if (a.dbg == 3) return go(conv_wino_f32<4, 3>);
         if (a.dbg == 4) return go(conv_wino_f32<4, 4>);
         if (a.dbg == 5) return go(conv_wino_f32<4, 5>);
+        if (a.dbg == 6) return go(conv_wino_f32<4, 6>);
+        if (a.dbg == 7) return go(conv_wino_f32<4, 7>);
     }
 #endif
     if (nb == 4) return launch_k(conv_wino_f32<4>, grid, dim3(256), kWinoLdsB, s, a);

@@ -817,13 +817,12 @@ struct grnet {
         L.cin_pad = bf ? (L.in.c + 31) / 32 * 32 : (cin + kConvCK - 1) / kConvCK * kConvCK;
         L.cout_pad = bf ? (L.cout + 31) / 32 * 32 : (L.cout + TC - 1) / TC * TC;
         std::vector<float> wp((size_t)taps * L.cin_pad * L.cout_pad, 0.f), bp(L.cout_pad, 0.f);
-        // Which eligible layers take the Winograd kernel: the wide ones (>= 64 output channels, >= 64 input channels: layer1, upsample heads,
-        // PARE head) and transition1's 256 -> 32.  NOT the 32 -> 32 convolutions of the 56x56 HR branch, although the kernel is faster on
-        // them in isolation (14.2 vs 19.0 us): a Winograd workgroup owns a CU's LDS, and those launches live on overlapping with the
-        // other branches' launches (measured in context: 2 758 frames/s with them, 2 800 without).
+        // Every eligible layer takes the Winograd kernel: layer1, upsample heads, PARE head, transition1's 256 -> 32 and the 32 -> 32
+        // convolutions of the 56x56 HR branch.  (While the kernel staged its weights through the LDS a workgroup owned the CU's whole
+        // 160 KB and the 32 -> 32 layers lost in context what they won in isolation -- 2 758 vs 2 800 frames/s; with the B fragments
+        // loaded straight into registers it holds 87 KB and they win: 2 930 -> 3 030 frames/s.)
         const bool wino = !bf && conv_wino_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size()) && L.cin_pad % 8 == 0 &&
-                          L.cout_pad % (L.cout % 64 == 0 ? 64 : 32) == 0 && (L.adds.empty() || L.adds[0].shift == 0) &&
-                          ((L.cout % 64 == 0 && L.in.c >= 64) || L.in.c >= 128);
+                          L.cout_pad % (L.cout % 64 == 0 ? 64 : 32) == 0 && (L.adds.empty() || L.adds[0].shift == 0);
         std::vector<double> wfold(wino ? (size_t)L.cout * cin * 9 : 0);     // BN-folded weights (cout, cin, 3, 3) for the filter transform
         int co0 = 0;
         for (auto& s : L.segs) {
