@@ -328,6 +328,25 @@ def test_dataflow_hr_section_parity_and_determinism(pkg, golden):
 WINO_CASES = [(64, 64), (128, 128), (256, 256), (480, 256), (128, 64), (72, 192), (32, 32), (256, 32), (40, 96)]
 
 
+@pytest.mark.parametrize("case", [(5, 32, 256), (16, 32, 256), (7, 40, 192), (6, 64, 64)], ids=lambda c: "x".join(map(str, c)))
+def test_winograd_last_round_split(model, oracle, case):
+    """Layers whose last round of workgroups is at most half full run it as half-size workgroups (the 32-channel kernel on the weights
+    packed for the 64-channel one): 280 = 256 + 24 tiles (plain tile order), 896 = 768 + 128 (XCD-aware order, the 16-frame PARE
+    layers), 294 = 256 + 38 with three channel blocks; 6 x 64 -> 64 (84 tiles) stays one launch.  With and without the residual."""
+    n, cin, cout = case
+    g = np.random.Generator(np.random.Philox(key=[78, n * 100000 + cin * 1000 + cout]))
+    x = g.standard_normal((n, cin, 56, 56)).astype(np.float32)
+    w = (g.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (cin * 9))).astype(np.float32)
+    b = (g.standard_normal((cout,)) * 0.1).astype(np.float32)
+    r = g.standard_normal((n, cout, 56, 56)).astype(np.float32)
+    conv = oracle.conv2d(x, w, stride=1, bias=b)
+    xd = torch.from_numpy(x).cuda()
+    got = model.op_conv2d(xd, w, b, stride=1, relu=True, tile_hint=2000).cpu().numpy()
+    assert rel_err(got, torch.relu(conv).numpy()) < 2e-5
+    got = model.op_conv2d(xd, w, b, stride=1, relu=True, add=torch.from_numpy(r).cuda(), tile_hint=2000).cpu().numpy()
+    assert rel_err(got, torch.relu(conv + torch.from_numpy(r)).numpy()) < 2e-5
+
+
 @pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_winograd_conv_kernel(model, oracle, case):
     """conv_wino_f32 (Winograd F(2x2,3x3) on the fp32 matrix cores) on single convolutions vs the oracle's direct convolution: every

@@ -12,3 +12,11 @@ for cin, cout in shapes:
     b = np.zeros(cout, np.float32)
     for hint in (0, 2000):
         m.op_conv2d(x, w, b, relu=True, tile_hint=hint)
+# the BasicBlock form of the 56x56 HR branch: residual addend, same shape as the output
+for cin, cout in ((32, 32), (64, 64)):
+    x = torch.randn(n, cin, 56, 56, device="cuda")
+    r = torch.randn(n, cout, 56, 56, device="cuda")
+    w = (np.random.randn(cout, cin, 3, 3) * 0.02).astype(np.float32)
+    print(f"[with residual] {cin}->{cout}", file=sys.stderr)
+    for hint in (0, 2000):
+        m.op_conv2d(x, w, np.zeros(cout, np.float32), relu=True, add=r, tile_hint=hint)

@@ -30,6 +30,7 @@ constexpr int kWCK = 8;                 // input channels per chunk
 constexpr int kWTiles = 56;             // real tiles per workgroup (2 tile rows of 28)
 constexpr int kWRaw = 6 * 56;           // raw floats per channel: 6 input rows
 constexpr int kWV = 16 * kWCK * 64;      // V[point][channel][64 tile slots]
+constexpr int kWinoCUs = 256;          // CUs of an MI355X: workgroups of a full round
 constexpr int kWMrow = 17;              // epilogue: [point][tile][16 channels + 1]
 constexpr size_t kWinoLdsB = sizeof(float) * (2 * kWCK * kWRaw + 2 * kWV);     // 87 040 B
 static_assert(sizeof(float) * 16 * 64 * kWMrow <= kWinoLdsB, "the epilogue tile reuses the staging area");
@@ -50,20 +51,23 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a) {
     float* V = raw + 2 * kWCK * kWRaw;                  // [2][16][8][16][4]   (a lane's four tile blocks contiguous)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
 
-    // block -> (image, tile-row group, channel block); XCD-aware like conv_kernels.hip: the channel blocks of one input tile are
-    // consecutive blocks of ONE XCD (ids congruent mod 8) and an XCD owns a contiguous range of tiles (a speed heuristic only)
+    // block -> (image, tile-row group, channel block).  Tile ids are dense.  With gx % 8 == 0 the order is XCD-aware like
+    // conv_kernels.hip: the channel blocks of one input tile are consecutive ids of ONE XCD (ids congruent mod 8) and an XCD owns a
+    // contiguous range of input tiles (a speed heuristic only).  a.wsplit: two half-workgroups (32 channels each) per tile id.
+    const int id = a.blk0 + (a.wsplit ? (int)(blockIdx.x >> 1) : (int)blockIdx.x), half = a.wsplit ? (int)(blockIdx.x & 1) : 0;
     int bx, by;
     if (a.xcd) {
-        const int id = blockIdx.x, j = id >> 3, x = id & 7, q = j / a.gy;
+        const int j = id >> 3, x = id & 7, q = j / a.gy;
         by = j - q * a.gy;
-        bx = ((x * a.gx) >> 3) + q;
-        if (bx >= (((x + 1) * a.gx) >> 3)) return;
+        bx = x * (a.gx >> 3) + q;
     } else {
-        by = blockIdx.x / a.gx;
-        bx = blockIdx.x - by * a.gx;
+        bx = id / a.gy;
+        by = id - bx * a.gy;
     }
     const int groups = a.H >> 2;                         // tile-row groups per image (14)
-    const int img = bx / groups, r = bx - img * groups, co0 = by * TC;
+    const int img = bx / groups, r = bx - img * groups;
+    const int co0 = a.wsplit ? by * 64 : by * TC;           // first channel of the weight block; channel n*16 + l sits at l*cstr + n
+    const int cstr = a.wsplit ? 4 : NB, nb0 = 2 * half;
     const int HW = a.H * a.W;
     const float* inb = a.in + ((size_t)img * a.in_ctot + a.in_coff) * HW;
     const int g0 = (4 * r - 1) * 56;                     // plane index of raw[.][0]
@@ -75,7 +79,7 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a) {
     // transformed weights: a wave's MFMA B fragments are ITS four points' rows -- no other wave reads them, so they go from L2 straight
     // into registers (one 16-byte load per lane and MFMA group, requested a whole chunk ahead), not through the LDS
     typedef float bfrag __attribute__((ext_vector_type(NB)));
-    const int ub = ((wave * 4 * a.CinPad + lq) * a.CoutPad + co0 + l15 * NB) * 4;
+    const int ub = ((wave * 4 * a.CinPad + lq) * a.CoutPad + co0 + l15 * cstr + nb0) * 4;
     const int u_point = a.CinPad * a.CoutPad * 4, u_kstep = 4 * a.CoutPad * 4, u_chunk = kWCK * a.CoutPad * 4;
     auto load_u = [&](int chunk, int g) -> bfrag {                           // group g = (point wave*4 + g/2, k-step g%2)
         const int soff = chunk * u_chunk + (g >> 1) * u_point + (g & 1) * u_kstep;
@@ -247,7 +251,7 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a) {
         __syncthreads();
         for (int pr = tid; pr < kWTiles * 16; pr += 256) {
             const int c = pr / kWTiles, t = pr - c * kWTiles, ty2 = t >= 28 ? 1 : 0, tx = t - 28 * ty2;
-            const int co = co0 + nt * 16 + c;
+            const int co = co0 + (nb0 + nt) * 16 + c;
             if (co >= a.Cout) continue;
             float m[16];
             const int pairo = t >> 1, ri = (2 * (pairo >> 4) + (t & 1)) * 16 + (pairo & 15);     // the tile's MFMA row (see the V layout)
@@ -294,11 +298,14 @@ hipError_t launch_conv_wino(ConvArgs a, hipStream_t s) {
     if (a.n_add == 1 && a.add_shift[0] != 0) return hipErrorInvalidValue;
     a.gx = a.N * (a.H >> 2);
     a.gy = a.CoutPad / (nb * 16);
-    a.gx8 = (a.gx + 7) / 8;
-    a.xcd = a.gx >= 16 ? 1 : 0;
-    const dim3 grid((a.xcd ? a.gx8 * 8 : a.gx) * a.gy);
+    a.xcd = a.gx % 8 == 0 && a.gx >= 16 ? 1 : 0;
+    a.blk0 = 0;
+    a.wsplit = 0;
+    const int total = a.gx * a.gy;
+    static const int split_env = getenv("GRNET_WINO_SPLIT") ? atoi(getenv("GRNET_WINO_SPLIT")) : 1;
 #ifdef GRNET_ABLATION
     if (nb == 4 && a.dbg) {
+        const dim3 grid(total);
         auto go = [&](auto kern) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLdsB); return launch_k(kern, grid, dim3(256), kWinoLdsB, s, a); };
         if (a.dbg == 1) return go(conv_wino_f32<4, 1>);
         if (a.dbg == 2) return go(conv_wino_f32<4, 2>);
@@ -309,8 +316,19 @@ hipError_t launch_conv_wino(ConvArgs a, hipStream_t s) {
         if (a.dbg == 7) return go(conv_wino_f32<4, 7>);
     }
 #endif
-    if (nb == 4) return launch_k(conv_wino_f32<4>, grid, dim3(256), kWinoLdsB, s, a);
-    return launch_k(conv_wino_f32<2>, grid, dim3(256), kWinoLdsB, s, a);
+    if (nb == 2) return launch_k(conv_wino_f32<2>, dim3(total), dim3(256), kWinoLdsB, s, a);
+    // One workgroup per CU (kWinoCUs of them): a layer whose last round is at most half full (896 workgroups at 16 frames and 256
+    // output channels: 3.5 rounds) runs that round as twice as many HALF workgroups -- the 32-channel kernel on the same packed
+    // weights -- so the round costs about 0.6 of a full one instead of 1.
+    const int full = total / kWinoCUs * kWinoCUs, rest = total - full;
+    if (split_env && full > 0 && rest > 0 && 2 * rest <= kWinoCUs && (!a.xcd || full % 8 == 0)) {
+        hipError_t e = launch_k(conv_wino_f32<4>, dim3(full), dim3(256), kWinoLdsB, s, a);
+        if (e != hipSuccess) return e;
+        a.blk0 = full;
+        a.wsplit = 1;
+        return launch_k(conv_wino_f32<2>, dim3(2 * rest), dim3(256), kWinoLdsB, s, a);
+    }
+    return launch_k(conv_wino_f32<4>, dim3(total), dim3(256), kWinoLdsB, s, a);
 }
 
 // U = G g G^T per (cout, cin) in fp64 -> [16][cin_pad][cout_pad] fp32; w: (cout, cin, 3, 3) folded weights (double)
