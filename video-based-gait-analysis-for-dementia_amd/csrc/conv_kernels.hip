@@ -98,7 +98,7 @@ struct EpiCtx { int y0, g0, HoWo, RW, qlimit; float inv_RW, inv_Wo; bool vec_ok,
 __device__ __forceinline__ EpiCtx make_epi_ctx(const ConvArgs& a, int y0, int g0) {
     EpiCtx e;
     e.y0 = y0; e.g0 = g0; e.HoWo = a.Ho * a.Wo; e.RW = a.R * a.Wo; e.qlimit = a.G * e.RW;
-    e.inv_RW = 1.0f / (float)e.RW; e.inv_Wo = 1.0f / (float)a.Wo;
+    e.inv_RW = a.inv_RW; e.inv_Wo = a.inv_Wo;
     e.vec_ok = (e.RW % 4 == 0) && (e.HoWo % 4 == 0) && ((y0 * a.Wo) % 4 == 0);
     e.pre0 = e.vec_ok && a.n_add >= 1 && a.add_shift[0] == 0;     // addend 0 (the residual) can be fetched before the main loop
     return e;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
     const bool fast_in = ROWS && CK * upc_i <= NII * NT && (a.Cin % CK) == 0;
     int ioff[NII];
     if constexpr (ROWS) {
-        const float inv_upc = 1.0f / (float)upc_i;
+        const float inv_upc = a.inv_upc;
 #pragma unroll
         for (int it = 0; it < NII; ++it) {
             const int u = it * NT + tid;
@@ -310,11 +310,12 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
     // A operand: lane holds pixel (lane&15) of its sub-tile, channel (lane>>4) of the k-group.
     int abase[PSW];
     unsigned lmask = 0, rmask = 0;                         // ROWS: sub-tiles whose pixel sits on the left / right image edge
-    const float inv_RW = 1.0f / (float)RW, inv_Wo = 1.0f / (float)a.Wo;
+    const float inv_RW = a.inv_RW, inv_Wo = a.inv_Wo;
 #pragma unroll
     for (int ps = 0; ps < PSW; ++ps) {
         const int q = (wp * PSW + ps) * 16 + l15;
-        const int gl = fdiv(q, inv_RW), rem = q - gl * RW;
+        // rows mode: one image per tile (gl = 0 wherever q < RW, and nothing below reads yl / x of the pixels past it)
+        const int gl = ROWS ? 0 : fdiv(q, inv_RW), rem = q - gl * RW;
         const int yl = fdiv(rem, inv_Wo), x = rem - yl * a.Wo;
         int off;
         if constexpr (ROWS) {
@@ -472,7 +473,7 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
     int ioff[NII];
     if constexpr (ROWS) {
         const int upc = a.PSTR >> 2;
-        const float inv_upc = 1.0f / (float)upc;
+        const float inv_upc = a.inv_upc;
 #pragma unroll
         for (int it = 0; it < NII; ++it) {
             const int u2 = it * 64 + lane;
@@ -554,21 +555,27 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
     int abase[PSW];
     unsigned lmask = 0, rmask = 0;
     unsigned vmask[PLANES ? PSW : 1] = {};                  // PLANES: bit tap = that tap of this pixel is inside the image
-    const float inv_RW = 1.0f / (float)RW, inv_Wo = 1.0f / (float)a.Wo;
+    const float inv_RW = a.inv_RW, inv_Wo = a.inv_Wo;
 #pragma unroll
     for (int ps = 0; ps < PSW; ++ps) {
         const int q = ps * 16 + l15;
-        const int gl = fdiv(q, inv_RW), rem = q - gl * RW;
+        // rows / planes mode: one image per tile (gl = 0 wherever q < RW, and nothing below reads yl / x of the pixels past it)
+        const int gl = (ROWS || PLANES) ? 0 : fdiv(q, inv_RW), rem = q - gl * RW;
         const int yl = fdiv(rem, inv_Wo), x = rem - yl * a.Wo;
         int off;
         if constexpr (PLANES) {
             off = (q < RW) ? (yl * S - pad) * a.W + x * S - pad : 0;     // may be negative: lands in the weight slab, masked
-            if (q < RW) {
+            if (q < RW) {                                   // tap (ky, kx) is inside the image iff its row and its column are: KS + KS tests, not KS * KS
+                unsigned rb = 0, cb = 0;
 #pragma unroll
-                for (int t = 0; t < TAPS; ++t) {
-                    const int yy = yl * S + t / KS - pad, xx = x * S + t % KS - pad;
-                    if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) vmask[ps] |= 1u << t;
+                for (int k = 0; k < KS; ++k) {
+                    const int yy = yl * S + k - pad, xx = x * S + k - pad;
+                    if (yy >= 0 && yy < a.H) rb |= 1u << k;
+                    if (xx >= 0 && xx < a.W) cb |= 1u << k;
                 }
+#pragma unroll
+                for (int ky = 0; ky < KS; ++ky)
+                    if (rb >> ky & 1) vmask[ps] |= cb << (ky * KS);
             }
         } else if constexpr (ROWS) {
             off = (q < RW) ? (y0 * S - pad + yl * S) * a.W + x * S - pad - gal : 0;
@@ -945,7 +952,7 @@ namespace {
 constexpr size_t kMaxLds = 160 * 1024;
 constexpr int kSplitWaves = 4;
 
-void plan_tile(ConvArgs& a, int tps, int family) {
+static void plan_tile_geom(ConvArgs& a, int tps, int family) {
     const int TP = tps * 16, HoWo = a.Ho * a.Wo;
     if (HoWo <= TP) {
         a.G = TP / HoWo;
@@ -983,6 +990,16 @@ void plan_tile(ConvArgs& a, int tps, int family) {
     } else {
         a.PSTR = need | 1;   // stride-2 rows touch even banks; an odd plane stride moves channel k+1 to the odd ones
     }
+}
+
+// The reciprocals the kernels' index math divides by (fdiv): uniform values, but a float division in a kernel is ~10 vector
+// instructions in EVERY lane of every wave -- and on gfx950 vector-ALU time is fp32-MFMA time.
+void plan_tile(ConvArgs& a, int tps, int family) {
+    plan_tile_geom(a, tps, family);
+    if (a.R < 1) return;
+    a.inv_RW = 1.0f / (float)(a.R * a.Wo);
+    a.inv_Wo = 1.0f / (float)a.Wo;
+    a.inv_upc = 1.0f / (float)(a.PSTR >> 2);
 }
 
 // A launch configuration: family 0 = whole-K tiles with a workgroup barrier per chunk (conv_mfma_f32),

@@ -31,9 +31,9 @@ constexpr int kWTiles = 56;             // real tiles per workgroup (2 tile rows
 constexpr int kWRaw = 6 * 56;           // raw floats per channel: 6 input rows
 constexpr int kWV = 16 * kWCK * 64;      // V[point][channel][64 tile slots]
 constexpr int kWinoCUs = 256;          // CUs of an MI355X: workgroups of a full round
-constexpr int kWMrow = 17;              // epilogue: [point][tile][16 channels + 1]
+constexpr int kWMrow = 68;              // epilogue: [point][channel][64 MFMA rows + 4]
 constexpr size_t kWinoLdsB = sizeof(float) * (2 * kWCK * kWRaw + 2 * kWV);     // 87 040 B
-static_assert(sizeof(float) * 16 * 64 * kWMrow <= kWinoLdsB, "the epilogue tile reuses the staging area");
+static_assert(sizeof(float) * 16 * 16 * kWMrow <= kWinoLdsB, "the epilogue tile reuses the staging area");
 
 // a use of x the compiler cannot move: its wait for the LDS read that produces x lands here (a "v" constraint is a device-side
 // thing: inside the __global__ template itself the host pass rejects it and silently drops the kernel's stub)
@@ -233,7 +233,7 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a) {
     chunk((nchunks - 1) & 1, false, 0);
 
     // ---- epilogue: inverse transform, + bias, ReLU, store; 16 output channels per pass
-    float* Mx = smem;                                                        // [16][64][17]
+    float* Mx = smem;                                                        // [16 points][16 channels][68]
     const bool has_add = a.n_add == 1;                                       // the BasicBlock residual (same shape as the output)
     for (int nt = 0; nt < NB; ++nt) {
         __syncthreads();                                                     // staging area / previous pass no longer read
@@ -245,8 +245,9 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a) {
                 // static register index: select the pass's channel block without dynamic indexing of the accumulator array
                 if constexpr (NB == 4) v = nt == 0 ? acc[pi][m][0] : nt == 1 ? acc[pi][m][1] : nt == 2 ? acc[pi][m][2] : acc[pi][m][3];
                 else v = nt == 0 ? acc[pi][m][0] : acc[pi][m][1];
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) Mx[((wave * 4 + pi) * 64 + m * 16 + lq * 4 + rr) * kWMrow + l15] = v[rr];
+                // the 4 MFMA rows of a lane are consecutive: one 16-byte write (a quarter wave = 16 channels x 16 bytes at a stride of
+                // 68 floats: all 64 banks once)
+                *reinterpret_cast<f32x4*>(Mx + ((wave * 4 + pi) * 16 + l15) * kWMrow + m * 16 + lq * 4) = v;
             }
         __syncthreads();
         for (int pr = tid; pr < kWTiles * 16; pr += 256) {
@@ -256,7 +257,7 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a) {
             float m[16];
             const int pairo = t >> 1, ri = (2 * (pairo >> 4) + (t & 1)) * 16 + (pairo & 15);     // the tile's MFMA row (see the V layout)
 #pragma unroll
-            for (int p = 0; p < 16; ++p) m[p] = Mx[(p * 64 + ri) * kWMrow + c];
+            for (int p = 0; p < 16; ++p) m[p] = Mx[(p * 16 + c) * kWMrow + ri];
             float s[4], q[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) { s[j] = m[j] + m[4 + j] + m[8 + j]; q[j] = m[4 + j] - m[8 + j] - m[12 + j]; }

@@ -79,6 +79,7 @@ struct ConvArgs {
     const float* zeros;        // >= 64 B of zeros in HBM: source for halo / padded-channel loads
     // filled by the launcher
     int R, G, Rin, Wp, PSTR, tiles_y, groups, TC, rows;
+    float inv_RW, inv_Wo, inv_upc;   // 1 / (R*Wo), 1 / Wo, 1 / (PSTR/4) for the kernels' reciprocal-multiply divisions
     int nbuf;                  // bf16 kernel: patch buffers in LDS (2 = chunks double-buffered)
     int gx, gy, gx8, xcd;           // pixel tiles x output-channel blocks of the 1-D grid; xcd: XCD-aware block order (see xcd_block)
     int dbg;                   // timing-only ablation bits (tools/conv_micro.py); 0 in the product path
