@@ -328,6 +328,27 @@ def test_dataflow_hr_section_parity_and_determinism(pkg, golden):
 WINO_CASES = [(64, 64), (128, 128), (256, 256), (480, 256), (128, 64), (72, 192), (32, 32), (256, 32), (40, 96)]
 
 
+@pytest.mark.parametrize("case", [(1, 128, 128), (3, 256, 256), (2, 64, 64), (3, 40, 96), (1, 32, 32), (20, 32, 256)], ids=lambda c: "x".join(map(str, c)))
+def test_winograd_conv_kernel_28(model, oracle, case):
+    """The same kernel on 28x28 maps (upsample heads: 256 -> 256, 128 -> 128): a workgroup's 56 tiles are 4 tile rows of 14, the
+    image's 14 tile rows make 3.5 groups -- the last group's lower half reads zeros and stores nothing.  1-3 images, odd channel
+    counts, the 32-channel variant, 20 images x 256 channels (320 workgroups: the last 64 run as half-size ones); bias + ReLU, with
+    and without a residual."""
+    n, cin, cout = case
+    g = np.random.Generator(np.random.Philox(key=[79, n * 100000 + cin * 1000 + cout]))
+    x = g.standard_normal((n, cin, 28, 28)).astype(np.float32)
+    w = (g.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (cin * 9))).astype(np.float32)
+    b = (g.standard_normal((cout,)) * 0.1).astype(np.float32)
+    r = g.standard_normal((n, cout, 28, 28)).astype(np.float32)
+    conv = oracle.conv2d(x, w, stride=1, bias=b)
+    xd = torch.from_numpy(x).cuda()
+    got = model.op_conv2d(xd, w, b, stride=1, relu=True, tile_hint=2000).cpu().numpy()
+    assert got.shape == conv.shape
+    assert rel_err(got, torch.relu(conv).numpy()) < 2e-5
+    got = model.op_conv2d(xd, w, b, stride=1, relu=True, add=torch.from_numpy(r).cuda(), tile_hint=2000).cpu().numpy()
+    assert rel_err(got, torch.relu(conv + torch.from_numpy(r)).numpy()) < 2e-5
+
+
 @pytest.mark.parametrize("case", [(5, 32, 256), (16, 32, 256), (7, 40, 192), (6, 64, 64)], ids=lambda c: "x".join(map(str, c)))
 def test_winograd_last_round_split(model, oracle, case):
     """Layers whose last round of workgroups is at most half full run it as half-size workgroups (the 32-channel kernel on the weights
@@ -371,7 +392,7 @@ def test_winograd_conv_kernel(model, oracle, case):
         assert rel_err(got_lin, ref_lin) < 2e-5, (case, n)
         assert rel_err(got_lin[:, :, [0, 55]], ref_lin[:, :, [0, 55]]) < 2e-5 and rel_err(got_lin[..., [0, 55]], ref_lin[..., [0, 55]]) < 2e-5
     with pytest.raises(Exception):
-        model.op_conv2d(torch.zeros(1, 64, 28, 28).cuda(), np.zeros((64, 64, 3, 3), np.float32), tile_hint=2000)   # not a 56x56 map: refused, no fallback
+        model.op_conv2d(torch.zeros(1, 64, 14, 14).cuda(), np.zeros((64, 64, 3, 3), np.float32), tile_hint=2000)   # not a 56x56 / 28x28 map: refused, no fallback
 
 
 def test_winograd_layers_match_direct_layers(pkg, golden):

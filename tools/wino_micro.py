@@ -20,3 +20,9 @@ for cin, cout in ((32, 32), (64, 64)):
     print(f"[with residual] {cin}->{cout}", file=sys.stderr)
     for hint in (0, 2000):
         m.op_conv2d(x, w, np.zeros(cout, np.float32), relu=True, add=r, tile_hint=hint)
+# 28x28 maps (upsample heads)
+for cin, cout in ((256, 256), (128, 128), (64, 64)):
+    x = torch.randn(n, cin, 28, 28, device="cuda")
+    w = (np.random.randn(cout, cin, 3, 3) * 0.02).astype(np.float32)
+    for hint in (0, 2000):
+        m.op_conv2d(x, w, np.zeros(cout, np.float32), relu=True, tile_hint=hint)

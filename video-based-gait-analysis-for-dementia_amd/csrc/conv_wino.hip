@@ -28,11 +28,11 @@ namespace {
 
 constexpr int kWCK = 8;                 // input channels per chunk
 constexpr int kWTiles = 56;             // real tiles per workgroup (2 tile rows of 28)
-constexpr int kWRaw = 6 * 56;           // raw floats per channel: 6 input rows
+constexpr int kWRawMax = 6 * 56;        // raw floats per channel: 6 input rows of 56 (10 rows of 28 are fewer)
 constexpr int kWV = 16 * kWCK * 64;      // V[point][channel][64 tile slots]
 constexpr int kWinoCUs = 256;          // CUs of an MI355X: workgroups of a full round
 constexpr int kWMrow = 68;              // epilogue: [point][channel][64 MFMA rows + 4]
-constexpr size_t kWinoLdsB = sizeof(float) * (2 * kWCK * kWRaw + 2 * kWV);     // 87 040 B
+constexpr size_t kWinoLdsB = sizeof(float) * (2 * kWCK * kWRawMax + 2 * kWV);     // 87 040 B
 static_assert(sizeof(float) * 16 * 16 * kWMrow <= kWinoLdsB, "the epilogue tile reuses the staging area");
 
 // a use of x the compiler cannot move: its wait for the LDS read that produces x lands here (a "v" constraint is a device-side
@@ -43,12 +43,17 @@ __device__ __forceinline__ void landed(T& x) { asm volatile("" : "+v"(x)); }
 // NB: 16-channel blocks per workgroup -- 4 (64 output channels) or 2 (the 32-channel layers: 56x56 branch of the HR modules, transition1)
 // (the body is a __device__ function: the host pass type-checks the body of a __global__ template, rejects device-only constructs
 // in it without a diagnostic and then emits no launch stub -- the library fails to load with an undefined kernel symbol)
-template <int NB, int ABL>
+// WD: map width, 56 or 28.  A workgroup's 56 tiles are 2 tile rows of 28 (WD = 56: output rows 4r .. 4r+3, 6 input rows) or 4 tile rows
+// of 14 (WD = 28: output rows 8r .. 8r+7, 10 input rows; 14 tile rows per image = 3.5 groups, the last group's lower half lies below
+// the image: its input rows are zeros, its outputs are not stored).
+template <int NB, int WD, int ABL>
 __device__ __forceinline__ void conv_wino_body(const ConvArgs& a) {
     constexpr int TC = NB * 16;
+    constexpr int TRW = WD / 2, TRG = 56 / TRW, kWRaw = (2 * TRG + 2) * WD, UPC = kWRaw / 4;   // tiles per tile row, tile rows per workgroup, raw floats / 16-byte units per channel
+    static_assert(WD == 56 || WD == 28, "tile geometry");
     extern __shared__ __align__(16) float smem[];
-    float* raw = smem;                                  // [2][8][336]
-    float* V = raw + 2 * kWCK * kWRaw;                  // [2][16][8][16][4]   (a lane's four tile blocks contiguous)
+    float* raw = smem;                                  // [2][8][kWRaw]
+    float* V = raw + 2 * kWCK * kWRawMax;                  // [2][16][8][16][4]   (a lane's four tile blocks contiguous)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
 
     // block -> (image, tile-row group, channel block).  Tile ids are dense.  With gx % 8 == 0 the order is XCD-aware like
@@ -64,13 +69,13 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a) {
         bx = id / a.gy;
         by = id - bx * a.gy;
     }
-    const int groups = a.H >> 2;                         // tile-row groups per image (14)
+    const int groups = ((a.H >> 1) + TRG - 1) / TRG;     // tile-row groups per image (14 or 4)
     const int img = bx / groups, r = bx - img * groups;
     const int co0 = a.wsplit ? by * 64 : by * TC;           // first channel of the weight block; channel n*16 + l sits at l*cstr + n
     const int cstr = a.wsplit ? 4 : NB, nb0 = 2 * half;
     const int HW = a.H * a.W;
     const float* inb = a.in + ((size_t)img * a.in_ctot + a.in_coff) * HW;
-    const int g0 = (4 * r - 1) * 56;                     // plane index of raw[.][0]
+    const int g0 = (2 * TRG * r - 1) * WD;               // plane index of raw[.][0]
 
     // ---- LDS-DMA through buffer descriptors: per-lane byte offsets are chunk-invariant (a VGPR each), the chunk moves the scalar
     // offset -- no vector-ALU address arithmetic in the loop (on gfx950 every vector-ALU instruction is matrix-pipe time, see below)
@@ -89,10 +94,10 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a) {
     int roff[3];                                         // raw rows: 672 units per chunk; -1 = no unit or a row outside the image
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const int u = i * 256 + tid, ch = u / 84, k = u - ch * 84, gi = g0 + 4 * k;
-        const bool unit = u < kWCK * 84, inside = gi >= 0 && gi < HW;
+        const int u = i * 256 + tid, ch = u / UPC, k = u - ch * UPC, gi = g0 + 4 * k;
+        const bool unit = u < kWCK * UPC, inside = gi >= 0 && gi < HW;
         roff[i] = unit && inside ? (ch * HW + gi) * 4 : -1;
-        if (unit && !inside) {                           // rows -1 / 56 of the image: zero once in both buffers, the DMA never writes there
+        if (unit && !inside) {                           // rows above / below the image: zero once in both buffers, the DMA never writes there
             *reinterpret_cast<f32x4*>(raw + u * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
             *reinterpret_cast<f32x4*>(raw + kWCK * kWRaw + u * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -113,23 +118,25 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a) {
     // padding on the left, an idle lane's zero on the right.  V[point][channel][pair & 15][2 * (pair >> 4) + half]: the MFMA row tile m
     // of a tile is 2 * (pair >> 4) + (tile & 1), its row pair & 15 -- so the four A fragments of a lane are 16 contiguous bytes, and a
     // thread's two results per point one 8-byte write.
-    const int row16 = tid >> 4, px = tid & 15, chn = row16 >> 1, ty2t = row16 & 1;
-    const bool real = px < 14;
-    const int pairt = real ? 14 * ty2t + px : 28 + 2 * ty2t + (px - 14);
-    const int rpos = chn * kWRaw + (2 * ty2t) * 56 + 4 * (real ? px : 13);
+    // WD = 28: the 16 lanes are two tile rows of 7 pairs + 1 idle lane each; idle lanes supply the zero on BOTH sides there.
+    const int row16 = tid >> 4, px = tid & 15, chn = row16 >> 1, rh = row16 & 1;
+    const int pc = WD == 56 ? px : (px & 7), trl = WD == 56 ? rh : 2 * rh + (px >> 3);       // pair column, tile row within the workgroup
+    const bool real = pc < TRW / 2;
+    const int pairt = real ? trl * (TRW / 2) + pc : 28 + 2 * rh + (WD == 56 ? px - 14 : (px >> 3));
+    const int rpos = chn * kWRaw + (2 * trl) * WD + 4 * (real ? pc : TRW / 2 - 1);
     const int vpos = chn * 64 + (pairt & 15) * 4 + 2 * (pairt >> 4);
     struct Tf { float d[4][6]; float e[4][6]; };
     auto tf_read = [&](Tf& t, const float* rp) {        // 4 LDS reads
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(rp + i * 56);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rp + i * WD);
             t.d[i][1] = v[0]; t.d[i][2] = v[1]; t.d[i][3] = v[2]; t.d[i][4] = v[3];
         }
     };
     auto tf_halo = [&](Tf& t) {                         // 12 vector-ALU instructions
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            t.d[i][0] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t.d[i][4]), 0x111, 0xf, 0xf, true));                 // row_shr:1
+            t.d[i][0] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(WD == 56 || real ? t.d[i][4] : 0.f), 0x111, 0xf, 0xf, true));   // row_shr:1
             t.d[i][5] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(real ? t.d[i][1] : 0.f), 0x101, 0xf, 0xf, true));    // row_shl:1
         }
     };
@@ -251,7 +258,9 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a) {
             }
         __syncthreads();
         for (int pr = tid; pr < kWTiles * 16; pr += 256) {
-            const int c = pr / kWTiles, t = pr - c * kWTiles, ty2 = t >= 28 ? 1 : 0, tx = t - 28 * ty2;
+            const int c = pr / kWTiles, t = pr - c * kWTiles, tro = t / TRW, tx = t - TRW * tro;
+            const int orow = 2 * (TRG * r + tro);                            // output row of the tile's upper pixel pair
+            if (WD == 28 && orow >= a.H) continue;                           // the last group's lower half (below the image)
             const int co = co0 + (nb0 + nt) * 16 + c;
             if (co >= a.Cout) continue;
             float m[16];
@@ -264,40 +273,31 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a) {
             const float b = a.bias[co];
             float y00 = s[0] + s[1] + s[2] + b, y01 = s[1] - s[2] - s[3] + b, y10 = q[0] + q[1] + q[2] + b, y11 = q[1] - q[2] - q[3] + b;
             if (has_add) {
-                const float* ap = a.add[0] + ((size_t)img * a.add_ctot[0] + a.add_coff[0] + co) * HW + (4 * r + 2 * ty2) * 56 + 2 * tx;
-                const f32x2 r0 = *reinterpret_cast<const f32x2*>(ap), r1 = *reinterpret_cast<const f32x2*>(ap + 56);
+                const float* ap = a.add[0] + ((size_t)img * a.add_ctot[0] + a.add_coff[0] + co) * HW + orow * WD + 2 * tx;
+                const f32x2 r0 = *reinterpret_cast<const f32x2*>(ap), r1 = *reinterpret_cast<const f32x2*>(ap + WD);
                 y00 += r0[0]; y01 += r0[1]; y10 += r1[0]; y11 += r1[1];
             }
             if (a.relu) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
-            float* op = a.out + ((size_t)img * a.out_ctot + a.out_coff + co) * HW + (4 * r + 2 * ty2) * 56 + 2 * tx;
+            float* op = a.out + ((size_t)img * a.out_ctot + a.out_coff + co) * HW + orow * WD + 2 * tx;
             *reinterpret_cast<f32x2*>(op) = f32x2{y00, y01};
-            *reinterpret_cast<f32x2*>(op + 56) = f32x2{y10, y11};
+            *reinterpret_cast<f32x2*>(op + WD) = f32x2{y10, y11};
         }
     }
 }
 
-template <int NB, int ABL = 0>                         // ABL: timing-only ablations (GRNET_ABLATION builds, tools/wino_micro.py); 0 in the product
-__global__ __launch_bounds__(256) void conv_wino_f32(const ConvArgs a) { conv_wino_body<NB, ABL>(a); }
+template <int NB, int WD = 56, int ABL = 0>            // ABL: timing-only ablations (GRNET_ABLATION builds, tools/wino_micro.py); 0 in the product
+__global__ __launch_bounds__(256) void conv_wino_f32(const ConvArgs a) { conv_wino_body<NB, WD, ABL>(a); }
 
 }  // namespace
 
 bool conv_wino_eligible(int cin, int cout, int ks, int stride, int h, int w, int n_add) {
-    return ks == 3 && stride == 1 && h == 56 && w == 56 && n_add <= 1 && cin % kWCK == 0 && cout % 32 == 0 && cin >= 32;
+    return ks == 3 && stride == 1 && ((h == 56 && w == 56) || (h == 28 && w == 28)) && n_add <= 1 && cin % kWCK == 0 && cout % 32 == 0 && cin >= 32;
 }
 
-// a.w: transformed weights [16][CinPad][CoutPad] (pack_wino_weights), CinPad % 8 == 0, CoutPad % 64 == 0
-hipError_t launch_conv_wino(ConvArgs a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_f32<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLdsB);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_f32<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLdsB);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    const int nb = a.Cout % 64 == 0 ? 4 : 2;
-    if (!conv_wino_eligible(a.Cin, a.Cout, a.ks, a.stride, a.H, a.W, a.n_add) || a.CinPad % kWCK != 0 || a.CoutPad % (nb * 16) != 0) return hipErrorInvalidValue;
-    if (a.n_add == 1 && a.add_shift[0] != 0) return hipErrorInvalidValue;
-    a.gx = a.N * (a.H >> 2);
+template <int WD>
+static hipError_t launch_wino_w(ConvArgs a, hipStream_t s, int nb) {
+    constexpr int TRG = 56 / (WD / 2);
+    a.gx = a.N * (((a.H >> 1) + TRG - 1) / TRG);
     a.gy = a.CoutPad / (nb * 16);
     a.xcd = a.gx % 8 == 0 && a.gx >= 16 ? 1 : 0;
     a.blk0 = 0;
@@ -305,31 +305,49 @@ hipError_t launch_conv_wino(ConvArgs a, hipStream_t s) {
     const int total = a.gx * a.gy;
     static const int split_env = getenv("GRNET_WINO_SPLIT") ? atoi(getenv("GRNET_WINO_SPLIT")) : 1;
 #ifdef GRNET_ABLATION
-    if (nb == 4 && a.dbg) {
-        const dim3 grid(total);
-        auto go = [&](auto kern) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLdsB); return launch_k(kern, grid, dim3(256), kWinoLdsB, s, a); };
-        if (a.dbg == 1) return go(conv_wino_f32<4, 1>);
-        if (a.dbg == 2) return go(conv_wino_f32<4, 2>);
-        if (a.dbg == 3) return go(conv_wino_f32<4, 3>);
-        if (a.dbg == 4) return go(conv_wino_f32<4, 4>);
-        if (a.dbg == 5) return go(conv_wino_f32<4, 5>);
-        if (a.dbg == 6) return go(conv_wino_f32<4, 6>);
-        if (a.dbg == 7) return go(conv_wino_f32<4, 7>);
+    if constexpr (WD == 56) {
+        if (nb == 4 && a.dbg) {
+            const dim3 grid(total);
+            auto go = [&](auto kern) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLdsB); return launch_k(kern, grid, dim3(256), kWinoLdsB, s, a); };
+            if (a.dbg == 1) return go(conv_wino_f32<4, 56, 1>);
+            if (a.dbg == 2) return go(conv_wino_f32<4, 56, 2>);
+            if (a.dbg == 3) return go(conv_wino_f32<4, 56, 3>);
+            if (a.dbg == 4) return go(conv_wino_f32<4, 56, 4>);
+            if (a.dbg == 5) return go(conv_wino_f32<4, 56, 5>);
+            if (a.dbg == 6) return go(conv_wino_f32<4, 56, 6>);
+            if (a.dbg == 7) return go(conv_wino_f32<4, 56, 7>);
+        }
     }
 #endif
-    if (nb == 2) return launch_k(conv_wino_f32<2>, dim3(total), dim3(256), kWinoLdsB, s, a);
+    if (nb == 2) return launch_k(conv_wino_f32<2, WD>, dim3(total), dim3(256), kWinoLdsB, s, a);
     // One workgroup per CU (kWinoCUs of them): a layer whose last round is at most half full (896 workgroups at 16 frames and 256
     // output channels: 3.5 rounds) runs that round as twice as many HALF workgroups -- the 32-channel kernel on the same packed
     // weights -- so the round costs about 0.6 of a full one instead of 1.
     const int full = total / kWinoCUs * kWinoCUs, rest = total - full;
     if (split_env && full > 0 && rest > 0 && 2 * rest <= kWinoCUs && (!a.xcd || full % 8 == 0)) {
-        hipError_t e = launch_k(conv_wino_f32<4>, dim3(full), dim3(256), kWinoLdsB, s, a);
+        hipError_t e = launch_k(conv_wino_f32<4, WD>, dim3(full), dim3(256), kWinoLdsB, s, a);
         if (e != hipSuccess) return e;
         a.blk0 = full;
         a.wsplit = 1;
-        return launch_k(conv_wino_f32<2>, dim3(2 * rest), dim3(256), kWinoLdsB, s, a);
+        return launch_k(conv_wino_f32<2, WD>, dim3(2 * rest), dim3(256), kWinoLdsB, s, a);
     }
-    return launch_k(conv_wino_f32<4>, dim3(total), dim3(256), kWinoLdsB, s, a);
+    return launch_k(conv_wino_f32<4, WD>, dim3(total), dim3(256), kWinoLdsB, s, a);
+}
+
+// a.w: transformed weights [16][CinPad][CoutPad] (pack_wino_weights), CinPad % 8 == 0, CoutPad % 64 == 0 (or 32: the 32-channel kernel)
+hipError_t launch_conv_wino(ConvArgs a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipSuccess;
+        auto set = [&](auto kern) { if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLdsB); };
+        set(conv_wino_f32<4, 56>); set(conv_wino_f32<2, 56>); set(conv_wino_f32<4, 28>); set(conv_wino_f32<2, 28>);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int nb = a.Cout % 64 == 0 ? 4 : 2;
+    if (!conv_wino_eligible(a.Cin, a.Cout, a.ks, a.stride, a.H, a.W, a.n_add) || a.CinPad % kWCK != 0 || a.CoutPad % (nb * 16) != 0) return hipErrorInvalidValue;
+    if (a.n_add == 1 && a.add_shift[0] != 0) return hipErrorInvalidValue;
+    return a.W == 56 ? launch_wino_w<56>(a, s, nb) : launch_wino_w<28>(a, s, nb);
 }
 
 // U = G g G^T per (cout, cin) in fp64 -> [16][cin_pad][cout_pad] fp32; w: (cout, cin, 3, 3) folded weights (double)

@@ -817,12 +817,15 @@ struct grnet {
         L.cin_pad = bf ? (L.in.c + 31) / 32 * 32 : (cin + kConvCK - 1) / kConvCK * kConvCK;
         L.cout_pad = bf ? (L.cout + 31) / 32 * 32 : (L.cout + TC - 1) / TC * TC;
         std::vector<float> wp((size_t)taps * L.cin_pad * L.cout_pad, 0.f), bp(L.cout_pad, 0.f);
-        // Every eligible layer takes the Winograd kernel: layer1, upsample heads, PARE head, transition1's 256 -> 32 and the 32 -> 32
-        // convolutions of the 56x56 HR branch.  (While the kernel staged its weights through the LDS a workgroup owned the CU's whole
-        // 160 KB and the 32 -> 32 layers lost in context what they won in isolation -- 2 758 vs 2 800 frames/s; with the B fragments
-        // loaded straight into registers it holds 87 KB and they win: 2 930 -> 3 030 frames/s.)
+        // Every eligible layer on a 56x56 map takes the Winograd kernel: layer1, upsample heads, PARE head, transition1's 256 -> 32 and
+        // the 32 -> 32 convolutions of the 56x56 HR branch.  (While the kernel staged its weights through the LDS a workgroup owned the
+        // CU's whole 160 KB and the 32 -> 32 layers lost in context what they won in isolation -- 2 758 vs 2 800 frames/s; with the B
+        // fragments loaded straight into registers it holds 87 KB and they win: 2 930 -> 3 030 frames/s.)  On 28x28 maps only the wide
+        // upsample-head layers (256 -> 256: 196 -> 96 us, 128 -> 128: 62 -> 51 at 16 frames): the 64 -> 64 branch convolutions would be
+        // 64 workgroups of 8 chunks each, 31 us against the split-K kernel's 16.
         const bool wino = !bf && conv_wino_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size()) && L.cin_pad % 8 == 0 &&
-                          L.cout_pad % (L.cout % 64 == 0 ? 64 : 32) == 0 && (L.adds.empty() || L.adds[0].shift == 0);
+                          L.cout_pad % (L.cout % 64 == 0 ? 64 : 32) == 0 && (L.adds.empty() || L.adds[0].shift == 0) &&
+                          (L.in.w == 56 || (L.in.c >= 128 && L.cout % 64 == 0));
         std::vector<double> wfold(wino ? (size_t)L.cout * cin * 9 : 0);     // BN-folded weights (cout, cin, 3, 3) for the filter transform
         int co0 = 0;
         for (auto& s : L.segs) {
