@@ -136,7 +136,7 @@ def timed_steps(do_step, device_sync, steps, warmup, dist, reduce_device):
 
 
 # ------------------------------------------------------------------------------------------- the JSON line
-def roofline_object(fps_per_gpu, dtype, conv_flops_per_frame, conv_ms, conv_ms_serial, n_conv, n, extra=None):
+def roofline_object(fps_per_gpu, dtype, conv_flops_per_frame, conv_ms, conv_ms_serial, n_conv, n, extra=None, executed_flops_per_frame=None):
     """achieved = frames/s per GPU x F_frame; the conv-only figure (same FLOPs / wall time of the conv launches
     alone) and the serial per-launch average (what rocprofv3 --stats averages add up to) sit beside it."""
     peak = PEAK_BF16_MFMA_TFLOPS if dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
@@ -145,13 +145,17 @@ def roofline_object(fps_per_gpu, dtype, conv_flops_per_frame, conv_ms, conv_ms_s
     r = {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
          "definition": "frames/s per GPU x F_frame (SURVEY 8d: 30.883 GFLOP of convolutions per frame = the ALGORITHMIC, direct-convolution "
                        "count); the whole step -- pooling, tail, SMPL, launch gaps -- is charged to the convolutions.  On the fp32 path the Winograd "
-                       "layers (42 % of F_frame) execute 2.25x fewer multiplies than counted here, in fp32 throughout",
+                       "layers (64 % of F_frame) execute 2.25x fewer multiplies than counted here, in fp32 throughout",
          "traffic": None,
          "kernel": ("conv_mfma_f32 + conv_splitk_f32 (fp32 MFMA implicit-GEMM convolution) + conv_wino_f32 (Winograd F(2x2,3x3) on the fp32 matrix cores "
-                    "for the 3x3 layers with >= 64 channels on 56x56 maps), all launches of a step" if dtype == "f32"
+                    "for the 3x3 stride-1 layers on 56x56 maps and the >= 128-channel ones on 28x28 maps), all launches of a step" if dtype == "f32"
                     else "conv_bf16_nhwc (bf16 MFMA implicit-GEMM convolution on NHWC activations, all launches of a step)"),
          "conv_launches_per_step": n_conv, "conv_gflop_per_step": round(conv_flops / 1e9, 3),
          "gflop_per_launch": round(conv_flops / 1e9 / max(n_conv, 1), 4)}
+    if executed_flops_per_frame and executed_flops_per_frame != conv_flops_per_frame:
+        ex = fps_per_gpu * executed_flops_per_frame / 1e12
+        r.update(executed_gflop_per_step=round(executed_flops_per_frame * n / 1e9, 3), executed_achieved=round(ex, 3), executed_frac=round(ex / peak, 4),
+                 executed_note="the multiplies the matrix cores were asked to do: Winograd layers at 4/9 of their direct-convolution count")
     if conv_ms:
         r.update(conv_only_ms_per_step=round(conv_ms, 4), conv_only_achieved=round(conv_flops / (conv_ms * 1e-3) / 1e12, 3),
                  conv_only_frac=round(conv_flops / (conv_ms * 1e-3) / 1e12 / peak, 4),
@@ -303,7 +307,8 @@ class GpuWorkload:
         conv_ms_serial = min(model.time_convs(n) for _ in range(3))
         model.set_option(pkg._lib.OPT_MULTI_LANE, 1)
         return roofline_object(fps_per_gpu, self.args.dtype, model.conv_flops_per_frame(), conv_ms, conv_ms_serial,
-                               model.num_conv_launches(), n, stored_traffic(n, self.args.dtype))
+                               model.num_conv_launches(), n, stored_traffic(n, self.args.dtype),
+                               executed_flops_per_frame=model.conv_executed_flops_per_frame())
 
     def extras(self, line):
         """cpu_baseline + parity: rank 0 at N = 1 only, after the timed region."""

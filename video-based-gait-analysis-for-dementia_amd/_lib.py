@@ -42,6 +42,7 @@ EXPORTS = {
     "grnet_num_kernel_launches": (C.c_int, [C.c_void_p]),
     "grnet_num_conv_launches": (C.c_int, [C.c_void_p]),
     "grnet_conv_flops_per_frame": (C.c_double, [C.c_void_p]),
+    "grnet_conv_executed_flops_per_frame": (C.c_double, [C.c_void_p]),
     "grnet_describe_conv": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_char_p, C.c_int]),
     "grnet_time_convs": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "grnet_op_conv2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

@@ -1952,6 +1952,13 @@ double grnet_conv_flops_per_frame(grnet_t* h) {
     return 2.0 * m;
 }
 
+double grnet_conv_executed_flops_per_frame(grnet_t* h) {
+    if (!h) return 0;
+    double m = 0;
+    for (auto& L : h->convs) m += L.macs_per_frame * (L.wino_dev && h->wino_mode && h->dtype == 0 ? 4.0 / 9.0 : 1.0);
+    return 2.0 * m;
+}
+
 int grnet_describe_conv(grnet_t* h, int pos, int32_t* info, char* name, int name_size) {
     if (!h || !info || !h->finalized || pos < 0) return GRNET_EINVAL;
     int seen = 0;

@@ -285,6 +285,11 @@ class GRNet:
     def conv_flops_per_frame(self):
         return self._lib.grnet_conv_flops_per_frame(self._h)
 
+    def conv_executed_flops_per_frame(self):
+        """Winograd layers counted at the 4/9 of their multiplies they execute (reporting only)."""
+        self.finalize()
+        return self._lib.grnet_conv_executed_flops_per_frame(self._h)
+
     def describe_convs(self):
         """The convolution launches of one forward in un-grouped launch order: list of dicts (shape, fused addends, weight key)."""
         self.finalize()
