@@ -179,9 +179,11 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const EpiCtx& e, f
 // falls outside the row select 0).  Otherwise (multi-image tiles of the 7x7 maps): a zero-padded patch
 // [G][Rin][Wp] gathered float by float through the source-offset table.
 
-// CK = input channels per K-chunk: 8 for 3x3 (72 k-steps of 4 per chunk ... 18 MFMA steps), 32 for 1x1 convolutions,
-// whose chunks would otherwise hold only 2 MFMA steps between barriers and run latency-bound.
-template <bool ROWS, int KS, int S, int TPS, int TCS, int WP, int WC, int CK = (KS == 1 ? 32 : kConvCK)>
+// CK = input channels per K-chunk: 8 for 3x3 (72 k-steps of 4 per chunk ... 18 MFMA steps), kConvCK1 = 16 for 1x1 convolutions:
+// 8 would hold only 2 MFMA steps between barriers (latency-bound: 34.7 us for 64 -> 256 @56x56, 16 frames), 32 doubles the staging
+// buffers to ~100 KB and leaves one workgroup per CU with nobody to overlap its load and store phases (35.0 us); 16: 32.1 us.
+constexpr int kConvCK1 = 16;
+template <bool ROWS, int KS, int S, int TPS, int TCS, int WP, int WC, int CK = (KS == 1 ? kConvCK1 : kConvCK)>
 __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
     constexpr int NT = WP * WC * 64, TC = TCS * 16;
     constexpr int PSW = TPS / WP, CSW = TCS / WC, TAPS = KS * KS;
@@ -1009,7 +1011,7 @@ struct Cfg { int family, tps, tcs; int nw = 4; };   // nw: split-K waves per wor
 size_t lds_bytes(const ConvArgs& a, const Cfg& c) {
     const int taps = a.ks * a.ks, TC = c.tcs * 16;
     const size_t tab = a.rows ? 0 : a.PSTR;
-    const size_t ck = a.ks == 1 ? 32 : kConvCK;
+    const size_t ck = a.ks == 1 ? kConvCK1 : kConvCK;
     if (c.family == 0) return sizeof(float) * (2 * (size_t)taps * ck * TC + 2 * ck * a.PSTR + tab);
     const size_t stage = (size_t)taps * 4 * TC + 4 * (size_t)a.PSTR;
     const size_t staging = c.nw * stage + tab, red = (size_t)c.nw * c.tps * c.tcs * 256;
@@ -1021,7 +1023,7 @@ size_t lds_bytes(const ConvArgs& a, const Cfg& c) {
 double cfg_cost(ConvArgs a, const Cfg& c, bool* ok) {
     plan_tile(a, c.tps, c.family);
     *ok = a.R >= 1 && lds_bytes(a, c) <= kMaxLds && a.CoutPad % (c.tcs * 16) == 0 &&
-          !(c.family == 0 && a.ks == 1 && a.CinPad % 32 != 0);       // whole-K 1x1 tiles stage 32 channels per chunk
+          !(c.family == 0 && a.ks == 1 && a.CinPad % kConvCK1 != 0);       // whole-K 1x1 tiles stage kConvCK1 channels per chunk
     if (!*ok) return 0;
     const double blocks = (double)a.tiles_y * a.groups * (a.CoutPad / (c.tcs * 16));
     const int kgroups = a.CinPad / 4, taps = a.ks * a.ks;
@@ -1319,7 +1321,7 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s, int tile_hint) {
         const double n = h[4] ? (double)h[4] : 1.0;
         fprintf(stderr, "[f32 whole-K phases] %d->%d k%d s%d %dx%d N%d tps %d tcs %d wgs %llu: per WG ticks  index math %.0f  first wait %.0f  chunk loop %.0f "
                 "(%d chunks)  epilogue %.0f\n", a.Cin, a.Cout, a.ks, a.stride, a.H, a.W, a.N, best.tps, best.tcs, h[4], h[0] / n, h[1] / n, h[2] / n,
-                a.CinPad / (a.ks == 1 ? 32 : kConvCK), h[3] / n);
+                a.CinPad / (a.ks == 1 ? kConvCK1 : kConvCK), h[3] / n);
     }
     if (phases && e == hipSuccess && best.family == 1) {
         unsigned long long h[8] = {}, z[8] = {};
