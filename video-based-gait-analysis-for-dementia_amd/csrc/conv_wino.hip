@@ -49,6 +49,10 @@ __device__ __forceinline__ void landed(T& x) { asm volatile("" : "+v"(x)); }
 template <int NB, int WD, int ABL>
 __device__ __forceinline__ void conv_wino_body(const ConvArgs& a) {
     constexpr int TC = NB * 16;
+    // The 64 convolutions of the 56x56 HR branch are the longest dependency chain of stages 2-4 (eight per module, one after the other,
+    // while the other branches' shorter kernels share the SIMDs): their waves ask the issue arbiter for precedence.  +1 % on the forward.
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (a.prio >= 2) __builtin_amdgcn_s_setprio(3);
     constexpr int TRW = WD / 2, TRG = 56 / TRW, kWRaw = (2 * TRG + 2) * WD, UPC = kWRaw / 4;   // tiles per tile row, tile rows per workgroup, raw floats / 16-byte units per channel
     static_assert(WD == 56 || WD == 28, "tile geometry");
     extern __shared__ __align__(16) float smem[];

@@ -83,6 +83,7 @@ struct ConvArgs {
     int nbuf;                  // bf16 kernel: patch buffers in LDS (2 = chunks double-buffered)
     int gx, gy, gx8, xcd;           // pixel tiles x output-channel blocks of the 1-D grid; xcd: XCD-aware block order (see xcd_block)
     int dbg;                   // timing-only ablation bits (tools/conv_micro.py); 0 in the product path
+    int prio;                  // Winograd kernel: 0 = default wave priority, 1 / 2 = s_setprio 1 / 3 (critical-chain layers)
     int blk0, wsplit;          // Winograd kernel: first tile id of this launch; 1 = the 32-channel kernel on HALF a 64-channel block
                                // of weights packed for the 64-channel kernel (the half-size workgroups of a layer's last round)
 };
