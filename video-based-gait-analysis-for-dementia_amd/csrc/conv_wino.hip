@@ -299,7 +299,8 @@ bool conv_wino_eligible(int cin, int cout, int ks, int stride, int h, int w, int
 }
 
 template <int WD>
-static hipError_t launch_wino_w(ConvArgs a, hipStream_t s, int nb) {
+static hipError_t launch_wino_w(ConvArgs a, hipStream_t s, int nb, int* n_launches) {
+    if (n_launches) *n_launches = 1;
     constexpr int TRG = 56 / (WD / 2);
     a.gx = a.N * (((a.H >> 1) + TRG - 1) / TRG);
     a.gy = a.CoutPad / (nb * 16);
@@ -333,13 +334,14 @@ static hipError_t launch_wino_w(ConvArgs a, hipStream_t s, int nb) {
         if (e != hipSuccess) return e;
         a.blk0 = full;
         a.wsplit = 1;
+        if (n_launches) *n_launches = 2;
         return launch_k(conv_wino_f32<2, WD>, dim3(2 * rest), dim3(256), kWinoLdsB, s, a);
     }
     return launch_k(conv_wino_f32<4, WD>, dim3(total), dim3(256), kWinoLdsB, s, a);
 }
 
 // a.w: transformed weights [16][CinPad][CoutPad] (pack_wino_weights), CinPad % 8 == 0, CoutPad % 64 == 0 (or 32: the 32-channel kernel)
-hipError_t launch_conv_wino(ConvArgs a, hipStream_t s) {
+hipError_t launch_conv_wino(ConvArgs a, hipStream_t s, int* n_launches) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipSuccess;
@@ -351,7 +353,7 @@ hipError_t launch_conv_wino(ConvArgs a, hipStream_t s) {
     const int nb = a.Cout % 64 == 0 ? 4 : 2;
     if (!conv_wino_eligible(a.Cin, a.Cout, a.ks, a.stride, a.H, a.W, a.n_add) || a.CinPad % kWCK != 0 || a.CoutPad % (nb * 16) != 0) return hipErrorInvalidValue;
     if (a.n_add == 1 && a.add_shift[0] != 0) return hipErrorInvalidValue;
-    return a.W == 56 ? launch_wino_w<56>(a, s, nb) : launch_wino_w<28>(a, s, nb);
+    return a.W == 56 ? launch_wino_w<56>(a, s, nb, n_launches) : launch_wino_w<28>(a, s, nb, n_launches);
 }
 
 // U = G g G^T per (cout, cin) in fp64 -> [16][cin_pad][cout_pad] fp32; w: (cout, cin, 3, 3) folded weights (double)

@@ -1396,7 +1396,9 @@ struct grnet {
                         wa.w = L.wino_dev;
                         static const int chain_prio = getenv("GRNET_WINO_PRIO") ? atoi(getenv("GRNET_WINO_PRIO")) : 1;
                         wa.prio = L.cout == 32 ? chain_prio : 0;       // the 56x56 HR branch: the critical chain of stages 2-4 (conv_wino.hip)
-                        HIP_TRY(launch_conv_wino(wa, s));
+                        int nl = 1;
+                        HIP_TRY(launch_conv_wino(wa, s, &nl));
+                        launches += nl - 1;
                     } else HIP_TRY(launch_conv(conv_args(L, frames, n), s, hint_for(L, n)));
                     ++launches;
                     break;

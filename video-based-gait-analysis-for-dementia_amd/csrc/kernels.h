@@ -99,7 +99,7 @@ const char* conv_dominant_kernel_name();
 
 // ---- Winograd F(2x2,3x3) for the wide 3x3 stride-1 layers on 56x56 maps (conv_wino.hip) -------------------------------------------
 bool conv_wino_eligible(int cin, int cout, int ks, int stride, int h, int w, int n_add);
-hipError_t launch_conv_wino(ConvArgs a, hipStream_t s);      // a.w = transformed weights [16][CinPad][CoutPad]
+hipError_t launch_conv_wino(ConvArgs a, hipStream_t s, int* n_launches = nullptr);   // a.w = transformed weights [16][CinPad][CoutPad]; *n_launches: 1, or 2 when the last round is split
 void pack_wino_weights(const double* w_folded /* (cout,cin,3,3) */, int cout, int cin, int cin_pad, int cout_pad, float* out);
 
 // ---- per-XCD dataflow execution of the HR stages (conv_kernels.hip: hr_dataflow_f32) -------------------------------------------
