@@ -429,13 +429,20 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
 // applied through a per-lane 9-bit tap-validity mask when the A operand is read).
 // tid_in: the thread index as the caller wants the body to see it (the persistent dataflow kernel passes it through an opaque
 // register copy per task, so that no lane-derived value of any body variant is loop-invariant across tasks and kept live in registers)
-template <int MODE, int KS, int S, int PSW, int CSW, int NW>
+// WPT > 0 (rows mode, 3x3): the image width as a compile-time constant.  The row pitch of the patch then folds into the ds_read
+// immediates, which frees registers for per-lane LEFT and RIGHT tap pointers: a lane whose pixel sits on the image's left (right) edge
+// reads its kx = 0 (kx = 2) taps from a zero block of its wave instead of masking the value afterwards.  42 v_cndmask per stage of 63
+// MFMAs are gone from the loop -- on gfx950 vector-ALU instructions inside an fp32 MFMA loop are matrix-pipe time (conv_wino.hip).
+constexpr int kEdgeZeros = 128;                          // floats of the per-wave zero block: offsets 0 .. 2 * WPT are read
+template <int MODE, int KS, int S, int PSW, int CSW, int NW, int WPT = 0>
 __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, const int by, float* smem, const int tid_in = -1) {
     constexpr int TC = CSW * 16, TAPS = KS * KS, WFL = TAPS * 4 * TC, NT = PSW * CSW;
+    constexpr bool EDGEPTR = WPT > 0;
+    static_assert(!EDGEPTR || (MODE == 1 && KS == 3 && 2 * WPT + 3 <= kEdgeZeros), "edge pointers: rows mode, 3x3");
     const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     GRK_TICK(t_start);
-    const int stage_floats = WFL + 4 * a.PSTR;           // [weights TAPS*4 x TC | input 4 x PSTR], ONE stage per wave:
+    const int stage_floats = WFL + 4 * a.PSTR + (EDGEPTR ? kEdgeZeros : 0);   // [weights TAPS*4 x TC | input 4 x PSTR | zeros], ONE stage per wave:
     int* tab = reinterpret_cast<int*>(smem + NW * stage_floats);   // the co-resident waves hide the DMA (a second stage per wave
     float* mine = smem + wave * stage_floats;                        // measured no faster), and a fixed buffer keeps LDS addresses loop-invariant
 
@@ -593,12 +600,26 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
     for (int cs = 0; cs < CSW; ++cs) bbase[cs] = lq * TC + ((cs * 16 + l15) ^ (TC == 32 ? ((lq & 1) << 4) : 0));
 
     // loop-invariant LDS row pointers: the kx offset of a tap becomes the immediate of ds_read_b32
-    const float* arow[PSW][KS];
+    const float* arow[EDGEPTR ? 1 : PSW][KS];
+    const float* pN[EDGEPTR ? PSW : 1], *pL[EDGEPTR ? PSW : 1], *pR[EDGEPTR ? PSW : 1];      // EDGEPTR: centre / left-tap / right-tap pointer of a pixel
     const float* brow[CSW];
+    if constexpr (EDGEPTR) {
+        float* zreg = mine + WFL + 4 * a.PSTR;           // this wave's zero block (never a DMA target); same-wave LDS accesses stay in order
+        zreg[lane] = 0.f;
+        zreg[64 + lane] = 0.f;
 #pragma unroll
-    for (int ps = 0; ps < PSW; ++ps)
+        for (int ps = 0; ps < PSW; ++ps) {
+            const float* P = mine + abase[ps];
+            pN[ps] = P;
+            pL[ps] = (lmask >> ps & 1) ? zreg : P;                        // read at + ky * WPT + 0
+            pR[ps] = (S == 1 && (rmask >> ps & 1)) ? zreg - 2 : P;        // read at + ky * WPT + 2
+        }
+    } else {
 #pragma unroll
-        for (int ky = 0; ky < KS; ++ky) arow[ps][ky] = mine + abase[ps] + ky * a.Wp;
+        for (int ps = 0; ps < PSW; ++ps)
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) arow[ps][ky] = mine + abase[ps] + ky * a.Wp;
+    }
 #pragma unroll
     for (int cs = 0; cs < CSW; ++cs) brow[cs] = mine + bbase[cs];
 #ifdef GRNET_ABLATION
@@ -619,7 +640,10 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
 #pragma unroll
                 for (int cs = 0; cs < CSW; ++cs) br[cs] = brow[cs][tap * 4 * TC];
 #pragma unroll
-                for (int ps = 0; ps < PSW; ++ps) ar[ps] = arow[ps][tap / KS][tap % KS];
+                for (int ps = 0; ps < PSW; ++ps) {
+                    if constexpr (EDGEPTR) ar[ps] = (tap % KS == 0 ? pL[ps] : tap % KS == 2 ? pR[ps] : pN[ps])[(tap / KS) * WPT + tap % KS];
+                    else ar[ps] = arow[ps][tap / KS][tap % KS];
+                }
             };
 #pragma unroll
             for (int t = 0; t < LD && t < TAPS; ++t) load_tap(t, av[t], bv[t]);
@@ -632,7 +656,7 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
 #pragma unroll
                 for (int ps = 0; ps < PSW; ++ps) {
                     v[ps] = av[cur][ps];
-                    if constexpr (ROWS && KS == 3) {
+                    if constexpr (ROWS && KS == 3 && !EDGEPTR) {
                         if (tap % KS == 0) v[ps] = (lmask >> ps & 1) ? 0.f : v[ps];
                         if (tap % KS == 2 && S == 1) v[ps] = (rmask >> ps & 1) ? 0.f : v[ps];
                     }
@@ -697,12 +721,12 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
 #endif
 }
 
-template <int MODE, int KS, int S, int PSW, int CSW, int NW>
+template <int MODE, int KS, int S, int PSW, int CSW, int NW, int WPT = 0>
 __global__ __launch_bounds__(NW * 64) void conv_splitk_f32(const ConvArgs a) {
     extern __shared__ __align__(16) float smem[];
     int bx, by;
     if (!xcd_block(a, bx, by)) return;
-    splitk_body<MODE, KS, S, PSW, CSW, NW>(a, bx, by, smem);
+    splitk_body<MODE, KS, S, PSW, CSW, NW, WPT>(a, bx, by, smem);
 }
 
 // Grouped launch: up to kMaxGroup independent convolutions (the same-depth convolutions of the
@@ -1008,12 +1032,20 @@ void plan_tile(ConvArgs& a, int tps, int family) {
 // family 1 = split-K independent waves (conv_splitk_f32).
 struct Cfg { int family, tps, tcs; int nw = 4; };   // nw: split-K waves per workgroup (4, or 8 = two per SIMD for launches of about one workgroup per CU)
 
+// The image width the split-K kernel is compiled for (edge-pointer variants: splitk_body), 0 = the generic kernel.
+int splitk_width_variant(const ConvArgs& a, const Cfg& c) {
+    static const int on = getenv("GRNET_EDGEPTR") ? atoi(getenv("GRNET_EDGEPTR")) : 1;
+    if (!on || c.family != 1 || a.rows != 1 || a.ks != 3 || c.tcs != 1) return 0;
+    if (!((c.tps == 7 && (c.nw == 8 || c.nw == 4)) || (c.tps == 4 && c.nw == 8))) return 0;
+    return (a.W == 56 || a.W == 28 || a.W == 14) ? a.W : 0;
+}
+
 size_t lds_bytes(const ConvArgs& a, const Cfg& c) {
     const int taps = a.ks * a.ks, TC = c.tcs * 16;
     const size_t tab = a.rows ? 0 : a.PSTR;
     const size_t ck = a.ks == 1 ? kConvCK1 : kConvCK;
     if (c.family == 0) return sizeof(float) * (2 * (size_t)taps * ck * TC + 2 * ck * a.PSTR + tab);
-    const size_t stage = (size_t)taps * 4 * TC + 4 * (size_t)a.PSTR;
+    const size_t stage = (size_t)taps * 4 * TC + 4 * (size_t)a.PSTR + (splitk_width_variant(a, c) ? kEdgeZeros : 0);
     const size_t staging = c.nw * stage + tab, red = (size_t)c.nw * c.tps * c.tcs * 256;
     return sizeof(float) * (staging > red ? staging : red);
 }
@@ -1067,6 +1099,14 @@ hipError_t init_ks() {
     if ((e = set_lds(conv_splitk_f32<ROWS ? 1 : 0, KS, S, 4, 2, kSplitWaves>)) != hipSuccess) return e;
     if ((e = set_lds(conv_splitk_f32<ROWS ? 1 : 0, KS, S, 7, 1, 8>)) != hipSuccess) return e;
     if ((e = set_lds(conv_splitk_f32<ROWS ? 1 : 0, KS, S, 4, 1, 8>)) != hipSuccess) return e;
+    if constexpr (ROWS && KS == 3) {
+#define GRK_SET_W(W) \
+        if ((e = set_lds(conv_splitk_f32<1, KS, S, 7, 1, 8, W>)) != hipSuccess) return e; \
+        if ((e = set_lds(conv_splitk_f32<1, KS, S, 7, 1, kSplitWaves, W>)) != hipSuccess) return e; \
+        if ((e = set_lds(conv_splitk_f32<1, KS, S, 4, 1, 8, W>)) != hipSuccess) return e;
+        GRK_SET_W(56) GRK_SET_W(28) GRK_SET_W(14)
+#undef GRK_SET_W
+    }
     if (!ROWS) {
         if ((e = set_lds(conv_splitk_f32<2, KS, S, 4, 1, kSplitWaves>)) != hipSuccess) return e;
         if ((e = set_lds(conv_splitk_f32<2, KS, S, 4, 2, kSplitWaves>)) != hipSuccess) return e;
@@ -1100,6 +1140,17 @@ hipError_t dispatch(const ConvArgs& a_in, const Cfg& c, size_t lds, hipStream_t 
         if (c.tps == 7 && c.tcs == 4) GRK_LAUNCH((conv_mfma_f32<ROWS, KS, S, 7, 4, 1, 4>), 256);
         if (c.tps == 7 && c.tcs == 2) GRK_LAUNCH((conv_mfma_f32<ROWS, KS, S, 7, 2, 1, 2>), 128);
     } else {
+        if constexpr (ROWS && KS == 3) {                   // width-specialised variants without edge masks in the loop (splitk_body)
+            const int wv = splitk_width_variant(a, c);
+#define GRK_LAUNCH_W(W) \
+            if (wv == W) { \
+                if (c.tps == 7 && c.nw == 8) GRK_LAUNCH((conv_splitk_f32<1, KS, S, 7, 1, 8, W>), 512); \
+                if (c.tps == 7 && c.nw == 4) GRK_LAUNCH((conv_splitk_f32<1, KS, S, 7, 1, kSplitWaves, W>), kSplitWaves * 64); \
+                if (c.tps == 4 && c.nw == 8) GRK_LAUNCH((conv_splitk_f32<1, KS, S, 4, 1, 8, W>), 512); \
+            }
+            GRK_LAUNCH_W(56) GRK_LAUNCH_W(28) GRK_LAUNCH_W(14)
+#undef GRK_LAUNCH_W
+        }
         if (c.tps == 7 && c.tcs == 1 && c.nw == 8) GRK_LAUNCH((conv_splitk_f32<ROWS ? 1 : 0, KS, S, 7, 1, 8>), 512);
         if (c.tps == 4 && c.tcs == 1 && c.nw == 8) GRK_LAUNCH((conv_splitk_f32<ROWS ? 1 : 0, KS, S, 4, 1, 8>), 512);
         if (c.tps == 7 && c.tcs == 1) GRK_LAUNCH((conv_splitk_f32<ROWS ? 1 : 0, KS, S, 7, 1, kSplitWaves>), kSplitWaves * 64);
