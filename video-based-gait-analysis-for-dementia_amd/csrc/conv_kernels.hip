@@ -437,12 +437,14 @@ constexpr int kEdgeZeros = 128;                          // floats of the per-wa
 template <int MODE, int KS, int S, int PSW, int CSW, int NW, int WPT = 0>
 __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, const int by, float* smem, const int tid_in = -1) {
     constexpr int TC = CSW * 16, TAPS = KS * KS, WFL = TAPS * 4 * TC, NT = PSW * CSW;
-    constexpr bool EDGEPTR = WPT > 0;
+    // planes mode (whole small images, all zero padding by tap validity) always reads invalid taps from the zero block: its row pitch is
+    // already folded into per-(pixel, filter row) pointers, three of them (centre / left tap / right tap) instead of one.
+    constexpr bool EDGEPTR = WPT > 0, ZPLANES = MODE == 2, ZBLOCK = EDGEPTR || ZPLANES;
     static_assert(!EDGEPTR || (MODE == 1 && KS == 3 && 2 * WPT + 3 <= kEdgeZeros), "edge pointers: rows mode, 3x3");
     const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     GRK_TICK(t_start);
-    const int stage_floats = WFL + 4 * a.PSTR + (EDGEPTR ? kEdgeZeros : 0);   // [weights TAPS*4 x TC | input 4 x PSTR | zeros], ONE stage per wave:
+    const int stage_floats = WFL + 4 * a.PSTR + (ZBLOCK ? kEdgeZeros : 0);   // [weights TAPS*4 x TC | input 4 x PSTR | zeros], ONE stage per wave:
     int* tab = reinterpret_cast<int*>(smem + NW * stage_floats);   // the co-resident waves hide the DMA (a second stage per wave
     float* mine = smem + wave * stage_floats;                        // measured no faster), and a fixed buffer keeps LDS addresses loop-invariant
 
@@ -602,8 +604,27 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
     // loop-invariant LDS row pointers: the kx offset of a tap becomes the immediate of ds_read_b32
     const float* arow[EDGEPTR ? 1 : PSW][KS];
     const float* pN[EDGEPTR ? PSW : 1], *pL[EDGEPTR ? PSW : 1], *pR[EDGEPTR ? PSW : 1];      // EDGEPTR: centre / left-tap / right-tap pointer of a pixel
+    const float* qL[ZPLANES ? PSW : 1][KS], *qR[ZPLANES ? PSW : 1][KS];                      // ZPLANES: left / right-tap pointers per filter row (arow = centre)
     const float* brow[CSW];
-    if constexpr (EDGEPTR) {
+    if constexpr (ZPLANES) {
+        float* zreg = mine + WFL + 4 * a.PSTR;           // this wave's zero block (never a DMA target); same-wave LDS accesses stay in order
+        zreg[lane] = 0.f;
+        zreg[64 + lane] = 0.f;
+#pragma unroll
+        for (int ps = 0; ps < PSW; ++ps)
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) {
+                const float* P = mine + abase[ps] + ky * a.Wp;
+                const unsigned m = vmask[ps] >> (ky * KS);                // validity of the row's KS taps
+                if constexpr (KS == 3) {
+                    arow[ps][ky] = (m & 2u) ? P : zreg;                   // read at + 1
+                    qL[ps][ky] = (m & 1u) ? P : zreg;                     // read at + 0
+                    qR[ps][ky] = (m & 4u) ? P : zreg;                     // read at + 2
+                } else {
+                    arow[ps][ky] = (m & 1u) ? P : zreg;
+                }
+            }
+    } else if constexpr (EDGEPTR) {
         float* zreg = mine + WFL + 4 * a.PSTR;           // this wave's zero block (never a DMA target); same-wave LDS accesses stay in order
         zreg[lane] = 0.f;
         zreg[64 + lane] = 0.f;
@@ -642,6 +663,7 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
 #pragma unroll
                 for (int ps = 0; ps < PSW; ++ps) {
                     if constexpr (EDGEPTR) ar[ps] = (tap % KS == 0 ? pL[ps] : tap % KS == 2 ? pR[ps] : pN[ps])[(tap / KS) * WPT + tap % KS];
+                    else if constexpr (ZPLANES && KS == 3) ar[ps] = (tap % KS == 0 ? qL[ps][tap / KS] : tap % KS == 2 ? qR[ps][tap / KS] : arow[ps][tap / KS])[tap % KS];
                     else ar[ps] = arow[ps][tap / KS][tap % KS];
                 }
             };
@@ -660,7 +682,7 @@ __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, con
                         if (tap % KS == 0) v[ps] = (lmask >> ps & 1) ? 0.f : v[ps];
                         if (tap % KS == 2 && S == 1) v[ps] = (rmask >> ps & 1) ? 0.f : v[ps];
                     }
-                    if constexpr (PLANES) v[ps] = (vmask[ps] >> tap & 1) ? v[ps] : 0.f;
+                    if constexpr (PLANES && !ZPLANES) v[ps] = (vmask[ps] >> tap & 1) ? v[ps] : 0.f;
                     asm volatile("" : "+v"(v[ps]));
                 }
 #pragma unroll
@@ -1045,7 +1067,7 @@ size_t lds_bytes(const ConvArgs& a, const Cfg& c) {
     const size_t tab = a.rows ? 0 : a.PSTR;
     const size_t ck = a.ks == 1 ? kConvCK1 : kConvCK;
     if (c.family == 0) return sizeof(float) * (2 * (size_t)taps * ck * TC + 2 * ck * a.PSTR + tab);
-    const size_t stage = (size_t)taps * 4 * TC + 4 * (size_t)a.PSTR + (splitk_width_variant(a, c) ? kEdgeZeros : 0);
+    const size_t stage = (size_t)taps * 4 * TC + 4 * (size_t)a.PSTR + ((splitk_width_variant(a, c) || a.rows == 2) ? kEdgeZeros : 0);
     const size_t staging = c.nw * stage + tab, red = (size_t)c.nw * c.tps * c.tcs * 256;
     return sizeof(float) * (staging > red ? staging : red);
 }
