@@ -15,7 +15,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
-src, dst = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+# optional second argument: a sub-directory of gpurun_out/ holding the same layout (e.g. "bf16" for tools/gpu_profile_bf16.sh;
+# the round tag then carries the variant: `summarize_profiles.py r02_bf16_n256 bf16`)
+src, dst = os.path.join(ROOT, "gpurun_out", *(sys.argv[2:3])), os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 stats = os.path.join(src, "prof", "bench_kernel_stats.csv")
