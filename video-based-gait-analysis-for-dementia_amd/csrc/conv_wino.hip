@@ -1,20 +1,25 @@
-// Winograd F(2x2, 3x3) convolution on the fp32 matrix cores for the wide 3x3 stride-1 layers on 56x56 maps (upsample heads and
-// PARE head: hrnet.py:444-451, pare.py:197-210,388-397 -- Conv2d 3x3 pad 1 + BatchNorm2d(eval) + ReLU, no residual): 42 % of the
-// path's multiplies.  Y = A^T [ (G g G^T) . (B^T d B) ] A turns every 2x2 output tile into 16 independent products, so the layer is
-// 16 GEMMs  M_p[tile][cout] = sum_cin V_p[tile][cin] U_p[cin][cout]  with 4 multiplies per output instead of 9 (2.25x fewer MFMAs).
+// Winograd F(2x2, 3x3) convolution on the fp32 matrix cores for the 3x3 stride-1 layers on 56x56 maps (layer1, HR branch 0,
+// transition1, upsample heads, PARE head: hrnet.py:54-57,444-451, pare.py:197-210,388-397 -- Conv2d 3x3 pad 1 + BatchNorm2d(eval)
+// [+ residual] + ReLU) and the wide ones on 28x28 maps (upsample heads): 64 % of the path's multiplies.
+// Y = A^T [ (G g G^T) . (B^T d B) ] A turns every 2x2 output tile into 16 independent products, so the layer is 16 GEMMs
+// M_p[tile][cout] = sum_cin V_p[tile][cin] U_p[cin][cout]  with 4 multiplies per output instead of 9 (2.25x fewer MFMAs).
 // The filter transform U = G g G^T is applied to the BN-folded weights once at load, in fp64.  Same fp32 operands, fp32 accumulation;
 // the sums are re-associated (transform adds before the products), so results agree with the direct kernel to ~1e-6 of the output
 // scale, not bit for bit -- inside the 1e-3 bar by three orders of magnitude and covered by the same parity tests.
 //
-// One workgroup (4 waves): one image, 2 tile rows = 56 tiles (output rows 4r .. 4r+3, all 56 columns; padded to 64 = 4 MFMA row
-// tiles), 64 (or 32) output channels, ALL 16 transform points -- wave w owns points 4w .. 4w+3, i.e. 4 x (4 x 4) accumulator tiles = 256
-// accumulation registers.  Per chunk of 8 input channels:
-//   * the 6 input rows of the chunk (contiguous in the NCHW plane, 16-byte aligned: 84 units per channel) and the chunk's transformed
-//     weights [16][8][64] arrive by LDS-DMA (both double-buffered, requested a whole iteration ahead);
-//   * every thread transforms (tile, channel) patches: 16 LDS reads, 32 adds, 16 LDS writes into V[point][channel][tile];
-//   * 128 MFMAs per wave: per point and k-step 4 V fragments + 4 U fragments feed 16 MFMAs.
-// Epilogue in four passes of 16 channels: accumulators -> LDS [point][tile][channel], inverse transform A^T M A (24 adds per 2x2
-// tile), + folded-BN bias, ReLU, two 8-byte stores per thread with the lanes walking a row of the image.
+// One workgroup (4 waves, one per SIMD): one image, 56 tiles (2 tile rows of 28, or 4 of 14 on a 28-wide map; padded to 64 = 4 MFMA
+// row tiles), 64 (or 32) output channels, ALL 16 transform points -- wave w owns points 4w .. 4w+3, i.e. 4 x (4 x 4) accumulator
+// tiles = 256 accumulation registers.  Per chunk of 8 input channels:
+//   * the chunk's input rows (contiguous in the NCHW plane, 16-byte aligned) arrive by LDS-DMA, two buffers, a chunk ahead;
+//   * every thread transforms TWO adjacent tiles of one channel: 4 16-byte LDS reads, DPP for the neighbour columns, 56 adds,
+//     16 8-byte LDS writes into V[point][channel][16][4];
+//   * 128 MFMAs per wave: per (point, k-step) ONE 16-byte LDS read gives the 4 A fragments, ONE 16-byte load straight from L2
+//     (requested a chunk ahead) the 4 B fragments, feeding 16 MFMAs.
+// The loop is built around one fact of gfx950 (see "the chunk loop" below): the fp32 MFMA shares the SIMD's FP32 lanes with the
+// vector ALU, so every other instruction in the loop is matrix-pipe time -- few of them, clustered in front of each MFMA group.
+// Epilogue in passes of 16 channels: accumulators -> LDS [point][channel][68], inverse transform A^T M A (24 adds per 2x2 tile),
+// + folded-BN bias, + residual, ReLU, two 8-byte stores per thread with the lanes walking a row of the image.
+// DESIGN.md 4.1c has the measurements (direct kernel / first version / now per layer shape, ablations of the loop).
 #include "kernels.h"
 
 namespace grk {
@@ -27,7 +32,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 namespace {
 
 constexpr int kWCK = 8;                 // input channels per chunk
-constexpr int kWTiles = 56;             // real tiles per workgroup (2 tile rows of 28)
+constexpr int kWTiles = 56;             // real tiles per workgroup (2 tile rows of 28, or 4 of 14)
 constexpr int kWRawMax = 6 * 56;        // raw floats per channel: 6 input rows of 56 (10 rows of 28 are fewer)
 constexpr int kWV = 16 * kWCK * 64;      // V[point][channel][64 tile slots]
 constexpr int kWinoCUs = 256;          // CUs of an MI355X: workgroups of a full round
