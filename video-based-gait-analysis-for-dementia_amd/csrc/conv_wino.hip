@@ -347,7 +347,10 @@ static hipError_t launch_wino_w(ConvArgs a, hipStream_t s, int nb, int* n_launch
 
 // a.w: transformed weights [16][CinPad][CoutPad] (pack_wino_weights), CinPad % 8 == 0, CoutPad % 64 == 0 (or 32: the 32-channel kernel)
 hipError_t launch_conv_wino(ConvArgs a, hipStream_t s, int* n_launches) {
-    static bool attr_set = false;
+    static bool attr_done[64] = {};                       // per device: function attributes belong to the device's copy of the code object
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    bool& attr_set = attr_done[dev];
     if (!attr_set) {
         hipError_t e = hipSuccess;
         auto set = [&](auto kern) { if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLdsB); };
