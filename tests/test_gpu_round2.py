@@ -328,6 +328,31 @@ def test_dataflow_hr_section_parity_and_determinism(pkg, golden):
 WINO_CASES = [(64, 64), (128, 128), (256, 256), (480, 256), (128, 64), (72, 192), (32, 32), (256, 32), (40, 96)]
 
 
+@pytest.mark.parametrize("case", [(1, 64, 64), (3, 128, 128), (2, 256, 256), (1, 480, 256), (3, 72, 192), (5, 64, 256)], ids=lambda c: "x".join(map(str, c)))
+def test_winograd_f43_conv_kernel(model, oracle, case):
+    """conv_wino4_f32 (Winograd F(4x4,3x3): 36 points per 4x4 output tile) on single convolutions vs the oracle's direct convolution:
+    the layer shapes it is meant for and odd ones, 1-5 images (first / last tile rows carry the zero padding; 5 x 256 channels is
+    280 workgroups); bias + ReLU, residual, and the plain linear form.  Its transforms carry the coefficients 4, 5, 2, 8: the bound
+    here is 1e-4 of the output scale (measured ~1e-5), against 2e-5 for the F(2x2,3x3) kernel."""
+    n, cin, cout = case
+    g = np.random.Generator(np.random.Philox(key=[80, n * 100000 + cin * 1000 + cout]))
+    x = g.standard_normal((n, cin, 56, 56)).astype(np.float32)
+    w = (g.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (cin * 9))).astype(np.float32)
+    b = (g.standard_normal((cout,)) * 0.1).astype(np.float32)
+    r = g.standard_normal((n, cout, 56, 56)).astype(np.float32)
+    conv = oracle.conv2d(x, w, stride=1, bias=b)
+    xd = torch.from_numpy(x).cuda()
+    got = model.op_conv2d(xd, w, b, stride=1, relu=True, tile_hint=2001).cpu().numpy()
+    assert got.shape == conv.shape
+    assert rel_err(got, torch.relu(conv).numpy()) < 1e-4, rel_err(got, torch.relu(conv).numpy())
+    got = model.op_conv2d(xd, w, b, stride=1, relu=True, add=torch.from_numpy(r).cuda(), tile_hint=2001).cpu().numpy()
+    assert rel_err(got, torch.relu(conv + torch.from_numpy(r)).numpy()) < 1e-4
+    lin = oracle.conv2d(x, w, stride=1).numpy()
+    got = model.op_conv2d(xd, w, None, stride=1, relu=False, tile_hint=2001).cpu().numpy()
+    assert rel_err(got, lin) < 1e-4
+    assert rel_err(got[:, :, [0, 55]], lin[:, :, [0, 55]]) < 1e-4 and rel_err(got[..., [0, 55]], lin[..., [0, 55]]) < 1e-4
+
+
 @pytest.mark.parametrize("case", [(1, 128, 128), (3, 256, 256), (2, 64, 64), (3, 40, 96), (1, 32, 32), (20, 32, 256)], ids=lambda c: "x".join(map(str, c)))
 def test_winograd_conv_kernel_28(model, oracle, case):
     """The same kernel on 28x28 maps (upsample heads: 256 -> 256, 128 -> 128): a workgroup's 56 tiles are 4 tile rows of 14, the

@@ -1,0 +1,323 @@
+// Winograd F(4x4, 3x3) on the fp32 matrix cores for the widest 3x3 stride-1 layers on 56x56 maps (upsample head 256 -> 256, PARE head
+// 480 -> 256: hrnet.py:444-451, pare.py:197-210 -- Conv2d 3x3 pad 1 + BatchNorm2d(eval) + ReLU).  A 4x4 output tile is 36 independent
+// products instead of 144 multiplies: 2.25 per output against 4 for F(2x2, 3x3) (conv_wino.hip) and 9 for the direct kernel.  The
+// transforms have non-trivial coefficients (4, 5, 2, 8 and sixths in the filter transform, which is applied in fp64 at load):
+// measured on a 256-channel layer in fp32 the result is 7.8e-6 of the output rms away from the exact sum (F(2x2,3x3): 8e-7, the
+// direct fma chain: 1.9e-6) -- two orders of magnitude inside the 1e-3 bar, covered by the same parity tests.
+//
+// Same loop discipline as conv_wino.hip (on gfx950 every vector instruction between fp32 MFMAs is matrix-pipe time: few of them,
+// clustered).  One workgroup (4 waves): one image, ONE tile row = 14 tiles (output rows 4r .. 4r+3; one MFMA row tile, 2 rows
+// idle), 64 output channels, all 36 points -- wave w owns points 9w .. 9w+8 = 9 x 4 accumulator tiles (144 registers).  Per chunk of
+// 8 input channels: the 6 input rows of the chunk by LDS-DMA (the same raw layout as conv_wino.hip); thread (channel, tile, half)
+// transforms HALF of a 6x6 patch -- 6 16-byte LDS reads + DPP for the two edge columns, three rows of B^T d and their 18 products
+// with B, 18 LDS writes into V[point][channel][16 tiles]; 72 MFMAs per wave, A fragment = one LDS dword, the 4 B fragments = one
+// 16-byte load straight from L2, requested a chunk ahead.
+#include "kernels.h"
+
+namespace grk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define GRNET_LDS_AS __attribute__((address_space(3)))
+
+namespace {
+
+constexpr int kCK = 8;                       // input channels per chunk
+constexpr int kRaw = 6 * 56;                 // raw floats per channel: 6 input rows
+constexpr int kV = 36 * kCK * 16;            // V[point][channel][16 tile slots]
+constexpr int kMrow = 20;                    // epilogue: [point][channel][16 MFMA rows + 4]
+constexpr size_t kLdsB = sizeof(float) * (2 * kCK * kRaw + 2 * kV);     // 58 368 B
+static_assert(sizeof(float) * 36 * 16 * kMrow <= kLdsB, "the epilogue tile reuses the staging area");
+
+template <typename T>
+__device__ __forceinline__ void landed(T& x) { asm volatile("" : "+v"(x)); }
+
+// 1-D transforms.  B^T rows 0..2 / 3..5 of F(4,3) (Lavin & Gray):  [4 0 -5 0 1 0] [0 -4 -4 1 1 0] [0 4 -4 -1 1 0] /
+// [0 -2 -1 2 1 0] [0 2 -1 -2 1 0] [0 4 0 -5 0 1]
+__device__ __forceinline__ void bt_lo(const float* d, float& r0, float& r1, float& r2) {
+    const float t1 = fmaf(-4.f, d[2], d[4]), t2 = fmaf(-4.f, d[1], d[3]);
+    r0 = fmaf(4.f, d[0], fmaf(-5.f, d[2], d[4]));
+    r1 = t1 + t2;
+    r2 = t1 - t2;
+}
+__device__ __forceinline__ void bt_hi(const float* d, float& r3, float& r4, float& r5) {
+    const float u1 = d[4] - d[2], u2 = 2.f * (d[3] - d[1]);
+    r3 = u1 + u2;
+    r4 = u1 - u2;
+    r5 = fmaf(4.f, d[1], fmaf(-5.f, d[3], d[5]));
+}
+
+template <int ABL>
+__device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
+    extern __shared__ __align__(16) float smem[];
+    float* raw = smem;                                  // [2][8][336]
+    float* V = raw + 2 * kCK * kRaw;                    // [2][36][8][16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+
+    const int id = blockIdx.x;
+    int bx, by;
+    if (a.xcd) {
+        const int j = id >> 3, x = id & 7, q = j / a.gy;
+        by = j - q * a.gy;
+        bx = x * (a.gx >> 3) + q;
+    } else {
+        bx = id / a.gy;
+        by = id - bx * a.gy;
+    }
+    const int groups = a.H >> 2;                         // tile rows per image (14)
+    const int img = bx / groups, r = bx - img * groups, co0 = by * 64;
+    const int HW = a.H * a.W;
+    const float* inb = a.in + ((size_t)img * a.in_ctot + a.in_coff) * HW;
+    const int g0 = (4 * r - 1) * 56;                     // plane index of raw[.][0]
+
+    const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, 36 * a.CinPad * a.CoutPad * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, a.Cin * HW * 4, 0x00020000);
+    const int ub = ((wave * 9 * a.CinPad + lq) * a.CoutPad + co0 + l15 * 4) * 4;
+    const int u_point = a.CinPad * a.CoutPad * 4, u_kstep = 4 * a.CoutPad * 4, u_chunk = kCK * a.CoutPad * 4;
+    auto load_u = [&](int chunk, int g) -> f32x4 {                           // group g = (point wave*9 + g/2, k-step g%2)
+        const int soff = chunk * u_chunk + (g >> 1) * u_point + (g & 1) * u_kstep;
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, ub, soff, 0));
+    };
+    int roff[3];                                         // raw rows: 672 units per chunk; -1 = no unit or a row outside the image
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int u = i * 256 + tid, ch = u / 84, k = u - ch * 84, gi = g0 + 4 * k;
+        const bool unit = u < kCK * 84, inside = gi >= 0 && gi < HW;
+        roff[i] = unit && inside ? (ch * HW + gi) * 4 : -1;
+        if (unit && !inside) {                           // rows above / below the image: zero once in both buffers, the DMA never writes there
+            *reinterpret_cast<f32x4*>(raw + u * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(raw + kCK * kRaw + u * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    auto issue_raw = [&](int chunk) {
+        const int soff = chunk * (kCK * 4) * HW;
+        float* dst = raw + (chunk & 1) * (kCK * kRaw);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (roff[i] >= 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (GRNET_LDS_AS void*)(dst + (i * 256 + wave * 64) * 4), 16, roff[i], soff, 0, 0);
+        asm volatile("" ::: "memory");                   // later loads stay behind these requests: the vmcnt waits below count on the order
+    };
+
+    // ---- input transform.  16 rows of 16 lanes: row = (channel 0..7, half 0..1), lane = tile 0..13 (lanes 14, 15 idle: their zeros are the
+    // right neighbour of tile 13 and they write into the two padding tile slots).  A thread reads all 6 rows of its tile's 6x6 patch (own
+    // columns 4t .. 4t+3 as one 16-byte read per row, 4t-1 / 4t+4 from the neighbour lanes by DPP, whose out-of-row zero is the image's
+    // left padding) and produces rows 3*half .. 3*half+2 of B^T d B.
+    const int row16 = tid >> 4, px = tid & 15, chn = row16 & 7;
+    const int half = __builtin_amdgcn_readfirstlane(row16 >> 3);                         // wave-uniform: waves 0, 1 / 2, 3
+    const bool real = px < 14;
+    const int rpos = chn * kRaw + 4 * (real ? px : 13);
+    const int vpos = (half * 18) * (kCK * 16) + chn * 16 + px;                           // + (rr * 6 + c) * 128 for row rr of the half, column c
+    struct Tf { float d[6][6]; float e[3][6]; };
+    auto tf_read = [&](Tf& t, const float* rp) {        // 6 LDS reads
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rp + i * 56);
+            t.d[i][1] = v[0]; t.d[i][2] = v[1]; t.d[i][3] = v[2]; t.d[i][4] = v[3];
+        }
+    };
+    auto tf_halo = [&](Tf& t) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            t.d[i][0] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t.d[i][4]), 0x111, 0xf, 0xf, true));                 // row_shr:1
+            t.d[i][5] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(real ? t.d[i][1] : 0.f), 0x101, 0xf, 0xf, true));    // row_shl:1
+        }
+    };
+    auto tf_rows = [&](Tf& t) {                         // three rows of B^T d, per column
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float col[6] = {t.d[0][j], t.d[1][j], t.d[2][j], t.d[3][j], t.d[4][j], t.d[5][j]};
+            if (half == 0) bt_lo(col, t.e[0][j], t.e[1][j], t.e[2][j]);
+            else bt_hi(col, t.e[0][j], t.e[1][j], t.e[2][j]);
+        }
+    };
+    auto tf_cols = [&](Tf& t, float* vp) {              // (B^T d) B: all 6 columns of the three rows, 18 LDS writes
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            float o[6];
+            bt_lo(t.e[rr], o[0], o[1], o[2]);
+            bt_hi(t.e[rr], o[3], o[4], o[5]);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) vp[(rr * 6 + c) * (kCK * 16)] = o[c];
+        }
+    };
+
+    f32x4 acc[9][4];                                     // [point of this wave][channel block]
+#pragma unroll
+    for (int p = 0; p < 9; ++p)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[p][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = a.CinPad / kCK;
+    f32x4 bq[18];                                        // B fragments of the 18 MFMA groups; each is re-requested for the next chunk behind its group
+    issue_raw(0);
+    if (nchunks > 1) issue_raw(1);
+#pragma unroll
+    for (int g = 0; g < 18; ++g) bq[g] = load_u(0, g);
+    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");   // the raw rows (requested before the 18 weight loads) have landed
+    __syncthreads();
+    {
+        Tf t;
+        tf_read(t, raw + rpos);
+        tf_halo(t);
+        tf_rows(t);
+        tf_cols(t, V + vpos);
+    }
+    // ---- the chunk loop: three clusters of 24 MFMAs (three points x two k-steps x four channel blocks)
+    float av[2][6];
+    auto load_a = [&](int buf, int c, int set) {         // A fragments of cluster c: points 3c .. 3c+2 of this wave, both k-steps
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int p = wave * 9 + 3 * c + (k >> 1), ks = k & 1;
+            av[set][k] = V[buf * kV + p * (kCK * 16) + (ks * 4 + lq) * 16 + l15];
+        }
+    };
+    auto chunk = [&](int buf, bool with_transform, int next) {
+        Tf t;
+        const float* rp = raw + (next & 1) * (kCK * kRaw) + rpos;
+        float* vp = V + (next & 1) * kV + vpos;
+        if (ABL != 3) load_a(buf, 0, 0);
+        if (with_transform && ABL != 1 && next + 1 < nchunks) issue_raw(next + 1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            // cluster c: (1) everything requested one cluster ago has landed
+#pragma unroll
+            for (int k = 0; k < 6; ++k) landed(av[c & 1][k]);
+            if (with_transform && ABL != 2) {
+                if (c == 1) { tf_halo(t); tf_rows(t); }
+                if (c == 2) tf_cols(t, vp);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // (2) requests: the next cluster's A fragments, the next chunk's B fragments of the previous cluster, the next chunk's input rows
+            if (c < 2 && ABL != 3) load_a(buf, c + 1, (c + 1) & 1);
+            if (with_transform && ABL != 1 && c > 0) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) bq[6 * (c - 1) + k] = load_u(next, 6 * (c - 1) + k);
+            }
+            if (with_transform && ABL != 2 && c == 0) tf_read(t, rp);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const int pi = 3 * c + (k >> 1);
+                    acc[pi][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c & 1][k], bq[6 * c + k][n], acc[pi][n], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (with_transform && ABL != 1) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) bq[12 + k] = load_u(next, 12 + k);
+        }
+    };
+    auto meet = [&](bool last) {
+        // this wave's share of raw(ch+1) has landed: it was requested before the 18 weight loads of the previous iteration, which may stay
+        // in flight (loads return in order)
+        if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        __syncthreads();
+    };
+    for (int ch = 0; ch + 1 < nchunks; ++ch) {
+        meet(false);
+        chunk(ch & 1, true, ch + 1);
+    }
+    meet(nchunks > 1);
+    chunk((nchunks - 1) & 1, false, 0);
+
+    // ---- epilogue: inverse transform A^T M A (A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]), + bias, + residual, ReLU
+    float* Mx = smem;                                    // [36 points][16 channels][20]
+    const bool has_add = a.n_add == 1;
+    for (int nt = 0; nt < 4; ++nt) {
+        __syncthreads();
+#pragma unroll
+        for (int pi = 0; pi < 9; ++pi) {
+            const f32x4 v = nt == 0 ? acc[pi][0] : nt == 1 ? acc[pi][1] : nt == 2 ? acc[pi][2] : acc[pi][3];
+            *reinterpret_cast<f32x4*>(Mx + ((wave * 9 + pi) * 16 + l15) * kMrow + lq * 4) = v;
+        }
+        __syncthreads();
+        if (tid < 14 * 16) {
+            const int c = tid / 14, t = tid - c * 14;
+            const int co = co0 + nt * 16 + c;
+            if (co < a.Cout) {
+                float s[4][6];                           // A^T M: rows of the 4x6 intermediate
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    float m[6];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) m[i] = Mx[((i * 6 + j) * 16 + c) * kMrow + t];
+                    const float p12 = m[1] + m[2], m12 = m[1] - m[2], p34 = m[3] + m[4], m34 = m[3] - m[4];
+                    s[0][j] = m[0] + p12 + p34;
+                    s[1][j] = fmaf(2.f, m34, m12);
+                    s[2][j] = fmaf(4.f, p34, p12);
+                    s[3][j] = fmaf(8.f, m34, m12) + m[5];
+                }
+                const float b = a.bias[co];
+                const size_t obase = ((size_t)img * a.out_ctot + a.out_coff + co) * HW + (4 * r) * 56 + 4 * t;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float* q = s[i];
+                    const float p12 = q[1] + q[2], m12 = q[1] - q[2], p34 = q[3] + q[4], m34 = q[3] - q[4];
+                    f32x4 y = f32x4{q[0] + p12 + p34 + b, fmaf(2.f, m34, m12) + b, fmaf(4.f, p34, p12) + b, fmaf(8.f, m34, m12) + q[5] + b};
+                    if (has_add) y += *reinterpret_cast<const f32x4*>(a.add[0] + ((size_t)img * a.add_ctot[0] + a.add_coff[0] + co) * HW + (4 * r + i) * 56 + 4 * t);
+                    if (a.relu) { y[0] = fmaxf(y[0], 0.f); y[1] = fmaxf(y[1], 0.f); y[2] = fmaxf(y[2], 0.f); y[3] = fmaxf(y[3], 0.f); }
+                    *reinterpret_cast<f32x4*>(a.out + obase + i * 56) = y;
+                }
+            }
+        }
+    }
+}
+
+template <int ABL = 0>
+__global__ __launch_bounds__(256) void conv_wino4_f32(const ConvArgs a) { conv_wino4_body<ABL>(a); }
+
+}  // namespace
+
+bool conv_wino4_eligible(int cin, int cout, int ks, int stride, int h, int w, int n_add) {
+    return ks == 3 && stride == 1 && h == 56 && w == 56 && n_add <= 1 && cin % kCK == 0 && cout % 64 == 0 && cin >= 64;
+}
+
+// a.w: transformed weights [36][CinPad][CoutPad] (pack_wino4_weights), CoutPad % 64 == 0
+hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s) {
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_f32<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsB);
+        if (e != hipSuccess) return e;
+        attr_done[dev] = true;
+    }
+    if (!conv_wino4_eligible(a.Cin, a.Cout, a.ks, a.stride, a.H, a.W, a.n_add) || a.CinPad % kCK != 0 || a.CoutPad % 64 != 0) return hipErrorInvalidValue;
+    if (a.n_add == 1 && a.add_shift[0] != 0) return hipErrorInvalidValue;
+    a.gx = a.N * (a.H >> 2);
+    a.gy = a.CoutPad / 64;
+    a.xcd = a.gx % 8 == 0 && a.gx >= 16 ? 1 : 0;
+#ifdef GRNET_ABLATION
+    if (a.dbg >= 1 && a.dbg <= 3) {
+        auto go = [&](auto kern) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsB); return launch_k(kern, dim3(a.gx * a.gy), dim3(256), kLdsB, s, a); };
+        if (a.dbg == 1) return go(conv_wino4_f32<1>);
+        if (a.dbg == 2) return go(conv_wino4_f32<2>);
+        return go(conv_wino4_f32<3>);
+    }
+#endif
+    return launch_k(conv_wino4_f32<0>, dim3(a.gx * a.gy), dim3(256), kLdsB, s, a);
+}
+
+// U = G g G^T per (cout, cin) in fp64 -> [36][cin_pad][cout_pad] fp32; w: (cout, cin, 3, 3) folded weights (double)
+void pack_wino4_weights(const double* w, int cout, int cin, int cin_pad, int cout_pad, float* out) {
+    static const double G[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    for (size_t i = 0; i < (size_t)36 * cin_pad * cout_pad; ++i) out[i] = 0.f;
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            // within a workgroup's 64 channels, channel n*16 + l sits at l*4 + n: lane l's four MFMA B fragments are one 16-byte load
+            const int cpos = (co / 64) * 64 + (co % 16) * 4 + (co % 64) / 16;
+            const double* g = w + ((size_t)co * cin + ci) * 9;
+            double t[6][3];
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 3; ++j) t[i][j] = G[i][0] * g[j] + G[i][1] * g[3 + j] + G[i][2] * g[6 + j];
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j) {
+                    const double u = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
+                    out[((size_t)(i * 6 + j) * cin_pad + ci) * cout_pad + cpos] = (float)u;
+                }
+        }
+}
+
+}  // namespace grk

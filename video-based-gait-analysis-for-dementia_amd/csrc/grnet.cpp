@@ -63,6 +63,7 @@ struct ConvLayer {
     std::vector<AddRef> adds;
     float* w_dev = nullptr;
     float* b_dev = nullptr;
+    float* wino4_dev = nullptr; // transformed weights [36][cin_pad][cout_pad] of the Winograd F(4x4,3x3) kernel (the widest 56x56 layers only)
     float* wino_dev = nullptr;  // transformed weights [16][cin_pad][cout_pad] of the Winograd F(2x2,3x3) kernel (eligible fp32 layers only)
     int cin_pad = 0, cout_pad = 0;
     double macs_per_frame = 0;
@@ -826,6 +827,10 @@ struct grnet {
         const bool wino = !bf && conv_wino_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size()) && L.cin_pad % 8 == 0 &&
                           L.cout_pad % (L.cout % 64 == 0 ? 64 : 32) == 0 && (L.adds.empty() || L.adds[0].shift == 0) &&
                           (L.in.w == 56 || (L.in.c >= 128 && L.cout % 64 == 0));
+        // F(4x4,3x3) (conv_wino4.hip) where the multiplies dominate: >= 128 input channels, 64-channel output blocks, no residual
+        static const int wino4_env = getenv("GRNET_WINO4") ? atoi(getenv("GRNET_WINO4")) : 0;
+        const bool wino4 = wino && wino4_env && L.adds.empty() && L.in.c >= 128 &&
+                           conv_wino4_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, 0) && L.cout_pad % 64 == 0;
         std::vector<double> wfold(wino ? (size_t)L.cout * cin * 9 : 0);     // BN-folded weights (cout, cin, 3, 3) for the filter transform
         int co0 = 0;
         for (auto& s : L.segs) {
@@ -875,6 +880,11 @@ struct grnet {
             std::vector<float> uw((size_t)16 * L.cin_pad * L.cout_pad);
             pack_wino_weights(wfold.data(), L.cout, cin, L.cin_pad, L.cout_pad, uw.data());
             if ((rc = upload(uw, &L.wino_dev))) return rc;
+            if (wino4) {
+                std::vector<float> uw4((size_t)36 * L.cin_pad * L.cout_pad);
+                pack_wino4_weights(wfold.data(), L.cout, cin, L.cin_pad, L.cout_pad, uw4.data());
+                if ((rc = upload(uw4, &L.wino4_dev))) return rc;
+            }
         }
         return 0;
     }
@@ -1391,7 +1401,11 @@ struct grnet {
                 case Op::CONV: {
                     const ConvLayer& L = convs[op.conv_idx];
                     if (dtype == 1) HIP_TRY(launch_conv_bf16(conv_args(L, frames, n), s, hint_for(L, n)));
-                    else if (L.wino_dev && wino_mode && !conv_tile_hint) {
+                    else if (L.wino4_dev && wino_mode && !conv_tile_hint) {
+                        ConvArgs wa = conv_args(L, frames, n);
+                        wa.w = L.wino4_dev;
+                        HIP_TRY(launch_conv_wino4(wa, s));
+                    } else if (L.wino_dev && wino_mode && !conv_tile_hint) {
                         ConvArgs wa = conv_args(L, frames, n);
                         wa.w = L.wino_dev;
                         static const int chain_prio = getenv("GRNET_WINO_PRIO") ? atoi(getenv("GRNET_WINO_PRIO")) : 1;
@@ -1959,7 +1973,7 @@ double grnet_conv_flops_per_frame(grnet_t* h) {
 double grnet_conv_executed_flops_per_frame(grnet_t* h) {
     if (!h) return 0;
     double m = 0;
-    for (auto& L : h->convs) m += L.macs_per_frame * (L.wino_dev && h->wino_mode && h->dtype == 0 ? 4.0 / 9.0 : 1.0);
+    for (auto& L : h->convs) m += L.macs_per_frame * (h->wino_mode && h->dtype == 0 ? (L.wino4_dev ? 0.25 : L.wino_dev ? 4.0 / 9.0 : 1.0) : 1.0);
     return 2.0 * m;
 }
 
@@ -2047,13 +2061,29 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
         }
         a.w = ud;
     }
-    hipError_t e = tile_hint == 2000 ? launch_conv_wino(a, s) : launch_conv(a, s, tile_hint);
+    if (tile_hint == 2001) {                                   // the F(4x4,3x3) kernel on this one convolution
+        if (!conv_wino4_eligible(cin, cout, ks, stride, hgt, wid, add_dev ? 1 : 0) || cin_pad % 8 != 0 || cout_pad % 64 != 0) {
+            hipFree(wd); hipFree(bd);
+            return h->fail(GRNET_EINVAL, "shape not eligible for the F(4x4,3x3) kernel");
+        }
+        std::vector<double> wf((size_t)cout * cin * 9);
+        for (size_t i = 0; i < wf.size(); ++i) wf[i] = w_host[i];
+        std::vector<float> uw((size_t)36 * cin_pad * cout_pad);
+        pack_wino4_weights(wf.data(), cout, cin, cin_pad, cout_pad, uw.data());
+        if (hipMalloc(reinterpret_cast<void**>(&ud), uw.size() * 4) != hipSuccess || hipMemcpy(ud, uw.data(), uw.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            hipFree(wd); hipFree(bd); if (ud) hipFree(ud);
+            return h->fail(GRNET_ENOMEM, "Winograd test weights");
+        }
+        a.w = ud;
+    }
+    auto launch_one = [&]() { return tile_hint == 2000 ? launch_conv_wino(a, s) : tile_hint == 2001 ? launch_conv_wino4(a, s) : launch_conv(a, s, tile_hint); };
+    hipError_t e = launch_one();
     if (const char* r = getenv("GRNET_CONV_REPS")) {           // timing loop for tools/conv_micro.py
         const int reps = atoi(r);
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0, s);
-        for (int i = 0; i < reps; ++i) e = tile_hint == 2000 ? launch_conv_wino(a, s) : launch_conv(a, s, tile_hint);
+        for (int i = 0; i < reps; ++i) e = launch_one();
         hipEventRecord(e1, s);
         hipEventSynchronize(e1);
         float ms = 0;
