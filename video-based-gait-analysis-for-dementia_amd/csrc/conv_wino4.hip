@@ -46,14 +46,16 @@ __device__ __forceinline__ void bt_hi(const float* d, float& r3, float& r4, floa
     r5 = fmaf(4.f, d[1], fmaf(-5.f, d[3], d[5]));
 }
 
-template <int ABL>
+// NB: 16-channel blocks per workgroup: 4, or 2 = HALF a 64-channel block of the same packed weights (the half-size workgroups of a
+// layer's last round, ConvArgs::wsplit, as in conv_wino.hip)
+template <int NB, int ABL>
 __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
     extern __shared__ __align__(16) float smem[];
     float* raw = smem;                                  // [2][8][336]
     float* V = raw + 2 * kCK * kRaw;                    // [2][36][8][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
 
-    const int id = blockIdx.x;
+    const int id = a.blk0 + (a.wsplit ? (int)(blockIdx.x >> 1) : (int)blockIdx.x), nb0 = a.wsplit ? 2 * (int)(blockIdx.x & 1) : 0;
     int bx, by;
     if (a.xcd) {
         const int j = id >> 3, x = id & 7, q = j / a.gy;
@@ -71,11 +73,13 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
 
     const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, 36 * a.CinPad * a.CoutPad * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, a.Cin * HW * 4, 0x00020000);
-    const int ub = ((wave * 9 * a.CinPad + lq) * a.CoutPad + co0 + l15 * 4) * 4;
+    typedef float bfrag __attribute__((ext_vector_type(NB)));
+    const int ub = ((wave * 9 * a.CinPad + lq) * a.CoutPad + co0 + l15 * 4 + nb0) * 4;
     const int u_point = a.CinPad * a.CoutPad * 4, u_kstep = 4 * a.CoutPad * 4, u_chunk = kCK * a.CoutPad * 4;
-    auto load_u = [&](int chunk, int g) -> f32x4 {                           // group g = (point wave*9 + g/2, k-step g%2)
+    auto load_u = [&](int chunk, int g) -> bfrag {                           // group g = (point wave*9 + g/2, k-step g%2)
         const int soff = chunk * u_chunk + (g >> 1) * u_point + (g & 1) * u_kstep;
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, ub, soff, 0));
+        if constexpr (NB == 4) return __builtin_bit_cast(bfrag, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, ub, soff, 0));
+        else return __builtin_bit_cast(bfrag, __builtin_amdgcn_raw_buffer_load_b64(u_rsrc, ub, soff, 0));
     };
     int roff[3];                                         // raw rows: 672 units per chunk; -1 = no unit or a row outside the image
 #pragma unroll
@@ -140,14 +144,14 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
         }
     };
 
-    f32x4 acc[9][4];                                     // [point of this wave][channel block]
+    f32x4 acc[9][NB];                                    // [point of this wave][channel block]
 #pragma unroll
     for (int p = 0; p < 9; ++p)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[p][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NB; ++n) acc[p][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nchunks = a.CinPad / kCK;
-    f32x4 bq[18];                                        // B fragments of the 18 MFMA groups; each is re-requested for the next chunk behind its group
+    bfrag bq[18];                                        // B fragments of the 18 MFMA groups; each is re-requested for the next chunk behind its group
     issue_raw(0);
     if (nchunks > 1) issue_raw(1);
 #pragma unroll
@@ -197,7 +201,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
 #pragma unroll
             for (int k = 0; k < 6; ++k)
 #pragma unroll
-                for (int n = 0; n < 4; ++n) {
+                for (int n = 0; n < NB; ++n) {
                     const int pi = 3 * c + (k >> 1);
                     acc[pi][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c & 1][k], bq[6 * c + k][n], acc[pi][n], 0, 0, 0);
                 }
@@ -224,17 +228,19 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
     // ---- epilogue: inverse transform A^T M A (A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]), + bias, + residual, ReLU
     float* Mx = smem;                                    // [36 points][16 channels][20]
     const bool has_add = a.n_add == 1;
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int nt = 0; nt < NB; ++nt) {
         __syncthreads();
 #pragma unroll
         for (int pi = 0; pi < 9; ++pi) {
-            const f32x4 v = nt == 0 ? acc[pi][0] : nt == 1 ? acc[pi][1] : nt == 2 ? acc[pi][2] : acc[pi][3];
+            f32x4 v;
+            if constexpr (NB == 4) v = nt == 0 ? acc[pi][0] : nt == 1 ? acc[pi][1] : nt == 2 ? acc[pi][2] : acc[pi][3];
+            else v = nt == 0 ? acc[pi][0] : acc[pi][1];
             *reinterpret_cast<f32x4*>(Mx + ((wave * 9 + pi) * 16 + l15) * kMrow + lq * 4) = v;
         }
         __syncthreads();
         if (tid < 14 * 16) {
             const int c = tid / 14, t = tid - c * 14;
-            const int co = co0 + nt * 16 + c;
+            const int co = co0 + (nb0 + nt) * 16 + c;
             if (co < a.Cout) {
                 float s[4][6];                           // A^T M: rows of the 4x6 intermediate
 #pragma unroll
@@ -264,8 +270,8 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
     }
 }
 
-template <int ABL = 0>
-__global__ __launch_bounds__(256) void conv_wino4_f32(const ConvArgs a) { conv_wino4_body<ABL>(a); }
+template <int NB, int ABL = 0>
+__global__ __launch_bounds__(256) void conv_wino4_f32(const ConvArgs a) { conv_wino4_body<NB, ABL>(a); }
 
 }  // namespace
 
@@ -274,12 +280,13 @@ bool conv_wino4_eligible(int cin, int cout, int ks, int stride, int h, int w, in
 }
 
 // a.w: transformed weights [36][CinPad][CoutPad] (pack_wino4_weights), CoutPad % 64 == 0
-hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s) {
+hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s, int* n_launches) {
     static bool attr_done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_f32<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsB);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_f32<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsB);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_f32<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsB);
         if (e != hipSuccess) return e;
         attr_done[dev] = true;
     }
@@ -288,15 +295,31 @@ hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s) {
     a.gx = a.N * (a.H >> 2);
     a.gy = a.CoutPad / 64;
     a.xcd = a.gx % 8 == 0 && a.gx >= 16 ? 1 : 0;
+    a.blk0 = 0;
+    a.wsplit = 0;
+    if (n_launches) *n_launches = 1;
+    const int total = a.gx * a.gy;
 #ifdef GRNET_ABLATION
     if (a.dbg >= 1 && a.dbg <= 3) {
-        auto go = [&](auto kern) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsB); return launch_k(kern, dim3(a.gx * a.gy), dim3(256), kLdsB, s, a); };
-        if (a.dbg == 1) return go(conv_wino4_f32<1>);
-        if (a.dbg == 2) return go(conv_wino4_f32<2>);
-        return go(conv_wino4_f32<3>);
+        auto go = [&](auto kern) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsB); return launch_k(kern, dim3(total), dim3(256), kLdsB, s, a); };
+        if (a.dbg == 1) return go(conv_wino4_f32<4, 1>);
+        if (a.dbg == 2) return go(conv_wino4_f32<4, 2>);
+        return go(conv_wino4_f32<4, 3>);
     }
 #endif
-    return launch_k(conv_wino4_f32<0>, dim3(a.gx * a.gy), dim3(256), kLdsB, s, a);
+    // a last round of workgroups that is at most half full runs as twice as many half-size workgroups (conv_wino.hip)
+    static const int split_env = getenv("GRNET_WINO_SPLIT") ? atoi(getenv("GRNET_WINO_SPLIT")) : 1;
+    constexpr int kCUs = 256;
+    const int full = total / kCUs * kCUs, rest = total - full;
+    if (split_env && full > 0 && rest > 0 && 2 * rest <= kCUs && (!a.xcd || full % 8 == 0)) {
+        hipError_t e = launch_k(conv_wino4_f32<4>, dim3(full), dim3(256), kLdsB, s, a);
+        if (e != hipSuccess) return e;
+        a.blk0 = full;
+        a.wsplit = 1;
+        if (n_launches) *n_launches = 2;
+        return launch_k(conv_wino4_f32<2>, dim3(2 * rest), dim3(256), kLdsB, s, a);
+    }
+    return launch_k(conv_wino4_f32<4>, dim3(total), dim3(256), kLdsB, s, a);
 }
 
 // U = G g G^T per (cout, cin) in fp64 -> [36][cin_pad][cout_pad] fp32; w: (cout, cin, 3, 3) folded weights (double)

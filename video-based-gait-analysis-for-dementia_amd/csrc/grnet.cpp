@@ -828,7 +828,7 @@ struct grnet {
                           L.cout_pad % (L.cout % 64 == 0 ? 64 : 32) == 0 && (L.adds.empty() || L.adds[0].shift == 0) &&
                           (L.in.w == 56 || (L.in.c >= 128 && L.cout % 64 == 0));
         // F(4x4,3x3) (conv_wino4.hip) where the multiplies dominate: >= 128 input channels, 64-channel output blocks, no residual
-        static const int wino4_env = getenv("GRNET_WINO4") ? atoi(getenv("GRNET_WINO4")) : 0;
+        static const int wino4_env = getenv("GRNET_WINO4") ? atoi(getenv("GRNET_WINO4")) : 1;
         const bool wino4 = wino && wino4_env && L.adds.empty() && L.in.c >= 128 &&
                            conv_wino4_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, 0) && L.cout_pad % 64 == 0;
         std::vector<double> wfold(wino ? (size_t)L.cout * cin * 9 : 0);     // BN-folded weights (cout, cin, 3, 3) for the filter transform
@@ -1404,7 +1404,9 @@ struct grnet {
                     else if (L.wino4_dev && wino_mode && !conv_tile_hint) {
                         ConvArgs wa = conv_args(L, frames, n);
                         wa.w = L.wino4_dev;
-                        HIP_TRY(launch_conv_wino4(wa, s));
+                        int nl = 1;
+                        HIP_TRY(launch_conv_wino4(wa, s, &nl));
+                        launches += nl - 1;
                     } else if (L.wino_dev && wino_mode && !conv_tile_hint) {
                         ConvArgs wa = conv_args(L, frames, n);
                         wa.w = L.wino_dev;

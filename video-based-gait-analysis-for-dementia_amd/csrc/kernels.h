@@ -103,7 +103,7 @@ hipError_t launch_conv_wino(ConvArgs a, hipStream_t s, int* n_launches = nullptr
 void pack_wino_weights(const double* w_folded /* (cout,cin,3,3) */, int cout, int cin, int cin_pad, int cout_pad, float* out);
 // ---- Winograd F(4x4,3x3) for the widest of them (conv_wino4.hip): 2.25 multiplies per output
 bool conv_wino4_eligible(int cin, int cout, int ks, int stride, int h, int w, int n_add);
-hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s);     // a.w = transformed weights [36][CinPad][CoutPad]
+hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s, int* n_launches = nullptr);     // a.w = transformed weights [36][CinPad][CoutPad]
 void pack_wino4_weights(const double* w_folded /* (cout,cin,3,3) */, int cout, int cin, int cin_pad, int cout_pad, float* out);
 
 // ---- per-XCD dataflow execution of the HR stages (conv_kernels.hip: hr_dataflow_f32) -------------------------------------------
