@@ -328,7 +328,7 @@ def test_dataflow_hr_section_parity_and_determinism(pkg, golden):
 WINO_CASES = [(64, 64), (128, 128), (256, 256), (480, 256), (128, 64), (72, 192), (32, 32), (256, 32), (40, 96)]
 
 
-@pytest.mark.parametrize("case", [(1, 64, 64), (3, 128, 128), (2, 256, 256), (1, 480, 256), (3, 72, 192), (5, 64, 256), (16, 64, 256)], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("case", [(1, 64, 64), (3, 128, 128), (2, 256, 256), (1, 480, 256), (3, 72, 192), (5, 64, 256), (16, 64, 256), (3, 32, 32), (2, 256, 32), (3, 40, 96)], ids=lambda c: "x".join(map(str, c)))
 def test_winograd_f43_conv_kernel(model, oracle, case):
     """conv_wino4_f32 (Winograd F(4x4,3x3): 36 points per 4x4 output tile) on single convolutions vs the oracle's direct convolution:
     the layer shapes it is meant for and odd ones, 1-5 images (first / last tile rows carry the zero padding; 5 x 256 channels is

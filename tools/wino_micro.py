@@ -27,7 +27,7 @@ for cin, cout in ((256, 256), (128, 128), (64, 64)):
     for hint in (0, 2000):
         m.op_conv2d(x, w, np.zeros(cout, np.float32), relu=True, tile_hint=hint)
 # F(4x4,3x3) on the widest layers (hint 2001)
-for cin, cout in ((480, 256), (256, 256), (128, 128)):
+for cin, cout in ((480, 256), (256, 256), (128, 128), (64, 64), (32, 32), (256, 32)):
     x = torch.randn(n, cin, 56, 56, device="cuda")
     w = (np.random.randn(cout, cin, 3, 3) * 0.02).astype(np.float32)
     for hint in (2000, 2001):

@@ -66,7 +66,11 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
         by = id - bx * a.gy;
     }
     const int groups = a.H >> 2;                         // tile rows per image (14)
-    const int img = bx / groups, r = bx - img * groups, co0 = by * 64;
+    const int img = bx / groups, r = bx - img * groups;
+    const int co0 = a.wsplit ? by * 64 : by * (NB * 16);    // first channel of the weight block; channel n*16 + l sits at l*cstr + n
+    const int cstr = a.wsplit ? 4 : NB;
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(1);         // critical-chain layers (conv_wino.hip)
+    else if (a.prio >= 2) __builtin_amdgcn_s_setprio(3);
     const int HW = a.H * a.W;
     const float* inb = a.in + ((size_t)img * a.in_ctot + a.in_coff) * HW;
     const int g0 = (4 * r - 1) * 56;                     // plane index of raw[.][0]
@@ -74,7 +78,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
     const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, 36 * a.CinPad * a.CoutPad * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, a.Cin * HW * 4, 0x00020000);
     typedef float bfrag __attribute__((ext_vector_type(NB)));
-    const int ub = ((wave * 9 * a.CinPad + lq) * a.CoutPad + co0 + l15 * 4 + nb0) * 4;
+    const int ub = ((wave * 9 * a.CinPad + lq) * a.CoutPad + co0 + l15 * cstr + nb0) * 4;
     const int u_point = a.CinPad * a.CoutPad * 4, u_kstep = 4 * a.CoutPad * 4, u_chunk = kCK * a.CoutPad * 4;
     auto load_u = [&](int chunk, int g) -> bfrag {                           // group g = (point wave*9 + g/2, k-step g%2)
         const int soff = chunk * u_chunk + (g >> 1) * u_point + (g & 1) * u_kstep;
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(256) void conv_wino4_f32(const ConvArgs a) { conv_w
 }  // namespace
 
 bool conv_wino4_eligible(int cin, int cout, int ks, int stride, int h, int w, int n_add) {
-    return ks == 3 && stride == 1 && h == 56 && w == 56 && n_add <= 1 && cin % kCK == 0 && cout % 64 == 0 && cin >= 64;
+    return ks == 3 && stride == 1 && h == 56 && w == 56 && n_add <= 1 && cin % kCK == 0 && cout % 32 == 0 && cin >= 32;
 }
 
 // a.w: transformed weights [36][CinPad][CoutPad] (pack_wino4_weights), CoutPad % 64 == 0
@@ -290,10 +294,11 @@ hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s, int* n_launches) {
         if (e != hipSuccess) return e;
         attr_done[dev] = true;
     }
-    if (!conv_wino4_eligible(a.Cin, a.Cout, a.ks, a.stride, a.H, a.W, a.n_add) || a.CinPad % kCK != 0 || a.CoutPad % 64 != 0) return hipErrorInvalidValue;
+    const int nb = a.Cout % 64 == 0 ? 4 : 2;
+    if (!conv_wino4_eligible(a.Cin, a.Cout, a.ks, a.stride, a.H, a.W, a.n_add) || a.CinPad % kCK != 0 || a.CoutPad % (nb * 16) != 0) return hipErrorInvalidValue;
     if (a.n_add == 1 && a.add_shift[0] != 0) return hipErrorInvalidValue;
     a.gx = a.N * (a.H >> 2);
-    a.gy = a.CoutPad / 64;
+    a.gy = a.CoutPad / (nb * 16);
     a.xcd = a.gx % 8 == 0 && a.gx >= 16 ? 1 : 0;
     a.blk0 = 0;
     a.wsplit = 0;
@@ -307,6 +312,7 @@ hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s, int* n_launches) {
         return go(conv_wino4_f32<4, 3>);
     }
 #endif
+    if (nb == 2) return launch_k(conv_wino4_f32<2>, dim3(total), dim3(256), kLdsB, s, a);
     // a last round of workgroups that is at most half full runs as twice as many half-size workgroups (conv_wino.hip)
     static const int split_env = getenv("GRNET_WINO_SPLIT") ? atoi(getenv("GRNET_WINO_SPLIT")) : 1;
     constexpr int kCUs = 256;
@@ -326,11 +332,12 @@ hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s, int* n_launches) {
 void pack_wino4_weights(const double* w, int cout, int cin, int cin_pad, int cout_pad, float* out) {
     static const double G[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                                    {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    const int nb = cout % 64 == 0 ? 4 : 2, tc = nb * 16;                    // the kernel variant launch_conv_wino4 picks for this layer
     for (size_t i = 0; i < (size_t)36 * cin_pad * cout_pad; ++i) out[i] = 0.f;
     for (int co = 0; co < cout; ++co)
         for (int ci = 0; ci < cin; ++ci) {
-            // within a workgroup's 64 channels, channel n*16 + l sits at l*4 + n: lane l's four MFMA B fragments are one 16-byte load
-            const int cpos = (co / 64) * 64 + (co % 16) * 4 + (co % 64) / 16;
+            // within a workgroup's tc channels, channel n*16 + l sits at l*nb + n: lane l's nb MFMA B fragments are one load
+            const int cpos = (co / tc) * tc + (co % 16) * nb + (co % tc) / 16;
             const double* g = w + ((size_t)co * cin + ci) * 9;
             double t[6][3];
             for (int i = 0; i < 6; ++i)

@@ -828,9 +828,9 @@ struct grnet {
                           L.cout_pad % (L.cout % 64 == 0 ? 64 : 32) == 0 && (L.adds.empty() || L.adds[0].shift == 0) &&
                           (L.in.w == 56 || (L.in.c >= 128 && L.cout % 64 == 0));
         // F(4x4,3x3) (conv_wino4.hip) where the multiplies dominate: >= 128 input channels, 64-channel output blocks, no residual
-        static const int wino4_env = getenv("GRNET_WINO4") ? atoi(getenv("GRNET_WINO4")) : 1;
-        const bool wino4 = wino && wino4_env && L.adds.empty() && L.in.c >= 128 &&
-                           conv_wino4_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, 0) && L.cout_pad % 64 == 0;
+        static const int wino4_env = getenv("GRNET_WINO4") ? atoi(getenv("GRNET_WINO4")) : 2;      // 0: F(2x2,3x3) only, 1: F(4x4,3x3) for >= 64 channels, 2: for every eligible 56x56 layer
+        const bool wino4 = wino && wino4_env && L.in.c >= (wino4_env >= 2 ? 32 : 64) && L.cout >= (wino4_env >= 2 ? 32 : 64) &&
+                           conv_wino4_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size());
         std::vector<double> wfold(wino ? (size_t)L.cout * cin * 9 : 0);     // BN-folded weights (cout, cin, 3, 3) for the filter transform
         int co0 = 0;
         for (auto& s : L.segs) {
@@ -1404,6 +1404,8 @@ struct grnet {
                     else if (L.wino4_dev && wino_mode && !conv_tile_hint) {
                         ConvArgs wa = conv_args(L, frames, n);
                         wa.w = L.wino4_dev;
+                        static const int chain_prio4 = getenv("GRNET_WINO_PRIO") ? atoi(getenv("GRNET_WINO_PRIO")) : 1;
+                        wa.prio = L.cout == 32 ? chain_prio4 : 0;
                         int nl = 1;
                         HIP_TRY(launch_conv_wino4(wa, s, &nl));
                         launches += nl - 1;
@@ -2064,7 +2066,7 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
         a.w = ud;
     }
     if (tile_hint == 2001) {                                   // the F(4x4,3x3) kernel on this one convolution
-        if (!conv_wino4_eligible(cin, cout, ks, stride, hgt, wid, add_dev ? 1 : 0) || cin_pad % 8 != 0 || cout_pad % 64 != 0) {
+        if (!conv_wino4_eligible(cin, cout, ks, stride, hgt, wid, add_dev ? 1 : 0) || cin_pad % 8 != 0 || cout_pad % (cout % 64 == 0 ? 64 : 32) != 0) {
             hipFree(wd); hipFree(bd);
             return h->fail(GRNET_EINVAL, "shape not eligible for the F(4x4,3x3) kernel");
         }
