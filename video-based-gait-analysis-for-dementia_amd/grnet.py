@@ -286,7 +286,7 @@ class GRNet:
         return self._lib.grnet_conv_flops_per_frame(self._h)
 
     def conv_executed_flops_per_frame(self):
-        """Winograd layers counted at the 4/9 of their multiplies they execute (reporting only)."""
+        """Winograd layers counted at the 1/4 (F(4x4,3x3)) or 4/9 (F(2x2,3x3)) of their multiplies they execute (reporting only)."""
         self.finalize()
         return self._lib.grnet_conv_executed_flops_per_frame(self._h)
 
