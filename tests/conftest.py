@@ -56,3 +56,11 @@ def elem_ratio(a, b, rtol=1e-3):
     b = np.asarray(b, np.float64).reshape(a.shape)
     floor = rtol * float(np.sqrt(np.mean(b * b)))
     return float((np.abs(a - b) / (rtol * np.abs(b) + max(floor, 1e-30))).max())
+
+
+# Bound for comparisons between calls of DIFFERENT sizes (one frame vs sixteen, shards vs the whole clip).  Frames are independent, but
+# the launch configuration of the direct convolution kernels is picked per call size, so their summation order differs by ~1e-6 per
+# layer between such calls, and the Winograd F(4x4,3x3) layers downstream pass such differences on with the gain of their transforms
+# (coefficients up to 8): measured up to 3.3e-5 on the path's outputs with every eligible layer on that kernel (1.5e-5 with F(2x2,3x3)).
+# 5e-5 is a twentieth of the 1e-3 parity bar; identical call sizes and forced configurations are still compared bit for bit.
+CALL_SIZE_NOISE = 5e-5

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from .conftest import ROOT, rel_err
+from .conftest import CALL_SIZE_NOISE, ROOT, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -48,7 +48,7 @@ def test_demo_entry_point(pkg, tmp_path):
     m = pkg.build_synthetic_model(max_frames=30, with_gru=False)
     direct = m(torch.from_numpy(frames).cuda())[-1]
     torch.cuda.synchronize()
-    assert rel_err(r["joints3d"], direct["kp_3d"][0].cpu().numpy()) < 2e-5
+    assert rel_err(r["joints3d"], direct["kp_3d"][0].cpu().numpy()) < CALL_SIZE_NOISE
     assert rel_err(r["pose"], direct["theta"][0, :, 3:75].cpu().numpy()) < 2e-5
     m.close()
     # a second run must not overwrite the first (demo.py:258-266)

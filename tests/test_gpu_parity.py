@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from .conftest import rel_err
+from .conftest import CALL_SIZE_NOISE, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4          # well inside the 1e-3 bar
@@ -131,15 +131,16 @@ def test_forward_matches_oracle_full(run4, pkg, oracle, synth_weights, synth_smp
 def test_batch_invariance_full_size(model, pkg):
     """BASELINE config 2 size (16 frames): every frame is independent (grnet.py:136-152), so the
     16-frame call must reproduce single-frame and chunked calls -- bit for bit when the same kernel
-    configuration is forced, and to fp32 re-association noise when the cost model picks per-size tiles."""
+    configuration is forced, and to fp32 re-association noise when the cost model picks per-size tiles.
+    The noise bound is conftest.CALL_SIZE_NOISE (5e-5, a twentieth of the parity bar; rationale there)."""
     frames = torch.from_numpy(pkg.synth.make_frames(16)).cuda()
     full = model(frames)[-1]
     one = model(frames[5:6])[-1]
     part = model(frames[8:11])[-1]
     torch.cuda.synchronize()
     for k in ("theta", "kp_3d", "kp_2d", "verts", "rotmat"):
-        assert rel_err(full[k][0, 5].cpu().numpy(), one[k][0, 0].cpu().numpy()) < 2e-5, k
-        assert rel_err(full[k][0, 8:11].cpu().numpy(), part[k][0].cpu().numpy()) < 2e-5, k
+        assert rel_err(full[k][0, 5].cpu().numpy(), one[k][0, 0].cpu().numpy()) < CALL_SIZE_NOISE, k
+        assert rel_err(full[k][0, 8:11].cpu().numpy(), part[k][0].cpu().numpy()) < CALL_SIZE_NOISE, k
     model.set_option(pkg._lib.OPT_CONV_TILE, 7)
     try:
         full7 = model(frames)[-1]
@@ -163,7 +164,7 @@ def test_chunked_above_max_frames(pkg):
     b = m2(frames)[-1]
     torch.cuda.synchronize()
     for k in ("theta", "kp_3d", "verts"):
-        assert rel_err(a[k].cpu().numpy(), b[k].cpu().numpy()) < 2e-5, k
+        assert rel_err(a[k].cpu().numpy(), b[k].cpu().numpy()) < CALL_SIZE_NOISE, k
     m.close(); m2.close()
 
 
@@ -322,7 +323,7 @@ def test_config3_shape_256_frames_one_call(pkg, golden):
     sl = m(frames.reshape(256, 3, 224, 224)[96:112])[-1]               # a 16-frame call on a slice
     torch.cuda.synchronize()
     for k in ("theta", "kp_3d", "verts", "rotmat"):
-        assert rel_err(flat[k][96:112].cpu().numpy(), sl[k][0].cpu().numpy()) < 2e-5, k
+        assert rel_err(flat[k][96:112].cpu().numpy(), sl[k][0].cpu().numpy()) < CALL_SIZE_NOISE, k
     m.close()
 
 
@@ -343,7 +344,7 @@ def test_config4_frame_sharding_equals_one_process(pkg):
     assert sum(p["theta"].shape[1] for p in parts) == n_total
     for k in ("theta", "kp_3d", "kp_2d", "verts", "rotmat"):
         cat = torch.cat([p[k][0] for p in parts], 0)
-        assert rel_err(cat.cpu().numpy(), whole[k][0].cpu().numpy()) < 2e-5, k
+        assert rel_err(cat.cpu().numpy(), whole[k][0].cpu().numpy()) < CALL_SIZE_NOISE, k
     m.close()
 
 

@@ -48,10 +48,14 @@ __device__ __forceinline__ void bt_hi(const float* d, float& r3, float& r4, floa
 
 // NB: 16-channel blocks per workgroup: 4, or 2 = HALF a 64-channel block of the same packed weights (the half-size workgroups of a
 // layer's last round, ConvArgs::wsplit, as in conv_wino.hip)
-template <int NB, int ABL>
+// WD: map width, 56 or 28.  A workgroup's 14 tiles are one tile row of a 56-wide map (6 input rows) or two tile rows of 7 of a 28-wide
+// one (10 input rows; 7 tile rows per image = 3.5 groups: the last group's lower half reads zeros and stores nothing).
+template <int NB, int WD, int ABL>
 __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
+    constexpr int TPR = WD / 4, TRG = 14 / TPR, kRawW = (4 * TRG + 2) * WD, UPC = kRawW / 4;   // tiles per tile row, tile rows per workgroup, raw floats / units per channel
+    static_assert(WD == 56 || WD == 28, "tile geometry");
     extern __shared__ __align__(16) float smem[];
-    float* raw = smem;                                  // [2][8][336]
+    float* raw = smem;                                  // [2][8][kRawW]
     float* V = raw + 2 * kCK * kRaw;                    // [2][36][8][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
 
@@ -65,7 +69,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
         bx = id / a.gy;
         by = id - bx * a.gy;
     }
-    const int groups = a.H >> 2;                         // tile rows per image (14)
+    const int groups = ((a.H >> 2) + TRG - 1) / TRG;     // tile-row groups per image (14 or 4)
     const int img = bx / groups, r = bx - img * groups;
     const int co0 = a.wsplit ? by * 64 : by * (NB * 16);    // first channel of the weight block; channel n*16 + l sits at l*cstr + n
     const int cstr = a.wsplit ? 4 : NB;
@@ -73,7 +77,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
     else if (a.prio >= 2) __builtin_amdgcn_s_setprio(3);
     const int HW = a.H * a.W;
     const float* inb = a.in + ((size_t)img * a.in_ctot + a.in_coff) * HW;
-    const int g0 = (4 * r - 1) * 56;                     // plane index of raw[.][0]
+    const int g0 = (4 * TRG * r - 1) * WD;               // plane index of raw[.][0]
 
     const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, 36 * a.CinPad * a.CoutPad * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, a.Cin * HW * 4, 0x00020000);
@@ -88,17 +92,17 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
     int roff[3];                                         // raw rows: 672 units per chunk; -1 = no unit or a row outside the image
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const int u = i * 256 + tid, ch = u / 84, k = u - ch * 84, gi = g0 + 4 * k;
-        const bool unit = u < kCK * 84, inside = gi >= 0 && gi < HW;
+        const int u = i * 256 + tid, ch = u / UPC, k = u - ch * UPC, gi = g0 + 4 * k;
+        const bool unit = u < kCK * UPC, inside = gi >= 0 && gi < HW;
         roff[i] = unit && inside ? (ch * HW + gi) * 4 : -1;
         if (unit && !inside) {                           // rows above / below the image: zero once in both buffers, the DMA never writes there
             *reinterpret_cast<f32x4*>(raw + u * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(raw + kCK * kRaw + u * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(raw + kCK * kRawW + u * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     auto issue_raw = [&](int chunk) {
         const int soff = chunk * (kCK * 4) * HW;
-        float* dst = raw + (chunk & 1) * (kCK * kRaw);
+        float* dst = raw + (chunk & 1) * (kCK * kRawW);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
             if (roff[i] >= 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (GRNET_LDS_AS void*)(dst + (i * 256 + wave * 64) * 4), 16, roff[i], soff, 0, 0);
@@ -111,21 +115,24 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
     // left padding) and produces rows 3*half .. 3*half+2 of B^T d B.
     const int row16 = tid >> 4, px = tid & 15, chn = row16 & 7;
     const int half = __builtin_amdgcn_readfirstlane(row16 >> 3);                         // wave-uniform: waves 0, 1 / 2, 3
-    const bool real = px < 14;
-    const int rpos = chn * kRaw + 4 * (real ? px : 13);
-    const int vpos = (half * 18) * (kCK * 16) + chn * 16 + px;                           // + (rr * 6 + c) * 128 for row rr of the half, column c
+    // WD = 28: the 16 lanes are two tile rows of 7 tiles + 1 idle lane each; idle lanes supply the zero on BOTH sides there
+    const int pc = WD == 56 ? px : (px & 7), trl = WD == 56 ? 0 : (px >> 3);
+    const bool real = pc < TPR;
+    const int rpos = chn * kRawW + (4 * trl) * WD + 4 * (real ? pc : TPR - 1);
+    const int slot = real ? trl * TPR + pc : 14 + (WD == 56 ? px - 14 : trl);            // tile slot in V (14, 15: padding)
+    const int vpos = (half * 18) * (kCK * 16) + chn * 16 + slot;                         // + (rr * 6 + c) * 128 for row rr of the half, column c
     struct Tf { float d[6][6]; float e[3][6]; };
     auto tf_read = [&](Tf& t, const float* rp) {        // 6 LDS reads
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(rp + i * 56);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rp + i * WD);
             t.d[i][1] = v[0]; t.d[i][2] = v[1]; t.d[i][3] = v[2]; t.d[i][4] = v[3];
         }
     };
     auto tf_halo = [&](Tf& t) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            t.d[i][0] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t.d[i][4]), 0x111, 0xf, 0xf, true));                 // row_shr:1
+            t.d[i][0] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(WD == 56 || real ? t.d[i][4] : 0.f), 0x111, 0xf, 0xf, true));   // row_shr:1
             t.d[i][5] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(real ? t.d[i][1] : 0.f), 0x101, 0xf, 0xf, true));    // row_shl:1
         }
     };
@@ -180,7 +187,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
     };
     auto chunk = [&](int buf, bool with_transform, int next) {
         Tf t;
-        const float* rp = raw + (next & 1) * (kCK * kRaw) + rpos;
+        const float* rp = raw + (next & 1) * (kCK * kRawW) + rpos;
         float* vp = V + (next & 1) * kV + vpos;
         if (ABL != 3) load_a(buf, 0, 0);
         if (with_transform && ABL != 1 && next + 1 < nchunks) issue_raw(next + 1);
@@ -243,9 +250,9 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
         }
         __syncthreads();
         if (tid < 14 * 16) {
-            const int c = tid / 14, t = tid - c * 14;
-            const int co = co0 + (nb0 + nt) * 16 + c;
-            if (co < a.Cout) {
+            const int c = tid / 14, t = tid - c * 14, tro = t / TPR, tx = t - tro * TPR;
+            const int co = co0 + (nb0 + nt) * 16 + c, orow = 4 * (TRG * r + tro);
+            if (co < a.Cout && orow < a.H) {
                 float s[4][6];                           // A^T M: rows of the 4x6 intermediate
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
@@ -259,45 +266,34 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
                     s[3][j] = fmaf(8.f, m34, m12) + m[5];
                 }
                 const float b = a.bias[co];
-                const size_t obase = ((size_t)img * a.out_ctot + a.out_coff + co) * HW + (4 * r) * 56 + 4 * t;
+                const size_t obase = ((size_t)img * a.out_ctot + a.out_coff + co) * HW + orow * WD + 4 * tx;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float* q = s[i];
                     const float p12 = q[1] + q[2], m12 = q[1] - q[2], p34 = q[3] + q[4], m34 = q[3] - q[4];
                     f32x4 y = f32x4{q[0] + p12 + p34 + b, fmaf(2.f, m34, m12) + b, fmaf(4.f, p34, p12) + b, fmaf(8.f, m34, m12) + q[5] + b};
-                    if (has_add) y += *reinterpret_cast<const f32x4*>(a.add[0] + ((size_t)img * a.add_ctot[0] + a.add_coff[0] + co) * HW + (4 * r + i) * 56 + 4 * t);
+                    if (has_add) y += *reinterpret_cast<const f32x4*>(a.add[0] + ((size_t)img * a.add_ctot[0] + a.add_coff[0] + co) * HW + (orow + i) * WD + 4 * tx);
                     if (a.relu) { y[0] = fmaxf(y[0], 0.f); y[1] = fmaxf(y[1], 0.f); y[2] = fmaxf(y[2], 0.f); y[3] = fmaxf(y[3], 0.f); }
-                    *reinterpret_cast<f32x4*>(a.out + obase + i * 56) = y;
+                    *reinterpret_cast<f32x4*>(a.out + obase + i * WD) = y;
                 }
             }
         }
     }
 }
 
-template <int NB, int ABL = 0>
-__global__ __launch_bounds__(256) void conv_wino4_f32(const ConvArgs a) { conv_wino4_body<NB, ABL>(a); }
+template <int NB, int WD = 56, int ABL = 0>
+__global__ __launch_bounds__(256) void conv_wino4_f32(const ConvArgs a) { conv_wino4_body<NB, WD, ABL>(a); }
 
 }  // namespace
 
 bool conv_wino4_eligible(int cin, int cout, int ks, int stride, int h, int w, int n_add) {
-    return ks == 3 && stride == 1 && h == 56 && w == 56 && n_add <= 1 && cin % kCK == 0 && cout % 32 == 0 && cin >= 32;
+    return ks == 3 && stride == 1 && ((h == 56 && w == 56) || (h == 28 && w == 28)) && n_add <= 1 && cin % kCK == 0 && cout % 32 == 0 && cin >= 32;
 }
 
-// a.w: transformed weights [36][CinPad][CoutPad] (pack_wino4_weights), CoutPad % 64 == 0
-hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s, int* n_launches) {
-    static bool attr_done[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_f32<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsB);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_f32<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsB);
-        if (e != hipSuccess) return e;
-        attr_done[dev] = true;
-    }
-    const int nb = a.Cout % 64 == 0 ? 4 : 2;
-    if (!conv_wino4_eligible(a.Cin, a.Cout, a.ks, a.stride, a.H, a.W, a.n_add) || a.CinPad % kCK != 0 || a.CoutPad % (nb * 16) != 0) return hipErrorInvalidValue;
-    if (a.n_add == 1 && a.add_shift[0] != 0) return hipErrorInvalidValue;
-    a.gx = a.N * (a.H >> 2);
+template <int WD>
+static hipError_t launch_wino4_w(ConvArgs a, hipStream_t s, int nb, int* n_launches) {
+    constexpr int TRG = 14 / (WD / 4);
+    a.gx = a.N * (((a.H >> 2) + TRG - 1) / TRG);
     a.gy = a.CoutPad / (nb * 16);
     a.xcd = a.gx % 8 == 0 && a.gx >= 16 ? 1 : 0;
     a.blk0 = 0;
@@ -305,27 +301,47 @@ hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s, int* n_launches) {
     if (n_launches) *n_launches = 1;
     const int total = a.gx * a.gy;
 #ifdef GRNET_ABLATION
-    if (a.dbg >= 1 && a.dbg <= 3) {
-        auto go = [&](auto kern) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsB); return launch_k(kern, dim3(total), dim3(256), kLdsB, s, a); };
-        if (a.dbg == 1) return go(conv_wino4_f32<4, 1>);
-        if (a.dbg == 2) return go(conv_wino4_f32<4, 2>);
-        return go(conv_wino4_f32<4, 3>);
+    if constexpr (WD == 56) {
+        if (a.dbg >= 1 && a.dbg <= 3) {
+            auto go = [&](auto kern) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsB); return launch_k(kern, dim3(total), dim3(256), kLdsB, s, a); };
+            if (a.dbg == 1) return go(conv_wino4_f32<4, 56, 1>);
+            if (a.dbg == 2) return go(conv_wino4_f32<4, 56, 2>);
+            return go(conv_wino4_f32<4, 56, 3>);
+        }
     }
 #endif
-    if (nb == 2) return launch_k(conv_wino4_f32<2>, dim3(total), dim3(256), kLdsB, s, a);
+    if (nb == 2) return launch_k(conv_wino4_f32<2, WD>, dim3(total), dim3(256), kLdsB, s, a);
     // a last round of workgroups that is at most half full runs as twice as many half-size workgroups (conv_wino.hip)
     static const int split_env = getenv("GRNET_WINO_SPLIT") ? atoi(getenv("GRNET_WINO_SPLIT")) : 1;
     constexpr int kCUs = 256;
     const int full = total / kCUs * kCUs, rest = total - full;
     if (split_env && full > 0 && rest > 0 && 2 * rest <= kCUs && (!a.xcd || full % 8 == 0)) {
-        hipError_t e = launch_k(conv_wino4_f32<4>, dim3(full), dim3(256), kLdsB, s, a);
+        hipError_t e = launch_k(conv_wino4_f32<4, WD>, dim3(full), dim3(256), kLdsB, s, a);
         if (e != hipSuccess) return e;
         a.blk0 = full;
         a.wsplit = 1;
         if (n_launches) *n_launches = 2;
-        return launch_k(conv_wino4_f32<2>, dim3(2 * rest), dim3(256), kLdsB, s, a);
+        return launch_k(conv_wino4_f32<2, WD>, dim3(2 * rest), dim3(256), kLdsB, s, a);
     }
-    return launch_k(conv_wino4_f32<4>, dim3(total), dim3(256), kLdsB, s, a);
+    return launch_k(conv_wino4_f32<4, WD>, dim3(total), dim3(256), kLdsB, s, a);
+}
+
+// a.w: transformed weights [36][CinPad][CoutPad] (pack_wino4_weights), CoutPad % 64 == 0 (or 32: the 32-channel variant)
+hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s, int* n_launches) {
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_done[dev]) {
+        hipError_t e = hipSuccess;
+        auto set = [&](auto kern) { if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsB); };
+        set(conv_wino4_f32<4, 56>); set(conv_wino4_f32<2, 56>); set(conv_wino4_f32<4, 28>); set(conv_wino4_f32<2, 28>);
+        if (e != hipSuccess) return e;
+        attr_done[dev] = true;
+    }
+    const int nb = a.Cout % 64 == 0 ? 4 : 2;
+    if (!conv_wino4_eligible(a.Cin, a.Cout, a.ks, a.stride, a.H, a.W, a.n_add) || a.CinPad % kCK != 0 || a.CoutPad % (nb * 16) != 0) return hipErrorInvalidValue;
+    if (a.n_add == 1 && a.add_shift[0] != 0) return hipErrorInvalidValue;
+    return a.W == 56 ? launch_wino4_w<56>(a, s, nb, n_launches) : launch_wino4_w<28>(a, s, nb, n_launches);
 }
 
 // U = G g G^T per (cout, cin) in fp64 -> [36][cin_pad][cout_pad] fp32; w: (cout, cin, 3, 3) folded weights (double)
