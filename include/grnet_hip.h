@@ -106,11 +106,12 @@ int grnet_tsattn_forward(grnet_t* h, const float* x_dev, const float* xs_dev, in
 #define GRNET_OPT_DATAFLOW 5      /* HR section (transition1 .. stage 4) as ONE persistent per-XCD dataflow launch: 0 never (default: it is
                                    * correct but measured slower than the per-convolution launches this round), 1 wherever a plan exists,
                                    * 2 where grnet_tune measured it faster */
-#define GRNET_OPT_WINOGRAD 7       /* 1 (default): the 3x3 stride-1 layers on 56x56 maps (layer1, HR branch 0, transition1, upsample heads, PARE head) run as
-                                    * Winograd F(4x4,3x3) and the >= 128-channel ones on 28x28 maps (upsample heads) as F(2x2,3x3) on the fp32 matrix cores
-                                    * (4x / 2.25x fewer multiplies, fp32 throughout, sums re-associated: ~1e-5 / ~1e-6 of the output scale from the
-                                    * direct kernel per layer, 2.5e-5 on the path's outputs); 0: every convolution is the direct implicit GEMM.
-                                    * grnet_op_conv2d tile hints 2000 / 2001 run the F(2x2,3x3) / F(4x4,3x3) kernel on one convolution */
+#define GRNET_OPT_WINOGRAD 7       /* 1 (default): the 3x3 stride-1 layers on 56x56 maps (layer1, HR branch 0, transition1, upsample heads, PARE head) and the
+                                    * >= 128-channel ones on 28x28 maps (upsample heads) run as Winograd F(4x4,3x3) on the fp32 matrix cores (4x fewer
+                                    * multiplies, fp32 throughout, sums re-associated: ~1e-5 of the output scale from the direct kernel per layer,
+                                    * <= 3.5e-5 on the path's outputs); 0: every convolution is the direct implicit GEMM.  Environment GRNET_WINO4=0
+                                    * selects the F(2x2,3x3) kernel instead (2.25x fewer multiplies, ~1e-6).  grnet_op_conv2d tile hints 2000 / 2001 run
+                                    * the F(2x2,3x3) / F(4x4,3x3) kernel on one convolution */
 #define GRNET_OPT_DATAFLOW_FENCE 6 /* 1: device-scope release/acquire around every hand-off inside that launch (validation; slower) */
 int grnet_set_option(grnet_t* h, int option, int value);
 
