@@ -33,7 +33,7 @@ for cin, cout in ((480, 256), (256, 256), (128, 128), (64, 64), (32, 32), (256, 
     for hint in (2000, 2001):
         m.op_conv2d(x, w, np.zeros(cout, np.float32), relu=True, tile_hint=hint)
 # F(4x4,3x3) on 28x28 maps
-for cin, cout in ((256, 256), (128, 128)):
+for cin, cout in ((256, 256), (128, 128), (64, 64)):
     x = torch.randn(n, cin, 28, 28, device="cuda")
     w = (np.random.randn(cout, cin, 3, 3) * 0.02).astype(np.float32)
     for hint in (2000, 2001):

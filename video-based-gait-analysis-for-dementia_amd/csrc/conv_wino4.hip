@@ -286,6 +286,10 @@ __global__ __launch_bounds__(256) void conv_wino4_f32(const ConvArgs a) { conv_w
 
 }  // namespace
 
+// 16-channel blocks per workgroup: 4 where the output channels come in 64s -- except for exactly 64 channels on a 28x28 map, where
+// 32-channel workgroups double a grid that would otherwise be 64 workgroups for 256 CUs
+int conv_wino4_blocks(int cout, int w) { return (cout % 64 == 0 && !(w == 28 && cout == 64)) ? 4 : 2; }
+
 bool conv_wino4_eligible(int cin, int cout, int ks, int stride, int h, int w, int n_add) {
     return ks == 3 && stride == 1 && ((h == 56 && w == 56) || (h == 28 && w == 28)) && n_add <= 1 && cin % kCK == 0 && cout % 32 == 0 && cin >= 32;
 }
@@ -338,17 +342,17 @@ hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s, int* n_launches) {
         if (e != hipSuccess) return e;
         attr_done[dev] = true;
     }
-    const int nb = a.Cout % 64 == 0 ? 4 : 2;
+    const int nb = conv_wino4_blocks(a.Cout, a.W);
     if (!conv_wino4_eligible(a.Cin, a.Cout, a.ks, a.stride, a.H, a.W, a.n_add) || a.CinPad % kCK != 0 || a.CoutPad % (nb * 16) != 0) return hipErrorInvalidValue;
     if (a.n_add == 1 && a.add_shift[0] != 0) return hipErrorInvalidValue;
     return a.W == 56 ? launch_wino4_w<56>(a, s, nb, n_launches) : launch_wino4_w<28>(a, s, nb, n_launches);
 }
 
 // U = G g G^T per (cout, cin) in fp64 -> [36][cin_pad][cout_pad] fp32; w: (cout, cin, 3, 3) folded weights (double)
-void pack_wino4_weights(const double* w, int cout, int cin, int cin_pad, int cout_pad, float* out) {
+void pack_wino4_weights(const double* w, int cout, int cin, int cin_pad, int cout_pad, float* out, int wid) {
     static const double G[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                                    {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
-    const int nb = cout % 64 == 0 ? 4 : 2, tc = nb * 16;                    // the kernel variant launch_conv_wino4 picks for this layer
+    const int nb = conv_wino4_blocks(cout, wid), tc = nb * 16;              // the kernel variant launch_conv_wino4 picks for this layer
     for (size_t i = 0; i < (size_t)36 * cin_pad * cout_pad; ++i) out[i] = 0.f;
     for (int co = 0; co < cout; ++co)
         for (int ci = 0; ci < cin; ++ci) {

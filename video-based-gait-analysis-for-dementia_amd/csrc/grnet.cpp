@@ -818,17 +818,15 @@ struct grnet {
         L.cin_pad = bf ? (L.in.c + 31) / 32 * 32 : (cin + kConvCK - 1) / kConvCK * kConvCK;
         L.cout_pad = bf ? (L.cout + 31) / 32 * 32 : (L.cout + TC - 1) / TC * TC;
         std::vector<float> wp((size_t)taps * L.cin_pad * L.cout_pad, 0.f), bp(L.cout_pad, 0.f);
-        // Every eligible layer on a 56x56 map takes the Winograd kernel: layer1, upsample heads, PARE head, transition1's 256 -> 32 and
-        // the 32 -> 32 convolutions of the 56x56 HR branch.  (While the kernel staged its weights through the LDS a workgroup owned the
-        // CU's whole 160 KB and the 32 -> 32 layers lost in context what they won in isolation -- 2 758 vs 2 800 frames/s; with the B
-        // fragments loaded straight into registers it holds 87 KB and they win: 2 930 -> 3 030 frames/s.)  On 28x28 maps only the wide
-        // upsample-head layers (256 -> 256: 196 -> 96 us, 128 -> 128: 62 -> 51 at 16 frames): the 64 -> 64 branch convolutions would be
-        // 64 workgroups of 8 chunks each, 31 us against the split-K kernel's 16.
+        // Every eligible layer takes a Winograd kernel: on 56x56 maps layer1, upsample heads, PARE head, transition1's 256 -> 32 and the
+        // 32 -> 32 convolutions of the HR branch; on 28x28 maps the upsample-head layers and the 64 -> 64 convolutions of the HR branch
+        // (F(4x4,3x3) in 32-channel workgroups: 16.3 us per launch against the split-K kernel's 14.1 ALONE, but a third of its
+        // matrix-pipe time, and stages 2-4 are bound by the pipe time of four concurrent branches: 3 636 -> 3 713 frames/s).  With
+        // GRNET_WINO4=0 (F(2x2,3x3) only) the 28x28 branch layers lose: 31 us.
+        static const int wino4_env = getenv("GRNET_WINO4") ? atoi(getenv("GRNET_WINO4")) : 2;      // 0: F(2x2,3x3) only, 1: F(4x4,3x3) for >= 64 channels, 2: for every eligible layer
         const bool wino = !bf && conv_wino_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size()) && L.cin_pad % 8 == 0 &&
                           L.cout_pad % (L.cout % 64 == 0 ? 64 : 32) == 0 && (L.adds.empty() || L.adds[0].shift == 0) &&
-                          (L.in.w == 56 || (L.in.c >= 128 && L.cout % 64 == 0));
-        // F(4x4,3x3) (conv_wino4.hip) where the multiplies dominate: >= 128 input channels, 64-channel output blocks, no residual
-        static const int wino4_env = getenv("GRNET_WINO4") ? atoi(getenv("GRNET_WINO4")) : 2;      // 0: F(2x2,3x3) only, 1: F(4x4,3x3) for >= 64 channels, 2: for every eligible 56x56 layer
+                          (L.in.w == 56 || (L.in.c >= (wino4_env ? 64 : 128) && L.cout % 64 == 0));
         const bool wino4 = wino && wino4_env && L.in.c >= (wino4_env >= 2 ? 32 : 64) && L.cout >= (wino4_env >= 2 ? 32 : 64) &&
                            conv_wino4_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size());
         std::vector<double> wfold(wino ? (size_t)L.cout * cin * 9 : 0);     // BN-folded weights (cout, cin, 3, 3) for the filter transform
@@ -882,7 +880,7 @@ struct grnet {
             if ((rc = upload(uw, &L.wino_dev))) return rc;
             if (wino4) {
                 std::vector<float> uw4((size_t)36 * L.cin_pad * L.cout_pad);
-                pack_wino4_weights(wfold.data(), L.cout, cin, L.cin_pad, L.cout_pad, uw4.data());
+                pack_wino4_weights(wfold.data(), L.cout, cin, L.cin_pad, L.cout_pad, uw4.data(), L.in.w);
                 if ((rc = upload(uw4, &L.wino4_dev))) return rc;
             }
         }
@@ -2073,7 +2071,7 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
         std::vector<double> wf((size_t)cout * cin * 9);
         for (size_t i = 0; i < wf.size(); ++i) wf[i] = w_host[i];
         std::vector<float> uw((size_t)36 * cin_pad * cout_pad);
-        pack_wino4_weights(wf.data(), cout, cin, cin_pad, cout_pad, uw.data());
+        pack_wino4_weights(wf.data(), cout, cin, cin_pad, cout_pad, uw.data(), wid);
         if (hipMalloc(reinterpret_cast<void**>(&ud), uw.size() * 4) != hipSuccess || hipMemcpy(ud, uw.data(), uw.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
             hipFree(wd); hipFree(bd); if (ud) hipFree(ud);
             return h->fail(GRNET_ENOMEM, "Winograd test weights");

@@ -104,7 +104,8 @@ void pack_wino_weights(const double* w_folded /* (cout,cin,3,3) */, int cout, in
 // ---- Winograd F(4x4,3x3) for the widest of them (conv_wino4.hip): 2.25 multiplies per output
 bool conv_wino4_eligible(int cin, int cout, int ks, int stride, int h, int w, int n_add);
 hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s, int* n_launches = nullptr);     // a.w = transformed weights [36][CinPad][CoutPad]
-void pack_wino4_weights(const double* w_folded /* (cout,cin,3,3) */, int cout, int cin, int cin_pad, int cout_pad, float* out);
+void pack_wino4_weights(const double* w_folded /* (cout,cin,3,3) */, int cout, int cin, int cin_pad, int cout_pad, float* out, int map_width = 56);
+int conv_wino4_blocks(int cout, int map_width);   // 16-channel blocks per workgroup of that layer (4 or 2)
 
 // ---- per-XCD dataflow execution of the HR stages (conv_kernels.hip: hr_dataflow_f32) -------------------------------------------
 // One persistent launch runs every convolution of transition1 .. stage 4 (~270 launches otherwise).  Frames are independent and
