@@ -145,10 +145,10 @@ def roofline_object(fps_per_gpu, dtype, conv_flops_per_frame, conv_ms, conv_ms_s
     r = {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
          "definition": "frames/s per GPU x F_frame (SURVEY 8d: 30.883 GFLOP of convolutions per frame = the ALGORITHMIC, direct-convolution "
                        "count); the whole step -- pooling, tail, SMPL, launch gaps -- is charged to the convolutions.  On the fp32 path the Winograd "
-                       "layers (64 % of F_frame) execute 4x (F(4x4,3x3), 56x56 maps) or 2.25x (F(2x2,3x3), 28x28 maps) fewer multiplies than counted here, in fp32 throughout",
+                       "layers (76 % of F_frame) execute 4x fewer multiplies than counted here (F(4x4,3x3)), in fp32 throughout",
          "traffic": None,
-         "kernel": ("conv_wino4_f32 (Winograd F(4x4,3x3) on the fp32 matrix cores: the 3x3 stride-1 layers on 56x56 maps) + conv_wino_f32 (F(2x2,3x3): the "
-                    ">= 128-channel ones on 28x28 maps) + conv_mfma_f32 / conv_splitk_f32 (fp32 MFMA implicit-GEMM convolution: everything else), "
+         "kernel": ("conv_wino4_f32 (Winograd F(4x4,3x3) on the fp32 matrix cores: the 3x3 stride-1 layers on 56x56 maps and the >= 64-channel ones on "
+                    "28x28 maps) + conv_mfma_f32 / conv_splitk_f32 (fp32 MFMA implicit-GEMM convolution: everything else), "
                     "all launches of a step" if dtype == "f32"
                     else "conv_bf16_nhwc (bf16 MFMA implicit-GEMM convolution on NHWC activations, all launches of a step)"),
          "conv_launches_per_step": n_conv, "conv_gflop_per_step": round(conv_flops / 1e9, 3),

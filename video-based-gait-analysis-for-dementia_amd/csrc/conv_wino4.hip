@@ -287,7 +287,8 @@ __global__ __launch_bounds__(256) void conv_wino4_f32(const ConvArgs a) { conv_w
 }  // namespace
 
 // 16-channel blocks per workgroup: 4 where the output channels come in 64s -- except for exactly 64 channels on a 28x28 map, where
-// 32-channel workgroups double a grid that would otherwise be 64 workgroups for 256 CUs
+// 32-channel workgroups double a grid that would otherwise be 64 workgroups for 256 CUs (in context, 16 frames: 3 693 frames/s
+// against 3 310 with 64-channel workgroups there)
 int conv_wino4_blocks(int cout, int w) { return (cout % 64 == 0 && !(w == 28 && cout == 64)) ? 4 : 2; }
 
 bool conv_wino4_eligible(int cin, int cout, int ks, int stride, int h, int w, int n_add) {
