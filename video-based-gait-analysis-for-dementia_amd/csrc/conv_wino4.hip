@@ -50,8 +50,13 @@ __device__ __forceinline__ void bt_hi(const float* d, float& r3, float& r4, floa
 // layer's last round, ConvArgs::wsplit, as in conv_wino.hip)
 // WD: map width, 56 or 28.  A workgroup's 14 tiles are one tile row of a 56-wide map (6 input rows) or two tile rows of 7 of a 28-wide
 // one (10 input rows; 7 tile rows per image = 3.5 groups: the last group's lower half reads zeros and stores nothing).
-template <int NB, int WD, int ABL>
+// WSPLIT: the 32-channel kernel on HALF a 64-channel block of weights packed for the 64-channel kernel (last-round workgroups).  The
+// standalone 32-channel layers (NB = 2, !WSPLIT) have their own packing with the two k-steps of a chunk interleaved (pack_wino4_weights):
+// one 16-byte load brings a point's B fragments of BOTH k-steps, 9 weight loads per chunk and wave instead of 18.
+template <int NB, int WD, int ABL, bool WSPLIT>
 __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
+    constexpr bool PAIR = NB == 2 && !WSPLIT;
+    constexpr int NLD = PAIR ? 9 : 18;                   // weight loads per chunk and wave
     constexpr int TPR = WD / 4, TRG = 14 / TPR, kRawW = (4 * TRG + 2) * WD, UPC = kRawW / 4;   // tiles per tile row, tile rows per workgroup, raw floats / units per channel
     static_assert(WD == 56 || WD == 28, "tile geometry");
     extern __shared__ __align__(16) float smem[];
@@ -59,7 +64,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
     float* V = raw + 2 * kCK * kRaw;                    // [2][36][8][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
 
-    const int id = a.blk0 + (a.wsplit ? (int)(blockIdx.x >> 1) : (int)blockIdx.x), nb0 = a.wsplit ? 2 * (int)(blockIdx.x & 1) : 0;
+    const int id = a.blk0 + (WSPLIT ? (int)(blockIdx.x >> 1) : (int)blockIdx.x), nb0 = WSPLIT ? 2 * (int)(blockIdx.x & 1) : 0;
     int bx, by;
     if (a.xcd) {
         const int j = id >> 3, x = id & 7, q = j / a.gy;
@@ -71,8 +76,8 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
     }
     const int groups = ((a.H >> 2) + TRG - 1) / TRG;     // tile-row groups per image (14 or 4)
     const int img = bx / groups, r = bx - img * groups;
-    const int co0 = a.wsplit ? by * 64 : by * (NB * 16);    // first channel of the weight block; channel n*16 + l sits at l*cstr + n
-    const int cstr = a.wsplit ? 4 : NB;
+    const int co0 = WSPLIT ? by * 64 : by * (NB * 16);      // first channel of the weight block; channel n*16 + l sits at l*cstr + n
+    constexpr int cstr = WSPLIT ? 4 : NB;
     if (a.prio == 1) __builtin_amdgcn_s_setprio(1);         // critical-chain layers (conv_wino.hip)
     else if (a.prio >= 2) __builtin_amdgcn_s_setprio(3);
     const int HW = a.H * a.W;
@@ -81,12 +86,16 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
 
     const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, 36 * a.CinPad * a.CoutPad * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, a.Cin * HW * 4, 0x00020000);
-    typedef float bfrag __attribute__((ext_vector_type(NB)));
-    const int ub = ((wave * 9 * a.CinPad + lq) * a.CoutPad + co0 + l15 * cstr + nb0) * 4;
-    const int u_point = a.CinPad * a.CoutPad * 4, u_kstep = 4 * a.CoutPad * 4, u_chunk = kCK * a.CoutPad * 4;
-    auto load_u = [&](int chunk, int g) -> bfrag {                           // group g = (point wave*9 + g/2, k-step g%2)
-        const int soff = chunk * u_chunk + (g >> 1) * u_point + (g & 1) * u_kstep;
-        if constexpr (NB == 4) return __builtin_bit_cast(bfrag, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, ub, soff, 0));
+    typedef float bfrag __attribute__((ext_vector_type(PAIR ? 4 : NB)));   // PAIR: {k-step 0: n0 n1, k-step 1: n0 n1}
+    const int nchunks_u = a.CinPad / kCK;
+    // byte offsets: a lane's part (VGPR) + point / chunk part (scalar)
+    const int ub = PAIR ? ((lq * a.CoutPad * 2 + co0 * 2 + l15 * 4) * 4 + wave * 9 * nchunks_u * 4 * a.CoutPad * 2 * 4)
+                        : ((wave * 9 * a.CinPad + lq) * a.CoutPad + co0 + l15 * cstr + nb0) * 4;
+    const int u_point = PAIR ? nchunks_u * 4 * a.CoutPad * 2 * 4 : a.CinPad * a.CoutPad * 4;
+    const int u_kstep = 4 * a.CoutPad * 4, u_chunk = PAIR ? 4 * a.CoutPad * 2 * 4 : kCK * a.CoutPad * 4;
+    auto load_u = [&](int chunk, int g) -> bfrag {       // !PAIR: group g = (point wave*9 + g/2, k-step g%2); PAIR: g = point
+        const int soff = PAIR ? chunk * u_chunk + g * u_point : chunk * u_chunk + (g >> 1) * u_point + (g & 1) * u_kstep;
+        if constexpr (PAIR || NB == 4) return __builtin_bit_cast(bfrag, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, ub, soff, 0));
         else return __builtin_bit_cast(bfrag, __builtin_amdgcn_raw_buffer_load_b64(u_rsrc, ub, soff, 0));
     };
     int roff[3];                                         // raw rows: 672 units per chunk; -1 = no unit or a row outside the image
@@ -162,12 +171,13 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
         for (int n = 0; n < NB; ++n) acc[p][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nchunks = a.CinPad / kCK;
-    bfrag bq[18];                                        // B fragments of the 18 MFMA groups; each is re-requested for the next chunk behind its group
+    bfrag bq[NLD];                                       // B fragments of the 18 MFMA groups (PAIR: of the 9 points); each is re-requested for the next chunk behind its group
     issue_raw(0);
     if (nchunks > 1) issue_raw(1);
 #pragma unroll
-    for (int g = 0; g < 18; ++g) bq[g] = load_u(0, g);
-    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");   // the raw rows (requested before the 18 weight loads) have landed
+    for (int g = 0; g < NLD; ++g) bq[g] = load_u(0, g);
+    if constexpr (PAIR) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // the raw rows (requested before the weight loads) have landed
+    else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
     __syncthreads();
     {
         Tf t;
@@ -205,7 +215,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
             if (c < 2 && ABL != 3) load_a(buf, c + 1, (c + 1) & 1);
             if (with_transform && ABL != 1 && c > 0) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) bq[6 * (c - 1) + k] = load_u(next, 6 * (c - 1) + k);
+                for (int k = 0; k < NLD / 3; ++k) bq[(NLD / 3) * (c - 1) + k] = load_u(next, (NLD / 3) * (c - 1) + k);
             }
             if (with_transform && ABL != 2 && c == 0) tf_read(t, rp);
             __builtin_amdgcn_sched_barrier(0);
@@ -214,19 +224,22 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
 #pragma unroll
                 for (int n = 0; n < NB; ++n) {
                     const int pi = 3 * c + (k >> 1);
-                    acc[pi][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c & 1][k], bq[6 * c + k][n], acc[pi][n], 0, 0, 0);
+                    const float bfr = PAIR ? bq[pi][(k & 1) * 2 + n] : bq[6 * c + k][n];
+                    acc[pi][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c & 1][k], bfr, acc[pi][n], 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (with_transform && ABL != 1) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) bq[12 + k] = load_u(next, 12 + k);
+            for (int k = 0; k < NLD / 3; ++k) bq[2 * (NLD / 3) + k] = load_u(next, 2 * (NLD / 3) + k);
         }
     };
     auto meet = [&](bool last) {
         // this wave's share of raw(ch+1) has landed: it was requested before the 18 weight loads of the previous iteration, which may stay
         // in flight (loads return in order)
-        if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if constexpr (PAIR) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
         __syncthreads();
     };
     for (int ch = 0; ch + 1 < nchunks; ++ch) {
@@ -281,8 +294,8 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
     }
 }
 
-template <int NB, int WD = 56, int ABL = 0>
-__global__ __launch_bounds__(256) void conv_wino4_f32(const ConvArgs a) { conv_wino4_body<NB, WD, ABL>(a); }
+template <int NB, int WD = 56, int ABL = 0, bool WSPLIT = false>
+__global__ __launch_bounds__(256) void conv_wino4_f32(const ConvArgs a) { conv_wino4_body<NB, WD, ABL, WSPLIT>(a); }
 
 }  // namespace
 
@@ -326,7 +339,7 @@ static hipError_t launch_wino4_w(ConvArgs a, hipStream_t s, int nb, int* n_launc
         a.blk0 = full;
         a.wsplit = 1;
         if (n_launches) *n_launches = 2;
-        return launch_k(conv_wino4_f32<2, WD>, dim3(2 * rest), dim3(256), kLdsB, s, a);
+        return launch_k(conv_wino4_f32<2, WD, 0, true>, dim3(2 * rest), dim3(256), kLdsB, s, a);
     }
     return launch_k(conv_wino4_f32<4, WD>, dim3(total), dim3(256), kLdsB, s, a);
 }
@@ -340,6 +353,7 @@ hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s, int* n_launches) {
         hipError_t e = hipSuccess;
         auto set = [&](auto kern) { if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsB); };
         set(conv_wino4_f32<4, 56>); set(conv_wino4_f32<2, 56>); set(conv_wino4_f32<4, 28>); set(conv_wino4_f32<2, 28>);
+        set(conv_wino4_f32<2, 56, 0, true>); set(conv_wino4_f32<2, 28, 0, true>);
         if (e != hipSuccess) return e;
         attr_done[dev] = true;
     }
@@ -366,7 +380,12 @@ void pack_wino4_weights(const double* w, int cout, int cin, int cin_pad, int cou
             for (int i = 0; i < 6; ++i)
                 for (int j = 0; j < 6; ++j) {
                     const double u = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
-                    out[((size_t)(i * 6 + j) * cin_pad + ci) * cout_pad + cpos] = (float)u;
+                    const int p = i * 6 + j;
+                    if (nb == 4) out[((size_t)p * cin_pad + ci) * cout_pad + cpos] = (float)u;
+                    else {                               // 32-channel layers: [point][chunk][k % 4][32-channel block][channel l][k-step][n]
+                        const int chunk = ci / kCK, ks = (ci % kCK) / 4, kq = ci % 4;
+                        out[(((size_t)p * (cin_pad / kCK) + chunk) * 4 + kq) * ((size_t)cout_pad * 2) + (co / 32) * 64 + (co % 16) * 4 + ks * 2 + (co % 32) / 16] = (float)u;
+                    }
                 }
         }
 }
