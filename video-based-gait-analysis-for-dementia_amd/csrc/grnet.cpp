@@ -1403,7 +1403,9 @@ struct grnet {
                         ConvArgs wa = conv_args(L, frames, n);
                         wa.w = L.wino4_dev;
                         static const int chain_prio4 = getenv("GRNET_WINO_PRIO") ? atoi(getenv("GRNET_WINO_PRIO")) : 1;
-                        wa.prio = L.cout == 32 ? chain_prio4 : 0;
+                        // the BasicBlock chains of the 56x56 and 28x28 HR branches (32-channel workgroups): wave priority 1.  Worth +1 % when
+                        // only the 56x56 chain ran on a Winograd kernel; with both on F(4x4,3x3) every combination is within 0.5 %
+                        wa.prio = (L.in.c == L.cout && conv_wino4_blocks(L.cout, L.in.w) == 2) ? chain_prio4 : 0;
                         int nl = 1;
                         HIP_TRY(launch_conv_wino4(wa, s, &nl));
                         launches += nl - 1;
