@@ -145,6 +145,11 @@ int grnet_time_convs(grnet_t* h, int n_frames, void* stream, float* ms_out);
 int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, int wid, const float* w_host,
                     const float* bias_host, int cout, int ks, int stride, int relu, const float* add_dev,
                     float* out_dev, int tile_hint, void* stream);
+/* BasicBlock.forward -- lib/models/hrnet.py:43-59 (conv3x3-BN-ReLU-conv3x3-BN-(+x)-ReLU, no downsample) as ONE launch of the fused
+ * Winograd kernel (csrc/conv_wino4_block.hip) that the path uses for the 32-channel 56x56 and the 64-channel 28x28 HR branches
+ * (hrnet.py:141-187); other shapes are refused.  w*_host: (C,C,3,3) with BatchNorm already folded, b*_host: (C) or NULL. */
+int grnet_op_basic_block(grnet_t* h, const float* in_dev, int n, int c, int hgt, int wid, const float* w1_host, const float* b1_host,
+                         const float* w2_host, const float* b2_host, float* out_dev, void* stream);
 int grnet_op_bilinear2x(grnet_t* h, const float* in_dev, int n, int c, int hgt, int wid, float* out_dev, void* stream);
 
 /* SMPL(...) forward with rotation matrices -- lib/models/smpl.py:108-130 (smplx LBS + the 29 "spin2" joints) and, when

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgrnet_hip.so")
+# GRNET_LIB_PATH: a diagnostic build of the same library (make ABLATION=1 BUILD=build_abl LIB=../libgrnet_hip_abl.so), tools/ only
+LIB_PATH = os.environ.get("GRNET_LIB_PATH") or os.path.join(_HERE, "libgrnet_hip.so")
 
 OK, EINVAL, ENOENT, ENOMEM, EHIP, ESTATE = 0, -22, -2, -12, -5, -1
 DTYPE_F32, DTYPE_I64 = 0, 1
@@ -47,6 +48,8 @@ EXPORTS = {
     "grnet_time_convs": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "grnet_op_conv2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "grnet_op_basic_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "grnet_op_bilinear2x": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "grnet_smpl_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),

@@ -2105,6 +2105,56 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
     return 0;
 }
 
+int grnet_op_basic_block(grnet_t* h, const float* in_dev, int n, int c, int hgt, int wid, const float* w1_host, const float* b1_host,
+                         const float* w2_host, const float* b2_host, float* out_dev, void* stream) {
+    if (!h || !in_dev || !w1_host || !w2_host || !out_dev || n < 1) return GRNET_EINVAL;
+    if (h->dtype != 0) return h->fail(GRNET_EINVAL, "the fused BasicBlock kernel is fp32 only");
+    if (!bblock_wino4_eligible(c, hgt, wid)) return h->fail(GRNET_EINVAL, "shape not eligible for the fused BasicBlock kernel (32 ch @ 56x56 or 64 ch @ 28x28)");
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* dev[4] = {nullptr, nullptr, nullptr, nullptr};      // u1, u2, b1, b2
+    auto release = [&]() { for (float* q : dev) if (q) hipFree(q); };
+    const float* wsrc[2] = {w1_host, w2_host};
+    const float* bsrc[2] = {b1_host, b2_host};
+    for (int k = 0; k < 2; ++k) {
+        std::vector<double> wf((size_t)c * c * 9);
+        for (size_t i = 0; i < wf.size(); ++i) wf[i] = wsrc[k][i];
+        std::vector<float> uw((size_t)36 * c * c), bp(c, 0.f);
+        pack_wino4_weights(wf.data(), c, c, c, c, uw.data(), wid);
+        if (bsrc[k]) for (int i = 0; i < c; ++i) bp[i] = bsrc[k][i];
+        if (hipMalloc(reinterpret_cast<void**>(&dev[k]), uw.size() * 4) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&dev[2 + k]), bp.size() * 4) != hipSuccess ||
+            hipMemcpy(dev[k], uw.data(), uw.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(dev[2 + k], bp.data(), bp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            release();
+            return h->fail(GRNET_ENOMEM, "fused BasicBlock test weights");
+        }
+    }
+    BlockArgs a{};
+    a.in = in_dev; a.in_ctot = c; a.in_coff = 0;
+    a.out = out_dev; a.out_ctot = c; a.out_coff = 0;
+    a.N = n;
+    a.w1 = dev[0]; a.b1 = dev[2]; a.w2 = dev[1]; a.b2 = dev[3];
+    hipError_t e = launch_bblock_wino4(a, c, hgt, wid, s);
+    if (const char* r = getenv("GRNET_CONV_REPS")) {           // timing loop for tools/wino_micro.py
+        const int reps = atoi(r);
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0, s);
+        for (int i = 0; i < reps; ++i) e = launch_bblock_wino4(a, c, hgt, wid, s);
+        hipEventRecord(e1, s);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        fprintf(stderr, "[conv_micro] fused BasicBlock c %d hw %d n %d: %.2f us/launch\n", c, hgt, n, ms * 1e3f / reps);
+        hipEventDestroy(e0); hipEventDestroy(e1);
+    }
+    hipError_t e2 = hipStreamSynchronize(s);
+    release();
+    if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("launch_bblock_wino4: ") + hipGetErrorString(e));
+    if (e2 != hipSuccess) return h->fail(GRNET_EHIP, std::string("fused BasicBlock kernel: ") + hipGetErrorString(e2));
+    return 0;
+}
+
 int grnet_op_bilinear2x(grnet_t* h, const float* in_dev, int n, int c, int hgt, int wid, float* out_dev, void* stream) {
     if (!h || !in_dev || !out_dev) return GRNET_EINVAL;
     DeviceGuard guard(h->device);

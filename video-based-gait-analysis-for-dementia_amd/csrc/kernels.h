@@ -107,6 +107,20 @@ hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s, int* n_launches = nullpt
 void pack_wino4_weights(const double* w_folded /* (cout,cin,3,3) */, int cout, int cin, int cin_pad, int cout_pad, float* out, int map_width = 56);
 int conv_wino4_blocks(int cout, int map_width);   // 16-channel blocks per workgroup of that layer (4 or 2)
 
+// ---- a whole BasicBlock (conv3x3-BN-ReLU-conv3x3-BN-(+x)-ReLU, hrnet.py:30-59) of the 32-channel 56x56 / 64-channel 28x28 HR branches in
+// ONE launch (conv_wino4_block.hip): both convolutions as F(4x4,3x3), the intermediate tensor stays in LDS
+struct BlockArgs {
+    const float* in; int in_ctot, in_coff;     // x: input of conv1 and the residual
+    float* out; int out_ctot, out_coff;
+    int N;
+    const float* w1; const float* b1;          // conv1: transformed weights (pack_wino4_weights, 32-channel layout), folded BN shift
+    const float* w2; const float* b2;          // conv2
+    int prio;                                  // wave priority as ConvArgs::prio
+    int gx, xcd;                               // filled by the launcher
+};
+bool bblock_wino4_eligible(int channels, int h, int w);
+hipError_t launch_bblock_wino4(BlockArgs a, int channels, int h, int w, hipStream_t s);
+
 // ---- per-XCD dataflow execution of the HR stages (conv_kernels.hip: hr_dataflow_f32) -------------------------------------------
 // One persistent launch runs every convolution of transition1 .. stage 4 (~270 launches otherwise).  Frames are independent and
 // the 8 XCDs have private L2s, so XCD x takes the images [x*ipx, (x+1)*ipx) through the WHOLE section on its own: its workgroups pop

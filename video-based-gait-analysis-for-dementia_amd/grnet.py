@@ -459,6 +459,21 @@ class GRNet:
         _lib.check(self._lib, self._h, rc, "grnet_op_conv2d")
         return out
 
+    def op_basic_block(self, x, w1, b1, w2, b2):
+        """One fused BasicBlock launch (hrnet.py:43-59) on x (n,C,H,W): relu(conv2(relu(conv1(x)+b1))+b2+x), BN already folded."""
+        n, c, h, wd = x.shape
+        out = torch.empty_like(x)
+        w1n, w2n = _np32(w1), _np32(w2)
+        b1n = _np32(b1) if b1 is not None else None
+        b2n = _np32(b2) if b2 is not None else None
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        rc = self._lib.grnet_op_basic_block(self._h, x.data_ptr(), n, c, h, wd, w1n.ctypes.data_as(C.c_void_p),
+                                            b1n.ctypes.data_as(C.c_void_p) if b1n is not None else None,
+                                            w2n.ctypes.data_as(C.c_void_p),
+                                            b2n.ctypes.data_as(C.c_void_p) if b2n is not None else None, out.data_ptr(), stream)
+        _lib.check(self._lib, self._h, rc, "grnet_op_basic_block")
+        return out
+
     def op_bilinear2x(self, x):
         n, c, h, w = x.shape
         out = torch.empty(n, c, 2 * h, 2 * w, dtype=torch.float32, device=x.device)
