@@ -55,3 +55,63 @@ def test_fused_basic_block_is_refused_elsewhere(model):
         model.op_basic_block(torch.zeros(1, 128, 14, 14).cuda(), np.zeros((128, 128, 3, 3), np.float32), None, np.zeros((128, 128, 3, 3), np.float32), None)
     with pytest.raises(Exception):
         model.op_basic_block(torch.zeros(1, 32, 28, 28).cuda(), np.zeros((32, 32, 3, 3), np.float32), None, np.zeros((32, 32, 3, 3), np.float32), None)
+
+
+@pytest.mark.parametrize("case", [(1, 32, 56, 1), (3, 32, 56, 2), (16, 32, 56, 1), (16, 32, 56, 2), (1, 64, 28, 1), (3, 64, 28, 2), (5, 64, 28, 4),
+                                  (16, 64, 28, 1), (16, 64, 28, 2), (16, 64, 28, 4)], ids=lambda c: "x".join(map(str, c)))
+def test_register_resident_winograd_kernel(model, oracle, case):
+    """conv_wino4r_f32 (F(4x4,3x3) with a wave owning a whole MFMA row tile x 36 points x 16 output channels, patch rows loaded
+    straight into registers, zero padding = out-of-range buffer offsets) on single convolutions vs the oracle's direct convolution:
+    1 / 3 / 5 / 16 images (plain and XCD-aware block order; on 28x28 maps the last row tile of an image is half empty), 1 / 2 / 4 waves
+    splitting the input channels; bias + ReLU, + residual, and the plain linear form with the borders looked at separately.  Same
+    bound as the LDS-staged F(4x4,3x3) kernel: 1e-4 of the output scale."""
+    n, c, hw, ksplit = case
+    g = np.random.Generator(np.random.Philox(key=[91, n * 100000 + c * 100 + ksplit]))
+    x = g.standard_normal((n, c, hw, hw)).astype(np.float32)
+    w = (g.standard_normal((c, c, 3, 3)) * np.sqrt(2.0 / (c * 9))).astype(np.float32)
+    b = (g.standard_normal((c,)) * 0.1).astype(np.float32)
+    r = g.standard_normal((n, c, hw, hw)).astype(np.float32)
+    hint = 2010 + ksplit
+    conv = oracle.conv2d(x, w, stride=1, bias=b)
+    xd = torch.from_numpy(x).cuda()
+    got = model.op_conv2d(xd, w, b, stride=1, relu=True, tile_hint=hint).cpu().numpy()
+    assert got.shape == conv.shape
+    assert rel_err(got, torch.relu(conv).numpy()) < 1e-4, rel_err(got, torch.relu(conv).numpy())
+    got = model.op_conv2d(xd, w, b, stride=1, relu=True, add=torch.from_numpy(r).cuda(), tile_hint=hint).cpu().numpy()
+    assert rel_err(got, torch.relu(conv + torch.from_numpy(r)).numpy()) < 1e-4
+    lin = oracle.conv2d(x, w, stride=1).numpy()
+    got = model.op_conv2d(xd, w, None, stride=1, relu=False, tile_hint=hint).cpu().numpy()
+    assert rel_err(got, lin) < 1e-4
+    assert rel_err(got[:, :, [0, hw - 1]], lin[:, :, [0, hw - 1]]) < 1e-4 and rel_err(got[..., [0, hw - 1]], lin[..., [0, hw - 1]]) < 1e-4
+    again = model.op_conv2d(xd, w, None, stride=1, relu=False, tile_hint=hint).cpu().numpy()
+    assert np.array_equal(got, again)                                       # the K split adds its partial sums in a fixed order
+
+
+@pytest.mark.parametrize("case", [(1, 128, 14, 4), (3, 128, 14, 2), (16, 128, 14, 0), (1, 256, 7, 4), (5, 256, 7, 0), (16, 256, 7, 2), (16, 256, 7, 4), (3, 256, 14, 0)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_small_map_winograd_kernel(model, oracle, case):
+    """conv_wino4s_f32 (F(4x4,3x3) on 14x14 maps = 4x4 tiles padded to 16x16, and on 7x7 maps = 2x2 tiles padded to 8x8 with four
+    images per MFMA row tile) vs the oracle's direct convolution: the HR-branch shapes 128 @14x14 and 256 @7x7 and the upsample-head
+    layer 256 @14x14; 1 / 3 / 5 / 16 images (5 is not a multiple of the 4 images a 7x7 row tile holds), 2 / 4 waves splitting the
+    input channels; bias + ReLU, + residual, the linear form with the borders looked at separately (the right / bottom edge tiles are
+    partly outside the map), and bit-identical repeats.  Bound 1e-4 of the output scale, as for the other F(4x4,3x3) kernels."""
+    n, c, hw, ksplit = case
+    g = np.random.Generator(np.random.Philox(key=[92, n * 100000 + c * 100 + hw + ksplit]))
+    x = g.standard_normal((n, c, hw, hw)).astype(np.float32)
+    w = (g.standard_normal((c, c, 3, 3)) * np.sqrt(2.0 / (c * 9))).astype(np.float32)
+    b = (g.standard_normal((c,)) * 0.1).astype(np.float32)
+    r = g.standard_normal((n, c, hw, hw)).astype(np.float32)
+    hint = 2020 + ksplit
+    conv = oracle.conv2d(x, w, stride=1, bias=b)
+    xd = torch.from_numpy(x).cuda()
+    got = model.op_conv2d(xd, w, b, stride=1, relu=True, tile_hint=hint).cpu().numpy()
+    assert got.shape == conv.shape
+    assert rel_err(got, torch.relu(conv).numpy()) < 1e-4, rel_err(got, torch.relu(conv).numpy())
+    got = model.op_conv2d(xd, w, b, stride=1, relu=True, add=torch.from_numpy(r).cuda(), tile_hint=hint).cpu().numpy()
+    assert rel_err(got, torch.relu(conv + torch.from_numpy(r)).numpy()) < 1e-4
+    lin = oracle.conv2d(x, w, stride=1).numpy()
+    got = model.op_conv2d(xd, w, None, stride=1, relu=False, tile_hint=hint).cpu().numpy()
+    assert rel_err(got, lin) < 1e-4
+    assert rel_err(got[:, :, [0, hw - 1]], lin[:, :, [0, hw - 1]]) < 1e-4 and rel_err(got[..., [0, hw - 1]], lin[..., [0, hw - 1]]) < 1e-4
+    again = model.op_conv2d(xd, w, None, stride=1, relu=False, tile_hint=hint).cpu().numpy()
+    assert np.array_equal(got, again)

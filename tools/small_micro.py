@@ -1,18 +1,15 @@
-"""Fused BasicBlock launch vs its two F(4x4,3x3) convolution launches, us per launch (HIP events inside the single-op entry points)."""
+"""Small-map F(4x4,3x3) kernel vs the direct split-K kernel on the 14x14 / 7x7 layers, us per launch."""
 import importlib, os, sys, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("GRNET_CONV_REPS", "50")
 pkg = importlib.import_module("video-based-gait-analysis-for-dementia_amd")
 m = pkg.build_synthetic_model(max_frames=2, with_gru=False)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-for c, hw in ((32, 56), (64, 28)):
+for c, hw, hints in ((128, 14, (0, 2022, 2024)), (256, 7, (0, 2022, 2024)), (256, 14, (0, 2024))):
     x = torch.randn(n, c, hw, hw, device="cuda")
     r = torch.randn(n, c, hw, hw, device="cuda")
     w = (np.random.randn(c, c, 3, 3) * 0.05).astype(np.float32)
     b = np.zeros(c, np.float32)
     print(f"--- {c} ch @ {hw}x{hw}, n = {n}", file=sys.stderr)
-    m.op_conv2d(x, w, b, relu=True, tile_hint=2001)
-    m.op_conv2d(x, w, b, relu=True, add=r, tile_hint=2001)
-    m.op_basic_block(x, w, b, w, b)
-    for hint in ((2011, 2012) if hw == 56 else (2011, 2012, 2014)):
+    for hint in hints:
         m.op_conv2d(x, w, b, relu=True, add=r, tile_hint=hint)

@@ -363,6 +363,17 @@ hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s, int* n_launches) {
     return a.W == 56 ? launch_wino4_w<56>(a, s, nb, n_launches) : launch_wino4_w<28>(a, s, nb, n_launches);
 }
 
+// the filter transform of F(4x4,3x3), U = G g G^T, in fp64: g (3,3) row-major -> u[i * 6 + j]
+void wino4_transform_filter(const double* g, double* u) {
+    static const double G[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    double t[6][3];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 3; ++j) t[i][j] = G[i][0] * g[j] + G[i][1] * g[3 + j] + G[i][2] * g[6 + j];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) u[i * 6 + j] = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
+}
+
 // U = G g G^T per (cout, cin) in fp64 -> [36][cin_pad][cout_pad] fp32; w: (cout, cin, 3, 3) folded weights (double)
 void pack_wino4_weights(const double* w, int cout, int cin, int cin_pad, int cout_pad, float* out, int wid) {
     static const double G[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},

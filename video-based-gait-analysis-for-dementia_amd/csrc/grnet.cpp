@@ -65,9 +65,13 @@ struct ConvLayer {
     float* b_dev = nullptr;
     float* wino4_dev = nullptr; // transformed weights [36][cin_pad][cout_pad] of the Winograd F(4x4,3x3) kernel (the widest 56x56 layers only)
     float* wino_dev = nullptr;  // transformed weights [16][cin_pad][cout_pad] of the Winograd F(2x2,3x3) kernel (eligible fp32 layers only)
+    float* wino4r_dev = nullptr; // transformed weights of the register-resident F(4x4,3x3) kernels (conv_wino4r.hip: the narrow HR branches; conv_wino4s.hip: 14x14 / 7x7 maps)
+    bool small_map = false;      // wino4r_dev belongs to conv_wino4s.hip
     int cin_pad = 0, cout_pad = 0;
     double macs_per_frame = 0;
     int lane_hint = 0;          // lane of this convolution when it is launched on its own (not as a group member)
+    int block_role = 0;         // 1 / 2: first / second convolution of a BasicBlock that the fused kernel can run (conv_wino4_block.hip)
+    int block_peer = -1;        // index of the other convolution of that block
     std::map<int, int> tuned;   // n_frames -> launch configuration (tile hint) measured fastest by grnet_tune
 };
 
@@ -319,11 +323,13 @@ struct grnet {
         cur_lane = 0;
         for (int k = 0; k < 4; ++k) {
             std::vector<View> y(nb);
+            std::vector<int> first(nb);
             begin_group();
             for (int b = 0; b < nb; ++b) {
                 cur_lane = b;
                 const std::string q = p + "branches." + std::to_string(b) + "." + std::to_string(k) + ".";
                 y[b] = conv_bn(xs[b], q + "conv1.weight", q + "bn1", kBranchCh[b], 3, 1, true);
+                first[b] = (int)convs.size() - 1;
             }
             end_group();
             begin_group();
@@ -331,6 +337,11 @@ struct grnet {
                 cur_lane = b;
                 const std::string q = p + "branches." + std::to_string(b) + "." + std::to_string(k) + ".";
                 xs[b] = conv_bn(y[b], q + "conv2.weight", q + "bn2", kBranchCh[b], 3, 1, true, {AddRef{xs[b], 0}});
+                if (dtype == 0 && bblock_wino4_eligible(kBranchCh[b], xs[b].h, xs[b].w)) {
+                    const int second = (int)convs.size() - 1;
+                    convs[first[b]].block_role = 1; convs[first[b]].block_peer = second;
+                    convs[second].block_role = 2; convs[second].block_peer = first[b];
+                }
             }
             end_group();
         }
@@ -829,7 +840,9 @@ struct grnet {
                           (L.in.w == 56 || (L.in.c >= (wino4_env ? 64 : 128) && L.cout % 64 == 0));
         const bool wino4 = wino && wino4_env && L.in.c >= (wino4_env >= 2 ? 32 : 64) && L.cout >= (wino4_env >= 2 ? 32 : 64) &&
                            conv_wino4_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size());
-        std::vector<double> wfold(wino ? (size_t)L.cout * cin * 9 : 0);     // BN-folded weights (cout, cin, 3, 3) for the filter transform
+        const bool wino4s = !bf && wino4_env && cin == L.in.c && conv_wino4s_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size()) &&
+                            (L.adds.empty() || L.adds[0].shift == 0);          // the small maps: conv_wino4s.hip
+        std::vector<double> wfold(wino || wino4s ? (size_t)L.cout * cin * 9 : 0);     // BN-folded weights (cout, cin, 3, 3) for the filter transform
         int co0 = 0;
         for (auto& s : L.segs) {
             const HostTensor* w = find(s.wkey);
@@ -859,7 +872,7 @@ struct grnet {
                     for (int t = 0; t < taps; ++t) {
                         const double wv = (double)w->data[((size_t)co * cin + ci) * taps + t] * scale[co];
                         wp[bf ? ((((size_t)(ci / 32) * taps + t) * L.cout_pad + co0 + co) * 32 + ci % 32) : ((size_t)t * L.cin_pad + ci) * L.cout_pad + co0 + co] = (float)wv;
-                        if (wino) wfold[((size_t)(co0 + co) * cin + ci) * 9 + t] = wv;
+                        if (wino || wino4s) wfold[((size_t)(co0 + co) * cin + ci) * 9 + t] = wv;
                     }
             }
             co0 += s.cout;
@@ -874,6 +887,12 @@ struct grnet {
             return rc;
         }
         if ((rc = upload(bp, &L.b_dev))) return rc;
+        if (wino4s) {
+            std::vector<float> uwr((size_t)36 * cin * L.cout);
+            pack_wino4r_weights(wfold.data(), L.cout, cin, uwr.data());
+            if ((rc = upload(uwr, &L.wino4r_dev))) return rc;
+            L.small_map = true;
+        }
         if (wino) {                                            // U = G g G^T of the folded filter, fp64 -> fp32
             std::vector<float> uw((size_t)16 * L.cin_pad * L.cout_pad);
             pack_wino_weights(wfold.data(), L.cout, cin, L.cin_pad, L.cout_pad, uw.data());
@@ -882,6 +901,11 @@ struct grnet {
                 std::vector<float> uw4((size_t)36 * L.cin_pad * L.cout_pad);
                 pack_wino4_weights(wfold.data(), L.cout, cin, L.cin_pad, L.cout_pad, uw4.data(), L.in.w);
                 if ((rc = upload(uw4, &L.wino4_dev))) return rc;
+            }
+            if (wino4 && conv_wino4r_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size()) && cin == L.in.c) {
+                std::vector<float> uwr((size_t)36 * cin * L.cout);
+                pack_wino4r_weights(wfold.data(), L.cout, cin, uwr.data());
+                if ((rc = upload(uwr, &L.wino4r_dev))) return rc;
             }
         }
         return 0;
@@ -1398,8 +1422,39 @@ struct grnet {
                     break;
                 case Op::CONV: {
                     const ConvLayer& L = convs[op.conv_idx];
+                    static const int fuse_env = getenv("GRNET_FUSE_BLOCKS") ? atoi(getenv("GRNET_FUSE_BLOCKS")) : 0;
+                    const bool fuse = fuse_env && L.block_role && dtype == 0 && wino_mode && !conv_tile_hint && L.wino4_dev && convs[L.block_peer].wino4_dev &&
+                                      ((fuse_env & 1) || L.in.w != 56) && ((fuse_env & 2) || L.in.w != 28);
+                    if (fuse && L.block_role == 2) break;           // its launch happened with the first convolution of the block
+                    if (fuse) {
+                        const ConvLayer& L2 = convs[L.block_peer];
+                        BlockArgs ba{};
+                        ba.in = L.in.p; ba.in_ctot = L.in.ctot; ba.in_coff = L.in.coff;
+                        ba.out = L2.out.p; ba.out_ctot = L2.out.ctot; ba.out_coff = L2.out.coff;
+                        ba.N = n;
+                        ba.w1 = L.wino4_dev; ba.b1 = L.b_dev; ba.w2 = L2.wino4_dev; ba.b2 = L2.b_dev;
+                        ba.prio = 1;
+                        HIP_TRY(launch_bblock_wino4(ba, L.cout, L.in.h, L.in.w, s));
+                        ++launches;
+                        break;
+                    }
+                    static const int w4r_env = getenv("GRNET_WINO4R") ? atoi(getenv("GRNET_WINO4R")) : 0;      // bit 0: the 56x56 branch, bit 1: the 28x28 branch
+                    static const int w4r_ks56 = getenv("GRNET_WINO4R_KS56") ? atoi(getenv("GRNET_WINO4R_KS56")) : 2;
+                    static const int w4r_ks28 = getenv("GRNET_WINO4R_KS28") ? atoi(getenv("GRNET_WINO4R_KS28")) : 2;
+                    static const int w4s_env = getenv("GRNET_WINO4S") ? atoi(getenv("GRNET_WINO4S")) : 7;      // bit 0: 128 @14x14, bit 1: 256 @7x7, bit 2: 256 @14x14
+                    static const int w4s_ks = getenv("GRNET_WINO4S_KS") ? atoi(getenv("GRNET_WINO4S_KS")) : 0;
                     if (dtype == 1) HIP_TRY(launch_conv_bf16(conv_args(L, frames, n), s, hint_for(L, n)));
-                    else if (L.wino4_dev && wino_mode && !conv_tile_hint) {
+                    else if (L.wino4r_dev && L.small_map && wino_mode && !conv_tile_hint && (w4s_env & (L.in.w == 7 ? 2 : L.in.c == 128 ? 1 : 4))) {
+                        ConvArgs wa = conv_args(L, frames, n);
+                        wa.w = L.wino4r_dev;
+                        HIP_TRY(launch_conv_wino4s(wa, s, w4s_ks));
+                    } else if (L.wino4r_dev && !L.small_map && wino_mode && !conv_tile_hint && (w4r_env & (L.in.w == 56 ? 1 : 2))) {
+                        ConvArgs wa = conv_args(L, frames, n);
+                        wa.w = L.wino4r_dev;
+                        static const int chain_prio4r = getenv("GRNET_WINO_PRIO") ? atoi(getenv("GRNET_WINO_PRIO")) : 1;
+                        wa.prio = chain_prio4r;
+                        HIP_TRY(launch_conv_wino4r(wa, s, L.in.w == 56 ? w4r_ks56 : w4r_ks28));
+                    } else if (L.wino4_dev && wino_mode && !conv_tile_hint) {
                         ConvArgs wa = conv_args(L, frames, n);
                         wa.w = L.wino4_dev;
                         static const int chain_prio4 = getenv("GRNET_WINO_PRIO") ? atoi(getenv("GRNET_WINO_PRIO")) : 1;
@@ -1977,7 +2032,9 @@ double grnet_conv_flops_per_frame(grnet_t* h) {
 double grnet_conv_executed_flops_per_frame(grnet_t* h) {
     if (!h) return 0;
     double m = 0;
-    for (auto& L : h->convs) m += L.macs_per_frame * (h->wino_mode && h->dtype == 0 ? (L.wino4_dev ? 0.25 : L.wino_dev ? 4.0 / 9.0 : 1.0) : 1.0);
+    // F(4x4,3x3): 36 multiplies per 4x4 tile instead of 144; the small maps pay for their padding (14 -> 16, 7 -> 8 per side)
+    for (auto& L : h->convs)
+        m += L.macs_per_frame * (h->wino_mode && h->dtype == 0 ? (L.small_map ? 0.25 * (L.in.w == 14 ? 256.0 / 196.0 : 64.0 / 49.0) : L.wino4_dev ? 0.25 : L.wino_dev ? 4.0 / 9.0 : 1.0) : 1.0);
     return 2.0 * m;
 }
 
@@ -2080,7 +2137,43 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
         }
         a.w = ud;
     }
-    auto launch_one = [&]() { return tile_hint == 2000 ? launch_conv_wino(a, s) : tile_hint == 2001 ? launch_conv_wino4(a, s) : launch_conv(a, s, tile_hint); };
+    int w4r_ks = 0;
+    if (tile_hint >= 2010 && tile_hint <= 2014) {              // the register-resident F(4x4,3x3) kernel, 201k: k waves split the input channels (0: default)
+        w4r_ks = tile_hint == 2010 ? 2 : tile_hint - 2010;
+        if (!conv_wino4r_eligible(cin, cout, ks, stride, hgt, wid, add_dev ? 1 : 0) || (w4r_ks != 1 && w4r_ks != 2 && !(w4r_ks == 4 && wid == 28))) {
+            hipFree(wd); hipFree(bd);
+            return h->fail(GRNET_EINVAL, "shape not eligible for the register-resident F(4x4,3x3) kernel");
+        }
+        std::vector<double> wf((size_t)cout * cin * 9);
+        for (size_t i = 0; i < wf.size(); ++i) wf[i] = w_host[i];
+        std::vector<float> uw((size_t)36 * cin * cout);
+        pack_wino4r_weights(wf.data(), cout, cin, uw.data());
+        if (hipMalloc(reinterpret_cast<void**>(&ud), uw.size() * 4) != hipSuccess || hipMemcpy(ud, uw.data(), uw.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            hipFree(wd); hipFree(bd); if (ud) hipFree(ud);
+            return h->fail(GRNET_ENOMEM, "Winograd test weights");
+        }
+        a.w = ud;
+    }
+    int w4s_on = 0, w4s_ks = 0;
+    if (tile_hint >= 2020 && tile_hint <= 2024) {              // the small-map F(4x4,3x3) kernel, 202k: k waves split the input channels (0: default)
+        w4s_on = 1; w4s_ks = tile_hint - 2020;
+        if (!conv_wino4s_eligible(cin, cout, ks, stride, hgt, wid, add_dev ? 1 : 0)) {
+            hipFree(wd); hipFree(bd);
+            return h->fail(GRNET_EINVAL, "shape not eligible for the small-map F(4x4,3x3) kernel");
+        }
+        std::vector<double> wf((size_t)cout * cin * 9);
+        for (size_t i = 0; i < wf.size(); ++i) wf[i] = w_host[i];
+        std::vector<float> uw((size_t)36 * cin * cout);
+        pack_wino4r_weights(wf.data(), cout, cin, uw.data());
+        if (hipMalloc(reinterpret_cast<void**>(&ud), uw.size() * 4) != hipSuccess || hipMemcpy(ud, uw.data(), uw.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            hipFree(wd); hipFree(bd); if (ud) hipFree(ud);
+            return h->fail(GRNET_ENOMEM, "Winograd test weights");
+        }
+        a.w = ud;
+    }
+    auto launch_one = [&]() {
+        return w4s_on ? launch_conv_wino4s(a, s, w4s_ks) : w4r_ks ? launch_conv_wino4r(a, s, w4r_ks) : tile_hint == 2000 ? launch_conv_wino(a, s) : tile_hint == 2001 ? launch_conv_wino4(a, s) : launch_conv(a, s, tile_hint);
+    };
     hipError_t e = launch_one();
     if (const char* r = getenv("GRNET_CONV_REPS")) {           // timing loop for tools/conv_micro.py
         const int reps = atoi(r);

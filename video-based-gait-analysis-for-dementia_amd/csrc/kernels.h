@@ -107,6 +107,14 @@ hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s, int* n_launches = nullpt
 void pack_wino4_weights(const double* w_folded /* (cout,cin,3,3) */, int cout, int cin, int cin_pad, int cout_pad, float* out, int map_width = 56);
 int conv_wino4_blocks(int cout, int map_width);   // 16-channel blocks per workgroup of that layer (4 or 2)
 
+void wino4_transform_filter(const double* g33, double* u36);   // U = G g G^T of F(4x4,3x3) in fp64
+// ---- the register-resident F(4x4,3x3) kernel of the narrow HR branches (conv_wino4r.hip): 32 -> 32 @56x56, 64 -> 64 @28x28
+bool conv_wino4r_eligible(int cin, int cout, int ks, int stride, int h, int w, int n_add);
+hipError_t launch_conv_wino4r(ConvArgs a, hipStream_t s, int ksplit);      // a.w = pack_wino4r_weights; ksplit: waves splitting the input channels (1, 2; 4 on 28x28)
+void pack_wino4r_weights(const double* w_folded /* (cout,cin,3,3) */, int cout, int cin, float* out /* 36*cin*cout */);
+// ---- the same structure for the small maps (conv_wino4s.hip): 128 -> 128 @14x14, 256 -> 256 @7x7 (HR branches 2, 3), 256 -> 256 @14x14
+bool conv_wino4s_eligible(int cin, int cout, int ks, int stride, int h, int w, int n_add);
+hipError_t launch_conv_wino4s(ConvArgs a, hipStream_t s, int ksplit);      // a.w = pack_wino4r_weights; ksplit 0: the shape's default
 // ---- a whole BasicBlock (conv3x3-BN-ReLU-conv3x3-BN-(+x)-ReLU, hrnet.py:30-59) of the 32-channel 56x56 / 64-channel 28x28 HR branches in
 // ONE launch (conv_wino4_block.hip): both convolutions as F(4x4,3x3), the intermediate tensor stays in LDS
 struct BlockArgs {
