@@ -43,7 +43,10 @@ def flush_windows(n_videos, max_vid):
     return [(a, b) for a, b in zip(cuts, cuts[1:]) if b > a]
 
 
-def prepare_data(fv, vid_folder, outpath, pretrained_file=None, synthetic_weights=False, max_frames=128, dtype="f32", chunk=None):
+def prepare_data(fv, vid_folder, outpath, pretrained_file=None, synthetic_weights=False, max_frames=128, dtype="f32", chunk=None,
+                 model_factory=None, backend="nccl"):
+    """model_factory(local_rank) -> model and backend="gloo" are the seam of the CPU tests (tests/test_host_cpu.py): the window / plan /
+    run / gather / flush logic below then runs under two gloo ranks with a stand-in model and tensors on the CPU."""
     import joblib
     import torch
     pkg = importlib.import_module(PKG)
@@ -54,13 +57,20 @@ def prepare_data(fv, vid_folder, outpath, pretrained_file=None, synthetic_weight
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    torch.cuda.set_device(local_rank)
+    on_gpu = backend == "nccl"
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    if synthetic_weights:
+        if on_gpu:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    if model_factory is not None:
+        model = model_factory(local_rank)
+    elif synthetic_weights:
         model = pkg.build_synthetic_model(max_frames=max_frames, device_id=local_rank, with_gru=False, dtype=dtype)
     else:
         model = pkg.GRNet(writer=None, seqlen=100, featcorr=None, max_frames=max_frames, device_id=local_rank, dtype=dtype)
@@ -68,7 +78,7 @@ def prepare_data(fv, vid_folder, outpath, pretrained_file=None, synthetic_weight
         model.load_state_dict(ckpt, strict=True)              # batch_generation.py:218
         model.finalize()
     chunk = int(chunk or max_frames)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
     db = pipe.BatchDb(outpath) if rank == 0 else None
     vidnames = sorted(os.listdir(vid_folder), key=vid_sort_key)
     start, n_done = time.time(), 0
@@ -94,9 +104,10 @@ def prepare_data(fv, vid_folder, outpath, pretrained_file=None, synthetic_weight
                 continue
             # run_on_frames scales the boxes it is given by 1.1 in place (as Inference.__init__ does, inference.py:48):
             # hand it a copy of the UNSCALED rows; the database rows are scaled once below, on every rank alike
-            kp = pipe.run_on_frames(model, vids[vi][1], np.arange(lo, hi), vids[vi][2][lo:hi].copy(), batch_size=chunk)["kp_3d"]
-            mine.append(torch.from_numpy(kp.reshape(hi - lo, 75)))
-        local = torch.cat(mine, 0).to(dev) if mine else torch.zeros(0, 75, device=dev)
+            # the joints stay on the device: no host synchronisation per work item, one all-gather per window
+            kp = pipe.run_on_frames(model, vids[vi][1], np.arange(lo, hi), vids[vi][2][lo:hi].copy(), device=dev, batch_size=chunk, on_device=True)["kp_3d"]
+            mine.append(kp.reshape(hi - lo, 75))
+        local = torch.cat(mine, 0) if mine else torch.zeros(0, 75, device=dev)
         per_video = harness.gather_work_items(items, local, 75, world, rank, dist, dev)
         if rank == 0:
             for vi, (key, _, bboxes) in enumerate(vids):
@@ -110,7 +121,8 @@ def prepare_data(fv, vid_folder, outpath, pretrained_file=None, synthetic_weight
     if rank == 0:
         print(f"=====>>> Generation frame rate: {n_done / max(time.time() - start, 1e-9):.1f}")
         print(f"Save database to {db.flush()}.")
-    model.close()
+    if hasattr(model, "close"):
+        model.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -54,7 +54,7 @@ def parse_args(argv=None):
                     "2: + in-context greedy refinement (~20 s, untimed)")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32", help="f32: the headline (BASELINE configs[1]); bf16: bf16 storage / "
                     "fp32 accumulation on the bf16 matrix cores (configs[2] with --frames 256), errors vs the fp32 oracle reported in `parity`")
-    ap.add_argument("--tune-cache", default=None, help="tuning table file (default: the packaged table for this dtype and clip length, if any)")
+    ap.add_argument("--tune-cache", default=None, help="tuning table file written by a previous run (default: none, grnet_tune measures)")
     return ap.parse_args(argv)
 
 
@@ -147,16 +147,21 @@ def roofline_object(fps_per_gpu, dtype, conv_flops_per_frame, conv_ms, conv_ms_s
                        "count); the whole step -- pooling, tail, SMPL, launch gaps -- is charged to the convolutions.  On the fp32 path the Winograd "
                        "layers (76 % of F_frame) execute 4x fewer multiplies than counted here (F(4x4,3x3)), in fp32 throughout",
          "traffic": None,
-         "kernel": ("conv_wino4_f32 (Winograd F(4x4,3x3) on the fp32 matrix cores: the 3x3 stride-1 layers on 56x56 maps and the >= 64-channel ones on "
-                    "28x28 maps) + conv_mfma_f32 / conv_splitk_f32 (fp32 MFMA implicit-GEMM convolution: everything else), "
-                    "all launches of a step" if dtype == "f32"
+         "kernel": ("conv_wino4_f32 (Winograd F(4x4,3x3) on the fp32 matrix cores: the 3x3 stride-1 layers on 56x56 and 28x28 maps) + conv_wino4s_f32 "
+                    "(the same on 14x14 / 7x7 maps, register-resident) + conv_mfma_f32 / conv_splitk_f32 (fp32 MFMA implicit-GEMM convolution: "
+                    "1x1, stride-2 and stem layers), all launches of a step" if dtype == "f32"
                     else "conv_bf16_nhwc (bf16 MFMA implicit-GEMM convolution on NHWC activations, all launches of a step)"),
          "conv_launches_per_step": n_conv, "conv_gflop_per_step": round(conv_flops / 1e9, 3),
          "gflop_per_launch": round(conv_flops / 1e9 / max(n_conv, 1), 4)}
     if executed_flops_per_frame and executed_flops_per_frame != conv_flops_per_frame:
         ex = fps_per_gpu * executed_flops_per_frame / 1e12
-        r.update(executed_gflop_per_step=round(executed_flops_per_frame * n / 1e9, 3), executed_achieved=round(ex, 3), executed_frac=round(ex / peak, 4),
-                 executed_note="the multiplies the matrix cores were asked to do: F(4x4,3x3) layers at 1/4, F(2x2,3x3) layers at 4/9 of their direct-convolution count")
+        floor_ms = executed_flops_per_frame * n / (peak * 1e12) * 1e3
+        r.update(frac_is="effective (direct-convolution-equivalent) utilisation, NOT the share of peak the matrix cores executed: that is executed_frac",
+                 executed_gflop_per_step=round(executed_flops_per_frame * n / 1e9, 3), executed_achieved=round(ex, 3), executed_frac=round(ex / peak, 4),
+                 floor_ms=round(floor_ms, 4), step_over_floor=round(n / fps_per_gpu * 1e3 / floor_ms, 3),
+                 executed_note="the multiplies the matrix cores were asked to do: F(4x4,3x3) layers at 1/4 of their direct-convolution count (x 256/196 on "
+                               "14x14 and x 64/49 on 7x7 maps, whose tiles are padded to 16x16 / 8x8), F(2x2,3x3) layers at 4/9; floor_ms = that work at the "
+                               "fp32 matrix peak, step_over_floor = ms_per_step / floor_ms")
     if conv_ms:
         r.update(conv_only_ms_per_step=round(conv_ms, 4), conv_only_achieved=round(conv_flops / (conv_ms * 1e-3) / 1e12, 3),
                  conv_only_frac=round(conv_flops / (conv_ms * 1e-3) / 1e12 / peak, 4),
@@ -170,24 +175,30 @@ def roofline_object(fps_per_gpu, dtype, conv_flops_per_frame, conv_ms, conv_ms_s
     return r
 
 
-def stored_traffic(n, dtype):
-    """HBM bytes per step of the conv launches from the PMC passes (tools/gpu_pmc.sh -> profiles/): a static, committed
-    measurement of this same workload, not collected inside this run (counters need their own rocprofv3 passes)."""
+TRAFFIC_FILE = "r03_pmc_traffic.json"      # THIS round's counter passes (tools/gpu_profile_r03.sh -> tools/summarize_profiles.py r03)
+
+
+def stored_traffic(n, dtype, algorithmic_bytes=None):
+    """HBM bytes per step of the conv launches from the PMC passes (profiles/): a static, committed measurement of this same
+    workload and these same kernels, not collected inside this run (counters need their own rocprofv3 passes).  Only the
+    current round's file is read -- a missing or other-round file gives traffic = null with the reason, never an older number."""
+    out = {"traffic": None, "algorithmic_bytes": algorithmic_bytes}
     if not (n == FRAMES_PER_GPU and dtype == "f32"):
-        return None
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                tj = json.load(f)
-        except OSError:
-            continue
-        return {"traffic": tj.get("hbm_bytes_per_step_conv_kernels"),
-                "traffic_calibrated": tj.get("hbm_bytes_per_step_conv_kernels_calibrated"),
-                "algorithmic_bytes": tj.get("algorithmic_bytes_per_step_conv_kernels"),
-                "traffic_source": f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this workload "
-                                  "(FETCH x2 gfx950 correction), bytes of all conv launches of one step; a stored measurement, "
-                                  "not taken inside this run"}
-    return None
+        out["traffic_source"] = "none: counter passes exist for the fp32 16-frame workload only"
+        return out
+    path = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
+    try:
+        with open(path) as f:
+            tj = json.load(f)
+    except OSError:
+        out["traffic_source"] = f"none: profiles/{TRAFFIC_FILE} is missing (the counter passes of this round were not taken)"
+        return out
+    out["traffic"] = tj.get("hbm_bytes_per_step_conv_kernels")
+    out["traffic_over_algorithmic"] = round(out["traffic"] / algorithmic_bytes, 3) if out["traffic"] and algorithmic_bytes else None
+    out["traffic_source"] = (f"profiles/{TRAFFIC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this workload with this "
+                             "round's kernels (FETCH x2 gfx950 correction per MI355X_MICROARCH.md, an upper bound for the narrow staging patterns), "
+                             "bytes of all conv launches of one step; a stored measurement, not taken inside this run")
+    return out
 
 
 def cpu_baseline(pkg, frames_np, budget_s=20.0):
@@ -205,7 +216,7 @@ def cpu_baseline(pkg, frames_np, budget_s=20.0):
             continue
         torch.set_num_threads(t)
         t0 = time.perf_counter()
-        oracle.grnet_forward(frames_np[:4], sd, smpl)
+        oracle.grnet_forward(frames_np, sd, smpl)             # the probe runs the SAME clip the timed passes run
         dt = time.perf_counter() - t0
         if best_dt is None or dt < best_dt:
             best_t, best_dt = t, dt
@@ -220,7 +231,7 @@ def cpu_baseline(pkg, frames_np, budget_s=20.0):
     n = frames_np.shape[0] * passes
     return {"value": round(n / t_all, 3), "unit": "frames/s", "cores": best_t, "host_cores": os.cpu_count(), "kind": "port",
             "sample": f"{passes} passes of the oracle (torch-CPU oneDNN convs + numpy tail) over the same {frames_np.shape[0]} frames, "
-                      f"fp32, {best_t} threads used (fastest of a probe over 8..{all_threads}) on a host with {os.cpu_count()} logical cores"}, ref
+                      f"fp32, {best_t} threads used (fastest of a probe over 8..{all_threads} on the same clip) on a host with {os.cpu_count()} logical cores"}, ref
 
 
 def parity_vs_oracle(got, ref):
@@ -259,10 +270,7 @@ class GpuWorkload:
         self.model = pkg.build_synthetic_model(max_frames=n, device_id=local_rank, with_gru=False, dtype=args.dtype)
         self.frames_np = pkg.synth.make_frames(n, start=rank * n)
         frames = torch.from_numpy(self.frames_np).cuda()
-        cache = args.tune_cache or os.path.join(ROOT, PKG, "tuning", f"mi355x_{args.dtype}_n{n}.txt")
-        if not (args.tune_cache or os.path.isfile(cache)):
-            cache = None
-        self.cache = cache
+        cache = self.cache = args.tune_cache                  # a table exported by grnet_get_tuning; default: measure (grnet_tune)
         mk = lambda m: harness.ClipRunner(m, frames, use_graph=not args.no_graph, world=world, rank=rank, dist=dist,
                                           tune_level=args.tune_level, tune_cache=cache)
         self.runner = mk(self.model)
@@ -299,7 +307,9 @@ class GpuWorkload:
                 "frames_per_gpu": n, "clips_in_flight": len(self.runners), "launch": launch_desc,
                 "kernel_launches_per_step": model.num_kernel_launches(),
                 "launch_configs": ("stored table " + os.path.relpath(self.cache, ROOT)) if self.cache else f"grnet_tune level {args.tune_level}",
-                "exchange": "none (1 GPU)" if self.world == 1 else "RCCL all-gather of per-frame pose results"}
+                "exchange": "none (1 GPU)" if self.world == 1 else
+                            (("RCCL" if os.environ.get("GRNET_BENCH_BACKEND", "nccl") == "nccl" else os.environ["GRNET_BENCH_BACKEND"] + " (rehearsal backend)") +
+                             " all-gather of per-frame pose results")}
 
     def roofline(self, fps_per_gpu):
         model, n, pkg = self.model, self.n, self.pkg
@@ -307,8 +317,13 @@ class GpuWorkload:
         model.set_option(pkg._lib.OPT_MULTI_LANE, 0)          # the same launches one after another on one stream
         conv_ms_serial = min(model.time_convs(n) for _ in range(3))
         model.set_option(pkg._lib.OPT_MULTI_LANE, 1)
+        alg_bytes = None
+        if self.args.dtype == "f32":                          # input + fused addends + weights read once, output written once, fp32
+            alg_bytes = 0
+            for c in model.describe_convs():
+                alg_bytes += 4 * (n * (c["cin"] * c["hin"] * c["win"] + c["cout"] * c["hout"] * c["wout"] + c["add_elems"]) + c["ks"] * c["ks"] * c["cin"] * c["cout"])
         return roofline_object(fps_per_gpu, self.args.dtype, model.conv_flops_per_frame(), conv_ms, conv_ms_serial,
-                               model.num_conv_launches(), n, stored_traffic(n, self.args.dtype),
+                               model.num_conv_launches(), n, stored_traffic(n, self.args.dtype, alg_bytes),
                                executed_flops_per_frame=model.conv_executed_flops_per_frame())
 
     def extras(self, line):

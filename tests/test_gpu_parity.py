@@ -413,17 +413,29 @@ def test_temporal_modules_single_frame_and_long_clip(pkg, oracle):
 
 def test_parity_bar_holds_over_128_frames(pkg, oracle, synth_weights, synth_smpl):
     """The 1e-3 bar of the north star on 128 different frames (the shards of all 8 ranks of the weak-scaling bench), not only on the
-    golden four: the worst frame has nearly collinear 6-D rotation vectors, which amplifies the kernels' ~4e-6 by ~50x -- still 4x
-    inside the bar; the median frame is at 4e-6."""
+    golden four.  The worst frame is the one whose two 6-D rotation vectors are nearly collinear (Gram-Schmidt amplifies the kernels'
+    noise there); its distance to the bar is MEASURED here, written to gpurun_out/parity_128_frames.json (copied to profiles/ and
+    quoted in DESIGN.md) and held to half the bar, so a kernel change that eats the margin fails before it reaches the bar itself."""
+    import json, os
+    from .conftest import ROOT
     n = 128
     frames = pkg.synth.make_frames(n)
     m = pkg.build_synthetic_model(max_frames=64, with_gru=False)
     out = m(torch.from_numpy(frames).cuda())[-1]
     torch.cuda.synchronize()
     ref = oracle.grnet_forward(frames, synth_weights, synth_smpl)
+    report = {}
     for k in ("theta", "kp_3d", "kp_2d", "verts", "rotmat"):
         a, r = out[k].cpu().numpy().reshape(n, -1), np.asarray(ref[k]).reshape(n, -1)
         per_frame = np.abs(a - r).max(1) / np.abs(r).max()
-        assert per_frame.max() < 1e-3, (k, float(per_frame.max()), int(per_frame.argmax()))      # the bar itself
-        assert np.median(per_frame) < 2e-5, k
+        report[k] = {"worst_frame_rel_err": float(per_frame.max()), "worst_frame": int(per_frame.argmax()), "median_frame_rel_err": float(np.median(per_frame)),
+                     "bar": 1e-3, "margin_x": float(1e-3 / per_frame.max())}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "parity_128_frames.json"), "w") as f:
+        json.dump(report, f, indent=1)
+    print("parity over 128 frames:", json.dumps(report))
+    for k, v in report.items():
+        assert v["worst_frame_rel_err"] < 1e-3, f"{k}: worst of 128 frames {v['worst_frame_rel_err']:.3e} (frame {v['worst_frame']}) is outside the 1e-3 bar"
+        assert v["worst_frame_rel_err"] < 5e-4, f"{k}: worst of 128 frames {v['worst_frame_rel_err']:.3e} (frame {v['worst_frame']}): less than 2x inside the bar"
+        assert v["median_frame_rel_err"] < 2e-5, (k, v)
     m.close()

@@ -115,3 +115,25 @@ def test_small_map_winograd_kernel(model, oracle, case):
     assert rel_err(got[:, :, [0, hw - 1]], lin[:, :, [0, hw - 1]]) < 1e-4 and rel_err(got[..., [0, hw - 1]], lin[..., [0, hw - 1]]) < 1e-4
     again = model.op_conv2d(xd, w, None, stride=1, relu=False, tile_hint=hint).cpu().numpy()
     assert np.array_equal(got, again)
+
+
+def test_attention_block_takes_clips_longer_than_4096_frames(pkg, oracle):
+    """The attention block of the temporal branch on ONE clip of 4 200 frames (round 2 refused n > 4096 deep inside launch_tsattn,
+    after the GRU had been enqueued): same kernels, the softmax row over the clip's frames is 4 200 floats of LDS.  Checked against the
+    oracle; the limit that remains (32 768 frames per clip: 128 KB of LDS) is refused UP FRONT with a message that says what to do, by
+    grnet_tsattn_forward and by grnet_gait_correct alike."""
+    m = pkg.build_synthetic_model(max_frames=2, with_gru=True, with_tsattn=True, use_gait_feat=False)
+    tsd = pkg.synth.make_tsattn_state_dict()
+    x, xs = pkg.synth.make_tsattn_inputs(1, 4200)
+    y = m.tsattn_forward(torch.from_numpy(x).cuda(), torch.from_numpy(xs).cuda()).cpu().numpy()
+    ref = oracle.ts_attn_block(x, xs, tsd)
+    assert y.shape == ref.shape and rel_err(y, ref) < 5e-5, rel_err(y, ref)
+    with pytest.raises(pkg._lib.GrnetError, match="split the sequence into clips"):
+        m.tsattn_forward(torch.zeros(1, 32769, 128, 24).cuda(), torch.zeros(1, 32769, 128, 25).cuda())
+    m.close()
+    mg = pkg.build_synthetic_model(max_frames=2, with_gru=True, use_gait_feat=True)
+    t = 32769
+    with pytest.raises(pkg._lib.GrnetError, match="split the sequence into clips"):
+        mg.gait_correct(torch.zeros(t, 128, 24).cuda(), torch.zeros(t, 64, 24).cuda(), torch.zeros(t, 3).cuda(), torch.zeros(1, t, 4).cuda(),
+                        torch.zeros(1, t, 2).cuda(), 1, t)
+    mg.close()

@@ -283,3 +283,74 @@ def test_convert_kps_matches_reference_for_every_skeleton(pkg):
         pipe.convert_kps(g["j29"], "spin2", "no_such_skeleton")
     with pytest.raises(IndexError):
         pipe.convert_kps(g["j29"], "spin", "common")                          # 29 joints passed as the 49-joint layout: as the reference
+
+
+class _StandInModel:
+    """A stand-in for GRNet in the batch_generation CPU test: kp_3d of a frame is a fixed function of the frame's pixels, so the
+    database tells whether every frame went through exactly once and landed in its own row."""
+
+    def __call__(self, x):                                    # x (1, n, 3, 224, 224)
+        f = x[0].reshape(x.shape[1], -1)
+        base = f[:, :87].reshape(-1, 29, 3) * 2.0 + f.mean(1)[:, None, None]
+        return [{"kp_3d": base.unsqueeze(0)}]
+
+
+def _stand_in_factory(local_rank):
+    return _StandInModel()
+
+
+def _write_video_dir(root, lengths):
+    import joblib
+    vid_folder = os.path.join(root, "videos")
+    annos = {}
+    g = np.random.Generator(np.random.Philox(key=[55, len(lengths)]))
+    for vi, n in enumerate(lengths):
+        name = f"S{vi + 1:03d}C001P001R001A{vi + 1:03d}"
+        os.makedirs(os.path.join(vid_folder, name))
+        for fi in range(n):
+            np.save(os.path.join(vid_folder, name, f"{fi:06d}.npy"), g.standard_normal((3, 224, 224)).astype(np.float32))
+        annos[name] = np.tile(np.array([[112.0, 112.0, 200.0, 200.0]], np.float32), (n, 1))
+    fv = os.path.join(root, "bbox.pkl")
+    joblib.dump(annos, fv)
+    return fv, vid_folder
+
+
+def _batchgen_worker(rank, world, port, root, fv, vid_folder, chunk, q):
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    bg = importlib.import_module("batch_generation")
+    written = bg.prepare_data(fv, vid_folder, os.path.join(root, f"db_w{world}.json"), max_frames=chunk, chunk=chunk,
+                              model_factory=_stand_in_factory, backend="gloo")
+    q.put((rank, written))
+
+
+def test_batch_generation_two_gloo_ranks_equal_one_process(tmp_path):
+    """batch_generation.prepare_data end to end under two gloo ranks with a stand-in model (window of videos -> work items dealt to
+    the ranks -> every rank runs its items and keeps the joints as tensors -> ONE all-gather -> rank 0 appends to the database):
+    the database equals the one a single process writes -- same video names frame by frame, same boxes (scaled 1.1 once), same
+    joints bit for bit -- for clips shorter and longer than a work item, and one rank may get nothing of a video."""
+    import joblib
+    root = str(tmp_path)
+    fv, vid_folder = _write_video_dir(root, [7, 23, 3, 12, 1])
+    dbs = {}
+    for world in (1, 2):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_batchgen_worker, args=(r, world, port, root, fv, vid_folder, 8, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = dict(q.get(timeout=180) for _ in procs)
+        for p in procs:
+            p.join(timeout=60)
+        assert len(res[0]) == 1 and all(res[r] == [] for r in range(1, world)), res        # only rank 0 writes
+        dbs[world] = joblib.load(res[0][0])
+    a, b = dbs[1], dbs[2]
+    assert list(a["vid_name"]) == list(b["vid_name"]) and len(a["vid_name"]) == 46
+    assert np.array_equal(a["bbox"], b["bbox"]) and np.allclose(a["bbox"][:, 2:], 220.0)
+    assert a["joints3D"].shape == (46, 25, 3) and np.array_equal(a["joints3D"], b["joints3D"])
+    assert np.unique(a["joints3D"].reshape(46, -1), axis=0).shape[0] == 46                  # every frame is its own

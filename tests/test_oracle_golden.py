@@ -245,3 +245,6 @@ def test_cv_inverse_affine_follows_the_reference_steps(pkg):
     b32 = boxes.astype(np.float32)
     inv32 = pkg.pipeline.cv_inverse_affine(b32, 1.1)
     assert np.allclose(inv32, pkg.pipeline.cv_inverse_affine(b32.astype(np.float64), 1.1), rtol=0, atol=0)
+    # a non-square box takes the reference's TWO-warp branch (img_utils.py:97-106), which the single inverse map does not model: refused, not stretched
+    with pytest.raises(ValueError):
+        pkg.pipeline.cv_inverse_affine(np.array([[100.0, 50.0, 300.0, 200.0]]), 1.1)

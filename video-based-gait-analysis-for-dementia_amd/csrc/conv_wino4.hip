@@ -331,7 +331,11 @@ static hipError_t launch_wino4_w(ConvArgs a, hipStream_t s, int nb, int* n_launc
     if (nb == 2) return launch_k(conv_wino4_f32<2, WD>, dim3(total), dim3(256), kLdsB, s, a);
     // a last round of workgroups that is at most half full runs as twice as many half-size workgroups (conv_wino.hip)
     static const int split_env = getenv("GRNET_WINO_SPLIT") ? atoi(getenv("GRNET_WINO_SPLIT")) : 1;
-    constexpr int kCUs = 256;
+    static int cu_count[64] = {};                        // workgroups per round = CUs of this device (one workgroup fits a CU)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!cu_count[dev] && hipDeviceGetAttribute(&cu_count[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return hipErrorInvalidDevice;
+    const int kCUs = cu_count[dev];
     const int full = total / kCUs * kCUs, rest = total - full;
     if (split_env && full > 0 && rest > 0 && 2 * rest <= kCUs && (!a.xcd || full % 8 == 0)) {
         hipError_t e = launch_k(conv_wino4_f32<4, WD>, dim3(full), dim3(256), kLdsB, s, a);

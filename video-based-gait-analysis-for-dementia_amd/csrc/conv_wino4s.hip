@@ -70,6 +70,8 @@ __global__ __launch_bounds__(64 * KS) void conv_wino4s_f32(const ConvArgs a) {
     const int id = blockIdx.x, jd = id >> 3;
     const int nb = (id & 7) + 8 * (jd % (NBK / 8)), grp = jd / (NBK / 8);
     const int img0 = grp * IPW;
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (a.prio >= 2) __builtin_amdgcn_s_setprio(3);
 
     // tile of this lane as A-operand row: x-major, so that the x neighbours are SH lanes away inside the 16-lane row
     const int tx = WD == 14 ? (l15 >> 2) : (l15 >> 3), ty = WD == 14 ? (l15 & 3) : (l15 & 1), ii = WD == 14 ? 0 : ((l15 >> 1) & 3);

@@ -92,6 +92,15 @@ struct Op {
 constexpr int kLanes = 8;            // streams available to the lane scheduler (the hand-written plan uses 4)
 
 // Every entry point runs on the handle's device whatever the caller's current device is, and leaves the caller's device as it found it.
+// The few-row GEMMs borrow split-K scratch through a thread-local pointer (set_gemm_workspace); this lease takes it back on every
+// exit path, so a failed call never leaves the pointer aimed at scratch the handle may free later.
+struct GemmWorkspaceLease {
+    GemmWorkspaceLease(float* ws, size_t floats) { set_gemm_workspace(ws, floats); }
+    ~GemmWorkspaceLease() { set_gemm_workspace(nullptr, 0); }
+    GemmWorkspaceLease(const GemmWorkspaceLease&) = delete;
+    GemmWorkspaceLease& operator=(const GemmWorkspaceLease&) = delete;
+};
+
 struct DeviceGuard {
     int prev = -1;
     bool switched = false;
@@ -1447,6 +1456,8 @@ struct grnet {
                     else if (L.wino4r_dev && L.small_map && wino_mode && !conv_tile_hint && (w4s_env & (L.in.w == 7 ? 2 : L.in.c == 128 ? 1 : 4))) {
                         ConvArgs wa = conv_args(L, frames, n);
                         wa.w = L.wino4r_dev;
+                        static const int w4s_prio = getenv("GRNET_WINO4S_PRIO") ? atoi(getenv("GRNET_WINO4S_PRIO")) : 3;   // bit 0: 14x14 layers, bit 1: 7x7 layers at wave priority 1
+                        wa.prio = (w4s_prio & (L.in.w == 7 ? 2 : 1)) ? 1 : 0;
                         HIP_TRY(launch_conv_wino4s(wa, s, w4s_ks));
                     } else if (L.wino4r_dev && !L.small_map && wino_mode && !conv_tile_hint && (w4r_env & (L.in.w == 56 ? 1 : 2))) {
                         ConvArgs wa = conv_args(L, frames, n);
@@ -1669,7 +1680,7 @@ struct grnet {
         const size_t own = al(M * 3) + al((size_t)b * 3) + al(M * 4) + al(M * 3072);
         float* ws = nullptr;
         if (int rc = temporal_scratch(kGemmWsFloats + gru_need + featcorr_ws_floats(b, T) + own, &ws)) return rc;
-        set_gemm_workspace(ws, kGemmWsFloats);
+        GemmWorkspaceLease lease(ws, kGemmWsFloats);          // handed back on EVERY way out of this function
         float* p = ws + kGemmWsFloats;
         float* cparams = g.pred_cparam ? g.pred_cparam : p;   p += al(M * 3);
         float* avg = g.pred_avg ? g.pred_avg : p;             p += al((size_t)b * 3);
@@ -1687,7 +1698,6 @@ struct grnet {
         HIP_TRY(launch_gait_cparams(cam, cam_ld, bbox, cimg, cparams, (int)M, s));
         HIP_TRY(launch_gru(plf, cparams, gruw, w, avg, phase, xc_buf, b, T, s));
         HIP_TRY(launch_featcorr(plf, avg, phase, fcw, tsw, fws, new_plf, b, T, s));
-        set_gemm_workspace(nullptr, 0);
         for (size_t s0 = 0; s0 < M; s0 += (size_t)max_frames) {
             const int m = (int)std::min<size_t>((size_t)max_frames, M - s0);
             grnet_outputs_t oc{};
@@ -1916,7 +1926,7 @@ int grnet_gru_forward(grnet_t* h, const float* x, const float* cp, int b, int T,
     float* ws = nullptr;                                   // handle-owned scratch: no allocation once a size has been seen
     const size_t need = rows * 3072 * 2 + 2 * rows * 900 + 2 * rows * 600 + (size_t)b * 1200 + (size_t)b * 2400 + 1024;
     if (int rc = h->temporal_scratch(kGemmWsFloats + need, &ws)) return rc;
-    set_gemm_workspace(ws, kGemmWsFloats);
+    GemmWorkspaceLease lease(ws, kGemmWsFloats);
     ws += kGemmWsFloats;
     GruWorkspace w;
     w.xin = ws;
@@ -1927,22 +1937,22 @@ int grnet_gru_forward(grnet_t* h, const float* x, const float* cp, int b, int T,
     w.hfin = w.l1 + rows * 600;
     w.xbuf = reinterpret_cast<unsigned long long*>(w.hfin + (((size_t)b * 1200 + 63) & ~(size_t)63));
     hipError_t e = launch_gru(x, cp, h->gruw, w, y, phase, xc_buf, b, T, s);
-    set_gemm_workspace(nullptr, 0);
     if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("launch_gru: ") + hipGetErrorString(e));
     return 0;
 }
 
 int grnet_tsattn_forward(grnet_t* h, const float* x, const float* xs, int b, int n, float* y, void* stream) {
-    if (!h || !x || !xs || !y || b < 1 || n < 1 || n > 4096) return GRNET_EINVAL;
+    if (!h || !x || !xs || !y || b < 1 || n < 1) return GRNET_EINVAL;
+    if (n > kTsAttnMaxFrames) return h->fail(GRNET_EINVAL, "a clip of " + std::to_string(n) + " frames exceeds the attention block's limit of " + std::to_string(kTsAttnMaxFrames) +
+                                                             " frames per clip (its softmax row over the clip lives in LDS): split the sequence into clips");
     if (!h->tsattn_ready)
         return h->fail(GRNET_ESTATE, "attention-block weights were not loaded (keys tsattn.* or pfeat_corrector.featTencoder.0.*)");
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* ws = nullptr;                                   // handle-owned scratch, like the GRU's
     if (int rc = h->temporal_scratch(kGemmWsFloats + tsattn_ws_floats(b, n), &ws)) return rc;
-    set_gemm_workspace(ws, kGemmWsFloats);
+    GemmWorkspaceLease lease(ws, kGemmWsFloats);
     hipError_t e = launch_tsattn(x, xs, h->tsw, ws + kGemmWsFloats, y, b, n, s);
-    set_gemm_workspace(nullptr, 0);
     if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("launch_tsattn: ") + hipGetErrorString(e));
     return 0;
 }
@@ -2335,6 +2345,8 @@ int grnet_gait_correct(grnet_t* h, const float* plf_dev, const float* csf_dev, c
     if (!h->gru_ready || !h->tsattn_ready || !h->featcorr_ready)
         return h->fail(GRNET_ESTATE, "pose-feature corrector weights were not loaded (keys pfeat_corrector.*)");
     if ((long)b * T > 65536) return h->fail(GRNET_EINVAL, "b*T exceeds 65536 frames");
+    if (T > kTsAttnMaxFrames) return h->fail(GRNET_EINVAL, "a clip of " + std::to_string(T) + " frames exceeds the attention block's limit of " + std::to_string(kTsAttnMaxFrames) +
+                                                             " frames per clip: split the sequence into clips (b, T)");
     DeviceGuard guard(h->device);
     grnet_gait_outputs_t g{};
     if (gait) g = *gait;

@@ -247,10 +247,13 @@ __global__ __launch_bounds__(512) void gru_recurrent_split_kernel(const float* _
         if (step > 0 && tid < kH && (tid < u0 || tid >= u0 + nu)) {          // collect h_{t-1} of the other slices
             const unsigned long long* src = xb + (size_t)((step - 1) & 1) * kH + tid;
             unsigned long long v;
+            unsigned polls = 0;
             do {
                 v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } while ((unsigned)(v >> 32) != (unsigned)step);                // tag of step-1's result = (step-1)+1
-            h[tid] = __uint_as_float((unsigned)v);
+            } while ((unsigned)(v >> 32) != (unsigned)step && ++polls < (1u << 26));   // tag of step-1's result = (step-1)+1
+            // the bound (tens of seconds) is never reached while the launcher's residency check holds; if it ever is, the result is
+            // poisoned with NaN instead of hanging the GPU
+            h[tid] = (unsigned)(v >> 32) == (unsigned)step ? __uint_as_float((unsigned)v) : __builtin_nanf("");
         }
         __syncthreads();
         const float hv = (lane < kGruCols) ? h[c0 + lane] : 0.f;
@@ -328,11 +331,17 @@ hipError_t launch_gru(const float* x, const float* cparams, GruWeights w, GruWor
             if (e != hipSuccess) return e;
         }
         static const int split_env = getenv("GRNET_GRU_SPLIT") ? atoi(getenv("GRNET_GRU_SPLIT")) : 1;     // A/B: 0 = one workgroup per (sequence, direction)
-        if (split_env && ws.xbuf && b <= 16 && T >= 8) {
+        // the 8 slices of a (sequence, direction) spin on each other: every workgroup of the grid must be resident at once, i.e. the
+        // grid may not exceed one 512-thread workgroup per CU of THIS device (256 on MI355X; fewer on a partitioned or smaller part)
+        const int split_grid = 64 * ((2 * b + 7) / 8);
+        static int cu_count[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (!cu_count[dev]) GRK_TRY(hipDeviceGetAttribute(&cu_count[dev], hipDeviceAttributeMultiprocessorCount, dev));
+        if (split_env && ws.xbuf && b <= 16 && T >= 8 && split_grid <= cu_count[dev]) {
             // W_hh resident in registers, split over 8 workgroups per (sequence, direction); the exchange buffer starts zeroed
             GRK_TRY(hipMemsetAsync(ws.xbuf, 0, (size_t)b * 2 * 2 * kH * sizeof(unsigned long long), s));
-            const int ngroups = 2 * b;
-            GRK_TRY(launch_k(gru_recurrent_split_kernel, dim3(64 * ((ngroups + 7) / 8)), dim3(512), 0, s, (const float*)ws.gi, w.w_hh[layer][0], w.w_hh[layer][1],
+            GRK_TRY(launch_k(gru_recurrent_split_kernel, dim3(split_grid), dim3(512), 0, s, (const float*)ws.gi, w.w_hh[layer][0], w.w_hh[layer][1],
                              w.b_hh[layer][0], w.b_hh[layer][1], layer_out[layer], ws.hfin, layer * 600, b, T, ws.xbuf));
         } else {
             GRK_TRY(launch_k(gru_recurrent_kernel, dim3(b, 2), dim3(1024), 0, s, ws.gi, w.w_hh[layer][0], w.w_hh[layer][1],

@@ -257,6 +257,9 @@ struct TsAttnWeights {
     const float *jw1, *jw2;
 };
 size_t tsattn_ws_floats(int b, int n);
+// longest clip the temporal attention takes: its softmax row over the clip's frames lives in LDS ((512 + n) floats <= 160 KB)
+constexpr int kTsAttnMaxFrames = 32768;
+int tsattn_max_frames();
 // x (b,n,3072) index c*24+j, xs (b,n,3200) index c*25+t -> y (b,n,3072); ws: tsattn_ws_floats(b, n) floats of scratch.
 hipError_t launch_tsattn(const float* x, const float* xs, const TsAttnWeights& w, float* ws, float* y, int b, int n, hipStream_t s);
 

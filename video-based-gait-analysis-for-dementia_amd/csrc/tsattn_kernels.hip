@@ -196,8 +196,21 @@ size_t tsattn_ws_floats(int b, int n) {
     return 2 * R * 3 * kE + 2 * R * kE + 2 * (size_t)b * 2 * kE + 3 * R * kD + 64;
 }
 
+int tsattn_max_frames() { return kTsAttnMaxFrames; }
+
 hipError_t launch_tsattn(const float* x, const float* xs, const TsAttnWeights& w, float* ws, float* y, int b, int n, hipStream_t s) {
-    if (b < 1 || n < 1 || n > 4096) return hipErrorInvalidValue;
+    if (b < 1 || n < 1 || n > kTsAttnMaxFrames) return hipErrorInvalidValue;
+    const size_t attn_lds = (size_t)(256 + n + 256) * sizeof(float);       // query row + one softmax row over the n frames of the clip
+    if (attn_lds > 64 * 1024) {                                             // clips beyond ~15 800 frames: raise the kernel's dynamic LDS limit once per device
+        static bool attr_done[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (!attr_done[dev]) {
+            GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(temporal_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)((256 + kTsAttnMaxFrames + 256) * sizeof(float))));
+            attr_done[dev] = true;
+        }
+    }
     const size_t R = (size_t)b * n;
     float* qkv_t = ws;
     float* qkv_s = qkv_t + R * 3 * kE;
@@ -210,7 +223,7 @@ hipError_t launch_tsattn(const float* x, const float* xs, const TsAttnWeights& w
     float* x1 = ys + R * kD;
     GRK_TRY(launch_gemm_nt_bias(x, w.qkv_t_w, w.qkv_t_b, qkv_t, (int)R, 3 * kE, kD, 3 * kE, s));
     GRK_TRY(launch_gemm_nt_bias(xs, w.qkv_s_w, w.qkv_s_b, qkv_s, (int)R, 3 * kE, kD + kF, 3 * kE, s));
-    GRK_TRY(launch_k(temporal_attn_kernel, dim3(n, kH, b), dim3(256), (size_t)(256 + n + 256) * sizeof(float), s, qkv_t, xt, n));
+    GRK_TRY(launch_k(temporal_attn_kernel, dim3(n, kH, b), dim3(256), attn_lds, s, qkv_t, xt, n));
     GRK_TRY(launch_k(spatial_attn_kernel, dim3((unsigned)R, kH), dim3(256), 0, s, qkv_s, xsp));
     GRK_TRY(launch_k(gate_mean_kernel, dim3((2 * kE + 255) / 256, b), dim3(256), 0, s, xt, xsp, mean, n));
     GRK_TRY(launch_gemm_nt_bias(mean, w.ts_w, w.ts_b, logits, b, 2 * kE, 2 * kE, 2 * kE, s));

@@ -157,6 +157,11 @@ def cv_inverse_affine(bboxes, scale=1.0, crop_size=224):
     half = np.float32(crop_size * 0.5)
     dst = np.array([[half, half], [half, half + half], [half + half, half]], np.float32)
     for i, (cx, cy, w, h) in enumerate(bboxes):
+        if float(w) != float(h):
+            # generate_patch_image_cv (img_utils.py:97-106) crops a non-square box in TWO warps (aspect-preserving resize to
+            # (int(s*w), int(s*h)), then a translation into the patch): two resamplings, which this single map cannot reproduce
+            raise ValueError(f"box {i} is {float(w)} x {float(h)}: the OpenCV-exact crop models the reference's single-warp path (square boxes, "
+                             "what demo.py and batch_generation.py produce); GRNet.crop_normalise(mode='ideal') samples any box in one exact bilinear pass")
         src_w, src_h = float(w) * float(scale), float(h) * float(scale)
         centre = np.array([cx, cy], np.float64)
         src = np.zeros((3, 2), np.float32)
@@ -328,17 +333,25 @@ def make_demo_result(pred, bboxes, frames, orig_width, orig_height):
     }
 
 
-def run_on_frames(model, image_folder, frames, bboxes, device="cuda", batch_size=None):
+def run_on_frames(model, image_folder, frames, bboxes, device="cuda", batch_size=None, on_device=False):
     """batch_generation.py:289-371: one batch per video (batch_size = max(n_frames, 400)), kp_3d -> kinectv2.  ``bboxes`` is scaled
     by 1.1 IN PLACE, as the reference's Inference.__init__ does to the caller's array (inference.py:48).  Image files are cropped
-    and normalised by the HIP kernel (grnet_crop_normalise, row f1); .npy files hold ready crops."""
+    and normalised by the HIP kernel (grnet_crop_normalise, row f1); .npy files hold ready crops.
+    on_device: return {"kp_3d": (n,25,3) float32 tensor on ``device``} and never synchronise with the host (the multi-GPU driver
+    keeps every work item's joints on the device until its single all-gather); default: the reference's numpy array."""
     ds = InferenceFrames(image_folder, frames, bboxes, scale=1.1)
     joints = []
+    sel = torch.as_tensor(np.asarray(netspec.SPIN2_TO_KINECTV2), dtype=torch.long, device=device) if on_device else None
     for batch in ds.batches(batch_size or max(len(frames), MAX_SEQLEN), model=model):
         x = torch.as_tensor(batch, dtype=torch.float32).unsqueeze(0).to(device)
         out = model(x)[-1]
+        if on_device:
+            joints.append(out["kp_3d"].detach().squeeze(0).index_select(1, sel).to(torch.float32))
+            continue
         j = out["kp_3d"].detach().cpu().squeeze(0).numpy()
         joints.append(spin2_to_kinectv2(j).astype(np.float32))
+    if on_device:
+        return {"kp_3d": torch.cat(joints, 0) if joints else torch.zeros(0, 25, 3, dtype=torch.float32, device=device)}
     return {"kp_3d": np.concatenate(joints, 0) if joints else np.zeros((0, 25, 3), np.float32)}
 
 
