@@ -152,7 +152,7 @@ def test_multi_track_overlapped_preprocess_stream(pkg, dtype):
         batches = []
         for b in range(2):
             raw = rng.integers(0, 256, size=(12, 180, 240, 3), dtype=np.uint8)
-            bb = np.stack([np.array([120 + 3 * t + i, 90 - 2 * b + i, 140 + i, 150 + 2 * i], np.float32) for i in range(12)])
+            bb = np.stack([np.array([120 + 3 * t + i, 90 - 2 * b + i, 140 + 2 * i, 140 + 2 * i], np.float32) for i in range(12)])
             batches.append((raw, bb))
         tracks.append(batches)
     got = p.run_tracks_overlapped(m, tracks, batch_size=12)

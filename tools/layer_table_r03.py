@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Per-launch table of the convolution launches of one 16-frame step (round 3): duration one after another, TFLOP/s by the algorithmic
+(direct-convolution) count and by the multiplies the kernel executes, counter bytes (FETCH_SIZE x 2 + WRITE_SIZE, the guide's
+correction) next to the algorithmic bytes (input + fused addends + weights read once, output written once).
+
+    on the GPU box (tools/gpu_profile_r03.sh):  python3 tools/layer_table_r03.py --dump gpurun_out/layers/convs.json
+    here, after the run was merged back:        python3 tools/layer_table_r03.py r03   -> profiles/r03_layer_table.{md,csv}, r03_layer_traffic.json
+
+Join key: dispatch order.  With GRNET_MULTI_LANE=0, --no-graph and --tune-level 0 the convolution dispatches of every forward come
+in the order of grnet_describe_conv(); a layer whose last round runs as half-size workgroups is two dispatches (the second one is
+conv_wino4_f32<2, W, 0, true>) and is merged into one row."""
+import collections
+import csv
+import importlib
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = "video-based-gait-analysis-for-dementia_amd"
+N = 16
+
+
+def dump(path):
+    sys.path.insert(0, ROOT)
+    pkg = importlib.import_module(PKG)
+    m = pkg.build_synthetic_model(max_frames=N, with_gru=False)
+    json.dump(m.describe_convs(), open(path, "w"))
+    m.close()
+
+
+def short(name):
+    name = re.sub(r"void grk::\(anonymous namespace\)::|void grk::|grk::\(anonymous namespace\)::", "", name)
+    return name.split("(")[0]
+
+
+def conv_dispatches(path, value):
+    rows = [r for r in csv.DictReader(open(path)) if "conv_" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    out = []
+    for r in rows:
+        k = short(r["Kernel_Name"])
+        if re.match(r"conv_wino4_f32<2, \d+, 0, true>", k) and out:           # the half-size last round of the previous layer
+            out[-1] = (out[-1][0], out[-1][1] + value(r), out[-1][2] + 1)
+        else:
+            out.append((k, value(r), 1))
+    return out
+
+
+def per_position(rows, n_conv):
+    n_fw = len(rows) // n_conv
+    assert n_fw >= 2 and len(rows) == n_fw * n_conv, (len(rows), n_conv, "dispatches do not tile into forwards")
+    out = []
+    for k in range(n_conv):
+        names = {rows[f * n_conv + k][0] for f in range(n_fw)}
+        assert len(names) == 1, (k, names)
+        vals = [rows[f * n_conv + k][1] for f in range(1, n_fw)]
+        out.append((names.pop(), sum(vals) / len(vals), rows[k][2]))
+    return out
+
+
+def executed_ratio(kernel, c):
+    if kernel.startswith("conv_wino4s"):
+        return 0.25 * (256.0 / 196.0 if c["hin"] == 14 else 64.0 / 49.0)
+    if kernel.startswith("conv_wino4") or kernel.startswith("bblock"):
+        return 0.25
+    if kernel.startswith("conv_wino_"):
+        return 4.0 / 9.0
+    return 1.0
+
+
+def stage_of(name):
+    for key, st in (("backbone.conv", "stem"), ("backbone.layer1", "layer1"), ("transition1", "transition1"), ("stage2", "stage2"), ("transition2", "stage3"),
+                    ("stage3", "stage3"), ("transition3", "stage4"), ("stage4", "stage4"), ("upsample", "upsample heads"), ("head.", "PARE head")):
+        if key in name:
+            return st
+    return "other"
+
+
+def main(rnd):
+    src = os.path.join(ROOT, "gpurun_out")
+    convs = json.load(open(os.path.join(src, "layers", "convs.json")))
+    n_conv = len(convs)
+    dur = per_position(conv_dispatches(os.path.join(src, "prof_serial", "bench_kernel_trace.csv"), lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3), n_conv)
+    fetch = per_position(conv_dispatches(os.path.join(src, "pmc", "FETCH_SIZE_counter_collection.csv"), lambda r: float(r["Counter_Value"]) * 1024.0), n_conv)
+    write = per_position(conv_dispatches(os.path.join(src, "pmc", "WRITE_SIZE_counter_collection.csv"), lambda r: float(r["Counter_Value"]) * 1024.0), n_conv)
+    rows, by_stage, by_kernel = [], collections.OrderedDict(), collections.OrderedDict()
+    for c, (k, us, nd), (_, fb, _), (_, wb, _) in zip(convs, dur, fetch, write):
+        flop = 2.0 * N * c["cout"] * c["hout"] * c["wout"] * c["cin"] * c["ks"] * c["ks"]
+        alg_r = 4.0 * (N * (c["cin"] * c["hin"] * c["win"] + c["add_elems"]) + c["ks"] * c["ks"] * c["cin"] * c["cout"])
+        alg_w = 4.0 * N * c["cout"] * c["hout"] * c["wout"]
+        ex = executed_ratio(k, c)
+        rows.append(dict(name=c["name"], kernel=k, dispatches=nd, shape=f'{c["cin"]}->{c["cout"]} k{c["ks"]} s{c["stride"]} @{c["hin"]}', us=us, gflop=flop / 1e9,
+                         tflops=flop / us / 1e6, exec_tflops=flop * ex / us / 1e6, alg_mb=(alg_r + alg_w) / 1e6, counter_mb=(2 * fb + wb) / 1e6))
+        for key, table in ((stage_of(c["name"]), by_stage), (re.sub(r"<.*", "", k) + " " + rows[-1]["shape"], by_kernel)):
+            t = table.setdefault(key, dict(n=0, us=0.0, gflop=0.0, ex=0.0, alg=0.0, cnt=0.0))
+            t["n"] += 1; t["us"] += us; t["gflop"] += flop / 1e9; t["ex"] += flop * ex / 1e9; t["alg"] += (alg_r + alg_w) / 1e6; t["cnt"] += (2 * fb + wb) / 1e6
+    dst = os.path.join(ROOT, "profiles")
+    with open(os.path.join(dst, f"{rnd}_layer_table.csv"), "w") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0]))
+        w.writeheader()
+        w.writerows(rows)
+    tot = dict(n=len(rows), us=sum(r["us"] for r in rows), gflop=sum(r["gflop"] for r in rows), alg=sum(r["alg_mb"] for r in rows), cnt=sum(r["counter_mb"] for r in rows))
+    lines = [f"# Per-launch table of the {n_conv} convolutions of a 16-frame fp32 step ({rnd}), launched one after another (GRNET_MULTI_LANE=0)", "",
+             f"Total: {tot['us'] / 1e3:.3f} ms, {tot['gflop']:.1f} algorithmic GFLOP = {tot['gflop'] / tot['us'] * 1e3 / 1e3:.1f} TFLOP/s; counter bytes (FETCH_SIZE x 2 + WRITE_SIZE) "
+             f"{tot['cnt'] / 1e3:.2f} GB vs {tot['alg'] / 1e3:.2f} GB algorithmic ({tot['cnt'] / tot['alg']:.2f} x).",
+             "Peak of the fp32 matrix cores: 157.3 TFLOP/s.  `exec` = the multiplies the kernel issues (F(4x4,3x3): 1/4 of the direct count, x 1.31 on the padded 14x14 / 7x7 maps).", "",
+             "## By stage", "", "| stage | launches | ms | algorithmic TFLOP/s | executed TFLOP/s | counter MB | algorithmic MB |", "|---|---|---|---|---|---|---|"]
+    for k, t in by_stage.items():
+        lines.append(f"| {k} | {t['n']} | {t['us'] / 1e3:.3f} | {t['gflop'] / t['us'] * 1e3:.1f} | {t['ex'] / t['us'] * 1e3:.1f} | {t['cnt']:.0f} | {t['alg']:.0f} |")
+    lines += ["", "## By kernel and shape", "", "| kernel, shape | launches | us each | ms | algorithmic TFLOP/s | executed TFLOP/s (of 157.3) | counter / algorithmic bytes |", "|---|---|---|---|---|---|---|"]
+    for k, t in sorted(by_kernel.items(), key=lambda kv: -kv[1]["us"]):
+        lines.append(f"| {k} | {t['n']} | {t['us'] / t['n']:.1f} | {t['us'] / 1e3:.3f} | {t['gflop'] / t['us'] * 1e3:.1f} | {t['ex'] / t['us'] * 1e3:.1f} ({t['ex'] / t['us'] * 1e3 / 157.3:.2f}) | {t['cnt'] / t['alg']:.2f} |")
+    open(os.path.join(dst, f"{rnd}_layer_table.md"), "w").write("\n".join(lines) + "\n")
+    json.dump({"launches": n_conv, "serial_ms": tot["us"] / 1e3, "algorithmic_bytes": tot["alg"] * 1e6, "counter_bytes_fetch_x2_plus_write": tot["cnt"] * 1e6,
+               "by_stage": by_stage}, open(os.path.join(dst, f"{rnd}_layer_traffic.json"), "w"), indent=1)
+    print("\n".join(lines[:4]))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--dump":
+        dump(sys.argv[2])
+    else:
+        main(sys.argv[1] if len(sys.argv) > 1 else "r03")

@@ -56,7 +56,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         per_kernel[n][0] += float(r["Counter_Value"])
         per_kernel[n][1] += 1
     conv_launches_total = sum(v[1] for k, v in per_kernel.items() if "conv_" in k)
-    n_forwards = max(1, round(conv_launches_total / 316))     # every forward / conv-only timing pass has 316 conv launches
+    per_fw = int(os.environ.get("CONV_DISPATCHES_PER_FORWARD", "318"))   # 316 convolutions, two of them with a half-size last round (2 dispatches)
+    n_forwards = max(1, round(conv_launches_total / per_fw))
     conv_kb = sum(v[0] for k, v in per_kernel.items() if "conv_" in k)
     conv_launches = sum(v[1] for k, v in per_kernel.items() if "conv_" in k)
     all_kb = sum(v[0] for v in per_kernel.values())
@@ -71,15 +72,11 @@ if out:
         out["correction"] = "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B for 16 B/lane streaming reads), WRITE_SIZE x1"
         out["note"] = ("memory-side (fabric) requests of the L2: Infinity-Cache hits are counted, so this is an upper bound on HBM "
                        "bytes; the 16-frame working set (~1.7 GB of activations) does not fit the 256 MiB cache")
-    lt = os.path.join(dst, f"{rnd}_layer_traffic.json")          # tools/layer_table.py: the same counters joined per launch + calibration
-    lt_rnd = rnd
-    if not os.path.isfile(lt):                                    # the per-launch table was not re-taken this round: the convolution
-        lt, lt_rnd = os.path.join(dst, "r01_layer_traffic.json"), "r01"   # kernels and the workload are unchanged, so round 1's calibration still applies
+    lt = os.path.join(dst, f"{rnd}_layer_traffic.json")          # tools/layer_table_r03.py: the same counters joined per launch (THIS round's only)
     if os.path.isfile(lt):
         t = json.load(open(lt))
-        out["algorithmic_bytes_per_step_conv_kernels"] = t["algorithmic_read_bytes"] + t["algorithmic_write_bytes"]
-        out["hbm_bytes_per_step_conv_kernels_calibrated"] = t["fetch_calibrated_bytes"] + t["write_size_bytes"]
-        out["calibration"] = t["calibration"] + f" (profiles/{lt_rnd}_fetch_calibration.json, profiles/{lt_rnd}_layer_table.md)"
+        out["algorithmic_bytes_per_step_conv_kernels"] = t["algorithmic_bytes"]
+        out["per_launch_table"] = f"profiles/{rnd}_layer_table.md"
     json.dump(out, open(os.path.join(dst, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if not isinstance(v, dict)}, indent=1))
 

@@ -55,8 +55,10 @@ struct GeoS {
     static constexpr size_t lds_bytes = sizeof(float) * KS * OSLOT;
 };
 
-template <int WD, int C, int KS>
-__global__ __launch_bounds__(64 * KS) void conv_wino4s_f32(const ConvArgs a) {
+// LOW: fit two waves per SIMD (<= 256 registers): B fragments one dword per point and k-step instead of a pair, so that workgroups of 8 waves
+// (K split 8 ways) can be resident
+template <int WD, int C, int KS, bool LOW>
+__global__ __launch_bounds__(64 * KS, LOW ? 2 : 1) void conv_wino4s_f32(const ConvArgs a) {
     typedef GeoS<WD, KS> G;
     constexpr int HW = G::HW, IPW = G::IPW, NBK = C / 16, NKP = C / 8, NK = C / 4 / KS, SH = WD == 14 ? 4 : 8;
     static_assert(NK % 2 == 0 && NBK % 8 == 0, "k-steps come in pairs; channel blocks are dealt to the 8 XCDs");
@@ -104,10 +106,12 @@ __global__ __launch_bounds__(64 * KS) void conv_wino4s_f32(const ConvArgs a) {
         }
     };
     const int ub = lane * 8;
-    f32x2 bq[36];
+    typedef typename std::conditional<LOW, float, f32x2>::type bfrag;
+    bfrag bq[36];                                        // LOW: this k-step's fragments; else the k-pair's
     const int ubase = (nb * NKP + (ks0 >> 1)) * (36 * 512);
-    auto load_b = [&](int kp, int p) {
-        bq[p] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(u_rsrc, ub, ubase + (kp * 36 + p) * 512, 0));
+    auto load_b = [&](int ks, int p) {                   // ks: k-step of this wave (LOW) / its k-pair is loaded (else)
+        if constexpr (LOW) bq[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(u_rsrc, ub, ubase + ((ks >> 1) * 36 + p) * 512 + (ks & 1) * 4, 0));
+        else bq[p] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(u_rsrc, ub, ubase + ((ks >> 1) * 36 + p) * 512, 0));
     };
 
     f32x4 acc[36];
@@ -148,7 +152,11 @@ __global__ __launch_bounds__(64 * KS) void conv_wino4s_f32(const ConvArgs a) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 6; ++j)
-                acc[i * 6 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[j], bq[i * 6 + j][sel], acc[i * 6 + j], 0, 0, 0);
+            {
+                float bv;
+                if constexpr (LOW) bv = bq[i * 6 + j]; else bv = bq[i * 6 + j][sel];
+                acc[i * 6 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[j], bv, acc[i * 6 + j], 0, 0, 0);
+            }
             if constexpr (RELOAD) {
 #pragma unroll
                 for (int j = 0; j < 6; ++j) load_b(reload_kp, i * 6 + j);
@@ -161,13 +169,19 @@ __global__ __launch_bounds__(64 * KS) void conv_wino4s_f32(const ConvArgs a) {
     constexpr integral_constant<int, 1> c1{};
     constexpr integral_constant<bool, true> yes{};
     constexpr integral_constant<bool, false> no{};
+    if constexpr (LOW) {                                  // every k-step re-requests the next one's fragments
 #pragma unroll 1
-    for (int kp = 0; kp + 1 < NK / 2; ++kp) {
-        kstep(2 * kp, c0, no, no, 0);
-        kstep(2 * kp + 1, c1, yes, no, kp + 1);
+        for (int ks = 0; ks + 1 < NK; ++ks) kstep(ks, c0, yes, no, ks + 1);
+        kstep(NK - 1, c0, no, yes, 0);
+    } else {
+#pragma unroll 1
+        for (int kp = 0; kp + 1 < NK / 2; ++kp) {
+            kstep(2 * kp, c0, no, no, 0);
+            kstep(2 * kp + 1, c1, yes, no, 2 * kp + 2);
+        }
+        kstep(NK - 2, c0, no, no, 0);
+        kstep(NK - 1, c1, no, yes, 0);
     }
-    kstep(NK - 2, c0, no, no, 0);
-    kstep(NK - 1, c1, no, yes, 0);
 
     // ---- epilogue.  The residual of this wave's share of the read-out is requested now.
     const size_t slab0 = ((size_t)img0 * a.out_ctot + a.out_coff + nb * 16) * HW;          // first float of image img0's slab
@@ -242,19 +256,19 @@ __global__ __launch_bounds__(64 * KS) void conv_wino4s_f32(const ConvArgs a) {
     }
 }
 
-template <int WD, int C, int KS>
+template <int WD, int C, int KS, bool LOW = false>
 hipError_t launch_s(const ConvArgs& a, hipStream_t s) {
     typedef GeoS<WD, KS> G;
     static bool attr_done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_done[dev]) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4s_f32<WD, C, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4s_f32<WD, C, KS, LOW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes);
         if (e != hipSuccess) return e;
         attr_done[dev] = true;
     }
     const int groups = (a.N + G::IPW - 1) / G::IPW;
-    return launch_k(conv_wino4s_f32<WD, C, KS>, dim3(groups * (C / 16)), dim3(64 * KS), G::lds_bytes, s, a);
+    return launch_k(conv_wino4s_f32<WD, C, KS, LOW>, dim3(groups * (C / 16)), dim3(64 * KS), G::lds_bytes, s, a);
 }
 
 }  // namespace
@@ -269,9 +283,9 @@ hipError_t launch_conv_wino4s(ConvArgs a, hipStream_t s, int ksplit) {
     if (a.n_add == 1 && a.add_shift[0] != 0) return hipErrorInvalidValue;
     // more than 4 waves per workgroup would need two waves per SIMD, i.e. <= 256 registers per wave: the kernel holds 144 accumulation
     // registers + 72 of B fragments + the patch in flight
-    if (a.W == 14 && a.Cin == 128) return ksplit == 2 ? launch_s<14, 128, 2>(a, s) : launch_s<14, 128, 4>(a, s);
-    if (a.W == 14) return launch_s<14, 256, 4>(a, s);
-    return ksplit == 2 ? launch_s<7, 256, 2>(a, s) : launch_s<7, 256, 4>(a, s);
+    if (a.W == 14 && a.Cin == 128) return ksplit == 2 ? launch_s<14, 128, 2>(a, s) : ksplit == 8 ? launch_s<14, 128, 8, true>(a, s) : ksplit == 14 ? launch_s<14, 128, 4, true>(a, s) : launch_s<14, 128, 4>(a, s);
+    if (a.W == 14) return ksplit == 8 ? launch_s<14, 256, 8, true>(a, s) : launch_s<14, 256, 4>(a, s);
+    return ksplit == 2 ? launch_s<7, 256, 2>(a, s) : ksplit == 8 ? launch_s<7, 256, 8, true>(a, s) : ksplit == 14 ? launch_s<7, 256, 4, true>(a, s) : launch_s<7, 256, 4>(a, s);
 }
 
 }  // namespace grk
