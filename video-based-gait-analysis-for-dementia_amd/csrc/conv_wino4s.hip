@@ -55,10 +55,8 @@ struct GeoS {
     static constexpr size_t lds_bytes = sizeof(float) * KS * OSLOT;
 };
 
-// LOW: fit two waves per SIMD (<= 256 registers): B fragments one dword per point and k-step instead of a pair, so that workgroups of 8 waves
-// (K split 8 ways) can be resident
-template <int WD, int C, int KS, bool LOW>
-__global__ __launch_bounds__(64 * KS, LOW ? 2 : 1) void conv_wino4s_f32(const ConvArgs a) {
+template <int WD, int C, int KS>
+__global__ __launch_bounds__(64 * KS) void conv_wino4s_f32(const ConvArgs a) {
     typedef GeoS<WD, KS> G;
     constexpr int HW = G::HW, IPW = G::IPW, NBK = C / 16, NKP = C / 8, NK = C / 4 / KS, SH = WD == 14 ? 4 : 8;
     static_assert(NK % 2 == 0 && NBK % 8 == 0, "k-steps come in pairs; channel blocks are dealt to the 8 XCDs");
@@ -106,12 +104,10 @@ __global__ __launch_bounds__(64 * KS, LOW ? 2 : 1) void conv_wino4s_f32(const Co
         }
     };
     const int ub = lane * 8;
-    typedef typename std::conditional<LOW, float, f32x2>::type bfrag;
-    bfrag bq[36];                                        // LOW: this k-step's fragments; else the k-pair's
+    f32x2 bq[36];                                        // the k-pair's B fragments; each point's is re-requested for the next pair behind its last MFMA
     const int ubase = (nb * NKP + (ks0 >> 1)) * (36 * 512);
-    auto load_b = [&](int ks, int p) {                   // ks: k-step of this wave (LOW) / its k-pair is loaded (else)
-        if constexpr (LOW) bq[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(u_rsrc, ub, ubase + ((ks >> 1) * 36 + p) * 512 + (ks & 1) * 4, 0));
-        else bq[p] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(u_rsrc, ub, ubase + ((ks >> 1) * 36 + p) * 512, 0));
+    auto load_b = [&](int ks, int p) {                   // ks: a k-step of this wave; its k-pair is loaded
+        bq[p] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(u_rsrc, ub, ubase + ((ks >> 1) * 36 + p) * 512, 0));
     };
 
     f32x4 acc[36];
@@ -150,12 +146,21 @@ __global__ __launch_bounds__(64 * KS, LOW ? 2 : 1) void conv_wino4s_f32(const Co
             bt_lo(e[i], v[0], v[1], v[2]);
             bt_hi(e[i], v[3], v[4], v[5]);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 6; ++j)
             {
-                float bv;
-                if constexpr (LOW) bv = bq[i * 6 + j]; else bv = bq[i * 6 + j][sel];
-                acc[i * 6 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[j], bv, acc[i * 6 + j], 0, 0, 0);
+                // the six MFMAs of the row as ONE asm statement with the accumulator tied (D = C): left to the compiler, the 14x14
+                // variants kept two sets of the 144 accumulation registers and alternated between them (436 registers; 324 now, which
+                // lets a wave of the 184-register conv_wino4_f32<2,..> kernels of the other two HR branches share the SIMD).  hipcc pads
+                // nothing inside an asm string: s_nop 1 = the wait states between the vector instructions that just wrote v[] and the MFMA
+                const float b0 = bq[i * 6][sel], b1 = bq[i * 6 + 1][sel], b2 = bq[i * 6 + 2][sel], b3 = bq[i * 6 + 3][sel], b4 = bq[i * 6 + 4][sel], b5 = bq[i * 6 + 5][sel];
+                asm volatile("s_nop 1\n\t"
+                             "v_mfma_f32_16x16x4_f32 %0, %6, %12, %0\n\t"
+                             "v_mfma_f32_16x16x4_f32 %1, %7, %13, %1\n\t"
+                             "v_mfma_f32_16x16x4_f32 %2, %8, %14, %2\n\t"
+                             "v_mfma_f32_16x16x4_f32 %3, %9, %15, %3\n\t"
+                             "v_mfma_f32_16x16x4_f32 %4, %10, %16, %4\n\t"
+                             "v_mfma_f32_16x16x4_f32 %5, %11, %17, %5"
+                             : "+a"(acc[i * 6]), "+a"(acc[i * 6 + 1]), "+a"(acc[i * 6 + 2]), "+a"(acc[i * 6 + 3]), "+a"(acc[i * 6 + 4]), "+a"(acc[i * 6 + 5])
+                             : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(b4), "v"(b5));
             }
             if constexpr (RELOAD) {
 #pragma unroll
@@ -169,20 +174,15 @@ __global__ __launch_bounds__(64 * KS, LOW ? 2 : 1) void conv_wino4s_f32(const Co
     constexpr integral_constant<int, 1> c1{};
     constexpr integral_constant<bool, true> yes{};
     constexpr integral_constant<bool, false> no{};
-    if constexpr (LOW) {                                  // every k-step re-requests the next one's fragments
 #pragma unroll 1
-        for (int ks = 0; ks + 1 < NK; ++ks) kstep(ks, c0, yes, no, ks + 1);
-        kstep(NK - 1, c0, no, yes, 0);
-    } else {
-#pragma unroll 1
-        for (int kp = 0; kp + 1 < NK / 2; ++kp) {
-            kstep(2 * kp, c0, no, no, 0);
-            kstep(2 * kp + 1, c1, yes, no, 2 * kp + 2);
-        }
-        kstep(NK - 2, c0, no, no, 0);
-        kstep(NK - 1, c1, no, yes, 0);
+    for (int kp = 0; kp + 1 < NK / 2; ++kp) {
+        kstep(2 * kp, c0, no, no, 0);
+        kstep(2 * kp + 1, c1, yes, no, 2 * kp + 2);
     }
+    kstep(NK - 2, c0, no, no, 0);
+    kstep(NK - 1, c1, no, yes, 0);
 
+    asm volatile("s_nop 15" ::: "memory");            // the last MFMAs' results (8 passes) before anything but an MFMA reads them: 12 wait states
     // ---- epilogue.  The residual of this wave's share of the read-out is requested now.
     const size_t slab0 = ((size_t)img0 * a.out_ctot + a.out_coff + nb * 16) * HW;          // first float of image img0's slab
     const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + slab0), (short)0, ((IPW - 1) * a.out_ctot * HW + G::SLAB) * 4, 0x00020000);
@@ -256,19 +256,19 @@ __global__ __launch_bounds__(64 * KS, LOW ? 2 : 1) void conv_wino4s_f32(const Co
     }
 }
 
-template <int WD, int C, int KS, bool LOW = false>
+template <int WD, int C, int KS>
 hipError_t launch_s(const ConvArgs& a, hipStream_t s) {
     typedef GeoS<WD, KS> G;
     static bool attr_done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_done[dev]) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4s_f32<WD, C, KS, LOW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4s_f32<WD, C, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes);
         if (e != hipSuccess) return e;
         attr_done[dev] = true;
     }
     const int groups = (a.N + G::IPW - 1) / G::IPW;
-    return launch_k(conv_wino4s_f32<WD, C, KS, LOW>, dim3(groups * (C / 16)), dim3(64 * KS), G::lds_bytes, s, a);
+    return launch_k(conv_wino4s_f32<WD, C, KS>, dim3(groups * (C / 16)), dim3(64 * KS), G::lds_bytes, s, a);
 }
 
 }  // namespace
@@ -283,9 +283,9 @@ hipError_t launch_conv_wino4s(ConvArgs a, hipStream_t s, int ksplit) {
     if (a.n_add == 1 && a.add_shift[0] != 0) return hipErrorInvalidValue;
     // more than 4 waves per workgroup would need two waves per SIMD, i.e. <= 256 registers per wave: the kernel holds 144 accumulation
     // registers + 72 of B fragments + the patch in flight
-    if (a.W == 14 && a.Cin == 128) return ksplit == 2 ? launch_s<14, 128, 2>(a, s) : ksplit == 8 ? launch_s<14, 128, 8, true>(a, s) : ksplit == 14 ? launch_s<14, 128, 4, true>(a, s) : launch_s<14, 128, 4>(a, s);
-    if (a.W == 14) return ksplit == 8 ? launch_s<14, 256, 8, true>(a, s) : launch_s<14, 256, 4>(a, s);
-    return ksplit == 2 ? launch_s<7, 256, 2>(a, s) : ksplit == 8 ? launch_s<7, 256, 8, true>(a, s) : ksplit == 14 ? launch_s<7, 256, 4, true>(a, s) : launch_s<7, 256, 4>(a, s);
+    if (a.W == 14 && a.Cin == 128) return ksplit == 2 ? launch_s<14, 128, 2>(a, s) : launch_s<14, 128, 4>(a, s);
+    if (a.W == 14) return launch_s<14, 256, 4>(a, s);
+    return ksplit == 2 ? launch_s<7, 256, 2>(a, s) : launch_s<7, 256, 4>(a, s);
 }
 
 }  // namespace grk

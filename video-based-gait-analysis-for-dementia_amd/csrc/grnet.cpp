@@ -2165,7 +2165,7 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
         a.w = ud;
     }
     int w4s_on = 0, w4s_ks = 0;
-    if (tile_hint >= 2020 && tile_hint <= 2034) {              // the small-map F(4x4,3x3) kernel, 202k: k waves split the input channels (0: default)
+    if (tile_hint >= 2020 && tile_hint <= 2024) {              // the small-map F(4x4,3x3) kernel, 202k: k waves split the input channels (0: default)
         w4s_on = 1; w4s_ks = tile_hint - 2020;
         if (!conv_wino4s_eligible(cin, cout, ks, stride, hgt, wid, add_dev ? 1 : 0)) {
             hipFree(wd); hipFree(bd);
