@@ -103,7 +103,7 @@ def main(rnd):
         w.writerows(rows)
     tot = dict(n=len(rows), us=sum(r["us"] for r in rows), gflop=sum(r["gflop"] for r in rows), alg=sum(r["alg_mb"] for r in rows), cnt=sum(r["counter_mb"] for r in rows))
     lines = [f"# Per-launch table of the {n_conv} convolutions of a 16-frame fp32 step ({rnd}), launched one after another (GRNET_MULTI_LANE=0)", "",
-             f"Total: {tot['us'] / 1e3:.3f} ms, {tot['gflop']:.1f} algorithmic GFLOP = {tot['gflop'] / tot['us'] * 1e3 / 1e3:.1f} TFLOP/s; counter bytes (FETCH_SIZE x 2 + WRITE_SIZE) "
+             f"Total: {tot['us'] / 1e3:.3f} ms, {tot['gflop']:.1f} algorithmic GFLOP = {tot['gflop'] / tot['us'] * 1e3:.1f} TFLOP/s; counter bytes (FETCH_SIZE x 2 + WRITE_SIZE) "
              f"{tot['cnt'] / 1e3:.2f} GB vs {tot['alg'] / 1e3:.2f} GB algorithmic ({tot['cnt'] / tot['alg']:.2f} x).",
              "Peak of the fp32 matrix cores: 157.3 TFLOP/s.  `exec` = the multiplies the kernel issues (F(4x4,3x3): 1/4 of the direct count, x 1.31 on the padded 14x14 / 7x7 maps).", "",
              "## By stage", "", "| stage | launches | ms | algorithmic TFLOP/s | executed TFLOP/s | counter MB | algorithmic MB |", "|---|---|---|---|---|---|---|"]

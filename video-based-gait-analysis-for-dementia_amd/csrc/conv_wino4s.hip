@@ -104,10 +104,10 @@ __global__ __launch_bounds__(64 * KS) void conv_wino4s_f32(const ConvArgs a) {
         }
     };
     const int ub = lane * 8;
-    f32x2 bq[36];                                        // the k-pair's B fragments; each point's is re-requested for the next pair behind its last MFMA
+    f32x2 bq[36];
     const int ubase = (nb * NKP + (ks0 >> 1)) * (36 * 512);
-    auto load_b = [&](int ks, int p) {                   // ks: a k-step of this wave; its k-pair is loaded
-        bq[p] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(u_rsrc, ub, ubase + ((ks >> 1) * 36 + p) * 512, 0));
+    auto load_b = [&](int kp, int p) {
+        bq[p] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(u_rsrc, ub, ubase + (kp * 36 + p) * 512, 0));
     };
 
     f32x4 acc[36];
@@ -146,22 +146,9 @@ __global__ __launch_bounds__(64 * KS) void conv_wino4s_f32(const ConvArgs a) {
             bt_lo(e[i], v[0], v[1], v[2]);
             bt_hi(e[i], v[3], v[4], v[5]);
             __builtin_amdgcn_sched_barrier(0);
-            {
-                // the six MFMAs of the row as ONE asm statement with the accumulator tied (D = C): left to the compiler, the 14x14
-                // variants kept two sets of the 144 accumulation registers and alternated between them (436 registers; 324 now, which
-                // lets a wave of the 184-register conv_wino4_f32<2,..> kernels of the other two HR branches share the SIMD).  hipcc pads
-                // nothing inside an asm string: s_nop 1 = the wait states between the vector instructions that just wrote v[] and the MFMA
-                const float b0 = bq[i * 6][sel], b1 = bq[i * 6 + 1][sel], b2 = bq[i * 6 + 2][sel], b3 = bq[i * 6 + 3][sel], b4 = bq[i * 6 + 4][sel], b5 = bq[i * 6 + 5][sel];
-                asm volatile("s_nop 1\n\t"
-                             "v_mfma_f32_16x16x4_f32 %0, %6, %12, %0\n\t"
-                             "v_mfma_f32_16x16x4_f32 %1, %7, %13, %1\n\t"
-                             "v_mfma_f32_16x16x4_f32 %2, %8, %14, %2\n\t"
-                             "v_mfma_f32_16x16x4_f32 %3, %9, %15, %3\n\t"
-                             "v_mfma_f32_16x16x4_f32 %4, %10, %16, %4\n\t"
-                             "v_mfma_f32_16x16x4_f32 %5, %11, %17, %5"
-                             : "+a"(acc[i * 6]), "+a"(acc[i * 6 + 1]), "+a"(acc[i * 6 + 2]), "+a"(acc[i * 6 + 3]), "+a"(acc[i * 6 + 4]), "+a"(acc[i * 6 + 5])
-                             : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(b4), "v"(b5));
-            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                acc[i * 6 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[j], bq[i * 6 + j][sel], acc[i * 6 + j], 0, 0, 0);
             if constexpr (RELOAD) {
 #pragma unroll
                 for (int j = 0; j < 6; ++j) load_b(reload_kp, i * 6 + j);
@@ -177,12 +164,11 @@ __global__ __launch_bounds__(64 * KS) void conv_wino4s_f32(const ConvArgs a) {
 #pragma unroll 1
     for (int kp = 0; kp + 1 < NK / 2; ++kp) {
         kstep(2 * kp, c0, no, no, 0);
-        kstep(2 * kp + 1, c1, yes, no, 2 * kp + 2);
+        kstep(2 * kp + 1, c1, yes, no, kp + 1);
     }
     kstep(NK - 2, c0, no, no, 0);
     kstep(NK - 1, c1, no, yes, 0);
 
-    asm volatile("s_nop 15" ::: "memory");            // the last MFMAs' results (8 passes) before anything but an MFMA reads them: 12 wait states
     // ---- epilogue.  The residual of this wave's share of the read-out is requested now.
     const size_t slab0 = ((size_t)img0 * a.out_ctot + a.out_coff + nb * 16) * HW;          // first float of image img0's slab
     const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + slab0), (short)0, ((IPW - 1) * a.out_ctot * HW + G::SLAB) * 4, 0x00020000);
