@@ -300,7 +300,7 @@ class GpuWorkload:
         tm = model.tuned_mode(n) or {}
         eager = args.no_graph or tm.get("eager", False)
         launch_desc = ("eager launches on 4 lane streams" if eager else "hipGraph replay") + \
-                      (", grouped HR-module launches" if tm.get("grouped") else ", one launch per convolution / fused block") + \
+                      ", one launch per convolution" + \
                       (" (schedule picked by grnet_tune)" if tm else "")
         return {"workload": f"1 clip x {n} frames x 3x224x224 per GPU, {'fp32' if args.dtype == 'f32' else 'bf16 storage / fp32 accumulation'}, "
                             "MAX-GRNet per-frame path (HRNet-W32 + PARE head + SMPL LBS), seed-defined synthetic weights",

@@ -99,20 +99,16 @@ int grnet_gru_forward(grnet_t* h, const float* x_dev, const float* cparams_dev, 
 int grnet_tsattn_forward(grnet_t* h, const float* x_dev, const float* xs_dev, int b, int n, float* y_dev, void* stream);
 
 #define GRNET_OPT_USE_GRAPH 1     /* 1: capture each distinct (n, pointers) forward into a hipGraph and replay it */
-#define GRNET_OPT_CONV_TILE 2     /* 0 = cost model; 7 / 14 = whole-K tiles; 1071/1072/1041/1042 = split-K (psw,csw) (tests / tuning); any forced tile also
-                                   * switches the Winograd layers back to the direct kernel; grnet_op_conv2d: 2000 = the Winograd kernel */
+#define GRNET_OPT_CONV_TILE 2     /* 0 = cost model; 7 / 14 = whole-K tiles; 1071/1072/1041/1042/1171/1141 = split-K (psw,csw[,8 waves]) (tests / tuning); any forced
+                                   * tile also switches the Winograd layers back to the direct kernels */
 #define GRNET_OPT_MULTI_LANE 3    /* 1 (default): independent HR-module branches run on parallel streams / graph branches */
-#define GRNET_OPT_GROUPING 4      /* 1 (default): same-depth convolutions of an HR module are one grouped launch */
-#define GRNET_OPT_DATAFLOW 5      /* HR section (transition1 .. stage 4) as ONE persistent per-XCD dataflow launch: 0 never (default: it is
-                                   * correct but measured slower than the per-convolution launches this round), 1 wherever a plan exists,
-                                   * 2 where grnet_tune measured it faster */
-#define GRNET_OPT_WINOGRAD 7       /* 1 (default): the 3x3 stride-1 layers on 56x56 maps (layer1, HR branch 0, transition1, upsample heads, PARE head) and the
-                                    * >= 128-channel ones on 28x28 maps (upsample heads) run as Winograd F(4x4,3x3) on the fp32 matrix cores (4x fewer
-                                    * multiplies, fp32 throughout, sums re-associated: ~1e-5 of the output scale from the direct kernel per layer,
-                                    * <= 3.5e-5 on the path's outputs); 0: every convolution is the direct implicit GEMM.  Environment GRNET_WINO4=0
-                                    * selects the F(2x2,3x3) kernel instead (2.25x fewer multiplies, ~1e-6).  grnet_op_conv2d tile hints 2000 / 2001 run
-                                    * the F(2x2,3x3) / F(4x4,3x3) kernel on one convolution */
-#define GRNET_OPT_DATAFLOW_FENCE 6 /* 1: device-scope release/acquire around every hand-off inside that launch (validation; slower) */
+#define GRNET_OPT_WINOGRAD 7      /* 1 (default): the 3x3 stride-1 layers on 56x56 / 28x28 maps (layer1, HR branches 0 and 1, transition1, upsample heads, PARE
+                                   * head; csrc/conv_wino4.hip) and on 14x14 / 7x7 maps (HR branches 2 and 3, the 256 -> 256 upsample-head layer;
+                                   * csrc/conv_wino4s.hip) run as Winograd F(4x4,3x3) on the fp32 matrix cores (4x fewer multiplies, fp32 throughout, sums
+                                   * re-associated: ~1e-5 of the output scale from the direct kernel per layer, <= 3.5e-5 on the path's outputs); 0: every
+                                   * convolution is the direct implicit GEMM.  grnet_op_conv2d tile hints 2001 / 2020 (+ K split) run the two kernels on
+                                   * one convolution.  (Options 4, 5, 6 -- grouped launches, the persistent dataflow launch and its fence -- were removed
+                                   * in round 3 after losing every measurement; their sources are kept under tools/experiments/.) */
 int grnet_set_option(grnet_t* h, int option, int value);
 
 /* Optional, once per distinct n_frames after grnet_finalize_weights: times every launch configuration of every
@@ -145,11 +141,6 @@ int grnet_time_convs(grnet_t* h, int n_frames, void* stream, float* ms_out);
 int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, int wid, const float* w_host,
                     const float* bias_host, int cout, int ks, int stride, int relu, const float* add_dev,
                     float* out_dev, int tile_hint, void* stream);
-/* BasicBlock.forward -- lib/models/hrnet.py:43-59 (conv3x3-BN-ReLU-conv3x3-BN-(+x)-ReLU, no downsample) as ONE launch of the fused
- * Winograd kernel (csrc/conv_wino4_block.hip) that the path uses for the 32-channel 56x56 and the 64-channel 28x28 HR branches
- * (hrnet.py:141-187); other shapes are refused.  w*_host: (C,C,3,3) with BatchNorm already folded, b*_host: (C) or NULL. */
-int grnet_op_basic_block(grnet_t* h, const float* in_dev, int n, int c, int hgt, int wid, const float* w1_host, const float* b1_host,
-                         const float* w2_host, const float* b2_host, float* out_dev, void* stream);
 int grnet_op_bilinear2x(grnet_t* h, const float* in_dev, int n, int c, int hgt, int wid, float* out_dev, void* stream);
 
 /* SMPL(...) forward with rotation matrices -- lib/models/smpl.py:108-130 (smplx LBS + the 29 "spin2" joints) and, when

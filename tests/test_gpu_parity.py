@@ -217,17 +217,15 @@ def test_errors_are_loud(model, pkg):
 
 
 def test_schedules_and_tuning_agree(pkg):
-    """Grouped launches, parallel lanes, measured launch tables and a re-applied stored table are all
-    the same arithmetic in a different launch shape: results agree to fp32 re-association noise."""
+    """One stream instead of the lane streams, measured launch tables and a re-applied stored table (with every schedule bit: measured
+    table or cost model, graph replay or eager) are all the same arithmetic in a different launch shape: results agree to fp32
+    re-association noise."""
     import ctypes as C
     m = pkg.build_synthetic_model(max_frames=6, with_gru=False)
     frames = torch.from_numpy(pkg.synth.make_frames(6)).cuda()
     base = {k: v.clone() for k, v in m(frames)[-1].items()}
     lib = pkg._lib
     outs = {}
-    m.set_option(lib.OPT_GROUPING, 0)
-    outs["no_grouping"] = {k: v.clone() for k, v in m(frames)[-1].items()}
-    m.set_option(lib.OPT_GROUPING, 1)
     m.set_option(lib.OPT_MULTI_LANE, 0)
     outs["one_lane"] = {k: v.clone() for k, v in m(frames)[-1].items()}
     m.set_option(lib.OPT_MULTI_LANE, 1)
@@ -236,7 +234,7 @@ def test_schedules_and_tuning_agree(pkg):
     buf = C.create_string_buffer(1 << 16)
     n = m._lib.grnet_get_tuning(m._h, 6, buf, len(buf))
     assert n > 0 and buf.value.decode().startswith("mode ")
-    for forced_mode in (0, 1, 2, 3):                          # lanes/grouped x cost-model/measured
+    for forced_mode in (0, 1, 4, 5):                          # graph / eager x cost-model / measured
         text = "mode %d\n" % forced_mode + buf.value.decode().split("\n", 1)[1]
         assert m._lib.grnet_set_tuning(m._h, 6, text.encode()) == 0
         outs[f"mode{forced_mode}"] = {k: v.clone() for k, v in m(frames)[-1].items()}

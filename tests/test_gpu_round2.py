@@ -272,62 +272,6 @@ def test_frame_shards_gather_then_temporal_branch_equals_one_process(pkg):
     m.close()
 
 
-def test_dataflow_hr_section_parity_and_determinism(pkg, golden):
-    """The HR section (transition1 .. stage 4) as ONE persistent per-XCD dataflow launch (GRNET_OPT_DATAFLOW = 1): same results as
-    the per-convolution launches (different split-K variants: fp32 re-association noise), the reference goldens, bit-identical
-    between runs, bit-identical with device-scope fences around every hand-off (the fences change visibility, not arithmetic),
-    for frame counts that fill the 8 XCDs evenly, unevenly and not at all."""
-    lib = pkg._lib
-    m = pkg.build_synthetic_model(max_frames=40, with_gru=False)
-    frames = torch.from_numpy(pkg.synth.make_frames(40)).cuda()
-    keys = ("theta", "kp_3d", "kp_2d", "verts", "rotmat")
-    for n in (16, 4, 1, 11, 40):
-        x = frames[:n]
-        m.set_option(lib.OPT_DATAFLOW, 0)
-        base = {k: v.clone() for k, v in m(x, extras=("features",))[-1].items()}
-        launches_lanes = m.num_kernel_launches()
-        m.set_option(lib.OPT_DATAFLOW, 1)
-        a = {k: v.clone() for k, v in m(x, extras=("features",))[-1].items()}
-        assert m.num_kernel_launches() < launches_lanes - 250, (n, m.num_kernel_launches(), launches_lanes)   # the plan exists and was used
-        b = {k: v.clone() for k, v in m(x, extras=("features",))[-1].items()}
-        m.set_option(lib.OPT_DATAFLOW_FENCE, 1)
-        c = {k: v.clone() for k, v in m(x, extras=("features",))[-1].items()}
-        m.set_option(lib.OPT_DATAFLOW_FENCE, 0)
-        torch.cuda.synchronize()
-        for k in keys + ("features",):
-            assert rel_err(a[k].cpu().numpy(), base[k].cpu().numpy()) < 5e-5, (n, k, rel_err(a[k].cpu().numpy(), base[k].cpu().numpy()))
-            assert torch.equal(a[k], b[k]), (n, k, "run-to-run")
-            assert torch.equal(a[k], c[k]), (n, k, "fenced vs unfenced")
-        if n == 4:
-            g = golden["grnet_n4"]
-            for k in ("theta", "kp_3d", "kp_2d"):
-                assert rel_err(a[k].cpu().numpy().reshape(g[k].shape), g[k]) < 1e-4, k
-            assert rel_err(a["features"].cpu().numpy()[..., ::4, ::4], g["features_s4"]) < 1e-4
-    # stage taps still readable (the section writes the same buffers)
-    m(frames[:4])
-    t = m.debug_tensor("stage3.2", 4).cpu().numpy()
-    assert rel_err(t, golden["grnet_n4"]["stage3_2"]) < 1e-4
-    # graph replay of the dataflow schedule
-    m.set_option(lib.OPT_USE_GRAPH, 1)
-    outs = [m(frames[:16])[-1]["theta"].clone() for _ in range(1)]
-    import ctypes as C
-    fixed = {k: torch.empty(16, *s, device="cuda") for k, s in (("theta", (85,)), ("verts", (6890, 3)))}
-    o = lib.Outputs()
-    for k, v in fixed.items():
-        setattr(o, k, v.data_ptr())
-    x16 = frames[:16].contiguous()
-    for _ in range(3):                                        # eager, capture, replay
-        rc = m._lib.grnet_forward(m._h, C.c_void_p(x16.data_ptr()), 16, C.byref(o), C.c_void_p(torch.cuda.current_stream().cuda_stream))
-        assert rc == 0, m._lib.grnet_last_error(m._h)
-    torch.cuda.synchronize()
-    assert torch.equal(fixed["theta"], outs[0].reshape(16, 85))
-    m.set_option(lib.OPT_USE_GRAPH, 0)
-    m.close()
-
-
-WINO_CASES = [(64, 64), (128, 128), (256, 256), (480, 256), (128, 64), (72, 192), (32, 32), (256, 32), (40, 96)]
-
-
 @pytest.mark.parametrize("case", [(1, 64, 64), (3, 128, 128), (2, 256, 256), (1, 480, 256), (3, 72, 192), (5, 64, 256), (16, 64, 256), (3, 32, 32), (2, 256, 32), (3, 40, 96)], ids=lambda c: "x".join(map(str, c)))
 def test_winograd_f43_conv_kernel(model, oracle, case):
     """conv_wino4_f32 (Winograd F(4x4,3x3): 36 points per 4x4 output tile) on single convolutions vs the oracle's direct convolution:
@@ -375,27 +319,6 @@ def test_winograd_f43_conv_kernel_28(model, oracle, case):
     assert rel_err(got[:, :, [0, 27]], lin[:, :, [0, 27]]) < 1e-4 and rel_err(got[..., [0, 27]], lin[..., [0, 27]]) < 1e-4
 
 
-@pytest.mark.parametrize("case", [(1, 128, 128), (3, 256, 256), (2, 64, 64), (3, 40, 96), (1, 32, 32), (20, 32, 256)], ids=lambda c: "x".join(map(str, c)))
-def test_winograd_conv_kernel_28(model, oracle, case):
-    """The same kernel on 28x28 maps (upsample heads: 256 -> 256, 128 -> 128): a workgroup's 56 tiles are 4 tile rows of 14, the
-    image's 14 tile rows make 3.5 groups -- the last group's lower half reads zeros and stores nothing.  1-3 images, odd channel
-    counts, the 32-channel variant, 20 images x 256 channels (320 workgroups: the last 64 run as half-size ones); bias + ReLU, with
-    and without a residual."""
-    n, cin, cout = case
-    g = np.random.Generator(np.random.Philox(key=[79, n * 100000 + cin * 1000 + cout]))
-    x = g.standard_normal((n, cin, 28, 28)).astype(np.float32)
-    w = (g.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (cin * 9))).astype(np.float32)
-    b = (g.standard_normal((cout,)) * 0.1).astype(np.float32)
-    r = g.standard_normal((n, cout, 28, 28)).astype(np.float32)
-    conv = oracle.conv2d(x, w, stride=1, bias=b)
-    xd = torch.from_numpy(x).cuda()
-    got = model.op_conv2d(xd, w, b, stride=1, relu=True, tile_hint=2000).cpu().numpy()
-    assert got.shape == conv.shape
-    assert rel_err(got, torch.relu(conv).numpy()) < 2e-5
-    got = model.op_conv2d(xd, w, b, stride=1, relu=True, add=torch.from_numpy(r).cuda(), tile_hint=2000).cpu().numpy()
-    assert rel_err(got, torch.relu(conv + torch.from_numpy(r)).numpy()) < 2e-5
-
-
 @pytest.mark.parametrize("case", [(5, 32, 256), (16, 32, 256), (7, 40, 192), (6, 64, 64)], ids=lambda c: "x".join(map(str, c)))
 def test_winograd_last_round_split(model, oracle, case):
     """Layers whose last round of workgroups is at most half full run it as half-size workgroups (the 32-channel kernel on the weights
@@ -409,37 +332,12 @@ def test_winograd_last_round_split(model, oracle, case):
     r = g.standard_normal((n, cout, 56, 56)).astype(np.float32)
     conv = oracle.conv2d(x, w, stride=1, bias=b)
     xd = torch.from_numpy(x).cuda()
-    got = model.op_conv2d(xd, w, b, stride=1, relu=True, tile_hint=2000).cpu().numpy()
-    assert rel_err(got, torch.relu(conv).numpy()) < 2e-5
-    got = model.op_conv2d(xd, w, b, stride=1, relu=True, add=torch.from_numpy(r).cuda(), tile_hint=2000).cpu().numpy()
-    assert rel_err(got, torch.relu(conv + torch.from_numpy(r)).numpy()) < 2e-5
-
-
-@pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "x".join(map(str, c)))
-def test_winograd_conv_kernel(model, oracle, case):
-    """conv_wino_f32 (Winograd F(2x2,3x3) on the fp32 matrix cores) on single convolutions vs the oracle's direct convolution: every
-    eligible channel shape of the path plus odd ones (Cin not a multiple of the MFMA K, Cout = 3 channel blocks), 1 and 3 images
-    (first / last tile-row groups carry the zero padding), bias + ReLU epilogue."""
-    cin, cout = case
-    g = np.random.Generator(np.random.Philox(key=[77, cin * 1000 + cout]))
-    for n in (1, 3):
-        x = g.standard_normal((n, cin, 56, 56)).astype(np.float32)
-        w = (g.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (cin * 9))).astype(np.float32)
-        b = (g.standard_normal((cout,)) * 0.1).astype(np.float32)
-        ref = torch.relu(oracle.conv2d(x, w, stride=1, bias=b)).numpy()
-        got = model.op_conv2d(torch.from_numpy(x).cuda(), w, b, stride=1, relu=True, tile_hint=2000).cpu().numpy()
-        assert got.shape == ref.shape
-        assert rel_err(got, ref) < 2e-5, (case, n, rel_err(got, ref))
-        res = g.standard_normal((n, cout, 56, 56)).astype(np.float32)         # the BasicBlock form: + residual, then ReLU (hrnet.py:54-57)
-        ref_res = torch.relu(oracle.conv2d(x, w, stride=1, bias=b) + torch.from_numpy(res)).numpy()
-        got_res = model.op_conv2d(torch.from_numpy(x).cuda(), w, b, stride=1, relu=True, add=torch.from_numpy(res).cuda(), tile_hint=2000).cpu().numpy()
-        assert rel_err(got_res, ref_res) < 2e-5, (case, n, "residual")
-        ref_lin = oracle.conv2d(x, w, stride=1).numpy()                     # no bias, no ReLU: borders and signs exposed
-        got_lin = model.op_conv2d(torch.from_numpy(x).cuda(), w, None, stride=1, relu=False, tile_hint=2000).cpu().numpy()
-        assert rel_err(got_lin, ref_lin) < 2e-5, (case, n)
-        assert rel_err(got_lin[:, :, [0, 55]], ref_lin[:, :, [0, 55]]) < 2e-5 and rel_err(got_lin[..., [0, 55]], ref_lin[..., [0, 55]]) < 2e-5
+    got = model.op_conv2d(xd, w, b, stride=1, relu=True, tile_hint=2001).cpu().numpy()
+    assert rel_err(got, torch.relu(conv).numpy()) < 1e-4
+    got = model.op_conv2d(xd, w, b, stride=1, relu=True, add=torch.from_numpy(r).cuda(), tile_hint=2001).cpu().numpy()
+    assert rel_err(got, torch.relu(conv + torch.from_numpy(r)).numpy()) < 1e-4
     with pytest.raises(Exception):
-        model.op_conv2d(torch.zeros(1, 64, 14, 14).cuda(), np.zeros((64, 64, 3, 3), np.float32), tile_hint=2000)   # not a 56x56 / 28x28 map: refused, no fallback
+        model.op_conv2d(torch.zeros(1, 64, 14, 14).cuda(), np.zeros((64, 64, 3, 3), np.float32), tile_hint=2001)   # not a 56x56 / 28x28 map: refused, no fallback
 
 
 def test_winograd_layers_match_direct_layers(pkg, golden):

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("GRNET_LIB_PATH") or os.path.join(_HERE, "libgrnet_hip
 
 OK, EINVAL, ENOENT, ENOMEM, EHIP, ESTATE = 0, -22, -2, -12, -5, -1
 DTYPE_F32, DTYPE_I64 = 0, 1
-OPT_USE_GRAPH, OPT_CONV_TILE, OPT_MULTI_LANE, OPT_GROUPING, OPT_DATAFLOW, OPT_DATAFLOW_FENCE, OPT_WINOGRAD = 1, 2, 3, 4, 5, 6, 7
+OPT_USE_GRAPH, OPT_CONV_TILE, OPT_MULTI_LANE, OPT_WINOGRAD = 1, 2, 3, 7
 
 
 class Outputs(C.Structure):
@@ -48,8 +48,6 @@ EXPORTS = {
     "grnet_time_convs": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "grnet_op_conv2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
-    "grnet_op_basic_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "grnet_op_bilinear2x": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "grnet_smpl_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),

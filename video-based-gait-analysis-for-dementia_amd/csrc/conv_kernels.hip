@@ -432,7 +432,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_mfma_f32(const ConvArgs a) {
 // WPT > 0 (rows mode, 3x3): the image width as a compile-time constant.  The row pitch of the patch then folds into the ds_read
 // immediates, which frees registers for per-lane LEFT and RIGHT tap pointers: a lane whose pixel sits on the image's left (right) edge
 // reads its kx = 0 (kx = 2) taps from a zero block of its wave instead of masking the value afterwards.  42 v_cndmask per stage of 63
-// MFMAs are gone from the loop -- on gfx950 vector-ALU instructions inside an fp32 MFMA loop are matrix-pipe time (conv_wino.hip).
+// MFMAs are gone from the loop -- on gfx950 vector-ALU instructions inside an fp32 MFMA loop are matrix-pipe time.
 constexpr int kEdgeZeros = 128;                          // floats of the per-wave zero block: offsets 0 .. 2 * WPT are read
 template <int MODE, int KS, int S, int PSW, int CSW, int NW, int WPT = 0>
 __device__ __forceinline__ void splitk_body(const ConvArgs& a, const int bx, const int by, float* smem, const int tid_in = -1) {
@@ -751,247 +751,6 @@ __global__ __launch_bounds__(NW * 64) void conv_splitk_f32(const ConvArgs a) {
     splitk_body<MODE, KS, S, PSW, CSW, NW, WPT>(a, bx, by, smem);
 }
 
-// Grouped launch: up to kMaxGroup independent convolutions (the same-depth convolutions of the
-// branches of an HR module, the 1x1 fuse convolutions, ...) share ONE launch; the blocks of the grid are
-// partitioned over the problems.  Independent small layers then co-reside on the CUs by construction
-// (no reliance on how the runtime maps streams / graph branches to hardware queues) and the launch
-// count of a forward drops.  Every member runs the split-K body in its own (mode, tile) variant.
-struct GroupArgs {
-    int n;
-    int first_block[kMaxGroup + 1];
-    int grid_x[kMaxGroup];
-    int variant[kMaxGroup];      // 0: rows 7x1, 1: rows 7x2, 2: rows 4x1, 3: planes 4x1, 4: gather 4x1, 5: gather 7x1
-    ConvArgs c[kMaxGroup];
-};
-
-template <int KS, int S>
-__global__ __launch_bounds__(256) void conv_group_f32(const GroupArgs g) {
-    extern __shared__ __align__(16) float smem[];
-    int b = blockIdx.x, p = 0;
-    if (1 < g.n && b >= g.first_block[1]) p = 1;
-    if (2 < g.n && b >= g.first_block[2]) p = 2;
-    if (3 < g.n && b >= g.first_block[3]) p = 3;
-    if (4 < g.n && b >= g.first_block[4]) p = 4;
-    if (5 < g.n && b >= g.first_block[5]) p = 5;
-    // select the member with compile-time indices only: a run-time index into the kernel-argument struct
-    // would make hipcc copy the whole array to scratch
-    ConvArgs a = g.c[0];
-    int first = g.first_block[0], gx = g.grid_x[0], variant = g.variant[0];
-#define GRK_PICK(I) if (p == I) { a = g.c[I]; first = g.first_block[I]; gx = g.grid_x[I]; variant = g.variant[I]; }
-    GRK_PICK(1) GRK_PICK(2) GRK_PICK(3) GRK_PICK(4) GRK_PICK(5)
-#undef GRK_PICK
-    b -= first;
-    const int bx = b % gx, by = b / gx;
-    switch (variant) {
-        case 0: splitk_body<1, KS, S, 7, 1, 4>(a, bx, by, smem); break;
-        case 1: splitk_body<1, KS, S, 7, 2, 4>(a, bx, by, smem); break;
-        case 2: splitk_body<1, KS, S, 4, 1, 4>(a, bx, by, smem); break;
-        case 3: splitk_body<2, KS, S, 4, 1, 4>(a, bx, by, smem); break;
-        case 4: splitk_body<0, KS, S, 4, 1, 4>(a, bx, by, smem); break;
-        default: splitk_body<0, KS, S, 7, 1, 4>(a, bx, by, smem); break;
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// Persistent per-XCD dataflow kernel for the HR stages (see kernels.h).  256 threads = the 4 split-K waves of splitk_body.
-__device__ __forceinline__ int xcc_id() {
-    int v;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-    return v & 7;
-}
-
-// fuse output 0 of an HR module: out = relu(x0 + up2(t1) + up4(t2) + up8(t3)) (hrnet.py:258-265) for R rows of one image
-__device__ __forceinline__ void df_sum_tile(const ConvArgs& a, int img, int ty) {
-    const int HW = a.Ho * a.Wo, pix0 = ty * a.R * a.Wo, npx = min(a.R * a.Wo, HW - pix0);
-    const int units = a.Cout * (npx >> 2);
-    for (int u = threadIdx.x; u < units; u += 256) {
-        const int c = u / (npx >> 2), pix = pix0 + 4 * (u - c * (npx >> 2));
-        f32x4 v = *reinterpret_cast<const f32x4*>(a.in + ((size_t)img * a.in_ctot + a.in_coff + c) * HW + pix);
-#pragma unroll
-        for (int k = 0; k < kMaxAdd; ++k) {
-            if (k >= a.n_add) break;
-            const int sh = a.add_shift[k], hs = a.Ho >> sh, ws = a.Wo >> sh;
-            const float* ap = a.add[k] + ((size_t)img * a.add_ctot[k] + a.add_coff[k] + c) * (hs * ws);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int y = (pix + r) / a.Wo, x = (pix + r) - y * a.Wo;
-                v[r] += ap[(y >> sh) * ws + (x >> sh)];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        *reinterpret_cast<f32x4*>(a.out + ((size_t)img * a.out_ctot + a.out_coff + c) * HW + pix) = v;
-    }
-}
-
-// Each body variant is a SEPARATE (non-inlined) device function with its own register allocation: inlined into one switch, the nine
-// bodies made the kernel need 350-512 registers (block-invariant and task-invariant index math of every variant hoisted and kept
-// live at once; with an occupancy bound the allocator spilled 500-1500 VGPRs instead).  Arguments arrive in VGPRs by the ABI and are
-// made wave-uniform again with readfirstlane; the LDS base comes as an address-space-3 pointer so the body's accesses stay ds_* / LDS-DMA.
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-template <int MODE, int KS, int S, int PSW>
-__device__ __attribute__((noinline)) void df_body(const DfConv* cg, int bx, int by0, int by1, GRNET_LDS_AS float* smem_lds) {
-    const unsigned long long pu = ((unsigned long long)(unsigned)uni((int)((unsigned long long)cg >> 32)) << 32) | (unsigned)uni((int)(unsigned long long)cg);
-    const DfConv* c = reinterpret_cast<const DfConv*>(pu);
-    const ConvArgs a = c->a;                                 // uniform address: scalar loads
-    float* smem = (float*)smem_lds;
-    bx = uni(bx); by0 = uni(by0); by1 = uni(by1);
-    for (int b2 = by0; b2 < by1; ++b2) {
-        if (b2 != by0) __syncthreads();                       // the previous block's cross-wave reduction is done with the staging area
-        splitk_body<MODE, KS, S, PSW, 1, 4>(a, bx, b2, smem);
-    }
-}
-__device__ __forceinline__ void df_run_conv(const DfConv* c, int variant, int bx, int by0, int by1, GRNET_LDS_AS float* smem) {
-    switch (variant) {                                       // (ks, stride) x {rows 7x1, rows 4x1, planes 4x1}
-        case 0: df_body<1, 3, 1, 7>(c, bx, by0, by1, smem); break;
-#ifndef GRNET_DF_ONE
-        case 1: df_body<1, 3, 1, 4>(c, bx, by0, by1, smem); break;
-        case 2: df_body<2, 3, 1, 4>(c, bx, by0, by1, smem); break;
-        case 3: df_body<1, 3, 2, 7>(c, bx, by0, by1, smem); break;
-        case 4: df_body<1, 3, 2, 4>(c, bx, by0, by1, smem); break;
-        case 5: df_body<2, 3, 2, 4>(c, bx, by0, by1, smem); break;
-        case 6: df_body<1, 1, 1, 7>(c, bx, by0, by1, smem); break;
-        case 7: df_body<1, 1, 1, 4>(c, bx, by0, by1, smem); break;
-        case 8: df_body<2, 1, 1, 4>(c, bx, by0, by1, smem); break;
-#endif
-        default: break;
-    }
-}
-__device__ __attribute__((noinline)) void df_sum_body(const DfConv* cg, int img, int ty) {
-    const unsigned long long pu = ((unsigned long long)(unsigned)uni((int)((unsigned long long)cg >> 32)) << 32) | (unsigned)uni((int)(unsigned long long)cg);
-    const ConvArgs a = reinterpret_cast<const DfConv*>(pu)->a;
-    df_sum_tile(a, uni(img), uni(ty));
-}
-
-// Run the queue of XCD `q`.  fence = true when this workgroup may sit on another XCD than the queue's producers / consumers.
-// Control flow around the barriers is kept WAVE-UNIFORM on purpose (conditions on SGPR values: the wave index through readfirstlane,
-// loaded words through readfirstlane): a lane-divergent `if (threadIdx.x == 0)` at the head of this loop made the compiler's CFG
-// structuriser split the loop so that waves met different numbers of s_barrier per iteration (the kernel hung on its second task).
-// Where one lane must act (queue pop, counter increment) the whole wave executes the atomic with an addend of 1 in lane 0 and 0 elsewhere.
-__device__ __forceinline__ void df_run_queue(const DfParams& p, int q, bool fence, float* smem, int* s_task) {
-    unsigned* ctr = p.counters + (size_t)q * p.ctr_stride;
-    unsigned* done = ctr + 16;
-    const int first_img = q * p.ipx, img_end = min(p.n, first_img + p.ipx), nimg = img_end - first_img;
-    if (nimg <= 0) return;
-    const int nblk = (nimg + p.B - 1) / p.B, total = nblk * p.tasks_per_blk;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const unsigned one = (threadIdx.x & 63) == 0 ? 1u : 0u;
-    int last_ci = -1, last_il = -1, last_blk = -1;
-    for (;;) {
-        if (wave == 0) {
-            const unsigned old = atomicAdd(&ctr[0], one);       // one hardware atomic per wave (lane 0 receives the old head)
-            *s_task = __builtin_amdgcn_readfirstlane((int)old);
-        }
-        __syncthreads();
-        const int t = __builtin_amdgcn_readfirstlane(*s_task);
-        if (t >= total) break;
-        const int blk = t / p.tasks_per_blk, ti = t - blk * p.tasks_per_blk;
-        const DfTask task = p.tasks[ti];
-        const int ci = __builtin_amdgcn_readfirstlane((int)task.conv);
-        const int il = __builtin_amdgcn_readfirstlane((int)task.img);
-        const int ty = __builtin_amdgcn_readfirstlane((int)task.ty), by = __builtin_amdgcn_readfirstlane((int)task.by);
-        const int img = first_img + blk * p.B + il;
-        if (img < img_end) {
-            const DfConv* c = p.convs + ci;
-            if (wave == 0 && !(ci == last_ci && il == last_il && blk == last_blk)) {   // (the same convolution of the same image again: already satisfied)
-                // wait for the producers of this image (earlier in the queue: already popped); the <= 4 counters are read together
-                const int ndeps = __builtin_amdgcn_readfirstlane(c->ndeps);
-                unsigned spins = 0;
-                for (;;) {
-                    unsigned missing = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (k < ndeps) {
-                            const int dep = __builtin_amdgcn_readfirstlane(c->dep[k]);
-                            const unsigned* d = done + ((size_t)blk * p.nconv + dep) * p.B + il;
-                            missing |= __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)c->need[k] ? 1u << k : 0u;
-                        }
-                    }
-                    const int m = __builtin_amdgcn_readfirstlane((int)missing);
-                    if (m == 0) break;
-                    __builtin_amdgcn_s_sleep(2);
-                    // bounded: a hand-off that never arrives (a bug, not a placement) ends the wait, is counted in ctr[3] with the
-                    // waiting task in ctr[4..6], and the launch completes with wrong data instead of hanging the GPU
-                    if (++spins > (1u << 18)) {
-                        const unsigned first = atomicAdd(&ctr[3], one);
-                        if (__builtin_amdgcn_readfirstlane((int)first) == 0) { ctr[4] = (unsigned)t; ctr[5] = (unsigned)ci; ctr[6] = (unsigned)m; }
-                        break;
-                    }
-                }
-                if (fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-            last_ci = ci; last_il = il; last_blk = blk;
-            __syncthreads();
-            {
-                const int variant = __builtin_amdgcn_readfirstlane(c->variant);
-                const int tiles_y = __builtin_amdgcn_readfirstlane(c->a.tiles_y), gy = __builtin_amdgcn_readfirstlane(c->a.gy);
-                const int bchunk = __builtin_amdgcn_readfirstlane(c->bchunk);
-                GRNET_LDS_AS float* lds = (GRNET_LDS_AS float*)smem;
-                // one task = one pixel tile x `bchunk` output-channel blocks (the plan picks bchunk so that a convolution of one image
-                // still splits into >= ~16 tasks: the pop, the wait and the descriptor are shared by the blocks of a task)
-                if (p.fence >= 2) {                            // diagnostic: queue and hand-offs only (2), or only one family of bodies (3: sums, 4+v: variant v)
-                    if (p.fence == 3 && variant < 0) df_sum_body(c, img, ty);
-                    if (p.fence >= 4 && variant == p.fence - 4) df_run_conv(c, variant, img * tiles_y + ty, by, by + 1, lds);
-                } else if (variant < 0) df_sum_body(c, img, ty);
-                else df_run_conv(c, variant, img * tiles_y + ty, by, min(gy, by + bchunk), lds);
-            }
-            // every wave's stores have left (vmcnt 0) before the workgroup's barrier; then ONE increment publishes the task.  The
-            // consumers are on this XCD: its L2 is the coherence point (a CU's L1 holds no line of a tensor before that tensor is complete)
-            if (fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (wave == 0) __hip_atomic_fetch_add(done + ((size_t)blk * p.nconv + ci) * p.B + il, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            __syncthreads();                                   // s_task is re-written right away: keep the barrier count equal on both paths
-        }
-    }
-}
-
-__global__ __launch_bounds__(256, 2) void hr_dataflow_f32(const DfParams p) {
-    extern __shared__ __align__(16) float smem[];
-    __shared__ int s_task;
-    __shared__ int s_flag;
-    const int xcd = xcc_id();
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const unsigned one = (threadIdx.x & 63) == 0 ? 1u : 0u;
-    // census + handshake (sequentially consistent device-scope read-modify-writes): an own worker registers, THEN reads the queue's
-    // "foreign workers present" flag; a foreign worker raises the flag, THEN re-reads the census.  At least one sees the other, so a
-    // queue is never run by unfenced own workers and fenced foreign workers that do not know of each other.
-    if (wave == 0) {
-        unsigned* ctr = p.counters + (size_t)xcd * p.ctr_stride;
-        atomicAdd(&ctr[1], one);
-        s_flag = __builtin_amdgcn_readfirstlane((int)atomicAdd(&ctr[2], 0u));
-    }
-    __syncthreads();
-    const bool own_fenced = p.fence == 1 || __builtin_amdgcn_readfirstlane(s_flag) != 0;
-    __syncthreads();
-    df_run_queue(p, xcd, own_fenced, smem, &s_task);
-    // Placement independence: an XCD that received no workgroup of this launch (the dispatcher promises nothing) still has a queue.
-    // Workgroups that finished their own queue take over queues whose census is still zero, with device-scope fences (correct from
-    // any XCD).  On the observed round-robin dispatch this loop finds nothing to do.
-    for (int q = 0; q < 8; ++q) {
-        if (q == xcd) continue;
-        if (wave == 0) {
-            unsigned* ctr = p.counters + (size_t)q * p.ctr_stride;
-            int take = 0;
-            if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
-                atomicOr(&ctr[2], 1u);
-                take = __builtin_amdgcn_readfirstlane((int)atomicAdd(&ctr[1], 0u)) == 0;
-            }
-            s_flag = take;
-        }
-        __syncthreads();
-        const bool take = __builtin_amdgcn_readfirstlane(s_flag) != 0;
-        __syncthreads();
-        if (take) df_run_queue(p, q, true, smem, &s_task);
-    }
-}
-
-__global__ void df_probe_kernel(int* out) {
-    if (threadIdx.x == 0) atomicAdd(&out[xcc_id()], 1);
-}
-
 // ---------------------------------------------------------------------------------------------
 int conv_pick_tc(int Cout) { return Cout >= 64 ? 64 : 32; }
 
@@ -1200,138 +959,7 @@ hipError_t conv_init() {
     if ((e = init_ks<true, 1, 1>()) != hipSuccess) return e;
     if ((e = init_ks<true, 3, 1>()) != hipSuccess) return e;
     if ((e = init_ks<true, 3, 2>()) != hipSuccess) return e;
-    if ((e = set_lds(conv_group_f32<1, 1>)) != hipSuccess) return e;
-    if ((e = set_lds(conv_group_f32<3, 1>)) != hipSuccess) return e;
-    if ((e = set_lds(conv_group_f32<3, 2>)) != hipSuccess) return e;
     return hipSuccess;
-}
-
-// Grouped launch of n (<= kMaxGroup) convolutions with identical (ks, stride).  Members must fit one of the
-// split-K variants; the launcher falls back to separate launches when they do not.
-hipError_t launch_conv_group(const ConvArgs* list, int n, hipStream_t s) {
-    if (n < 1 || n > kMaxGroup) return hipErrorInvalidValue;
-    GroupArgs g{};
-    g.n = n;
-    size_t lds = 0;
-    bool ok_all = true;
-    static const int allow_csw2 = getenv("GRNET_GROUP_CSW2") ? atoi(getenv("GRNET_GROUP_CSW2")) : 1;
-    // members with the longest per-wave MFMA chain first: their blocks are dispatched first and the short
-    // ones fill the tail of the launch
-    int order[kMaxGroup];
-    double chain_len[kMaxGroup];
-    for (int i = 0; i < n; ++i) {
-        order[i] = i;
-        chain_len[i] = (double)list[i].CinPad * list[i].ks * list[i].ks;
-    }
-    for (int i = 0; i < n; ++i)
-        for (int j = i + 1; j < n; ++j)
-            if (chain_len[order[j]] > chain_len[order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
-    for (int i = 0; i < n && ok_all; ++i) {
-        ConvArgs a = list[order[i]];
-        if (a.ks != list[0].ks || a.stride != list[0].stride) { ok_all = false; break; }
-        const int TCpack = conv_pick_tc(a.Cout);
-        if (a.CoutPad % TCpack != 0 || a.CinPad % kConvCK != 0) return hipErrorInvalidValue;
-        // candidate variants in order of preference: larger tiles first (less staging traffic)
-        const Cfg cands[] = {{1, 7, 2}, {1, 7, 1}, {1, 4, 1}};
-        bool found = false;
-        Cfg best{1, 7, 1};
-        double best_cost = 0;
-        for (const Cfg& c : cands) {
-            if (a.Wo > c.tps * 16) continue;
-            if (c.tcs == 2 && !allow_csw2) continue;
-            bool ok;
-            double cost = cfg_cost(a, c, &ok);
-            if (!ok) continue;
-            if (c.tcs == 2) cost *= 0.9;                  // grouped launches have waves to spare: prefer the wider cout tile
-            if (!found || cost < best_cost) { best = c; best_cost = cost; found = true; }
-        }
-        if (!found) { ok_all = false; break; }
-        plan_tile(a, best.tps, 1);
-        a.TC = best.tcs * 16;
-        int variant;
-        if (a.rows == 1) variant = best.tps == 7 ? (best.tcs == 2 ? 1 : 0) : 2;
-        else if (a.rows == 2) variant = 3;
-        else variant = best.tps == 4 ? 4 : 5;
-        if ((variant == 2 || variant == 3 || variant == 4) && best.tcs != 1) { ok_all = false; break; }
-        if (variant == 5 && best.tcs != 1) { ok_all = false; break; }
-        g.c[i] = a;
-        g.variant[i] = variant;
-        g.grid_x[i] = a.tiles_y * a.groups;
-        const int blocks = g.grid_x[i] * (a.CoutPad / a.TC);
-        g.first_block[i + 1] = g.first_block[i] + blocks;
-        const size_t l = lds_bytes(a, best);
-        if (l > lds) lds = l;
-    }
-    if (!ok_all) {                                        // not groupable: separate launches, same results
-        for (int i = 0; i < n; ++i) {
-            hipError_t e = launch_conv(list[i], s, 0);
-            if (e != hipSuccess) return e;
-        }
-        return hipSuccess;
-    }
-    const dim3 grid(g.first_block[n]);
-    if (list[0].ks == 1) return launch_k(conv_group_f32<1, 1>, grid, dim3(256), lds, s, g);
-    return list[0].stride == 1 ? launch_k(conv_group_f32<3, 1>, grid, dim3(256), lds, s, g)
-                               : launch_k(conv_group_f32<3, 2>, grid, dim3(256), lds, s, g);
-}
-
-
-// ---- host side of the dataflow kernel ------------------------------------------------------------------------------------------
-int df_plan_conv(ConvArgs& a, size_t* lds_out) {
-    if (a.CoutPad % 16 != 0 || a.CinPad % kConvCK != 0) return -1;
-    int ksid;
-    if (a.ks == 3 && a.stride == 1) ksid = 0;
-    else if (a.ks == 3 && a.stride == 2) ksid = 1;
-    else if (a.ks == 1 && a.stride == 1) ksid = 2;
-    else return -1;
-    const int tps_cands[2] = {7, 4};
-    for (int tps : tps_cands) {
-        if (a.Wo > tps * 16) continue;
-        ConvArgs t = a;
-        plan_tile(t, tps, 1);
-        if (t.R < 1 || t.G != 1) continue;                     // a tile never spans two images: dependencies are per image
-        if (t.rows == 0) continue;                             // gather staging has no variant here
-        if (t.rows == 2 && tps != 4) continue;                 // planes mode exists for 4x1 tiles
-        if (tps == 4 && t.rows == 1 && a.Ho * a.Wo > 64 * 8 && false) continue;
-        const Cfg c{1, tps, 1, 4};
-        const size_t lds = lds_bytes(t, c);
-        if (lds > kMaxLds) continue;
-        // prefer 7x1 rows where the map is wide enough to fill it (56 and 28 pixel rows), 4x1 otherwise
-        if (tps == 7 && t.rows == 1 && (t.R * t.Wo) * 10 < 112 * 8) continue;      // < 80 % of the 112-pixel tile used
-        a = t;
-        a.TC = 16;
-        a.gx = a.tiles_y * a.groups;
-        a.gy = a.CoutPad / 16;
-        a.xcd = 0;
-        *lds_out = lds;
-        return ksid * 3 + (t.rows == 2 ? 2 : (tps == 7 ? 0 : 1));
-    }
-    return -1;
-}
-
-hipError_t launch_hr_dataflow(const DfParams& p, size_t lds, int wgs_per_xcd, hipStream_t s) {
-    static bool lds_set = false;
-    if (!lds_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hr_dataflow_f32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds - 1024);   // the kernel also has a few static LDS words
-        if (e != hipSuccess) return e;
-        lds_set = true;
-    }
-    return launch_k(hr_dataflow_f32, dim3(8 * wgs_per_xcd), dim3(256), lds, s, p);
-}
-
-hipError_t df_probe_xcc(int wgs_per_xcd, int* ok, hipStream_t s) {
-    int* d = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d), 8 * sizeof(int));
-    if (e != hipSuccess) return e;
-    int h[8] = {};
-    e = hipMemsetAsync(d, 0, sizeof(h), s);
-    if (e == hipSuccess) { hipLaunchKernelGGL(df_probe_kernel, dim3(8 * wgs_per_xcd), dim3(256), 0, s, d); e = hipGetLastError(); }
-    if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    hipFree(d);
-    *ok = 1;
-    for (int x = 0; x < 8; ++x) if (h[x] != wgs_per_xcd) *ok = 0;
-    return e;
 }
 
 const char* conv_dominant_kernel_name() { return "conv_mfma_f32 / conv_splitk_f32"; }

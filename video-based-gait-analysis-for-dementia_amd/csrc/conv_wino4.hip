@@ -1,14 +1,14 @@
 // Winograd F(4x4, 3x3) on the fp32 matrix cores for the widest 3x3 stride-1 layers on 56x56 maps (upsample head 256 -> 256, PARE head
 // 480 -> 256: hrnet.py:444-451, pare.py:197-210 -- Conv2d 3x3 pad 1 + BatchNorm2d(eval) + ReLU).  A 4x4 output tile is 36 independent
-// products instead of 144 multiplies: 2.25 per output against 4 for F(2x2, 3x3) (conv_wino.hip) and 9 for the direct kernel.  The
+// products instead of 144 multiplies: 2.25 per output against 4 for F(2x2, 3x3) (round 2: tools/experiments/conv_wino.hip) and 9 for the direct kernel.  The
 // transforms have non-trivial coefficients (4, 5, 2, 8 and sixths in the filter transform, which is applied in fp64 at load):
 // measured on a 256-channel layer in fp32 the result is 7.8e-6 of the output rms away from the exact sum (F(2x2,3x3): 8e-7, the
 // direct fma chain: 1.9e-6) -- two orders of magnitude inside the 1e-3 bar, covered by the same parity tests.
 //
-// Same loop discipline as conv_wino.hip (on gfx950 every vector instruction between fp32 MFMAs is matrix-pipe time: few of them,
+// Loop discipline (worked out on the round-2 F(2x2,3x3) kernel): on gfx950 every vector instruction between fp32 MFMAs is matrix-pipe time: few of them,
 // clustered).  One workgroup (4 waves): one image, ONE tile row = 14 tiles (output rows 4r .. 4r+3; one MFMA row tile, 2 rows
 // idle), 64 output channels, all 36 points -- wave w owns points 9w .. 9w+8 = 9 x 4 accumulator tiles (144 registers).  Per chunk of
-// 8 input channels: the 6 input rows of the chunk by LDS-DMA (the same raw layout as conv_wino.hip); thread (channel, tile, half)
+// 8 input channels: the 6 input rows of the chunk by LDS-DMA (rows contiguous in the NCHW plane, 16-byte units); thread (channel, tile, half)
 // transforms HALF of a 6x6 patch -- 6 16-byte LDS reads + DPP for the two edge columns, three rows of B^T d and their 18 products
 // with B, 18 LDS writes into V[point][channel][16 tiles]; 72 MFMAs per wave, A fragment = one LDS dword, the 4 B fragments = one
 // 16-byte load straight from L2, requested a chunk ahead.
@@ -47,7 +47,7 @@ __device__ __forceinline__ void bt_hi(const float* d, float& r3, float& r4, floa
 }
 
 // NB: 16-channel blocks per workgroup: 4, or 2 = HALF a 64-channel block of the same packed weights (the half-size workgroups of a
-// layer's last round, ConvArgs::wsplit, as in conv_wino.hip)
+// layer's last round, ConvArgs::wsplit)
 // WD: map width, 56 or 28.  A workgroup's 14 tiles are one tile row of a 56-wide map (6 input rows) or two tile rows of 7 of a 28-wide
 // one (10 input rows; 7 tile rows per image = 3.5 groups: the last group's lower half reads zeros and stores nothing).
 // WSPLIT: the 32-channel kernel on HALF a 64-channel block of weights packed for the 64-channel kernel (last-round workgroups).  The
@@ -78,7 +78,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
     const int img = bx / groups, r = bx - img * groups;
     const int co0 = WSPLIT ? by * 64 : by * (NB * 16);      // first channel of the weight block; channel n*16 + l sits at l*cstr + n
     constexpr int cstr = WSPLIT ? 4 : NB;
-    if (a.prio == 1) __builtin_amdgcn_s_setprio(1);         // critical-chain layers (conv_wino.hip)
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(1);         // critical-chain layers
     else if (a.prio >= 2) __builtin_amdgcn_s_setprio(3);
     const int HW = a.H * a.W;
     const float* inb = a.in + ((size_t)img * a.in_ctot + a.in_coff) * HW;
@@ -329,7 +329,7 @@ static hipError_t launch_wino4_w(ConvArgs a, hipStream_t s, int nb, int* n_launc
     }
 #endif
     if (nb == 2) return launch_k(conv_wino4_f32<2, WD>, dim3(total), dim3(256), kLdsB, s, a);
-    // a last round of workgroups that is at most half full runs as twice as many half-size workgroups (conv_wino.hip)
+    // a last round of workgroups that is at most half full runs as twice as many half-size workgroups
     static const int split_env = getenv("GRNET_WINO_SPLIT") ? atoi(getenv("GRNET_WINO_SPLIT")) : 1;
     static int cu_count[64] = {};                        // workgroups per round = CUs of this device (one workgroup fits a CU)
     int dev = 0;

@@ -5,14 +5,15 @@
 // together keeping the FP32 pipe (matrix + vector instructions share it on gfx950) busy all the time, and the two small-map branches
 // asking for 80 % of that time -- 9 multiplies per output where F(4x4,3x3) needs 2.25 (x 1.31 for padding 14 -> 16 / 7 -> 8).
 //
-// Same register-resident structure as conv_wino4r.hip.  A 14x14 map is 4x4 tiles of 4x4 outputs (16 tiles = the 16 rows of ONE MFMA
+// Register-resident: nothing of the main loop goes through the LDS and there is no workgroup barrier in it.  A 14x14 map is 4x4 tiles of 4x4 outputs (16 tiles = the 16 rows of ONE MFMA
 // row tile = one image), a 7x7 map 2x2 tiles (an MFMA row tile = 4 images).  A wave owns (row tile, 16 output channels, all 36
 // points, the k-steps of its K slice):
 //   * lane (tile, channel k of the k-step) loads its own 6 patch rows straight into registers (rows / images outside are out-of-range
 //     buffer offsets = zeros; the columns past the map's right edge are an out-of-range second half on 14-wide maps, one select on
 //     7-wide ones), column pass on its own 4 columns, halo columns TRANSFORMED from the x-neighbour tiles by DPP row shifts of 4 / 8
 //     lanes (tiles are laid out x-major in the 16 lanes so that a shift past the row's end IS the zero padding), row pass, 36 MFMAs;
-//   * B fragments as in conv_wino4r.hip (pack_wino4r_weights, one 8-byte load per point and k-pair, re-requested behind its MFMA);
+//   * B fragments: one 8-byte load per point and pair of k-steps, packed per (channel block, k-pair, point) as 64 lanes x 2 floats
+//     (pack_wino4r_weights), re-requested for the next pair right behind the point's last MFMA;
 //   * KS waves of a workgroup split the input channels (K = 128 / 256 needs it: 8 k-steps per wave).  Every wave inverse-transforms
 //     its partial sums in registers (the transform is linear) and writes them to ITS slot of an LDS tile laid out like the output
 //     (16 channels x H x W are one contiguous run of the NCHW tensor per image); after one barrier the waves share the read-out:
@@ -272,6 +273,19 @@ hipError_t launch_conv_wino4s(ConvArgs a, hipStream_t s, int ksplit) {
     if (a.W == 14 && a.Cin == 128) return ksplit == 2 ? launch_s<14, 128, 2>(a, s) : launch_s<14, 128, 4>(a, s);
     if (a.W == 14) return launch_s<14, 256, 4>(a, s);
     return ksplit == 2 ? launch_s<7, 256, 2>(a, s) : launch_s<7, 256, 4>(a, s);
+}
+
+// U = G g G^T per (cout, cin) in fp64 -> [cout/16][cin/8][36][lane = (cin%4)*16 + cout%16][k-step of the pair]; w: (cout, cin, 3, 3) folded weights
+void pack_wino4r_weights(const double* w, int cout, int cin, float* out) {
+    const int nkp = cin / 8;
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            double u[36];
+            wino4_transform_filter(w + ((size_t)co * cin + ci) * 9, u);
+            const int nb = co / 16, l15 = co % 16, ks = ci / 4, lq = ci % 4;
+            for (int p = 0; p < 36; ++p)
+                out[((((size_t)nb * nkp + ks / 2) * 36 + p) * 64 + lq * 16 + l15) * 2 + (ks & 1)] = (float)u[p];
+        }
 }
 
 }  // namespace grk

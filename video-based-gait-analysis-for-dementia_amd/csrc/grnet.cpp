@@ -57,29 +57,22 @@ struct ConvLayer {
     View in, out;
     std::vector<ConvSeg> segs;
     int cout = 0, ks = 1, stride = 1, relu = 0;
-    bool hr = false;            // inside the HR section (transition1 .. stage 4) that the dataflow kernel can run as ONE persistent launch
     bool solo = false;          // runs with no other launch beside it (stem, layer1, PARE head): isolated timings predict it well
     int cin_w = 0;              // input channels of the weight tensor (< in.c only for the bf16 stem: 3 of the 8 stored)
     std::vector<AddRef> adds;
     float* w_dev = nullptr;
     float* b_dev = nullptr;
     float* wino4_dev = nullptr; // transformed weights [36][cin_pad][cout_pad] of the Winograd F(4x4,3x3) kernel (the widest 56x56 layers only)
-    float* wino_dev = nullptr;  // transformed weights [16][cin_pad][cout_pad] of the Winograd F(2x2,3x3) kernel (eligible fp32 layers only)
-    float* wino4r_dev = nullptr; // transformed weights of the register-resident F(4x4,3x3) kernels (conv_wino4r.hip: the narrow HR branches; conv_wino4s.hip: 14x14 / 7x7 maps)
-    bool small_map = false;      // wino4r_dev belongs to conv_wino4s.hip
+    float* wino4s_dev = nullptr; // transformed weights of the register-resident F(4x4,3x3) kernel of the 14x14 / 7x7 maps (conv_wino4s.hip)
     int cin_pad = 0, cout_pad = 0;
     double macs_per_frame = 0;
     int lane_hint = 0;          // lane of this convolution when it is launched on its own (not as a group member)
-    int block_role = 0;         // 1 / 2: first / second convolution of a BasicBlock that the fused kernel can run (conv_wino4_block.hip)
-    int block_peer = -1;        // index of the other convolution of that block
     std::map<int, int> tuned;   // n_frames -> launch configuration (tile hint) measured fastest by grnet_tune
 };
 
 struct Op {
-    enum Kind { CONV, GROUP, SUM, BILINEAR, POOL, TAIL, SMPL, CONVERT, DATAFLOW } kind;
-    bool hr = false;          // member of the HR section (see ConvLayer::hr)
+    enum Kind { CONV, SUM, BILINEAR, POOL, TAIL, SMPL, CONVERT } kind;
     int conv_idx = -1;
-    std::vector<int> group;   // GROUP: indices into convs[] launched together (independent, same ks/stride)
     SumArgs sum{};
     View bin, bout;   // bilinear
     // multi-lane execution: independent branches of the HR modules run on parallel HIP streams
@@ -131,23 +124,9 @@ struct grnet {
 
     std::unordered_map<std::string, HostTensor> tensors;
     std::vector<ConvLayer> convs;
-    std::vector<Op> ops;        // schedule A: grouped launches (GROUP ops) on lane 0 + lanes for the heads
-    std::vector<Op> ops_flat;   // schedule B: every GROUP expanded into per-member launches on the members' lanes
+    std::vector<Op> ops;        // the plan in the order it is written (build_plan)
+    std::vector<Op> ops_flat;   // the same ops placed on the lane streams by schedule_lanes(): the enqueue order
     std::vector<hipEvent_t> op_events_flat;
-    // schedule C: the HR section of schedule B replaced by ONE Op::DATAFLOW (hr_dataflow_f32), the rest on the lane streams
-    std::vector<Op> ops_df;
-    std::vector<hipEvent_t> op_events_df;
-    std::vector<const float*> df_reads, df_writes;   // buffers the section reads from outside / writes
-    struct DfPlan {
-        std::vector<DfConv> convs; std::vector<DfTask> tasks;
-        DfConv* d_convs = nullptr; DfTask* d_tasks = nullptr; unsigned* d_counters = nullptr;
-        int tasks_per_blk = 0, nconv = 0, B = 2, ipx = 0, ctr_stride = 0; size_t lds = 0, ctr_bytes = 0; bool ok = false;
-    };
-    std::map<int, DfPlan> df_plans;                  // per frames-per-call
-    int df_mode = 0;                                 // GRNET_OPT_DATAFLOW: 0 never (default: measured slower than the lane streams this round), 1 wherever a plan exists, 2 where grnet_tune measured it faster
-    int df_probe = -1;                               // -1 not probed yet, 0 the dispatcher does not spread this grid over the 8 XCDs evenly, 1 it does
-    int df_wgs_per_xcd = 96;                         // 32 CUs x 3 resident workgroups
-    int df_fence = 0;                                // validation: device-scope fences around every hand-off
     int wino_mode = 1;                               // GRNET_OPT_WINOGRAD: 1 = the eligible 3x3 layers on 56x56 maps run the Winograd kernel
 
     // planned buffers: (pointer slot, floats per image)
@@ -184,10 +163,8 @@ struct grnet {
     hipStream_t side[kLanes] = {};      // lanes 1.. (lane 0 = the caller's stream)
     hipEvent_t ev_fork = nullptr, ev_join[kLanes] = {};
     int lanes_used = 1;
-    std::vector<hipEvent_t> op_events;
     int cur_lane = 0;
     bool multi_lane = true;
-    bool grouping = true;      // GROUP ops as one grouped launch (false: one launch per member; same results)
     int launches_last = 0;
 
     int fail(int code, const std::string& msg) {
@@ -221,9 +198,7 @@ struct grnet {
             if (ev_join[l]) (void)hipEventDestroy(ev_join[l]);
         }
         if (ev_fork) (void)hipEventDestroy(ev_fork);
-        for (hipEvent_t e : op_events) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : op_events_flat) if (e) (void)hipEventDestroy(e);
-        for (hipEvent_t e : op_events_df) if (e) (void)hipEventDestroy(e);
         for (void* p : dev_allocs) (void)hipFree(p);
         if (temporal_ws) (void)hipFree(temporal_ws);
         if (arena) (void)hipFree(arena);
@@ -271,44 +246,15 @@ struct grnet {
         L.macs_per_frame = (double)ho * wo * cout * L.cin_w * ks * ks;
         L.lane_hint = cur_lane;
         L.solo = solo_region;
-        L.hr = hr_region;
         convs.push_back(L);
-        if (group_open) {
-            open_group.push_back((int)convs.size() - 1);
-            return convs.back().out;
-        }
         Op op;
         op.kind = Op::CONV;
         op.conv_idx = (int)convs.size() - 1;
         op.lane = cur_lane;
-        op.hr = hr_region;
         ops.push_back(op);
         return convs.back().out;
     }
-    // Convolutions added between begin_group() and end_group() are independent of each other and have
-    // the same kernel size / stride: they become ONE grouped launch.
     bool solo_region = false;   // build_plan: convolutions added now are part of a chain nothing else overlaps
-    bool hr_region = false;     // build_plan: ops added now belong to the HR section
-    bool group_open = false;
-    std::vector<int> open_group;
-    void begin_group() { group_open = true; open_group.clear(); }
-    void end_group() {
-        group_open = false;
-        if (open_group.empty()) return;
-        Op op;
-        op.hr = hr_region;
-        op.lane = 0;                                         // a grouped launch runs on lane 0; its members keep their own lane hints
-        if (open_group.size() == 1) {
-            op.lane = convs[open_group[0]].lane_hint;
-            op.kind = Op::CONV;
-            op.conv_idx = open_group[0];
-        } else {
-            op.kind = Op::GROUP;
-            op.group = open_group;
-        }
-        ops.push_back(op);
-        open_group.clear();
-    }
     View conv_bn(View in, const std::string& wkey, const std::string& bn, int cout, int ks, int stride, bool relu,
                  std::vector<AddRef> adds = {}, const View* out_override = nullptr) {
         return add_conv(in, {ConvSeg{wkey, bn, "", cout}}, ks, stride, relu, std::move(adds), out_override);
@@ -325,46 +271,32 @@ struct grnet {
     }
 
     // HighResolutionModule (hrnet.py:249-267).  out0 (optional) receives fused output 0.
-    // The branches advance in lock step: the same-depth convolutions of all branches are one grouped launch
-    // (8 launches for the 4 BasicBlocks of every branch), and the fuse layer is grouped by dependency level.
+    // Every convolution is its own launch on the lane of its branch; schedule_lanes() places the fuse layer's launches.
     std::vector<View> hr_module(std::vector<View> xs, const std::string& p, const View* out0) {
         const int nb = (int)xs.size();
         cur_lane = 0;
         for (int k = 0; k < 4; ++k) {
             std::vector<View> y(nb);
-            std::vector<int> first(nb);
-            begin_group();
             for (int b = 0; b < nb; ++b) {
                 cur_lane = b;
                 const std::string q = p + "branches." + std::to_string(b) + "." + std::to_string(k) + ".";
                 y[b] = conv_bn(xs[b], q + "conv1.weight", q + "bn1", kBranchCh[b], 3, 1, true);
-                first[b] = (int)convs.size() - 1;
             }
-            end_group();
-            begin_group();
             for (int b = 0; b < nb; ++b) {
                 cur_lane = b;
                 const std::string q = p + "branches." + std::to_string(b) + "." + std::to_string(k) + ".";
                 xs[b] = conv_bn(y[b], q + "conv2.weight", q + "bn2", kBranchCh[b], 3, 1, true, {AddRef{xs[b], 0}});
-                if (dtype == 0 && bblock_wino4_eligible(kBranchCh[b], xs[b].h, xs[b].w)) {
-                    const int second = (int)convs.size() - 1;
-                    convs[first[b]].block_role = 1; convs[first[b]].block_peer = second;
-                    convs[second].block_role = 2; convs[second].block_peer = first[b];
-                }
             }
-            end_group();
         }
         // up terms t[i][j], j > i: conv1x1 + BN at the resolution of branch j (nearest upsample is
-        // applied where the term is consumed: it commutes with the per-pixel conv/BN) -- one grouped launch
+        // applied where the term is consumed: it commutes with the per-pixel conv/BN)
         std::vector<std::vector<View>> t(nb, std::vector<View>(nb));
-        begin_group();
         for (int i = 0; i < nb; ++i)
             for (int j = i + 1; j < nb; ++j) {
                 const std::string q = p + "fuse_layers." + std::to_string(i) + "." + std::to_string(j) + ".";
                 cur_lane = j;
                 t[i][j] = conv_bn(xs[j], q + "0.weight", q + "1", kBranchCh[i], 1, 1, false);
             }
-        end_group();
         cur_lane = 0;
         std::vector<View> outs(nb);
         {   // output 0: elementwise sum of the identity and the upsampled terms
@@ -372,7 +304,6 @@ struct grnet {
             Op op;
             op.kind = Op::SUM;
             op.lane = 0;
-            op.hr = hr_region;
             SumArgs& sa = op.sum;
             sa.C = kBranchCh[0]; sa.H = xs[0].h; sa.W = xs[0].w; sa.relu = 1;
             sa.n_add = nb;
@@ -390,7 +321,6 @@ struct grnet {
         for (int i = 2; i < nb; ++i)
             for (int j = 0; j < i - 1; ++j) d[i][j] = xs[j];
         for (int level = 0; level < nb; ++level) {
-            begin_group();
             for (int i = 2; i < nb; ++i)
                 for (int j = 0; j < i - 1; ++j) {
                     if (level >= i - j) continue;
@@ -409,7 +339,6 @@ struct grnet {
                 const std::string q = p + "fuse_layers." + std::to_string(i) + "." + std::to_string(i - 1) + ".0.";
                 outs[i] = conv_bn(xs[i - 1], q + "0.weight", q + "1", kBranchCh[i], 3, 2, true, adds);
             }
-            end_group();
         }
         cur_lane = 0;
         return outs;
@@ -444,7 +373,6 @@ struct grnet {
         }
         name_view("layer1", x);
         solo_region = false;
-        hr_region = true;                                   // transition1 .. stage 4: one persistent dataflow launch when enabled
         std::vector<View> xs;
         xs.push_back(conv_bn(x, b + "transition1.0.0.weight", b + "transition1.0.1", 32, 3, 1, true));
         cur_lane = 1;
@@ -466,7 +394,6 @@ struct grnet {
             xs = hr_module(xs, b + "stage4." + std::to_string(m) + ".", m == 2 ? &o0 : nullptr);
         }
         for (size_t i = 0; i < xs.size(); ++i) name_view("stage4." + std::to_string(i), xs[i]);
-        hr_region = false;
         int coff = 32;
         for (int idx = 2; idx <= 4; ++idx) {                // upsample heads (hrnet.py:440-453,521-523)
             const int br = idx - 1, c = kBranchCh[br], n_layers = idx - 1;
@@ -546,62 +473,20 @@ struct grnet {
         for (auto& nv : named) resolve(nv.second);
         resolve(v_cat); resolve(v_heat); resolve(v_smpl_feats); resolve(v_csmap);
         if (dtype == 1) resolve(v_in8);
-        ops_flat.clear();
-        for (const Op& op : ops) {
-            if (op.kind != Op::GROUP) { ops_flat.push_back(op); continue; }
-            for (int ci : op.group) {
-                Op m;
-                m.kind = Op::CONV;
-                m.conv_idx = ci;
-                m.lane = convs[ci].lane_hint;
-                m.hr = convs[ci].hr;
-                ops_flat.push_back(m);
-            }
-        }
+        ops_flat = ops;
         static const int sched_env = getenv("GRNET_LANE_SCHED") ? atoi(getenv("GRNET_LANE_SCHED")) : 1;   // 0: lanes as written in the plan
         if (sched_env) schedule_lanes(ops_flat, max_frames);
-        {   // schedule C
-            std::map<const float*, int> wr, rd;
-            bool placed = false;
-            for (const Op& op : ops_flat) {
-                if (!op.hr) { ops_df.push_back(op); ops_df.back().waits.clear(); ops_df.back().record = false; continue; }
-                if (!placed) {
-                    Op d;
-                    d.kind = Op::DATAFLOW;
-                    d.lane = 0;
-                    ops_df.push_back(d);
-                    placed = true;
-                }
-                std::vector<const float*> r;
-                op_reads(op, r);
-                for (const float* b : r) rd[b] = 1;
-                if (const float* o = op_writes(op)) wr[o] = 1;
-            }
-            for (auto& kv : wr) df_writes.push_back(kv.first);
-            for (auto& kv : rd) if (!wr.count(kv.first)) df_reads.push_back(kv.first);
-            if (sched_env) schedule_lanes(ops_df, max_frames);
-        }
-        analyze_dependencies(ops, op_events);
         analyze_dependencies(ops_flat, op_events_flat);
-        analyze_dependencies(ops_df, op_events_df);
         // streams / events of the parallel lanes are created here, never inside a stream capture
         if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return fail(GRNET_EHIP, "hipEventCreate failed");
         lanes_used = 1;                                        // only the streams the two schedules really use are created / forked / joined
-        for (const Op& op : ops) lanes_used = std::max(lanes_used, op.lane + 1);
         for (const Op& op : ops_flat) lanes_used = std::max(lanes_used, op.lane + 1);
-        for (const Op& op : ops_df) lanes_used = std::max(lanes_used, op.lane + 1);
         for (int l = 1; l < lanes_used; ++l) {
             if (hipStreamCreateWithFlags(&side[l], hipStreamNonBlocking) != hipSuccess) return fail(GRNET_EHIP, "hipStreamCreate failed");
             if (hipEventCreateWithFlags(&ev_join[l], hipEventDisableTiming) != hipSuccess) return fail(GRNET_EHIP, "hipEventCreate failed");
         }
-        for (size_t i = 0; i < ops.size(); ++i)
-            if (ops[i].record && hipEventCreateWithFlags(&op_events[i], hipEventDisableTiming) != hipSuccess)
-                return fail(GRNET_EHIP, "hipEventCreate failed");
         for (size_t i = 0; i < ops_flat.size(); ++i)
             if (ops_flat[i].record && hipEventCreateWithFlags(&op_events_flat[i], hipEventDisableTiming) != hipSuccess)
-                return fail(GRNET_EHIP, "hipEventCreate failed");
-        for (size_t i = 0; i < ops_df.size(); ++i)
-            if (ops_df[i].record && hipEventCreateWithFlags(&op_events_df[i], hipEventDisableTiming) != hipSuccess)
                 return fail(GRNET_EHIP, "hipEventCreate failed");
         if (hipStreamCreateWithFlags(&capture_stream, hipStreamNonBlocking) != hipSuccess) return fail(GRNET_EHIP, "hipStreamCreate failed");
         const size_t n = max_frames;
@@ -639,7 +524,6 @@ struct grnet {
                 break;
             case Op::BILINEAR: r.push_back(op.bin.p); break;
             case Op::POOL: r.push_back(v_heat.p); r.push_back(v_smpl_feats.p); r.push_back(v_csmap.p); break;
-            case Op::DATAFLOW: r = df_reads; break;
             default: break;
         }
     }
@@ -651,7 +535,7 @@ struct grnet {
         return nullptr;
     }
 
-    // Static list scheduling of the un-grouped op list onto the kLanes streams.  The plan writes "branch b on lane b",
+    // Static list scheduling of the op list onto the kLanes streams.  The plan writes "branch b on lane b",
     // which leaves the fuse layer of an HR module as a chain of small launches on the lane of the slowest branch
     // (measured: ~210 us per stage-4 module in which mostly one small kernel runs at a time).  Here every op gets an
     // estimated duration, and ops are placed earliest-start-first (ties: longest remaining path first) on the lane
@@ -675,7 +559,6 @@ struct grnet {
                     est[i] = fix_us + gf / (gf > 20 ? 0.105 : gf > 3 ? 0.085 : 0.060);     // us; GFLOP per us = TFLOP/s / 1000
                     break;
                 }
-                case Op::DATAFLOW: est[i] = 2500; break;
                 case Op::POOL: est[i] = 50; break;
                 case Op::TAIL: est[i] = 50; break;
                 case Op::SMPL: est[i] = 60; break;
@@ -693,8 +576,6 @@ struct grnet {
                 prev_tail = i;
             }
             if (const float* o = op_writes(op)) writers[o].push_back(i);
-            if (op.kind == Op::DATAFLOW)
-                for (const float* o : df_writes) writers[o].push_back(i);
         }
         for (int i = 0; i < m; ++i)
             for (int d : deps[i]) users[d].push_back(i);
@@ -719,7 +600,7 @@ struct grnet {
                 int from = -1;
                 for (int d : deps[i])
                     if (finish[d] >= ready) { ready = finish[d]; from = d; }
-                const bool pinned = list[i].kind == Op::POOL || list[i].kind == Op::TAIL || list[i].kind == Op::SMPL || list[i].kind == Op::DATAFLOW;
+                const bool pinned = list[i].kind == Op::POOL || list[i].kind == Op::TAIL || list[i].kind == Op::SMPL;
                 int lane = 0;
                 double start = std::max(ready, lane_free[0]);
                 if (!pinned) {
@@ -767,19 +648,12 @@ struct grnet {
                     for (auto& a : L.adds) r.push_back(a.v.p);
                     break;
                 }
-                case Op::GROUP:
-                    for (int ci : op.group) {
-                        r.push_back(convs[ci].in.p);
-                        for (auto& a : convs[ci].adds) r.push_back(a.v.p);
-                    }
-                    break;
                 case Op::SUM:
                     for (auto& a : sum_views[op.conv_idx].second) r.push_back(a.v.p);
                     break;
                 case Op::BILINEAR: r.push_back(op.bin.p); break;
                 case Op::POOL: r.push_back(v_heat.p); r.push_back(v_smpl_feats.p); r.push_back(v_csmap.p); break;
-                case Op::DATAFLOW: r = df_reads; break;
-                default: break;                                 // TAIL / SMPL follow POOL on lane 0
+                    default: break;                                 // TAIL / SMPL follow POOL on lane 0
             }
         };
         std::vector<const float*> r;
@@ -803,10 +677,6 @@ struct grnet {
             else if (op.kind == Op::BILINEAR) out = op.bout.p;
             else if (op.kind == Op::CONVERT) out = v_in8.p;
             if (out) writers[out].push_back(i);
-            if (op.kind == Op::GROUP)
-                for (int ci : op.group) writers[convs[ci].out.p].push_back(i);
-            if (op.kind == Op::DATAFLOW)
-                for (const float* o : df_writes) writers[o].push_back(i);
         }
         op_events.assign(ops.size(), nullptr);
         if (getenv("GRNET_TRACE")) {
@@ -838,20 +708,17 @@ struct grnet {
         L.cin_pad = bf ? (L.in.c + 31) / 32 * 32 : (cin + kConvCK - 1) / kConvCK * kConvCK;
         L.cout_pad = bf ? (L.cout + 31) / 32 * 32 : (L.cout + TC - 1) / TC * TC;
         std::vector<float> wp((size_t)taps * L.cin_pad * L.cout_pad, 0.f), bp(L.cout_pad, 0.f);
-        // Every eligible layer takes a Winograd kernel: on 56x56 maps layer1, upsample heads, PARE head, transition1's 256 -> 32 and the
-        // 32 -> 32 convolutions of the HR branch; on 28x28 maps the upsample-head layers and the 64 -> 64 convolutions of the HR branch
-        // (F(4x4,3x3) in 32-channel workgroups: 16.3 us per launch against the split-K kernel's 14.1 ALONE, but a third of its
-        // matrix-pipe time, and stages 2-4 are bound by the pipe time of four concurrent branches: 3 636 -> 3 713 frames/s).  With
-        // GRNET_WINO4=0 (F(2x2,3x3) only) the 28x28 branch layers lose: 31 us.
-        static const int wino4_env = getenv("GRNET_WINO4") ? atoi(getenv("GRNET_WINO4")) : 2;      // 0: F(2x2,3x3) only, 1: F(4x4,3x3) for >= 64 channels, 2: for every eligible layer
-        const bool wino = !bf && conv_wino_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size()) && L.cin_pad % 8 == 0 &&
-                          L.cout_pad % (L.cout % 64 == 0 ? 64 : 32) == 0 && (L.adds.empty() || L.adds[0].shift == 0) &&
-                          (L.in.w == 56 || (L.in.c >= (wino4_env ? 64 : 128) && L.cout % 64 == 0));
-        const bool wino4 = wino && wino4_env && L.in.c >= (wino4_env >= 2 ? 32 : 64) && L.cout >= (wino4_env >= 2 ? 32 : 64) &&
-                           conv_wino4_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size());
+        // Every eligible 3x3 stride-1 layer takes a Winograd F(4x4,3x3) kernel: on 56x56 maps layer1, upsample heads, PARE head, transition1's
+        // 256 -> 32 and the 32 -> 32 convolutions of the HR branch; on 28x28 maps the upsample-head layers and the 64 -> 64 convolutions of
+        // the HR branch (conv_wino4.hip); on 14x14 / 7x7 maps the 128- / 256-channel HR branches and the 256 -> 256 upsample-head layer
+        // (conv_wino4s.hip).  GRNET_WINO4=0 leaves every layer on the direct kernels (as GRNET_OPT_WINOGRAD = 0 does at run time).
+        static const int wino4_env = getenv("GRNET_WINO4") ? atoi(getenv("GRNET_WINO4")) : 2;
+        const bool wino4 = !bf && wino4_env && conv_wino4_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size()) && L.cin_pad % 8 == 0 &&
+                           L.cout_pad % (L.cout % 64 == 0 ? 64 : 32) == 0 && (L.adds.empty() || L.adds[0].shift == 0) &&
+                           (L.in.w == 56 || (L.in.c >= 64 && L.cout % 64 == 0));
         const bool wino4s = !bf && wino4_env && cin == L.in.c && conv_wino4s_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size()) &&
                             (L.adds.empty() || L.adds[0].shift == 0);          // the small maps: conv_wino4s.hip
-        std::vector<double> wfold(wino || wino4s ? (size_t)L.cout * cin * 9 : 0);     // BN-folded weights (cout, cin, 3, 3) for the filter transform
+        std::vector<double> wfold(wino4 || wino4s ? (size_t)L.cout * cin * 9 : 0);     // BN-folded weights (cout, cin, 3, 3) for the filter transform
         int co0 = 0;
         for (auto& s : L.segs) {
             const HostTensor* w = find(s.wkey);
@@ -881,7 +748,7 @@ struct grnet {
                     for (int t = 0; t < taps; ++t) {
                         const double wv = (double)w->data[((size_t)co * cin + ci) * taps + t] * scale[co];
                         wp[bf ? ((((size_t)(ci / 32) * taps + t) * L.cout_pad + co0 + co) * 32 + ci % 32) : ((size_t)t * L.cin_pad + ci) * L.cout_pad + co0 + co] = (float)wv;
-                        if (wino || wino4s) wfold[((size_t)(co0 + co) * cin + ci) * 9 + t] = wv;
+                        if (wino4 || wino4s) wfold[((size_t)(co0 + co) * cin + ci) * 9 + t] = wv;
                     }
             }
             co0 += s.cout;
@@ -896,26 +763,15 @@ struct grnet {
             return rc;
         }
         if ((rc = upload(bp, &L.b_dev))) return rc;
-        if (wino4s) {
-            std::vector<float> uwr((size_t)36 * cin * L.cout);
-            pack_wino4r_weights(wfold.data(), L.cout, cin, uwr.data());
-            if ((rc = upload(uwr, &L.wino4r_dev))) return rc;
-            L.small_map = true;
+        if (wino4s) {                                          // U = G g G^T of the folded filter, fp64 -> fp32
+            std::vector<float> uws((size_t)36 * cin * L.cout);
+            pack_wino4r_weights(wfold.data(), L.cout, cin, uws.data());
+            if ((rc = upload(uws, &L.wino4s_dev))) return rc;
         }
-        if (wino) {                                            // U = G g G^T of the folded filter, fp64 -> fp32
-            std::vector<float> uw((size_t)16 * L.cin_pad * L.cout_pad);
-            pack_wino_weights(wfold.data(), L.cout, cin, L.cin_pad, L.cout_pad, uw.data());
-            if ((rc = upload(uw, &L.wino_dev))) return rc;
-            if (wino4) {
-                std::vector<float> uw4((size_t)36 * L.cin_pad * L.cout_pad);
-                pack_wino4_weights(wfold.data(), L.cout, cin, L.cin_pad, L.cout_pad, uw4.data(), L.in.w);
-                if ((rc = upload(uw4, &L.wino4_dev))) return rc;
-            }
-            if (wino4 && conv_wino4r_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size()) && cin == L.in.c) {
-                std::vector<float> uwr((size_t)36 * cin * L.cout);
-                pack_wino4r_weights(wfold.data(), L.cout, cin, uwr.data());
-                if ((rc = upload(uwr, &L.wino4r_dev))) return rc;
-            }
+        if (wino4) {
+            std::vector<float> uw4((size_t)36 * L.cin_pad * L.cout_pad);
+            pack_wino4_weights(wfold.data(), L.cout, cin, L.cin_pad, L.cout_pad, uw4.data(), L.in.w);
+            if ((rc = upload(uw4, &L.wino4_dev))) return rc;
         }
         return 0;
     }
@@ -1075,11 +931,10 @@ struct grnet {
     }
 
     // Measure, don't guess: time every launch configuration of every distinct convolution shape on this GPU
-    // for n frames (3 launches each, HIP events) and keep the fastest; then time whole forwards with the HR-module
-    // convolutions grouped vs on parallel lanes and keep the faster schedule.  Activation buffers are used as
+    // for n frames (3 launches each, HIP events) and keep the fastest; then time whole forwards as a replayed hipGraph and as eager
+    // launches on the lane streams, with the cost model's and the measured table, and keep the fastest.  Activation buffers are used as
     // scratch (contents are garbage afterwards, like after any forward).
-    std::map<int, int> tuned_mode;     // n -> bit0: measured per-shape configurations (else cost model), bit1: grouped launches,
-                                       //      bit2: eager launches on the lane streams even if graphs are enabled
+    std::map<int, int> tuned_mode;     // n -> bit 0: measured per-shape configurations (else cost model), bit 2: eager launches on the lane streams even if graphs are enabled
     int tune(int n, hipStream_t s, int level = 1) {
         if (!finalized) return fail(GRNET_ESTATE, "grnet_tune before grnet_finalize_weights");
         if (n < 1 || n > max_frames) return fail(GRNET_EINVAL, "n_frames outside [1, max_frames]");
@@ -1088,16 +943,15 @@ struct grnet {
         // whatever way this function is left: events destroyed, half-built graphs dropped, the caller's schedule switches restored,
         // and -- unless the tuning completed -- no partial entry for n left behind
         struct Restore {
-            grnet* g; int n; bool grouping, use_graph, done = false; hipEvent_t *e0, *e1;
+            grnet* g; int n; bool use_graph, done = false; hipEvent_t *e0, *e1;
             ~Restore() {
                 if (*e0) (void)hipEventDestroy(*e0);
                 if (*e1) (void)hipEventDestroy(*e1);
                 g->drop_graphs();
-                g->grouping = grouping;
                 g->use_graph = use_graph;
                 if (!done) { g->tuned_mode.erase(n); for (auto& L : g->convs) L.tuned.erase(n); }
             }
-        } restore{this, n, grouping, use_graph, false, &e0, &e1};
+        } restore{this, n, use_graph, false, &e0, &e1};
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         std::map<std::tuple<int, int, int, int, int, int, int>, int> by_shape;
@@ -1127,22 +981,16 @@ struct grnet {
             L.tuned[n] = best_hint;
             by_shape[key] = best_hint;
         }
-        // schedule: {parallel lanes, grouped launches} x {cost model, measured table} x {replayed hipGraph, eager launches
-        // on the four lane streams} -- the graph executor of ROCm 7.2 maps parallel branches to fewer hardware queues
-        // than explicit streams do, so eager multi-stream launching can win although it costs CPU time per launch
-        // bit 3: the HR section as ONE persistent per-XCD dataflow launch (hr_dataflow_f32) instead of ~270 launches
-        float t_mode[16];
+        // schedule: {cost model, measured table} x {replayed hipGraph, eager launches on the four lane streams} -- the graph executor of
+        // ROCm 7.2 maps parallel branches to fewer hardware queues than explicit streams do, so eager multi-stream launching can win
+        // although it costs CPU time per launch.  Mode bits: 1 = measured per-shape table, 4 = eager.
+        float t_mode[8];
         for (float& t : t_mode) t = 1e30f;
-        const bool keep = grouping, keep_graph = use_graph;
-        const int keep_df = df_mode;
-        for (int mode = 0; mode < 16; ++mode) {
+        const bool keep_graph = use_graph;
+        for (int mode : {0, 1, 4, 5}) {
             if ((mode & 4) == 0 && !keep_graph) continue;                               // graphs not enabled by the caller
-            if (dtype == 1 && (mode & 11)) continue;                                    // bf16: no per-shape table, no grouped launches, no dataflow
-            if ((mode & 8) && ((mode & 2) || keep_df == 0)) continue;                   // dataflow replaces grouping; switched off by the caller
-            if (!(mode & 8) && keep_df == 1 && dtype == 0) continue;                    // dataflow forced by the caller
-            if (mode & 8) { tuned_mode[n] = mode; df_mode = 1; if (!dataflow_for(n)) { df_mode = keep_df; continue; } df_mode = keep_df; }
+            if (dtype == 1 && (mode & 1)) continue;                                     // bf16: no per-shape table
             use_graph = (mode & 4) == 0;
-            grouping = dtype != 1;
             tuned_mode[n] = mode;
             drop_graphs();
             seen_once.clear();
@@ -1155,12 +1003,11 @@ struct grnet {
             HIP_TRY(hipEventSynchronize(e1));
             HIP_TRY(hipEventElapsedTime(&t_mode[mode], e0, e1));
         }
-        grouping = keep;
         use_graph = keep_graph;
-        int best_mode = 0;
-        for (int mode = 1; mode < 16; ++mode)
-            if (t_mode[mode] < t_mode[best_mode]) best_mode = mode;
-        if (t_mode[best_mode] >= 1e30f) return fail(GRNET_ESTATE, "no schedule could be timed");
+        int best_mode = -1;
+        for (int mode : {0, 1, 4, 5})
+            if (t_mode[mode] < 1e30f && (best_mode < 0 || t_mode[mode] < t_mode[best_mode])) best_mode = mode;
+        if (best_mode < 0) return fail(GRNET_ESTATE, "no schedule could be timed");
         tuned_mode[n] = best_mode;
         // in-context refinement (level 2): greedy coordinate descent on the time of the whole replayed forward --
         // a configuration that wins alone can lose when four lanes share the CUs.  Shapes in order of their FLOP share.
@@ -1224,145 +1071,10 @@ struct grnet {
         restore.done = true;
         seen_once.clear();
         if (getenv("GRNET_TRACE"))
-            fprintf(stderr, "[grnet] tuned n=%d: forward ms graph[lanes/model %.3f lanes/measured %.3f grouped/model %.3f grouped/measured %.3f] "
-                    "eager[%.3f %.3f %.3f %.3f] dataflow graph[%.3f %.3f] eager[%.3f %.3f] -> mode %d\n",
-                    n, t_mode[0] / 3, t_mode[1] / 3, t_mode[2] / 3, t_mode[3] / 3, t_mode[4] / 3, t_mode[5] / 3, t_mode[6] / 3, t_mode[7] / 3,
-                    t_mode[8] / 3, t_mode[9] / 3, t_mode[12] / 3, t_mode[13] / 3, best_mode);
+            fprintf(stderr, "[grnet] tuned n=%d: forward ms graph[model %.3f measured %.3f] eager[model %.3f measured %.3f] -> mode %d\n",
+                    n, t_mode[0] / 3, t_mode[1] / 3, t_mode[4] / 3, t_mode[5] / 3, best_mode);
         return 0;
     }
-    bool grouping_for(int n) const {
-        if (conv_tile_hint || !grouping) return false;
-        auto it = tuned_mode.find(n);
-        return it == tuned_mode.end() ? false : (it->second & 2) != 0;
-    }
-
-    // ------------------------------------------------------------------ dataflow plan of the HR section
-    // Tile variant, task list and dependency table for calls of n frames (cached).  Images are dealt to the XCDs in contiguous ranges
-    // of ipx = ceil(n / 8); the task list covers one block of B images and repeats for every block of an XCD's range.
-    int build_df_plan(int n, DfPlan& pl) {
-        pl.ok = false;
-        if (dtype != 0) return 0;
-        std::map<const float*, int> producer;                  // buffer -> index in pl.convs of the section op that writes it
-        std::vector<int> need;                                 // tasks per image of each section op
-        struct Item { int conv; int tiles_y, gy, bchunk; };
-        static const int min_tasks = getenv("GRNET_DF_MINTASKS") ? atoi(getenv("GRNET_DF_MINTASKS")) : 16;
-        std::vector<Item> items;
-        pl.convs.clear(); pl.tasks.clear(); pl.lds = 0;
-        for (const Op& op : ops_flat) {
-            if (!op.hr) continue;
-            DfConv c{};
-            std::vector<const float*> reads;
-            const float* out = nullptr;
-            int tiles_y = 0, gy = 1;
-            if (op.kind == Op::CONV) {
-                const ConvLayer& L = convs[op.conv_idx];
-                c.a = conv_args(L, nullptr, n);
-                size_t lds = 0;
-                c.variant = df_plan_conv(c.a, &lds);
-                if (c.variant < 0) return 0;                   // a shape without a dataflow variant: the section stays on the lane streams
-                pl.lds = std::max(pl.lds, lds);
-                tiles_y = c.a.tiles_y; gy = c.a.gy;
-                reads.push_back(L.in.p);
-                for (auto& a : L.adds) reads.push_back(a.v.p);
-                out = L.out.p;
-            } else if (op.kind == Op::SUM) {
-                const auto& sv = sum_views[op.conv_idx];
-                if ((int)sv.second.size() < 2 || (int)sv.second.size() > 1 + kMaxAdd || sv.second[0].shift != 0) return 0;
-                c.variant = -1;
-                ConvArgs& a = c.a;
-                a.N = n; a.Cout = sv.first.c; a.Ho = sv.first.h; a.Wo = sv.first.w; a.relu = 1;
-                a.out = sv.first.p; a.out_ctot = sv.first.ctot; a.out_coff = sv.first.coff;
-                a.in = sv.second[0].v.p; a.in_ctot = sv.second[0].v.ctot; a.in_coff = sv.second[0].v.coff;
-                a.n_add = (int)sv.second.size() - 1;
-                for (int k = 0; k < a.n_add; ++k) {
-                    a.add[k] = sv.second[k + 1].v.p; a.add_ctot[k] = sv.second[k + 1].v.ctot; a.add_coff[k] = sv.second[k + 1].v.coff;
-                    a.add_shift[k] = sv.second[k + 1].shift;
-                }
-                a.R = 8;                                       // 8 rows per task
-                if ((a.R * a.Wo) % 4 != 0) return 0;
-                a.tiles_y = (a.Ho + a.R - 1) / a.R;
-                tiles_y = a.tiles_y;
-                for (auto& r : sv.second) reads.push_back(r.v.p);
-                out = sv.first.p;
-            } else {
-                return 0;
-            }
-            for (const float* b : reads) {
-                auto it = producer.find(b);
-                if (it == producer.end()) continue;            // written before the section (layer1)
-                bool dup = false;
-                for (int k = 0; k < c.ndeps; ++k) dup |= c.dep[k] == it->second;
-                if (dup) continue;
-                if (c.ndeps >= 4) return 0;
-                c.dep[c.ndeps] = it->second;
-                c.need[c.ndeps] = need[it->second];
-                ++c.ndeps;
-            }
-            const int idx = (int)pl.convs.size();
-            if (producer.count(out)) return 0;                 // two writers of one buffer inside the section: not expressible per image
-            producer[out] = idx;
-            c.bchunk = std::max(1, std::min(gy, tiles_y * gy / std::max(1, min_tasks)));      // >= ~min_tasks tasks per (convolution, image)
-            const int by_tasks = (gy + c.bchunk - 1) / c.bchunk;
-            need.push_back(tiles_y * by_tasks);
-            pl.convs.push_back(c);
-            items.push_back({idx, tiles_y, gy, c.bchunk});
-        }
-        if (pl.convs.empty() || pl.convs.size() > 65535) return 0;
-        pl.nconv = (int)pl.convs.size();
-        pl.ipx = (n + 7) / 8;
-        // all images of an XCD form ONE block: the queue is convolution-major across them, so the ready work of an XCD is
-        // (images per XCD) x (branches) x (tiles of a convolution), not two images' worth
-        pl.B = pl.ipx;
-        for (const Item& it : items)
-            for (int img = 0; img < pl.B; ++img)
-                for (int ty = 0; ty < it.tiles_y; ++ty)
-                    for (int by = 0; by < it.gy; by += it.bchunk)      // channel-block chunks of one pixel tile are neighbours in the queue: they share its input patch
-                        pl.tasks.push_back(DfTask{(unsigned short)it.conv, (unsigned short)img, (unsigned short)ty, (unsigned short)by});
-        pl.tasks_per_blk = (int)pl.tasks.size();
-        const int nblk = (pl.ipx + pl.B - 1) / pl.B;
-        pl.ctr_stride = (16 + nblk * pl.nconv * pl.B + 63) / 64 * 64;
-        pl.ctr_bytes = (size_t)8 * pl.ctr_stride * sizeof(unsigned);
-        void* q = nullptr;
-        if (hipMalloc(&q, pl.convs.size() * sizeof(DfConv)) != hipSuccess) return fail(GRNET_ENOMEM, "dataflow tables");
-        dev_allocs.push_back(q);
-        pl.d_convs = static_cast<DfConv*>(q);
-        HIP_TRY(hipMemcpy(q, pl.convs.data(), pl.convs.size() * sizeof(DfConv), hipMemcpyHostToDevice));
-        if (hipMalloc(&q, pl.tasks.size() * sizeof(DfTask)) != hipSuccess) return fail(GRNET_ENOMEM, "dataflow tables");
-        dev_allocs.push_back(q);
-        pl.d_tasks = static_cast<DfTask*>(q);
-        HIP_TRY(hipMemcpy(q, pl.tasks.data(), pl.tasks.size() * sizeof(DfTask), hipMemcpyHostToDevice));
-        if (hipMalloc(&q, pl.ctr_bytes) != hipSuccess) return fail(GRNET_ENOMEM, "dataflow counters");
-        dev_allocs.push_back(q);
-        pl.d_counters = static_cast<unsigned*>(q);
-        pl.ok = true;
-        if (getenv("GRNET_TRACE"))
-            fprintf(stderr, "[grnet] dataflow plan n=%d: %d ops, %d tasks per block of %d images, %d images per XCD, LDS %zu B\n", n, pl.nconv,
-                    pl.tasks_per_blk, pl.B, pl.ipx, pl.lds);
-        return 0;
-    }
-    // Is the HR section of an n-frame call run by the dataflow kernel?  (Builds and caches the plan on first use; never inside a capture.)
-    bool dataflow_for(int n) {
-        if (dtype != 0 || conv_tile_hint || df_mode == 0 || !finalized) return false;
-        if (df_mode == 2) {
-            auto it = tuned_mode.find(n);
-            if (it == tuned_mode.end() || !(it->second & 8)) return false;
-        }
-        if (df_probe < 0) {
-            int ok = 0;
-            if (df_probe_xcc(df_wgs_per_xcd, &ok, nullptr) != hipSuccess) ok = 0;
-            df_probe = ok;
-            if (getenv("GRNET_TRACE")) fprintf(stderr, "[grnet] XCC probe: a %d-workgroup grid %s all 8 XCDs evenly\n", 8 * df_wgs_per_xcd, ok ? "reaches" : "does NOT reach");
-        }
-        if (!df_probe) return false;
-        auto it = df_plans.find(n);
-        if (it == df_plans.end()) {
-            DfPlan pl;
-            if (build_df_plan(n, pl) != 0) pl.ok = false;
-            it = df_plans.emplace(n, std::move(pl)).first;
-        }
-        return it->second.ok;
-    }
-
     // ------------------------------------------------------------------ execution
     static const void* bf16_at(const View& v) { return reinterpret_cast<const uint16_t*>(v.p) + v.coff; }   // first channel of an NHWC bf16 view
     ConvArgs conv_args(const ConvLayer& L, const float* frames, int n) const {
@@ -1393,10 +1105,8 @@ struct grnet {
         float* verts = o.verts ? o.verts : d_verts;
         float* kp3d = o.kp_3d ? o.kp_3d : d_kp3d;
         float* kp2d = o.kp_2d ? o.kp_2d : d_kp2d;
-        const bool df_now = dataflow_for(n);
-        const bool group_now = !df_now && grouping_for(n);
-        const std::vector<Op>& ops = df_now ? ops_df : group_now ? this->ops : ops_flat;
-        const std::vector<hipEvent_t>& op_events = df_now ? op_events_df : group_now ? this->op_events : op_events_flat;
+        const std::vector<Op>& ops = ops_flat;
+        const std::vector<hipEvent_t>& op_events = op_events_flat;
         GraphRecorder* rec = g_recorder;                          // non-null: build graph nodes instead of launching
         const bool lanes = multi_lane && !rec;
         std::vector<hipGraphNode_t> lane_last(kLanes, nullptr), op_node(rec ? ops.size() : 0, nullptr);
@@ -1412,7 +1122,7 @@ struct grnet {
         hipStream_t caller = s;
         for (size_t oi = 0; oi < ops.size(); ++oi) {
             const Op& op = ops[oi];
-            if (convs_only && op.kind != Op::CONV && op.kind != Op::GROUP && op.kind != Op::DATAFLOW) continue;
+            if (convs_only && op.kind != Op::CONV) continue;
             s = lane_stream[op.lane];
             const int lane = multi_lane ? op.lane : 0;
             if (lanes)
@@ -1431,40 +1141,15 @@ struct grnet {
                     break;
                 case Op::CONV: {
                     const ConvLayer& L = convs[op.conv_idx];
-                    static const int fuse_env = getenv("GRNET_FUSE_BLOCKS") ? atoi(getenv("GRNET_FUSE_BLOCKS")) : 0;
-                    const bool fuse = fuse_env && L.block_role && dtype == 0 && wino_mode && !conv_tile_hint && L.wino4_dev && convs[L.block_peer].wino4_dev &&
-                                      ((fuse_env & 1) || L.in.w != 56) && ((fuse_env & 2) || L.in.w != 28);
-                    if (fuse && L.block_role == 2) break;           // its launch happened with the first convolution of the block
-                    if (fuse) {
-                        const ConvLayer& L2 = convs[L.block_peer];
-                        BlockArgs ba{};
-                        ba.in = L.in.p; ba.in_ctot = L.in.ctot; ba.in_coff = L.in.coff;
-                        ba.out = L2.out.p; ba.out_ctot = L2.out.ctot; ba.out_coff = L2.out.coff;
-                        ba.N = n;
-                        ba.w1 = L.wino4_dev; ba.b1 = L.b_dev; ba.w2 = L2.wino4_dev; ba.b2 = L2.b_dev;
-                        ba.prio = 1;
-                        HIP_TRY(launch_bblock_wino4(ba, L.cout, L.in.h, L.in.w, s));
-                        ++launches;
-                        break;
-                    }
-                    static const int w4r_env = getenv("GRNET_WINO4R") ? atoi(getenv("GRNET_WINO4R")) : 0;      // bit 0: the 56x56 branch, bit 1: the 28x28 branch
-                    static const int w4r_ks56 = getenv("GRNET_WINO4R_KS56") ? atoi(getenv("GRNET_WINO4R_KS56")) : 2;
-                    static const int w4r_ks28 = getenv("GRNET_WINO4R_KS28") ? atoi(getenv("GRNET_WINO4R_KS28")) : 2;
                     static const int w4s_env = getenv("GRNET_WINO4S") ? atoi(getenv("GRNET_WINO4S")) : 7;      // bit 0: 128 @14x14, bit 1: 256 @7x7, bit 2: 256 @14x14
                     static const int w4s_ks = getenv("GRNET_WINO4S_KS") ? atoi(getenv("GRNET_WINO4S_KS")) : 0;
                     if (dtype == 1) HIP_TRY(launch_conv_bf16(conv_args(L, frames, n), s, hint_for(L, n)));
-                    else if (L.wino4r_dev && L.small_map && wino_mode && !conv_tile_hint && (w4s_env & (L.in.w == 7 ? 2 : L.in.c == 128 ? 1 : 4))) {
+                    else if (L.wino4s_dev && wino_mode && !conv_tile_hint && (w4s_env & (L.in.w == 7 ? 2 : L.in.c == 128 ? 1 : 4))) {
                         ConvArgs wa = conv_args(L, frames, n);
-                        wa.w = L.wino4r_dev;
+                        wa.w = L.wino4s_dev;
                         static const int w4s_prio = getenv("GRNET_WINO4S_PRIO") ? atoi(getenv("GRNET_WINO4S_PRIO")) : 3;   // bit 0: 14x14 layers, bit 1: 7x7 layers at wave priority 1
                         wa.prio = (w4s_prio & (L.in.w == 7 ? 2 : 1)) ? 1 : 0;
                         HIP_TRY(launch_conv_wino4s(wa, s, w4s_ks));
-                    } else if (L.wino4r_dev && !L.small_map && wino_mode && !conv_tile_hint && (w4r_env & (L.in.w == 56 ? 1 : 2))) {
-                        ConvArgs wa = conv_args(L, frames, n);
-                        wa.w = L.wino4r_dev;
-                        static const int chain_prio4r = getenv("GRNET_WINO_PRIO") ? atoi(getenv("GRNET_WINO_PRIO")) : 1;
-                        wa.prio = chain_prio4r;
-                        HIP_TRY(launch_conv_wino4r(wa, s, L.in.w == 56 ? w4r_ks56 : w4r_ks28));
                     } else if (L.wino4_dev && wino_mode && !conv_tile_hint) {
                         ConvArgs wa = conv_args(L, frames, n);
                         wa.w = L.wino4_dev;
@@ -1475,60 +1160,8 @@ struct grnet {
                         int nl = 1;
                         HIP_TRY(launch_conv_wino4(wa, s, &nl));
                         launches += nl - 1;
-                    } else if (L.wino_dev && wino_mode && !conv_tile_hint) {
-                        ConvArgs wa = conv_args(L, frames, n);
-                        wa.w = L.wino_dev;
-                        static const int chain_prio = getenv("GRNET_WINO_PRIO") ? atoi(getenv("GRNET_WINO_PRIO")) : 1;
-                        wa.prio = L.cout == 32 ? chain_prio : 0;       // the 56x56 HR branch: the critical chain of stages 2-4 (conv_wino.hip)
-                        int nl = 1;
-                        HIP_TRY(launch_conv_wino(wa, s, &nl));
-                        launches += nl - 1;
                     } else HIP_TRY(launch_conv(conv_args(L, frames, n), s, hint_for(L, n)));
                     ++launches;
-                    break;
-                }
-                case Op::GROUP: {
-                    ConvArgs list[kMaxGroup];
-                    const int cnt = (int)op.group.size();
-                    for (int gi = 0; gi < cnt; ++gi) list[gi] = conv_args(convs[op.group[gi]], frames, n);
-                    if (group_now) {
-                        HIP_TRY(launch_conv_group(list, cnt, s));
-                        ++launches;
-                    } else {
-                        for (int gi = 0; gi < cnt; ++gi) {
-                            if (dtype == 1) HIP_TRY(launch_conv_bf16(list[gi], s, hint_for(convs[op.group[gi]], n)));
-                            else HIP_TRY(launch_conv(list[gi], s, hint_for(convs[op.group[gi]], n)));
-                        }
-                        launches += cnt;
-                    }
-                    break;
-                }
-                case Op::DATAFLOW: {
-                    DfPlan& pl = df_plans[n];                // built by dataflow_for(n)
-                    DfParams dp{};
-                    dp.convs = pl.d_convs; dp.tasks = pl.d_tasks; dp.tasks_per_blk = pl.tasks_per_blk; dp.nconv = pl.nconv;
-                    dp.n = n; dp.ipx = pl.ipx; dp.B = pl.B; dp.counters = pl.d_counters; dp.ctr_stride = pl.ctr_stride; dp.fence = df_fence;
-                    if (const char* lim = getenv("GRNET_DF_LIMIT")) dp.tasks_per_blk = std::min(dp.tasks_per_blk, atoi(lim));   // diagnostic: run a prefix of the queue
-                    if (rec) {                                // graph: a memset node in front of the kernel node
-                        hipMemsetParams mp{};
-                        mp.dst = pl.d_counters; mp.value = 0; mp.elementSize = 4; mp.width = pl.ctr_bytes / 4; mp.height = 1; mp.pitch = pl.ctr_bytes;
-                        hipGraphNode_t mnode = nullptr;
-                        HIP_TRY(hipGraphAddMemsetNode(&mnode, rec->graph, rec->deps.data(), rec->deps.size(), &mp));
-                        rec->deps.assign(1, mnode);
-                    } else {
-                        HIP_TRY(hipMemsetAsync(pl.d_counters, 0, pl.ctr_bytes, s));
-                    }
-                    HIP_TRY(launch_hr_dataflow(dp, pl.lds, df_wgs_per_xcd, s));
-                    ++launches;
-                    if (!rec && getenv("GRNET_DF_DEBUG")) {     // diagnostic: queue heads, census and timed-out waits per XCD
-                        HIP_TRY(hipStreamSynchronize(s));
-                        for (int x = 0; x < 8; ++x) {
-                            unsigned c8[8];
-                            HIP_TRY(hipMemcpy(c8, pl.d_counters + (size_t)x * pl.ctr_stride, sizeof(c8), hipMemcpyDeviceToHost));
-                            fprintf(stderr, "[grnet] dataflow xcd %d: head %u of %d, workers %u, foreign %u, timeouts %u (first: task %u conv %u waits for conv %u, has %u)\n",
-                                    x, c8[0], pl.tasks_per_blk * ((std::min(n, (x + 1) * pl.ipx) - x * pl.ipx + pl.B - 1) / pl.B), c8[1], c8[2], c8[3], c8[4], c8[5], c8[6], c8[7]);
-                        }
-                    }
                     break;
                 }
                 case Op::SUM: {
@@ -1782,12 +1415,8 @@ int grnet_create(grnet_t** out_handle, int device_id, int dtype, int max_frames)
     h->device = device_id;
     h->max_frames = max_frames;
     h->dtype = dtype;
-    if (dtype == 1) h->grouping = false;                   // grouped launches exist for the fp32 split-K kernels only
     if (const char* ml = getenv("GRNET_MULTI_LANE")) h->multi_lane = atoi(ml) != 0;   // profiling: per-kernel times without overlap
     if (const char* wn = getenv("GRNET_WINO")) h->wino_mode = atoi(wn) != 0;
-    if (const char* df = getenv("GRNET_DATAFLOW")) h->df_mode = std::max(0, std::min(2, atoi(df)));
-    if (const char* df = getenv("GRNET_DF_WGS")) h->df_wgs_per_xcd = std::max(8, std::min(256, atoi(df)));
-    if (const char* df = getenv("GRNET_DF_FENCE")) h->df_fence = atoi(df);
     h->build_plan();
     int rc = h->allocate();
     if (rc) { fprintf(stderr, "grnet_create: %s\n", h->err.c_str()); return rc; }
@@ -1961,27 +1590,13 @@ int grnet_set_option(grnet_t* h, int option, int value) {
     if (!h) return GRNET_EINVAL;
     if (option == GRNET_OPT_USE_GRAPH) { h->use_graph = value != 0; return 0; }
     if (option == GRNET_OPT_CONV_TILE) {
-        if (value != 0) h->grouping = false;                   // forced tiles apply to individual launches
-        else h->grouping = true;
         if (value != 0 && value != 7 && value != 14 && value != 1071 && value != 1072 && value != 1041 && value != 1042 && value != 1171 && value != 1141)
             return h->fail(GRNET_EINVAL, "conv tile must be 0, 7, 14 or a split-K code 1071/1072/1041/1042/1171/1141");
         h->conv_tile_hint = value;
         h->drop_graphs();
         return 0;
     }
-    if (option == GRNET_OPT_GROUPING) {
-        h->grouping = value != 0;
-        h->drop_graphs();
-        return 0;
-    }
-    if (option == GRNET_OPT_DATAFLOW) {
-        if (value < 0 || value > 2) return h->fail(GRNET_EINVAL, "dataflow option must be 0 (never), 1 (wherever possible) or 2 (where tuned faster)");
-        h->df_mode = value;
-        h->drop_graphs();
-        return 0;
-    }
     if (option == GRNET_OPT_WINOGRAD) { h->wino_mode = value != 0; h->drop_graphs(); return 0; }
-    if (option == GRNET_OPT_DATAFLOW_FENCE) { h->df_fence = value != 0; h->drop_graphs(); return 0; }
     if (option == GRNET_OPT_MULTI_LANE) {
         h->multi_lane = value != 0;
         h->drop_graphs();
@@ -2044,7 +1659,7 @@ double grnet_conv_executed_flops_per_frame(grnet_t* h) {
     double m = 0;
     // F(4x4,3x3): 36 multiplies per 4x4 tile instead of 144; the small maps pay for their padding (14 -> 16, 7 -> 8 per side)
     for (auto& L : h->convs)
-        m += L.macs_per_frame * (h->wino_mode && h->dtype == 0 ? (L.small_map ? 0.25 * (L.in.w == 14 ? 256.0 / 196.0 : 64.0 / 49.0) : L.wino4_dev ? 0.25 : L.wino_dev ? 4.0 / 9.0 : 1.0) : 1.0);
+        m += L.macs_per_frame * (h->wino_mode && h->dtype == 0 ? (L.wino4s_dev ? 0.25 * (L.in.w == 14 ? 256.0 / 196.0 : 64.0 / 49.0) : L.wino4_dev ? 0.25 : 1.0) : 1.0);
     return 2.0 * m;
 }
 
@@ -2117,21 +1732,6 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
     if (const char* d = getenv("GRNET_CONV_DBG")) a.dbg = atoi(d);
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* ud = nullptr;
-    if (tile_hint == 2000) {                                   // the Winograd kernel on this one convolution
-        if (!conv_wino_eligible(cin, cout, ks, stride, hgt, wid, add_dev ? 1 : 0) || cin_pad % 8 != 0 || cout_pad % (cout % 64 == 0 ? 64 : 32) != 0) {
-            hipFree(wd); hipFree(bd);
-            return h->fail(GRNET_EINVAL, "shape not eligible for the Winograd kernel");
-        }
-        std::vector<double> wf((size_t)cout * cin * 9);
-        for (size_t i = 0; i < wf.size(); ++i) wf[i] = w_host[i];
-        std::vector<float> uw((size_t)16 * cin_pad * cout_pad);
-        pack_wino_weights(wf.data(), cout, cin, cin_pad, cout_pad, uw.data());
-        if (hipMalloc(reinterpret_cast<void**>(&ud), uw.size() * 4) != hipSuccess || hipMemcpy(ud, uw.data(), uw.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
-            hipFree(wd); hipFree(bd); if (ud) hipFree(ud);
-            return h->fail(GRNET_ENOMEM, "Winograd test weights");
-        }
-        a.w = ud;
-    }
     if (tile_hint == 2001) {                                   // the F(4x4,3x3) kernel on this one convolution
         if (!conv_wino4_eligible(cin, cout, ks, stride, hgt, wid, add_dev ? 1 : 0) || cin_pad % 8 != 0 || cout_pad % (cout % 64 == 0 ? 64 : 32) != 0) {
             hipFree(wd); hipFree(bd);
@@ -2141,23 +1741,6 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
         for (size_t i = 0; i < wf.size(); ++i) wf[i] = w_host[i];
         std::vector<float> uw((size_t)36 * cin_pad * cout_pad);
         pack_wino4_weights(wf.data(), cout, cin, cin_pad, cout_pad, uw.data(), wid);
-        if (hipMalloc(reinterpret_cast<void**>(&ud), uw.size() * 4) != hipSuccess || hipMemcpy(ud, uw.data(), uw.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
-            hipFree(wd); hipFree(bd); if (ud) hipFree(ud);
-            return h->fail(GRNET_ENOMEM, "Winograd test weights");
-        }
-        a.w = ud;
-    }
-    int w4r_ks = 0;
-    if (tile_hint >= 2010 && tile_hint <= 2014) {              // the register-resident F(4x4,3x3) kernel, 201k: k waves split the input channels (0: default)
-        w4r_ks = tile_hint == 2010 ? 2 : tile_hint - 2010;
-        if (!conv_wino4r_eligible(cin, cout, ks, stride, hgt, wid, add_dev ? 1 : 0) || (w4r_ks != 1 && w4r_ks != 2 && !(w4r_ks == 4 && wid == 28))) {
-            hipFree(wd); hipFree(bd);
-            return h->fail(GRNET_EINVAL, "shape not eligible for the register-resident F(4x4,3x3) kernel");
-        }
-        std::vector<double> wf((size_t)cout * cin * 9);
-        for (size_t i = 0; i < wf.size(); ++i) wf[i] = w_host[i];
-        std::vector<float> uw((size_t)36 * cin * cout);
-        pack_wino4r_weights(wf.data(), cout, cin, uw.data());
         if (hipMalloc(reinterpret_cast<void**>(&ud), uw.size() * 4) != hipSuccess || hipMemcpy(ud, uw.data(), uw.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
             hipFree(wd); hipFree(bd); if (ud) hipFree(ud);
             return h->fail(GRNET_ENOMEM, "Winograd test weights");
@@ -2182,7 +1765,7 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
         a.w = ud;
     }
     auto launch_one = [&]() {
-        return w4s_on ? launch_conv_wino4s(a, s, w4s_ks) : w4r_ks ? launch_conv_wino4r(a, s, w4r_ks) : tile_hint == 2000 ? launch_conv_wino(a, s) : tile_hint == 2001 ? launch_conv_wino4(a, s) : launch_conv(a, s, tile_hint);
+        return w4s_on ? launch_conv_wino4s(a, s, w4s_ks) : tile_hint == 2001 ? launch_conv_wino4(a, s) : launch_conv(a, s, tile_hint);
     };
     hipError_t e = launch_one();
     if (const char* r = getenv("GRNET_CONV_REPS")) {           // timing loop for tools/conv_micro.py
@@ -2205,56 +1788,6 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
     if (ud) hipFree(ud);
     if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("launch_conv: ") + hipGetErrorString(e));
     if (e2 != hipSuccess) return h->fail(GRNET_EHIP, std::string("conv kernel: ") + hipGetErrorString(e2));
-    return 0;
-}
-
-int grnet_op_basic_block(grnet_t* h, const float* in_dev, int n, int c, int hgt, int wid, const float* w1_host, const float* b1_host,
-                         const float* w2_host, const float* b2_host, float* out_dev, void* stream) {
-    if (!h || !in_dev || !w1_host || !w2_host || !out_dev || n < 1) return GRNET_EINVAL;
-    if (h->dtype != 0) return h->fail(GRNET_EINVAL, "the fused BasicBlock kernel is fp32 only");
-    if (!bblock_wino4_eligible(c, hgt, wid)) return h->fail(GRNET_EINVAL, "shape not eligible for the fused BasicBlock kernel (32 ch @ 56x56 or 64 ch @ 28x28)");
-    DeviceGuard guard(h->device);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    float* dev[4] = {nullptr, nullptr, nullptr, nullptr};      // u1, u2, b1, b2
-    auto release = [&]() { for (float* q : dev) if (q) hipFree(q); };
-    const float* wsrc[2] = {w1_host, w2_host};
-    const float* bsrc[2] = {b1_host, b2_host};
-    for (int k = 0; k < 2; ++k) {
-        std::vector<double> wf((size_t)c * c * 9);
-        for (size_t i = 0; i < wf.size(); ++i) wf[i] = wsrc[k][i];
-        std::vector<float> uw((size_t)36 * c * c), bp(c, 0.f);
-        pack_wino4_weights(wf.data(), c, c, c, c, uw.data(), wid);
-        if (bsrc[k]) for (int i = 0; i < c; ++i) bp[i] = bsrc[k][i];
-        if (hipMalloc(reinterpret_cast<void**>(&dev[k]), uw.size() * 4) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&dev[2 + k]), bp.size() * 4) != hipSuccess ||
-            hipMemcpy(dev[k], uw.data(), uw.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(dev[2 + k], bp.data(), bp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
-            release();
-            return h->fail(GRNET_ENOMEM, "fused BasicBlock test weights");
-        }
-    }
-    BlockArgs a{};
-    a.in = in_dev; a.in_ctot = c; a.in_coff = 0;
-    a.out = out_dev; a.out_ctot = c; a.out_coff = 0;
-    a.N = n;
-    a.w1 = dev[0]; a.b1 = dev[2]; a.w2 = dev[1]; a.b2 = dev[3];
-    hipError_t e = launch_bblock_wino4(a, c, hgt, wid, s);
-    if (const char* r = getenv("GRNET_CONV_REPS")) {           // timing loop for tools/wino_micro.py
-        const int reps = atoi(r);
-        hipEvent_t e0, e1;
-        hipEventCreate(&e0); hipEventCreate(&e1);
-        hipEventRecord(e0, s);
-        for (int i = 0; i < reps; ++i) e = launch_bblock_wino4(a, c, hgt, wid, s);
-        hipEventRecord(e1, s);
-        hipEventSynchronize(e1);
-        float ms = 0;
-        hipEventElapsedTime(&ms, e0, e1);
-        fprintf(stderr, "[conv_micro] fused BasicBlock c %d hw %d n %d: %.2f us/launch\n", c, hgt, n, ms * 1e3f / reps);
-        hipEventDestroy(e0); hipEventDestroy(e1);
-    }
-    hipError_t e2 = hipStreamSynchronize(s);
-    release();
-    if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("launch_bblock_wino4: ") + hipGetErrorString(e));
-    if (e2 != hipSuccess) return h->fail(GRNET_EHIP, std::string("fused BasicBlock kernel: ") + hipGetErrorString(e2));
     return 0;
 }
 

@@ -90,70 +90,21 @@ struct ConvArgs {
 
 // Returns hipSuccess or the launch error.  `tile_hint`: 0 = auto, 7 / 14 = force pixel sub-tiles.
 hipError_t launch_conv(ConvArgs a, hipStream_t s, int tile_hint = 0);
-constexpr int kMaxGroup = 6;
-// n independent convolutions with identical (ks, stride) in ONE launch (falls back to n launches if a member does not fit)
-hipError_t launch_conv_group(const ConvArgs* list, int n, hipStream_t s);
 int conv_pick_tc(int Cout);                 // cout tile (32 or 64) -> defines CoutPad at pack time
 hipError_t conv_init();                     // sets max dynamic LDS on every instantiation
 const char* conv_dominant_kernel_name();
 
-// ---- Winograd F(2x2,3x3) for the wide 3x3 stride-1 layers on 56x56 maps (conv_wino.hip) -------------------------------------------
-bool conv_wino_eligible(int cin, int cout, int ks, int stride, int h, int w, int n_add);
-hipError_t launch_conv_wino(ConvArgs a, hipStream_t s, int* n_launches = nullptr);   // a.w = transformed weights [16][CinPad][CoutPad]; *n_launches: 1, or 2 when the last round is split
-void pack_wino_weights(const double* w_folded /* (cout,cin,3,3) */, int cout, int cin, int cin_pad, int cout_pad, float* out);
-// ---- Winograd F(4x4,3x3) for the widest of them (conv_wino4.hip): 2.25 multiplies per output
+// ---- Winograd F(4x4,3x3) on the fp32 matrix cores for the 3x3 stride-1 layers on 56x56 / 28x28 maps (conv_wino4.hip): 2.25 multiplies per output
 bool conv_wino4_eligible(int cin, int cout, int ks, int stride, int h, int w, int n_add);
 hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s, int* n_launches = nullptr);     // a.w = transformed weights [36][CinPad][CoutPad]
 void pack_wino4_weights(const double* w_folded /* (cout,cin,3,3) */, int cout, int cin, int cin_pad, int cout_pad, float* out, int map_width = 56);
 int conv_wino4_blocks(int cout, int map_width);   // 16-channel blocks per workgroup of that layer (4 or 2)
 
 void wino4_transform_filter(const double* g33, double* u36);   // U = G g G^T of F(4x4,3x3) in fp64
-// ---- the register-resident F(4x4,3x3) kernel of the narrow HR branches (conv_wino4r.hip): 32 -> 32 @56x56, 64 -> 64 @28x28
-bool conv_wino4r_eligible(int cin, int cout, int ks, int stride, int h, int w, int n_add);
-hipError_t launch_conv_wino4r(ConvArgs a, hipStream_t s, int ksplit);      // a.w = pack_wino4r_weights; ksplit: waves splitting the input channels (1, 2; 4 on 28x28)
-void pack_wino4r_weights(const double* w_folded /* (cout,cin,3,3) */, int cout, int cin, float* out /* 36*cin*cout */);
-// ---- the same structure for the small maps (conv_wino4s.hip): 128 -> 128 @14x14, 256 -> 256 @7x7 (HR branches 2, 3), 256 -> 256 @14x14
+// ---- register-resident F(4x4,3x3) for the small maps (conv_wino4s.hip): 128 -> 128 @14x14, 256 -> 256 @7x7 (HR branches 2, 3), 256 -> 256 @14x14
 bool conv_wino4s_eligible(int cin, int cout, int ks, int stride, int h, int w, int n_add);
 hipError_t launch_conv_wino4s(ConvArgs a, hipStream_t s, int ksplit);      // a.w = pack_wino4r_weights; ksplit 0: the shape's default
-// ---- a whole BasicBlock (conv3x3-BN-ReLU-conv3x3-BN-(+x)-ReLU, hrnet.py:30-59) of the 32-channel 56x56 / 64-channel 28x28 HR branches in
-// ONE launch (conv_wino4_block.hip): both convolutions as F(4x4,3x3), the intermediate tensor stays in LDS
-struct BlockArgs {
-    const float* in; int in_ctot, in_coff;     // x: input of conv1 and the residual
-    float* out; int out_ctot, out_coff;
-    int N;
-    const float* w1; const float* b1;          // conv1: transformed weights (pack_wino4_weights, 32-channel layout), folded BN shift
-    const float* w2; const float* b2;          // conv2
-    int prio;                                  // wave priority as ConvArgs::prio
-    int gx, xcd;                               // filled by the launcher
-};
-bool bblock_wino4_eligible(int channels, int h, int w);
-hipError_t launch_bblock_wino4(BlockArgs a, int channels, int h, int w, hipStream_t s);
-
-// ---- per-XCD dataflow execution of the HR stages (conv_kernels.hip: hr_dataflow_f32) -------------------------------------------
-// One persistent launch runs every convolution of transition1 .. stage 4 (~270 launches otherwise).  Frames are independent and
-// the 8 XCDs have private L2s, so XCD x takes the images [x*ipx, (x+1)*ipx) through the WHOLE section on its own: its workgroups pop
-// tile tasks from the XCD's queue (a static, topologically ordered list, the same for every block of B images) and a task waits only
-// for the (producer convolution, same image) counters it reads from.  Producer and consumer of every byte sit on the same XCD -- the
-// one read from the hardware register XCC_ID, not inferred from the block id -- so hand-offs go through that XCD's L2 and need no
-// cache write-back or invalidate; nothing depends on how the dispatcher places workgroups (an XCD that received none is served by a
-// second phase in which the remaining workgroups take over its queue with device-scope fences).
-struct DfTask { unsigned short conv, img, ty, by; };          // convolution (index into DfConv[]), image within the block, pixel tile, channel block
-struct DfConv {
-    ConvArgs a;                 // tile plan filled (plan_tile): N = frames of the call, image selected through bx
-    int variant;                // (ks,stride) x tile variant, see hr_dataflow_f32; -1: fuse sum (a.in = identity term, a.add = upsampled terms)
-    int bchunk;                 // output-channel blocks per task
-    int ndeps, dep[4], need[4]; // producers inside the section and their task count per image
-};
-struct DfParams {
-    const DfConv* convs; const DfTask* tasks;
-    int tasks_per_blk, nconv, n, ipx, B;
-    unsigned* counters; int ctr_stride;   // per XCD: [0] queue head, [1] arrived workgroups, [16 + (blk*nconv + conv)*B + img] finished tasks
-    int fence;                  // 1: device-scope release/acquire around every hand-off (validation / foreign-queue phase)
-};
-int df_plan_conv(ConvArgs& a, size_t* lds_bytes);              // picks the tile variant, fills the plan; -1 if the shape has none
-hipError_t launch_hr_dataflow(const DfParams& p, size_t lds, int wgs_per_xcd, hipStream_t s);
-hipError_t df_probe_xcc(int wgs_per_xcd, int* ok, hipStream_t s);   // does a grid of this shape reach all 8 XCDs evenly?
-
+void pack_wino4r_weights(const double* w_folded /* (cout,cin,3,3) */, int cout, int cin, float* out /* 36*cin*cout */);
 // out = relu?( sum_k nearest_up(add_k) ), 1..4 addends, out and every addend are Views.
 struct SumArgs {
     float* out; int out_ctot, out_coff;

@@ -268,12 +268,12 @@ class GRNet:
         return self
 
     def tuned_mode(self, n_frames):
-        """Schedule chosen by tune(): dict(measured_table, grouped, eager) or None if not tuned for n_frames."""
+        """Schedule chosen by tune(): dict(measured_table, eager) or None if not tuned for n_frames."""
         buf = C.create_string_buffer(1 << 16)
         if self._lib.grnet_get_tuning(self._h, int(n_frames), buf, len(buf)) <= 0:
             return None
         mode = int(buf.value.decode().split("\n", 1)[0].split()[1])
-        return {"measured_table": bool(mode & 1), "grouped": bool(mode & 2), "eager": bool(mode & 4), "dataflow": bool(mode & 8)}
+        return {"measured_table": bool(mode & 1), "eager": bool(mode & 4)}
 
     # ------------------------------------------------------------------ introspection (bench / tests)
     def num_kernel_launches(self):
@@ -291,7 +291,7 @@ class GRNet:
         return self._lib.grnet_conv_executed_flops_per_frame(self._h)
 
     def describe_convs(self):
-        """The convolution launches of one forward in un-grouped launch order: list of dicts (shape, fused addends, weight key)."""
+        """The convolution launches of one forward in launch order: list of dicts (shape, fused addends, weight key)."""
         self.finalize()
         keys = ("cin", "cout", "ks", "stride", "hin", "win", "hout", "wout", "n_add", "relu", "lane", "add_elems")
         out = []
@@ -457,21 +457,6 @@ class GRNet:
                                        int(relu), add.data_ptr() if add is not None else None, out.data_ptr(),
                                        tile_hint, stream)
         _lib.check(self._lib, self._h, rc, "grnet_op_conv2d")
-        return out
-
-    def op_basic_block(self, x, w1, b1, w2, b2):
-        """One fused BasicBlock launch (hrnet.py:43-59) on x (n,C,H,W): relu(conv2(relu(conv1(x)+b1))+b2+x), BN already folded."""
-        n, c, h, wd = x.shape
-        out = torch.empty_like(x)
-        w1n, w2n = _np32(w1), _np32(w2)
-        b1n = _np32(b1) if b1 is not None else None
-        b2n = _np32(b2) if b2 is not None else None
-        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        rc = self._lib.grnet_op_basic_block(self._h, x.data_ptr(), n, c, h, wd, w1n.ctypes.data_as(C.c_void_p),
-                                            b1n.ctypes.data_as(C.c_void_p) if b1n is not None else None,
-                                            w2n.ctypes.data_as(C.c_void_p),
-                                            b2n.ctypes.data_as(C.c_void_p) if b2n is not None else None, out.data_ptr(), stream)
-        _lib.check(self._lib, self._h, rc, "grnet_op_basic_block")
         return out
 
     def op_bilinear2x(self, x):

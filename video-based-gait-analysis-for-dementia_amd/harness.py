@@ -143,7 +143,7 @@ class ClipRunner:
         model.finalize()
         if use_graph:
             model.set_option(_lib.OPT_USE_GRAPH, 1)
-        if tune_level:                     # launch configurations AND schedule (lanes/grouped, graph/eager) measured on this GPU
+        if tune_level:                     # launch configurations AND schedule (graph replay / eager lane streams) measured on this GPU
             model.tune(n, level=tune_level, cache=tune_cache)
         self._lib, self._h = model._lib, model._h
         self._stream = torch.cuda.current_stream(dev)
