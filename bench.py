@@ -145,7 +145,7 @@ def roofline_object(fps_per_gpu, dtype, conv_flops_per_frame, conv_ms, conv_ms_s
     r = {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
          "definition": "frames/s per GPU x F_frame (SURVEY 8d: 30.883 GFLOP of convolutions per frame = the ALGORITHMIC, direct-convolution "
                        "count); the whole step -- pooling, tail, SMPL, launch gaps -- is charged to the convolutions.  On the fp32 path the Winograd "
-                       "layers (76 % of F_frame) execute 4x fewer multiplies than counted here (F(4x4,3x3)), in fp32 throughout",
+                       "layers (92 % of F_frame) execute 4x fewer multiplies than counted here (F(4x4,3x3)), in fp32 throughout",
          "traffic": None,
          "kernel": ("conv_wino4_f32 (Winograd F(4x4,3x3) on the fp32 matrix cores: the 3x3 stride-1 layers on 56x56 and 28x28 maps) + conv_wino4s_f32 "
                     "(the same on 14x14 / 7x7 maps, register-resident) + conv_mfma_f32 / conv_splitk_f32 (fp32 MFMA implicit-GEMM convolution: "
@@ -160,7 +160,7 @@ def roofline_object(fps_per_gpu, dtype, conv_flops_per_frame, conv_ms, conv_ms_s
                  executed_gflop_per_step=round(executed_flops_per_frame * n / 1e9, 3), executed_achieved=round(ex, 3), executed_frac=round(ex / peak, 4),
                  floor_ms=round(floor_ms, 4), step_over_floor=round(n / fps_per_gpu * 1e3 / floor_ms, 3),
                  executed_note="the multiplies the matrix cores were asked to do: F(4x4,3x3) layers at 1/4 of their direct-convolution count (x 256/196 on "
-                               "14x14 and x 64/49 on 7x7 maps, whose tiles are padded to 16x16 / 8x8), F(2x2,3x3) layers at 4/9; floor_ms = that work at the "
+                               "14x14 and x 64/49 on 7x7 maps, whose tiles are padded to 16x16 / 8x8); floor_ms = that work at the "
                                "fp32 matrix peak, step_over_floor = ms_per_step / floor_ms")
     if conv_ms:
         r.update(conv_only_ms_per_step=round(conv_ms, 4), conv_only_achieved=round(conv_flops / (conv_ms * 1e-3) / 1e12, 3),

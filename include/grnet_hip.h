@@ -123,9 +123,11 @@ int grnet_set_tuning(grnet_t* h, int n_frames, const char* text);
 int grnet_num_kernel_launches(grnet_t* h);      /* launches enqueued by one grnet_forward */
 int grnet_num_conv_launches(grnet_t* h);        /* convolution launches of one grnet_forward */
 double grnet_conv_flops_per_frame(grnet_t* h);  /* 2 * MACs of all convolutions on the path */
-/* The same with the layers that currently run a Winograd kernel counted at the 1/4 (F(4x4,3x3)) or 4/9 (F(2x2,3x3)) of their multiplies it executes
- * (fp32 handles with GRNET_OPT_WINOGRAD on; equal to grnet_conv_flops_per_frame otherwise).  Reporting only: the roofline figure
- * is quoted on the algorithmic count above, this one says what the matrix cores were actually asked to do. */
+/* The same with the layers that run a Winograd F(4x4,3x3) kernel counted at the 1/4 of their multiplies it executes (x 256/196 on 14x14 and
+ * x 64/49 on 7x7 maps, whose tiles are padded), under the kernel choice of the handle's latest forward (that of a 16-frame call before the
+ * first one: the 7x7 layers take the Winograd kernel from 12 frames per call on).  fp32 handles with GRNET_OPT_WINOGRAD on; equal to
+ * grnet_conv_flops_per_frame otherwise.  Reporting only: the roofline figure is quoted on the algorithmic count above, this one says what
+ * the matrix cores were actually asked to do. */
 double grnet_conv_executed_flops_per_frame(grnet_t* h);
 /* The pos-th convolution launch of one forward in the un-grouped launch order (the dispatch order of a
  * GRNET_OPT_MULTI_LANE=0, un-tuned run -- what tools/layer_table.py joins per-dispatch profiler rows on):

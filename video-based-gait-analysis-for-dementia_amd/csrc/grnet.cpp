@@ -934,6 +934,11 @@ struct grnet {
     // for n frames (3 launches each, HIP events) and keep the fastest; then time whole forwards as a replayed hipGraph and as eager
     // launches on the lane streams, with the cost model's and the measured table, and keep the fastest.  Activation buffers are used as
     // scratch (contents are garbage afterwards, like after any forward).
+    // conv_wino4s_f32 on this layer in a call of n frames?  A 7x7 row tile is four images: below three row tiles (n < 12) a launch is
+    // 16-32 workgroups whose waves each walk 16 k-steps, and the direct split-K kernel with its 8-wave workgroups is the shorter chain
+    // link (measured at 1 / 2 / 4 / 8 / 12 frames: -4 % / -3 % / -5 % / -4 % / +0.5 % with the 7x7 layers on it; 14x14: +2 ... +4 % throughout)
+    bool wino4s_runs(const ConvLayer& L, int n) const { return L.wino4s_dev && wino_mode && (L.in.w != 7 || n >= 12); }
+    int last_n = 16;                   // frame count of the latest forward (grnet_conv_executed_flops_per_frame reports for it)
     std::map<int, int> tuned_mode;     // n -> bit 0: measured per-shape configurations (else cost model), bit 2: eager launches on the lane streams even if graphs are enabled
     int tune(int n, hipStream_t s, int level = 1) {
         if (!finalized) return fail(GRNET_ESTATE, "grnet_tune before grnet_finalize_weights");
@@ -1097,6 +1102,7 @@ struct grnet {
 
     int enqueue(const float* frames, int n, const grnet_outputs_t& o, hipStream_t s, bool convs_only = false) {
         int launches = 0;
+        last_n = n;
         float* plf = o.point_local_feat ? o.point_local_feat : d_plf;
         float* csf = o.cam_shape_feats ? o.cam_shape_feats : d_csf;
         float* rot6d = o.pred_rot6d ? o.pred_rot6d : d_rot6d;
@@ -1144,7 +1150,7 @@ struct grnet {
                     static const int w4s_env = getenv("GRNET_WINO4S") ? atoi(getenv("GRNET_WINO4S")) : 7;      // bit 0: 128 @14x14, bit 1: 256 @7x7, bit 2: 256 @14x14
                     static const int w4s_ks = getenv("GRNET_WINO4S_KS") ? atoi(getenv("GRNET_WINO4S_KS")) : 0;
                     if (dtype == 1) HIP_TRY(launch_conv_bf16(conv_args(L, frames, n), s, hint_for(L, n)));
-                    else if (L.wino4s_dev && wino_mode && !conv_tile_hint && (w4s_env & (L.in.w == 7 ? 2 : L.in.c == 128 ? 1 : 4))) {
+                    else if (wino4s_runs(L, n) && !conv_tile_hint && (w4s_env & (L.in.w == 7 ? 2 : L.in.c == 128 ? 1 : 4))) {
                         ConvArgs wa = conv_args(L, frames, n);
                         wa.w = L.wino4s_dev;
                         static const int w4s_prio = getenv("GRNET_WINO4S_PRIO") ? atoi(getenv("GRNET_WINO4S_PRIO")) : 3;   // bit 0: 14x14 layers, bit 1: 7x7 layers at wave priority 1
@@ -1351,6 +1357,7 @@ struct grnet {
             return fail(GRNET_EINVAL, "n_frames " + std::to_string(n) + " outside [1, max_frames=" + std::to_string(max_frames) + "]");
         grnet_outputs_t o{};
         if (out) o = *out;
+        last_n = n;
         {
             auto tm = tuned_mode.find(n);
             const bool eager_tuned = tm != tuned_mode.end() && (tm->second & 4);
@@ -1659,7 +1666,7 @@ double grnet_conv_executed_flops_per_frame(grnet_t* h) {
     double m = 0;
     // F(4x4,3x3): 36 multiplies per 4x4 tile instead of 144; the small maps pay for their padding (14 -> 16, 7 -> 8 per side)
     for (auto& L : h->convs)
-        m += L.macs_per_frame * (h->wino_mode && h->dtype == 0 ? (L.wino4s_dev ? 0.25 * (L.in.w == 14 ? 256.0 / 196.0 : 64.0 / 49.0) : L.wino4_dev ? 0.25 : 1.0) : 1.0);
+        m += L.macs_per_frame * (h->wino_mode && h->dtype == 0 ? (h->wino4s_runs(L, h->last_n) ? 0.25 * (L.in.w == 14 ? 256.0 / 196.0 : 64.0 / 49.0) : L.wino4_dev ? 0.25 : 1.0) : 1.0);
     return 2.0 * m;
 }
 
