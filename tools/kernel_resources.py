@@ -27,7 +27,7 @@ out = [f"# Kernel resources ({rnd}): hipcc -O3 --offload-arch=gfx950, code-objec
        "capped at 8; static LDS only (the convolution kernels take their tiles as dynamic LDS, sized per launch).", "",
        "| file | kernel | vgpr (of which agpr) | waves/SIMD | sgpr | static LDS B | scratch B | spilled vgpr / sgpr |", "|---|---|---|---|---|---|---|---|"]
 for r, d in zip(rows, names):
-    d = re.sub(r"\(.*", "", d.replace("grk::", "").replace("void ", ""))
+    d = re.sub(r"\(.*", "", d.replace("(anonymous namespace)::", "").replace("grk::", "").replace("void ", ""))
     v = max(r[2], 1)
     occ = min(8, 512 // ((v + 7) // 8 * 8))
     out.append(f"| {r[0]} | `{d}` | {r[2]} ({r[3]}) | {occ} | {r[4]} | {r[5]} | {r[6]} | {r[7]} / {r[8]} |")

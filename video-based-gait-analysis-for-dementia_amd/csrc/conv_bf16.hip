@@ -64,8 +64,14 @@ __device__ unsigned long long g_phase[8];
 
 constexpr int kSlotU = 5;      // 16-byte DMA units per patch slot: 4 of data + 1 of padding (80-byte stride: conflict-free b128 reads)
 
-template <int KS, int S, int TPS, int TCS, int WP, int WC>
-__global__ __launch_bounds__(WP * WC * 64) void conv_bf16_nhwc(const ConvArgs a) {
+constexpr int kRegUnits = 8;   // DMA units a thread may own for their source offsets to live in registers (REG variants)
+
+// OCC: register budget.  true = four waves per SIMD for the 16-channel-per-wave variants (<= 128 registers), for launches with many
+// workgroups per CU, where residency hides the per-workgroup latencies; false = the compiler's own choice (136-140 registers, three
+// waves per SIMD, shorter code per wave), for launches of a few workgroups per CU, where one workgroup's latency is the launch's.
+template <int KS, int S, int TPS, int TCS, int WP, int WC, bool REG = false, bool OCC = false>
+__global__ __launch_bounds__(WP * WC * 64) __attribute__((amdgpu_waves_per_eu(TCS / WC == 1 ? (OCC ? 4 : 3) : 2)))     // 16 channels per wave: <= 128 registers (four waves per SIMD: 32 -> 32 @56x56 43 -> 40.7 us, 64 -> 256 1x1 312 -> 272), else <= 256
+void conv_bf16_nhwc(const ConvArgs a) {
     constexpr int NT = WP * WC * 64, PSW = TPS / WP, CSW = TCS / WC, TC = TCS * 16, TAPS = KS * KS;
     static_assert(TPS % WP == 0 && TCS % WC == 0, "wave grid must divide the tile");
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -99,14 +105,32 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_bf16_nhwc(const ConvArgs a)
 
     const float inv_RinWp = 1.0f / (float)RinWp, inv_Wp = 1.0f / (float)a.Wp, inv_RW = 1.0f / (float)RW, inv_Wo = 1.0f / (float)a.Wo;
     GRK_TICK(t_start);
-    for (int idx = tid; idx < a.PSTR; idx += NT) {
+    auto slot_pixel = [&](int idx) {                       // input pixel of patch slot idx, -1 = zero padding / outside the batch
         const int gl = fdiv(idx, inv_RinWp), rem = idx - gl * RinWp;
         const int ry = fdiv(rem, inv_Wp), rx = rem - ry * a.Wp;
         const int yin = y0 * S + ry - pad, xin = rx - pad;
         const bool ok = gl < a.G && (g0 + gl) < a.N && yin >= 0 && yin < a.H && xin >= 0 && xin < a.W;
-        tab[idx] = ok ? (g0 + gl) * HW + yin * a.W + xin : -1;
+        return ok ? (g0 + gl) * HW + yin * a.W + xin : -1;
+    };
+    // REG: a thread owns the same <= kRegUnits DMA units (slot, 16-byte part q) in every chunk, so their source offsets are worked out
+    // once, into registers: element offset of the slot's pixel (a multiple of 8) | q, or all ones for a unit that stays zero.  No table,
+    // no barrier before the first DMA, and a chunk's staging is a compare, an add and the DMA per unit instead of an LDS round trip,
+    // a branch and 64-bit address arithmetic (the per-chunk staging stood in front of every chunk's MFMAs: ~40 % of the chunk loop).
+    unsigned uoff[REG ? kRegUnits : 1];
+    if (REG) {
+#pragma unroll
+        for (int i = 0; i < kRegUnits; ++i) {
+            const int u = wave * 64 + i * NT + lane, slot = (int)(((unsigned)u * 52429u) >> 18), q = u - slot * kSlotU;
+            uoff[i] = 0xffffffffu;
+            if (u < aunits && q < 4 && slot < a.PSTR) {
+                const int px = slot_pixel(slot);
+                if (px >= 0) uoff[i] = (unsigned)px * (unsigned)a.in_ctot + (unsigned)a.in_coff + (unsigned)q;
+            }
+        }
+    } else {
+        for (int idx = tid; idx < a.PSTR; idx += NT) tab[idx] = slot_pixel(idx);
+        __syncthreads();
     }
-    __syncthreads();
 
     // One chunk = 32 input channels: weights [tap][TC] rows of 64 B straight from the packed [chunk][tap][CoutPad][32] array
     // (the 16-byte part a lane fetches is XOR-ed with (row >> 2) & 3, the read side applies the same involution), and the
@@ -114,9 +138,27 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_bf16_nhwc(const ConvArgs a)
     auto stage = [&](int chunk, int buf) {
         u16* adst = a_lds + (size_t)buf * aunits * 8;
         const int c0 = chunk * kCK;
+        if (REG) {
+#pragma unroll
+            for (int i = 0; i < kRegUnits; ++i) {
+                const int ub = wave * 64 + i * NT;
+                if (ub >= aunits) break;                     // wave-uniform
+                const unsigned o = uoff[i];
+                const int c = c0 + (int)(o & 7u) * 8;
+                const u16* src = (o != 0xffffffffu && c < a.Cin) ? in + (size_t)(o & ~7u) + c : zeros;
+#ifdef GRNET_ABLATION
+                if (a.dbg & 2) src = zeros;
+#endif
+                dma16(src, adst + ub * 8);
+            }
+            return;
+        }
         for (int ub = wave * 64; ub < aunits; ub += NT) {
             const int u = ub + lane, slot = (int)(((unsigned)u * 52429u) >> 18), q = u - slot * kSlotU;      // u / 5 for u < 2^16
             const u16* src = zeros;
+#ifdef GRNET_ABLATION
+            if (a.dbg & 2) { dma16(src, adst + ub * 8); continue; }      // timing only: no HBM reads of the patch
+#endif
             if (q < 4 && slot < a.PSTR) {
                 const int off = tab[slot], c = c0 + q * 8;
                 if (off >= 0 && c < a.Cin) src = in + (size_t)off * a.in_ctot + a.in_coff + c;
@@ -155,22 +197,33 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_bf16_nhwc(const ConvArgs a)
 #ifdef GRNET_ABLATION
     unsigned long long t_first = 0;
 #endif
+    // Weight fragments live in registers a chunk ahead: chunk 0's are requested here, under the first patch's flight, and every tap
+    // re-requests ITS registers for the next chunk right behind the MFMAs that consumed them -- the L2 round trip of a chunk's
+    // weights (1-2 us, formerly exposed after every barrier: the chunk loop ran at 4-8x its MFMA time) hides under the rest of the
+    // chunk.  The last chunk re-requests itself (an L2 hit nobody waits for) so that the tap loop carries no branch.
+    bf16x8 af[TAPS][CSW];
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+        for (int cs = 0; cs < CSW; ++cs) af[tap][cs] = *reinterpret_cast<const bf16x8*>(wlane[cs] + tap * wtap);
+    f32x4 biasv[CSW];
+    {
+        const int cstore0 = a.out_ctot - a.out_coff < a.CoutPad ? a.out_ctot - a.out_coff : a.CoutPad;
+#pragma unroll
+        for (int cs = 0; cs < CSW; ++cs) {
+            const int co = co0 + (wc * CSW + cs) * 16 + lq * 4;
+            biasv[cs] = co < cstore0 ? *reinterpret_cast<const f32x4*>(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = nbuf == 2 ? (ch & 1) : 0;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of chunk ch has landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of chunk ch has landed, and so have its weight fragments
         __syncthreads();                                     // ... and everybody else's; with two buffers the other one is free
 #ifdef GRNET_ABLATION
         if (ch == 0) t_first = __builtin_readcyclecounter();
 #endif
-        // all weight fragments of the chunk first: vmcnt retires in order, so fragments requested AFTER the next chunk's
-        // DMA batch could only be consumed once that whole batch had landed
-        const size_t wchunk = (size_t)ch * TAPS * wtap;
-        bf16x8 af[TAPS][CSW];
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap)
-#pragma unroll
-            for (int cs = 0; cs < CSW; ++cs) af[tap][cs] = *reinterpret_cast<const bf16x8*>(wlane[cs] + wchunk + tap * wtap);
         if (nbuf == 2 && ch + 1 < nchunks) stage(ch + 1, buf ^ 1);
+        const size_t wnext = (size_t)(ch + 1 < nchunks ? ch + 1 : ch) * TAPS * wtap;
         const u16* al = a_lds + (size_t)buf * aunits * 8;
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
@@ -182,6 +235,8 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_bf16_nhwc(const ConvArgs a)
             for (int cs = 0; cs < CSW; ++cs)
 #pragma unroll
                 for (int ps = 0; ps < PSW; ++ps) acc[cs][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tap][cs], bfr[ps], acc[cs][ps], 0, 0, 0);
+#pragma unroll
+            for (int cs = 0; cs < CSW; ++cs) af[tap][cs] = *reinterpret_cast<const bf16x8*>(wlane[cs] + wnext + tap * wtap);
         }
         if (nbuf == 1 && ch + 1 < nchunks) {
             __syncthreads();                                 // single buffer: everybody is done reading before it is refilled
@@ -202,12 +257,6 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_bf16_nhwc(const ConvArgs a)
         const int gl = fdiv(q, inv_RW), rem = q - gl * RW;
         img_[ps] = g0 + gl;
         pix_[ps] = (q < a.G * RW && img_[ps] < a.N && y0 * a.Wo + rem < HoWo) ? y0 * a.Wo + rem : -1;
-    }
-    f32x4 biasv[CSW];
-#pragma unroll
-    for (int cs = 0; cs < CSW; ++cs) {
-        const int co = co0 + (wc * CSW + cs) * 16 + lq * 4;
-        biasv[cs] = co < cstore ? *reinterpret_cast<const f32x4*>(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int k = 0; k < kMaxAdd; ++k) {
@@ -262,10 +311,13 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_bf16_nhwc(const ConvArgs a)
         const int img = g0 + gl, pix = y0 * a.Wo + rem;
         if (img >= a.N || pix >= HoWo || co0 + part * 8 >= cstore) continue;
         const u32x4 v = *reinterpret_cast<const u32x4*>(o_lds + pl * TCP + part * 8);
+#ifdef GRNET_ABLATION
+        if ((a.dbg & 4) && v[0] != 0x12345678u) continue;               // timing only: no stores
+#endif
         *reinterpret_cast<u32x4*>(out + ((size_t)img * HoWo + pix) * a.out_ctot + a.out_coff + co0 + part * 8) = v;
     }
 #ifdef GRNET_ABLATION
-    {
+    if (a.dbg & 8) {                                       // phase accounting on request only: 5 atomics per workgroup on one line distort the timing
         GRK_TICK(t_end);
         GRK_PHASE(0, t_start, t_tab);
         GRK_PHASE(1, t_tab, t_first);
@@ -447,7 +499,22 @@ template <int KS, int S>
 hipError_t dispatch_bf16(const ConvArgs& a, int tps, int tc, hipStream_t s) {
     const size_t lds = lds_bytes_bf16(a, tc, a.nbuf, tps * 16);
     const dim3 grid((a.xcd ? a.gx8 * 8 : a.gx) * a.gy);
+    // Register-held DMA offsets (REG) for the 64-channel tiles of the 56-wide 3x3 layers with two or more chunks: their chunk loop is
+    // where the per-chunk staging code stood in front of the MFMAs (256 -> 256 @56x56 at 256 frames: 1 127 -> 1 045 us, 480 -> 256:
+    // 1 924 -> 1 770).  The 16-channel-per-wave variants lose more to the registers (152 instead of 116: three waves per SIMD instead
+    // of four) than they gain: 32 -> 32 @56x56 40.7 -> 48.5 us, 64 -> 64 @28x28 32.3 -> 36.6, 64 -> 256 1x1 272 -> 300.
+    static const int reg_env = getenv("GRNET_BF16_REG") ? atoi(getenv("GRNET_BF16_REG")) : 1;
+    const int aunits = (a.PSTR * kSlotU + 63) & ~63;
+    if (reg_env && KS == 3 && tps == 14 && tc == 64 && a.CinPad >= 2 * kCK && aunits <= kRegUnits * 256 &&
+        (size_t)a.N * a.H * a.W * a.in_ctot < 0xfffffff0u)                                  // the offsets are 32-bit element counts
+        return launch_k(conv_bf16_nhwc<KS, S, 14, 4, 2, 2, true>, grid, dim3(256), lds, s, a);
     if (tps == 14 && tc == 64) return launch_k(conv_bf16_nhwc<KS, S, 14, 4, 2, 2>, grid, dim3(256), lds, s, a);
+    static const int occ_env = getenv("GRNET_BF16_OCC") ? atoi(getenv("GRNET_BF16_OCC")) : 3;      // workgroups per CU from which the four-wave variants run
+    if ((long)a.gx * a.gy >= (long)occ_env * 256) {
+        if (tps == 14 && tc == 32) return launch_k(conv_bf16_nhwc<KS, S, 14, 2, 2, 2, false, true>, grid, dim3(256), lds, s, a);
+        if (tps == 7 && tc == 64) return launch_k(conv_bf16_nhwc<KS, S, 7, 4, 1, 4, false, true>, grid, dim3(256), lds, s, a);
+        if (tps == 7 && tc == 32) return launch_k(conv_bf16_nhwc<KS, S, 7, 2, 1, 2, false, true>, grid, dim3(128), lds, s, a);
+    }
     if (tps == 14 && tc == 32) return launch_k(conv_bf16_nhwc<KS, S, 14, 2, 2, 2>, grid, dim3(256), lds, s, a);
     if (tps == 7 && tc == 64) return launch_k(conv_bf16_nhwc<KS, S, 7, 4, 1, 4>, grid, dim3(256), lds, s, a);
     if (tps == 7 && tc == 32) return launch_k(conv_bf16_nhwc<KS, S, 7, 2, 1, 2>, grid, dim3(128), lds, s, a);
@@ -464,6 +531,10 @@ hipError_t init_bf16_ks() {
     GRK_TRY(set_lds_bf16(conv_bf16_nhwc<KS, S, 14, 2, 2, 2>));
     GRK_TRY(set_lds_bf16(conv_bf16_nhwc<KS, S, 7, 4, 1, 4>));
     GRK_TRY(set_lds_bf16(conv_bf16_nhwc<KS, S, 7, 2, 1, 2>));
+    GRK_TRY(set_lds_bf16(conv_bf16_nhwc<KS, S, 14, 4, 2, 2, true>));
+    GRK_TRY(set_lds_bf16(conv_bf16_nhwc<KS, S, 14, 2, 2, 2, false, true>));
+    GRK_TRY(set_lds_bf16(conv_bf16_nhwc<KS, S, 7, 4, 1, 4, false, true>));
+    GRK_TRY(set_lds_bf16(conv_bf16_nhwc<KS, S, 7, 2, 1, 2, false, true>));
     return hipSuccess;
 }
 
@@ -492,6 +563,9 @@ hipError_t launch_conv_bf16(ConvArgs a, hipStream_t s, int tile_hint) {
         tps = tps == 14 ? 7 : 14;
         if (!plan_bf16(a, tps, tc)) return hipErrorInvalidValue;
     }
+#ifdef GRNET_ABLATION
+    if (getenv("GRNET_BF16_PHASES")) a.dbg |= 8;
+#endif
     hipError_t e = a.ks == 1 ? dispatch_bf16<1, 1>(a, tps, tc, s) : (a.stride == 1 ? dispatch_bf16<3, 1>(a, tps, tc, s) : dispatch_bf16<3, 2>(a, tps, tc, s));
 #ifdef GRNET_ABLATION
     static const bool phases = getenv("GRNET_BF16_PHASES") != nullptr;

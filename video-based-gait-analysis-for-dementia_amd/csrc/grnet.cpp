@@ -1283,7 +1283,23 @@ struct grnet {
         a.ks = ks; a.stride = stride; a.relu = relu;
         if (add_dev) { a.n_add = 1; a.add[0] = static_cast<const float*>(xadd); a.add_ctot[0] = cout8; a.add_coff[0] = 0; a.add_shift[0] = 0; }
         a.zeros = zeros;
+        if (const char* d = getenv("GRNET_CONV_DBG")) a.dbg = atoi(d);
         if (e == hipSuccess) e = launch_conv_bf16(a, s, tile_hint);
+        if (const char* r = getenv("GRNET_CONV_REPS")) {       // timing loop for tools/bf16_micro.py
+            const int reps = atoi(r);
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0); hipEventCreate(&e1);
+            hipEventRecord(e0, s);
+            for (int i = 0; i < reps && e == hipSuccess; ++i) e = launch_conv_bf16(a, s, tile_hint);
+            hipEventRecord(e1, s);
+            hipEventSynchronize(e1);
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            const double mb = (in_b + out_b * (add_dev ? 2 : 1)) / 1e6;
+            fprintf(stderr, "[bf16_micro] cin %d cout %d k %d s %d hw %d n %d hint %d add %d: %.2f us/launch, %.0f MB algorithmic = %.2f TB/s\n", cin, cout, ks, stride,
+                    hgt, n, tile_hint, add_dev ? 1 : 0, ms * 1e3f / reps, mb, mb / (ms * 1e3 / reps));
+            hipEventDestroy(e0); hipEventDestroy(e1);
+        }
         if (e == hipSuccess) e = launch_nhwc_bf16_to_nchw_f32(xout, out_dev, n, cout, ho, wo, cout8, 0, s);
         hipError_t e2 = hipStreamSynchronize(s);
         hipFree(wd); hipFree(bd); hipFree(xin); hipFree(xout);
