@@ -25,14 +25,13 @@ __device__ __forceinline__ float wave_max(float v) {
 // ---------------------------------------------------------------------------------------------
 // HR-module fuse output 0: y = relu(x_0 + up2(t_1) + up4(t_2) + up8(t_3)), nearest upsampling
 // (reference: HighResolutionModule.forward, hrnet.py:258-265; nn.Upsample(nearest), hrnet.py:208).
+// One workgroup per (frame, channel) plane, a thread per 4 consecutive pixels; 32-bit index arithmetic with one reciprocal multiply
+// for the row (the first version walked a flat 64-bit index: two 64-bit divisions per thread, 20 us for a 6 MB output on the chain
+// between two HR modules).  The sum order (x_0, then the addends as listed) and every rounding are unchanged.
 __global__ __launch_bounds__(256) void fuse_sum_kernel(const SumArgs a) {
-    const int HW = a.H * a.W;
-    const long total4 = (long)a.N * a.C * HW / 4;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-        const long e = i * 4;
-        const int pix = (int)(e % HW);
-        const long nc = e / HW;
-        const int c = (int)(nc % a.C), n = (int)(nc / a.C);
+    const int HW = a.H * a.W, n = blockIdx.x / a.C, c = blockIdx.x - n * a.C;
+    const float inv_w = 1.0f / (float)a.W;
+    for (int pix = threadIdx.x * 4; pix < HW; pix += 1024) {
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < a.n_add; ++k) {
             const int sh = a.add_shift[k];
@@ -43,7 +42,7 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(const SumArgs a) {
                 const float* ap = a.add[k] + ((size_t)n * a.add_ctot[k] + a.add_coff[k] + c) * (hs * ws);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int y = (pix + r) / a.W, x = (pix + r) - y * a.W;
+                    const int y = (int)(((float)(pix + r) + 0.5f) * inv_w), x = (pix + r) - y * a.W;      // exact for pix < 2^20
                     v[r] += ap[(y >> sh) * ws + (x >> sh)];
                 }
             }
@@ -58,10 +57,7 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(const SumArgs a) {
 
 hipError_t launch_fuse_sum(const SumArgs& a, hipStream_t s) {
     if ((a.H * a.W) % 4 != 0 || a.n_add < 1 || a.n_add > 4) return hipErrorInvalidValue;
-    const long total4 = (long)a.N * a.C * a.H * a.W / 4;
-    int blocks = (int)((total4 + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    GRK_TRY(launch_k(fuse_sum_kernel, dim3(blocks), dim3(256), 0, s, a));
+    GRK_TRY(launch_k(fuse_sum_kernel, dim3(a.N * a.C), dim3(256), 0, s, a));
     return hipGetLastError();
 }
 
@@ -123,7 +119,51 @@ __global__ __launch_bounds__(256) void bilinear2x_x4_kernel(const float* __restr
     }
 }
 
+// One workgroup per (frame, channel) plane of at most 32 x 32 inputs: the plane goes to LDS with coalesced 16-byte loads, every tap is
+// an LDS read, the output leaves as 16-byte stores with the lanes walking a row.  Same arithmetic per element as the two kernels above
+// (bit-identical results).  The upsampling launches sit on the critical path of the upsample heads, in front of their convolutions:
+// 28 -> 56 with 256 channels writes 51 MB and took 50 us with 16 gathered global loads and two 64-bit divisions per thread (1.3 TB/s).
+template <bool X4>
+__global__ __launch_bounds__(256) void bilinear2x_plane_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W) {
+    __shared__ __align__(16) float pl[32 * 32];
+    const int Ho = 2 * H, Wo = 2 * W, HW = H * W;
+    const float sy = (float)(H - 1) / (float)(Ho - 1), sx = (float)(W - 1) / (float)(Wo - 1);
+    const float* p = in + (size_t)blockIdx.x * HW;
+    float* o = out + (size_t)blockIdx.x * Ho * Wo;
+    if (X4) for (int u = threadIdx.x; u < HW / 4; u += 256) *reinterpret_cast<float4*>(pl + 4 * u) = *reinterpret_cast<const float4*>(p + 4 * u);
+    else for (int u = threadIdx.x; u < HW; u += 256) pl[u] = p[u];
+    __syncthreads();
+    const int Wq = X4 ? Wo >> 2 : Wo;                                           // units per output row: 4 pixels or 1
+    const float inv_wq = 1.0f / (float)Wq;
+    for (int i = threadIdx.x; i < Ho * Wq; i += 256) {
+        const int y = (int)(((float)i + 0.5f) * inv_wq), xq = i - y * Wq;      // exact for i < 2^20
+        const float fy = sy * y;
+        const int y0 = (int)fy, y1 = min(y0 + 1, H - 1);
+        const float ly = fy - y0, wy0 = 1.f - ly;
+        const float* p0 = pl + y0 * W;
+        const float* p1 = pl + y1 * W;
+        float r[4];
+#pragma unroll
+        for (int k = 0; k < (X4 ? 4 : 1); ++k) {
+            const int x = X4 ? xq * 4 + k : xq;
+            const float fx = sx * x;
+            const int x0 = (int)fx, x1 = min(x0 + 1, W - 1);
+            const float lx = fx - x0, wx0 = 1.f - lx;
+            const float top = __fmaf_rn(p0[x1], lx, __fmul_rn(p0[x0], wx0));
+            const float bot = __fmaf_rn(p1[x1], lx, __fmul_rn(p1[x0], wx0));
+            r[k] = __fmaf_rn(bot, ly, __fmul_rn(top, wy0));
+        }
+        if (X4) *reinterpret_cast<float4*>(o + y * Wo + xq * 4) = make_float4(r[0], r[1], r[2], r[3]);
+        else o[i] = r[0];
+    }
+}
+
 hipError_t launch_bilinear2x(const float* in, float* out, int N, int C, int H, int W, hipStream_t s) {
+    if (H <= 32 && W <= 32) {
+        if ((2 * W) % 4 == 0 && (H * W) % 4 == 0) GRK_TRY(launch_k(bilinear2x_plane_kernel<true>, dim3(N * C), dim3(256), 0, s, in, out, H, W));
+        else GRK_TRY(launch_k(bilinear2x_plane_kernel<false>, dim3(N * C), dim3(256), 0, s, in, out, H, W));
+        return hipGetLastError();
+    }
     const bool x4 = (2 * W) % 4 == 0;
     const long total = (long)N * C * 4 * H * W / (x4 ? 4 : 1);
     int blocks = (int)((total + 255) / 256);
@@ -237,7 +277,7 @@ __global__ __launch_bounds__(256) void softmax_stats_kernel(const float* __restr
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
     float s = 0.f;
-    for (int p = threadIdx.x; p < P; p += 256) s += expf(h[p] - m);
+    for (int p = threadIdx.x; p < P; p += 256) s += __expf(h[p] - m);      // the same exponential as attn_pool_kernel's (v_exp_f32; ~1e-7 relative)
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -247,62 +287,63 @@ __global__ __launch_bounds__(256) void softmax_stats_kernel(const float* __restr
     }
 }
 
-// block = (frame n, 32 channels of the stacked [featA | featB] map, one of kPoolSplit pixel ranges);
-// 256 threads = 16 channel pairs x 4 joint groups of 6 x 4 pixel phases; pixel tiles of 64 staged in
-// LDS.  Each block writes a partial sum; head_tail_kernel adds the kPoolSplit partials in a fixed order.
-constexpr int kPoolPT = 64;                                // pixels per staged tile (224-pixel tiles measured slower: 80 vs 44 us -- fewer, fatter workgroups hide less latency)
-__global__ __launch_bounds__(256) void attn_pool_kernel(const float* __restrict__ heat, int heat_ctot, const float* __restrict__ stats,
+// The pooling is a GEMM per frame -- out[c][j] = sum_p feat[c][p] * prob[j][p], M = 192 channels, N = 24 joints, K = 3136 positions --
+// and runs on the fp32 matrix cores: workgroup = (frame n, 96 channels, one of kPoolSplit position ranges) = 6 waves, wave = one
+// 16-channel row tile x both 16-joint column tiles (joints 24..31 are zero columns).  The workgroup first builds its range's
+// probabilities exp(h - max) / sum ONCE, in LDS (32 rows of 448 positions, rows 24..31 zero); then, with NCHW keeping a channel's
+// positions contiguous, a lane's 16-byte load IS its A operand of four consecutive k-steps (row = channel l15, k-step s <-> position
+// p0 + 4 lq + s) and the same reading of the LDS rows is the B operand.  Every wave writes its partial sums; head_tail_kernel adds the
+// kPoolSplit partials in a fixed order.  (Round 2's vector-ALU version staged 64-position tiles in LDS and took 44 us at 16 frames:
+// 8 LDS reads per 12 FMAs; a first matrix-core version with every wave rebuilding the probabilities from global memory took 27.)
+constexpr int kPoolChunk = 448, kPoolStride = kPoolChunk + 4;   // positions per range (3136 / kPoolSplit) and the LDS row stride
+__global__ __launch_bounds__(384) void attn_pool_kernel(const float* __restrict__ heat, int heat_ctot, const float* __restrict__ stats,
                                                           const float* __restrict__ featA, int CA, const float* __restrict__ featB,
                                                           int CB, float* __restrict__ part, int P) {
-    __shared__ float prob[24][kPoolPT + 1];
-    __shared__ float feat[32][kPoolPT + 1];
-    __shared__ float red[4][32][24];
-    const int n = blockIdx.x, cb = blockIdx.y * 32;
-    const int tid = threadIdx.x;
-    const int cp = tid & 15, jg = (tid >> 4) & 3, ph = tid >> 6;
-    const bool isA = cb < CA;
-    const float* fbase = isA ? featA + ((size_t)n * CA + cb) * P : featB + ((size_t)n * CB + (cb - CA)) * P;
-    const float* hbase = heat + ((size_t)n * heat_ctot + 1) * P;
-    float acc[2][6];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 6; ++b) acc[a][b] = 0.f;
-
-    const int chunk = (P + kPoolSplit - 1) / kPoolSplit;
-    const int pbeg = blockIdx.z * chunk, pend = min(P, pbeg + chunk);
-    for (int p0 = pbeg; p0 < pend; p0 += kPoolPT) {
-        for (int e = tid; e < 24 * kPoolPT; e += 256) {
-            const int j = e / kPoolPT, pp = e % kPoolPT;
+    __shared__ __align__(16) float prob[32 * kPoolStride];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int pbeg = blockIdx.z * kPoolChunk;
+    for (int u = tid; u < 32 * (kPoolChunk / 4); u += 384) {
+        const int j = u / (kPoolChunk / 4), q = u - j * (kPoolChunk / 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (j < 24) {
             const float m = stats[2 * (n * 24 + j)], inv = stats[2 * (n * 24 + j) + 1];
-            prob[j][pp] = (p0 + pp < pend) ? expf(hbase[(size_t)j * P + p0 + pp] - m) * inv : 0.f;
-        }
-        for (int e = tid; e < 32 * kPoolPT; e += 256) {
-            const int c = e / kPoolPT, pp = e % kPoolPT;
-            feat[c][pp] = (p0 + pp < pend) ? fbase[(size_t)c * P + p0 + pp] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int pp = ph; pp < kPoolPT; pp += 4) {
-            const float f0 = feat[2 * cp][pp], f1 = feat[2 * cp + 1][pp];
+            const f32x4 h = *reinterpret_cast<const f32x4*>(heat + ((size_t)n * heat_ctot + 1 + j) * P + pbeg + 4 * q);      // channel 0 = background
 #pragma unroll
-            for (int b = 0; b < 6; ++b) {
-                const float pr = prob[jg * 6 + b][pp];
-                acc[0][b] += f0 * pr;
-                acc[1][b] += f1 * pr;
+            for (int k = 0; k < 4; ++k) v[k] = __expf(h[k] - m) * inv;
+        }
+        *reinterpret_cast<f32x4*>(prob + j * kPoolStride + 4 * q) = v;
+    }
+    const int ct = blockIdx.y * 6 + (tid >> 6);                         // row tile: channels 16 ct .. 16 ct + 15 of [featA | featB]
+    const int c = ct * 16 + l15;
+    const float* frow = (c < CA ? featA + ((size_t)n * CA + c) * P : featB + ((size_t)n * CB + (c - CA)) * P) + pbeg + 4 * lq;
+    // four groups of 16 positions in flight per wave (a group is ~0.15 us of work, an L2 / HBM round trip 1-2 us)
+    f32x4 fa[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) fa[g] = *reinterpret_cast<const f32x4*>(frow + 16 * g);
+    __syncthreads();
+    const float* b0 = prob + l15 * kPoolStride + 4 * lq;
+    const float* b1 = prob + (16 + l15) * kPoolStride + 4 * lq;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int p0 = 0; p0 < kPoolChunk; p0 += 64) {
+        const int pn = p0 + 64 < kPoolChunk ? p0 + 64 : p0;             // the last round re-requests itself
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 f = fa[g];
+            fa[g] = *reinterpret_cast<const f32x4*>(frow + pn + 16 * g);
+            const f32x4 u = *reinterpret_cast<const f32x4*>(b0 + p0 + 16 * g), v = *reinterpret_cast<const f32x4*>(b1 + p0 + 16 * g);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(f[k], u[k], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f[k], v[k], acc1, 0, 0, 0);
             }
         }
-        __syncthreads();
     }
+    // D[row = 4 lq + r][col = l15]: channel 16 ct + 4 lq + r, joints l15 and 16 + l15
+    float* o = part + (((size_t)n * kPoolSplit + blockIdx.z) * (CA + CB) + ct * 16 + 4 * lq) * 24;      // [n][split][192][24]
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 6; ++b) red[ph][2 * cp + a][jg * 6 + b] = acc[a][b];
-    __syncthreads();
-    for (int e = tid; e < 32 * 24; e += 256) {
-        const int c = e / 24, j = e % 24;
-        const float v = red[0][c][j] + red[1][c][j] + red[2][c][j] + red[3][c][j];
-        part[(((size_t)n * kPoolSplit + blockIdx.z) * (CA + CB) + cb + c) * 24 + j] = v;      // [n][split][192][24]
+    for (int r = 0; r < 4; ++r) {
+        o[r * 24 + l15] = acc0[r];
+        if (l15 < 8) o[r * 24 + 16 + l15] = acc1[r];
     }
 }
 
@@ -311,10 +352,10 @@ size_t softmax_pool_ws_floats(int N) { return (size_t)N * 48 + (size_t)N * kPool
 hipError_t launch_softmax_pool(const float* heat, int heat_ctot, const float* featA, int CA, const float* featB, int CB,
                                float* outA, float* outB, float* stats_ws, int N, int P, hipStream_t s) {
     (void)outA; (void)outB;                                  // written by head_tail_kernel from the partial sums
-    if (CA != 128 || CB != 64) return hipErrorInvalidValue;
+    if (CA != 128 || CB != 64 || P != kPoolChunk * kPoolSplit) return hipErrorInvalidValue;      // 56 x 56 = 7 ranges x 7 rounds of 4 groups of 16 positions
     float* part = stats_ws + (size_t)N * 48;
     GRK_TRY(launch_k(softmax_stats_kernel, dim3(N * 24), dim3(256), 0, s, heat, heat_ctot, stats_ws, P));
-    GRK_TRY(launch_k(attn_pool_kernel, dim3(N, (CA + CB) / 32, kPoolSplit), dim3(256), 0, s, heat, heat_ctot, stats_ws, featA, CA, featB,
+    GRK_TRY(launch_k(attn_pool_kernel, dim3(N, (CA + CB) / 96, kPoolSplit), dim3(384), 0, s, heat, heat_ctot, stats_ws, featA, CA, featB,
                        CB, part, P));
     return hipGetLastError();
 }
@@ -373,10 +414,12 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
                                                           float* __restrict__ cam, float* __restrict__ rotmat,
                                                           float* __restrict__ theta) {
     __shared__ float s_plf[128 * 24];
-    __shared__ float s_csf[64 * 24];
+    __shared__ __align__(16) float s_csf[64 * 24];
     __shared__ float s_pose[24 * 6];
     __shared__ float s_sc[13];
-    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float s_pp[4][144];
+    __shared__ float s_sp[13][8];
+    const int n = blockIdx.x, tid = threadIdx.x;
     // add the pixel-range partials of the pooling in a fixed order; 6 elements x 7 partials of loads in flight per thread
     // (one block per frame: nothing else hides the L2 latency of this kernel, which sits on the critical path)
     static_assert((192 * 24) % (256 * 6) == 0, "partials loop");
@@ -401,20 +444,50 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
         }
     }
     __syncthreads();
+    // 154 KB of weights per frame (the same for every frame: L2 hits) and 38 k multiply-adds: this kernel is one workgroup per frame on
+    // the critical path of the step, so what counts is how many of its loads are in flight at once.  Threads 0..143: one 16-byte column
+    // group of pose_w's [c][j*6+o] rows x one quarter of the 128 channels (32 independent 16-byte loads each); threads 144..247: one
+    // eighth of one of the 13 shape / cam rows (48 independent 16-byte loads each); partial sums meet in LDS in a fixed order.
+    // (Round 2: 144 threads x 128 dependent-issue scalar loads, then 13 wave-wide dot products: 44 us at 16 frames.)
     if (tid < 144) {
-        const int j = tid / 6, o = tid % 6;
-        float acc = 0.f;
+        const int g = tid % 36, cq = tid / 36;
+        const f32x4* wp = reinterpret_cast<const f32x4*>(w.pose_w) + (size_t)(cq * 32) * 36 + g;
+        const float* pl = s_plf + cq * 32 * 24;
+        const int ja = (4 * g) / 6, jb = (4 * g + 1) / 6, jc = (4 * g + 2) / 6, jd = (4 * g + 3) / 6;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 16
-        for (int c = 0; c < 128; ++c) acc += s_plf[c * 24 + j] * w.pose_w[c * 144 + tid];      // [c][j][o]: the 144 threads read one contiguous row per c
-        s_pose[j * 6 + o] = acc;
-        rot6d[(size_t)n * 144 + j * 6 + o] = acc;
+        for (int c = 0; c < 32; ++c) {
+            const f32x4 wv = wp[c * 36];
+            acc[0] += pl[c * 24 + ja] * wv[0];
+            acc[1] += pl[c * 24 + jb] * wv[1];
+            acc[2] += pl[c * 24 + jc] * wv[2];
+            acc[3] += pl[c * 24 + jd] * wv[3];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_pp[cq][4 * g + k] = acc[k];
+    } else if (tid < 144 + 13 * 8) {
+        const int o = (tid - 144) >> 3, seg = (tid - 144) & 7;
+        const float* wr = (o < 10 ? w.shape_w + (size_t)o * 1536 : w.cam_w + (size_t)(o - 10) * 1536) + seg * 192;
+        const float* cs = s_csf + seg * 192;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 16
+        for (int k = 0; k < 48; ++k) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + 4 * k), x = *reinterpret_cast<const f32x4*>(cs + 4 * k);
+            acc += x * wv;
+        }
+        s_sp[o][seg] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     }
-    for (int o = wave; o < 13; o += 4) {
-        const float* wr = o < 10 ? w.shape_w + (size_t)o * 1536 : w.cam_w + (size_t)(o - 10) * 1536;
+    __syncthreads();
+    if (tid < 144) {
+        const float acc = (s_pp[0][tid] + s_pp[1][tid]) + (s_pp[2][tid] + s_pp[3][tid]);
+        s_pose[tid] = acc;                                   // tid = j * 6 + o
+        rot6d[(size_t)n * 144 + tid] = acc;
+    } else if (tid < 157) {
+        const int o = tid - 144;
         float acc = 0.f;
-        for (int k = lane; k < 1536; k += 64) acc += s_csf[k] * wr[k];
-        acc = wave_sum(acc);
-        if (lane == 0) s_sc[o] = acc + (o < 10 ? w.shape_b[o] : w.cam_b[o - 10]);
+#pragma unroll
+        for (int seg = 0; seg < 8; ++seg) acc += s_sp[o][seg];
+        s_sc[o] = acc + (o < 10 ? w.shape_b[o] : w.cam_b[o - 10]);
     }
     __syncthreads();
     if (tid < 24) {
