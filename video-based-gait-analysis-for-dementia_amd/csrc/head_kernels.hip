@@ -575,7 +575,11 @@ __global__ __launch_bounds__(64) void smpl_chain_kernel(const float* __restrict_
                                                           float* __restrict__ A_ws, float* __restrict__ kp3d, float* __restrict__ feat) {
     __shared__ float J[24][3];
     __shared__ float G[24][12];
+    __shared__ float Rs[216];                                    // the frame's rotations and the parent table in LDS: the serial chain below
+    __shared__ int par[24];                                      // used to fetch both from global memory joint by joint (13.7 us per call)
     const int n = blockIdx.x, tid = threadIdx.x;
+    for (int e = tid; e < 216; e += 64) Rs[e] = rotmat[(size_t)n * 216 + e];
+    if (tid < 24) par[tid] = t.parents[tid];
     for (int e = tid; e < 72; e += 64) {
         float v = t.J_template[e];
 #pragma unroll
@@ -591,9 +595,9 @@ __global__ __launch_bounds__(64) void smpl_chain_kernel(const float* __restrict_
     }
     __syncthreads();
     if (tid == 0) {
-        const float* R = rotmat + (size_t)n * 216;
+        const float* R = Rs;
         for (int i = 0; i < 24; ++i) {
-            const int p = t.parents[i];
+            const int p = par[i];
             float tl[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) tl[k] = J[i][k] - (i > 0 ? J[p][k] : 0.f);
