@@ -66,3 +66,28 @@ def test_attention_block_takes_clips_longer_than_4096_frames(pkg, oracle):
         mg.gait_correct(torch.zeros(t, 128, 24).cuda(), torch.zeros(t, 64, 24).cuda(), torch.zeros(t, 3).cuda(), torch.zeros(1, t, 4).cuda(),
                         torch.zeros(1, t, 2).cuda(), 1, t)
     mg.close()
+
+
+@pytest.mark.parametrize("case", [(1, 224), (3, 224), (16, 224), (2, 64)], ids=lambda c: "x".join(map(str, c)))
+def test_stem_kernel_with_flattened_reduction(model, oracle, case):
+    """conv_stem_f32 (3 -> 64, 3x3, stride 2, K = (channel, tap) flattened to 7 k-steps, operands straight from global memory) vs the
+    oracle's direct convolution: the path's 224 x 224 frames at 1 / 3 / 16 frames and a 64 x 64 map; bias + ReLU and the linear form,
+    the first / last rows and columns separately (the top row and the left column read the zero padding), bit-identical repeats."""
+    n, hw = case
+    g = np.random.Generator(np.random.Philox(key=[93, n * 1000 + hw]))
+    x = g.standard_normal((n, 3, hw, hw)).astype(np.float32)
+    w = (g.standard_normal((64, 3, 3, 3)) * np.sqrt(2.0 / 27)).astype(np.float32)
+    b = (g.standard_normal((64,)) * 0.1).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    ref = torch.relu(oracle.conv2d(x, w, stride=2, bias=b)).numpy()
+    got = model.op_conv2d(xd, w, b, stride=2, relu=True, tile_hint=3001).cpu().numpy()
+    assert got.shape == ref.shape == (n, 64, hw // 2, hw // 2)
+    assert rel_err(got, ref) < 1e-5, rel_err(got, ref)
+    lin = oracle.conv2d(x, w, stride=2).numpy()
+    got = model.op_conv2d(xd, w, None, stride=2, relu=False, tile_hint=3001).cpu().numpy()
+    assert rel_err(got, lin) < 1e-5
+    e = hw // 2 - 1
+    assert rel_err(got[:, :, [0, e]], lin[:, :, [0, e]]) < 1e-5 and rel_err(got[..., [0, e]], lin[..., [0, e]]) < 1e-5
+    assert np.array_equal(got, model.op_conv2d(xd, w, None, stride=2, relu=False, tile_hint=3001).cpu().numpy())
+    with pytest.raises(Exception):
+        model.op_conv2d(torch.zeros(1, 4, 64, 64).cuda(), np.zeros((64, 4, 3, 3), np.float32), None, stride=2, relu=False, tile_hint=3001)

@@ -606,7 +606,7 @@ hipError_t launch_softmax_pool_bf16(const void* heat, int hc, const void* featA,
                                     int P, hipStream_t s) {
     if (CA != 128 || CB != 64) return hipErrorInvalidValue;
     float* stats = pool_ws;
-    float* part = pool_ws + (size_t)N * 24 * 2;
+    float* part = pool_ws + (size_t)N * kPoolStatsFloats;
     GRK_TRY(launch_k(softmax_stats_bf16_kernel, dim3(N, 24), dim3(256), 0, s, reinterpret_cast<const u16*>(heat), hc, stats, P));
     return launch_k(attn_pool_bf16_kernel, dim3(N, kPoolSplitB), dim3(256), 0, s, reinterpret_cast<const u16*>(heat), hc, reinterpret_cast<const u16*>(featA), CA, ctA,
                     reinterpret_cast<const u16*>(featB), CB, ctB, stats, part, P);

@@ -63,6 +63,7 @@ struct ConvLayer {
     float* w_dev = nullptr;
     float* b_dev = nullptr;
     float* wino4_dev = nullptr; // transformed weights [36][cin_pad][cout_pad] of the Winograd F(4x4,3x3) kernel (the widest 56x56 layers only)
+    float* stem_dev = nullptr;   // flattened-K weights of the stem's first convolution (conv_stem.hip)
     float* wino4s_dev = nullptr; // transformed weights of the register-resident F(4x4,3x3) kernel of the 14x14 / 7x7 maps (conv_wino4s.hip)
     int cin_pad = 0, cout_pad = 0;
     double macs_per_frame = 0;
@@ -718,7 +719,9 @@ struct grnet {
                            (L.in.w == 56 || (L.in.c >= 64 && L.cout % 64 == 0));
         const bool wino4s = !bf && wino4_env && cin == L.in.c && conv_wino4s_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size()) &&
                             (L.adds.empty() || L.adds[0].shift == 0);          // the small maps: conv_wino4s.hip
-        std::vector<double> wfold(wino4 || wino4s ? (size_t)L.cout * cin * 9 : 0);     // BN-folded weights (cout, cin, 3, 3) for the filter transform
+        static const int stem_env = getenv("GRNET_STEM") ? atoi(getenv("GRNET_STEM")) : 1;
+        const bool stem = !bf && stem_env && cin == L.in.c && L.segs.size() == 1 && conv_stem_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size());
+        std::vector<double> wfold(wino4 || wino4s || stem ? (size_t)L.cout * cin * 9 : 0);     // BN-folded weights (cout, cin, 3, 3) for the filter transform
         int co0 = 0;
         for (auto& s : L.segs) {
             const HostTensor* w = find(s.wkey);
@@ -748,7 +751,7 @@ struct grnet {
                     for (int t = 0; t < taps; ++t) {
                         const double wv = (double)w->data[((size_t)co * cin + ci) * taps + t] * scale[co];
                         wp[bf ? ((((size_t)(ci / 32) * taps + t) * L.cout_pad + co0 + co) * 32 + ci % 32) : ((size_t)t * L.cin_pad + ci) * L.cout_pad + co0 + co] = (float)wv;
-                        if (wino4 || wino4s) wfold[((size_t)(co0 + co) * cin + ci) * 9 + t] = wv;
+                        if (wino4 || wino4s || stem) wfold[((size_t)(co0 + co) * cin + ci) * 9 + t] = wv;
                     }
             }
             co0 += s.cout;
@@ -763,6 +766,11 @@ struct grnet {
             return rc;
         }
         if ((rc = upload(bp, &L.b_dev))) return rc;
+        if (stem) {
+            std::vector<float> sw(7 * 4 * 64);
+            pack_stem_weights(wfold.data(), sw.data());
+            if ((rc = upload(sw, &L.stem_dev))) return rc;
+        }
         if (wino4s) {                                          // U = G g G^T of the folded filter, fp64 -> fp32
             std::vector<float> uws((size_t)36 * cin * L.cout);
             pack_wino4r_weights(wfold.data(), L.cout, cin, uws.data());
@@ -1156,6 +1164,10 @@ struct grnet {
                         static const int w4s_prio = getenv("GRNET_WINO4S_PRIO") ? atoi(getenv("GRNET_WINO4S_PRIO")) : 3;   // bit 0: 14x14 layers, bit 1: 7x7 layers at wave priority 1
                         wa.prio = (w4s_prio & (L.in.w == 7 ? 2 : 1)) ? 1 : 0;
                         HIP_TRY(launch_conv_wino4s(wa, s, w4s_ks));
+                    } else if (L.stem_dev && !conv_tile_hint) {
+                        ConvArgs wa = conv_args(L, frames, n);
+                        wa.w = L.stem_dev;
+                        HIP_TRY(launch_conv_stem(wa, s));
                     } else if (L.wino4_dev && wino_mode && !conv_tile_hint) {
                         ConvArgs wa = conv_args(L, frames, n);
                         wa.w = L.wino4_dev;
@@ -1198,7 +1210,7 @@ struct grnet {
                     launches += 2;
                     break;
                 case Op::TAIL:
-                    HIP_TRY(launch_head_tail(d_stats, plf, csf, tailw, rot6d, d_shape, d_cam, rotmat, theta, n, s));
+                    HIP_TRY(launch_head_tail(d_stats, dtype == 0, plf, csf, tailw, rot6d, d_shape, d_cam, rotmat, theta, n, s));
                     ++launches;
                     break;
                 case Op::SMPL:
@@ -1770,6 +1782,21 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
         }
         a.w = ud;
     }
+    if (tile_hint == 3001) {                                   // the flattened-K stem kernel on this one convolution
+        if (!conv_stem_eligible(cin, cout, ks, stride, hgt, wid, add_dev ? 1 : 0)) {
+            hipFree(wd); hipFree(bd);
+            return h->fail(GRNET_EINVAL, "shape not eligible for the stem kernel");
+        }
+        std::vector<double> wf((size_t)cout * cin * 9);
+        for (size_t i = 0; i < wf.size(); ++i) wf[i] = w_host[i];
+        std::vector<float> sw(7 * 4 * 64);
+        pack_stem_weights(wf.data(), sw.data());
+        if (hipMalloc(reinterpret_cast<void**>(&ud), sw.size() * 4) != hipSuccess || hipMemcpy(ud, sw.data(), sw.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            hipFree(wd); hipFree(bd); if (ud) hipFree(ud);
+            return h->fail(GRNET_ENOMEM, "stem test weights");
+        }
+        a.w = ud;
+    }
     int w4s_on = 0, w4s_ks = 0;
     if (tile_hint >= 2020 && tile_hint <= 2024) {              // the small-map F(4x4,3x3) kernel, 202k: k waves split the input channels (0: default)
         w4s_on = 1; w4s_ks = tile_hint - 2020;
@@ -1788,7 +1815,7 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
         a.w = ud;
     }
     auto launch_one = [&]() {
-        return w4s_on ? launch_conv_wino4s(a, s, w4s_ks) : tile_hint == 2001 ? launch_conv_wino4(a, s) : launch_conv(a, s, tile_hint);
+        return w4s_on ? launch_conv_wino4s(a, s, w4s_ks) : tile_hint == 2001 ? launch_conv_wino4(a, s) : tile_hint == 3001 ? launch_conv_stem(a, s) : launch_conv(a, s, tile_hint);
     };
     hipError_t e = launch_one();
     if (const char* r = getenv("GRNET_CONV_REPS")) {           // timing loop for tools/conv_micro.py

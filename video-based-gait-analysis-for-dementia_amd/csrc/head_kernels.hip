@@ -262,56 +262,47 @@ hipError_t launch_crop_normalise(const unsigned char* img, int H, int W, int per
 // ---------------------------------------------------------------------------------------------
 // Part attention (KeypointAttention.forward, keypoint_attention.py:42-48; called twice with the
 // same heat-maps, pare.py:331-332): softmax over the 3136 positions of each (frame, joint), then
-// out[n,c,j] = sum_p prob[n,j,p] * feat[n,c,p].  Pass 1: per-row max and 1/sum.  Pass 2: both
-// feature maps (128 + 64 channels) pooled with the probabilities rebuilt on the fly.
-__global__ __launch_bounds__(256) void softmax_stats_kernel(const float* __restrict__ heat, int heat_ctot, float* __restrict__ stats,
-                                                              int P) {
-    const int n = blockIdx.x / 24, j = blockIdx.x % 24;
-    const float* h = heat + ((size_t)n * heat_ctot + 1 + j) * P;      // channel 0 = background (pare.py:316)
-    __shared__ float red[4];
-    float m = -INFINITY;
-    for (int p = threadIdx.x; p < P; p += 256) m = fmaxf(m, h[p]);
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __syncthreads();
-    float s = 0.f;
-    for (int p = threadIdx.x; p < P; p += 256) s += __expf(h[p] - m);      // the same exponential as attn_pool_kernel's (v_exp_f32; ~1e-7 relative)
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        stats[2 * blockIdx.x] = m;
-        stats[2 * blockIdx.x + 1] = 1.f / (red[0] + red[1] + red[2] + red[3]);
-    }
-}
-
+// out[n,c,j] = sum_p prob[n,j,p] * feat[n,c,p], both feature maps (128 + 64 channels) in one launch.
 // The pooling is a GEMM per frame -- out[c][j] = sum_p feat[c][p] * prob[j][p], M = 192 channels, N = 24 joints, K = 3136 positions --
 // and runs on the fp32 matrix cores: workgroup = (frame n, 96 channels, one of kPoolSplit position ranges) = 6 waves, wave = one
 // 16-channel row tile x both 16-joint column tiles (joints 24..31 are zero columns).  The workgroup first builds its range's
-// probabilities exp(h - max) / sum ONCE, in LDS (32 rows of 448 positions, rows 24..31 zero); then, with NCHW keeping a channel's
+// range's exp(h - range max) ONCE, in LDS (32 rows of 448 positions, rows 24..31 zero); then, with NCHW keeping a channel's
 // positions contiguous, a lane's 16-byte load IS its A operand of four consecutive k-steps (row = channel l15, k-step s <-> position
 // p0 + 4 lq + s) and the same reading of the LDS rows is the B operand.  Every wave writes its partial sums; head_tail_kernel adds the
 // kPoolSplit partials in a fixed order.  (Round 2's vector-ALU version staged 64-position tiles in LDS and took 44 us at 16 frames:
 // 8 LDS reads per 12 FMAs; a first matrix-core version with every wave rebuilding the probabilities from global memory took 27.)
 constexpr int kPoolChunk = 448, kPoolStride = kPoolChunk + 4;   // positions per range (3136 / kPoolSplit) and the LDS row stride
-__global__ __launch_bounds__(384) void attn_pool_kernel(const float* __restrict__ heat, int heat_ctot, const float* __restrict__ stats,
+__global__ __launch_bounds__(384) void attn_pool_kernel(const float* __restrict__ heat, int heat_ctot, float* __restrict__ stats,
                                                           const float* __restrict__ featA, int CA, const float* __restrict__ featB,
                                                           int CB, float* __restrict__ part, int P) {
     __shared__ __align__(16) float prob[32 * kPoolStride];
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
     const int pbeg = blockIdx.z * kPoolChunk;
+    // the range's heat-map rows -> LDS, then per row (four rows per wave): max over the range, exp(h - max) in place, sum.  The softmax
+    // over all 3136 positions is finished by head_tail_kernel from the kPoolSplit (max, sum) pairs -- the usual online-softmax merge --
+    // so no pass over the heat maps runs in front of this kernel (softmax_stats_kernel was 8-10 us on the step's serial tail).
     for (int u = tid; u < 32 * (kPoolChunk / 4); u += 384) {
         const int j = u / (kPoolChunk / 4), q = u - j * (kPoolChunk / 4);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (j < 24) {
-            const float m = stats[2 * (n * 24 + j)], inv = stats[2 * (n * 24 + j) + 1];
-            const f32x4 h = *reinterpret_cast<const f32x4*>(heat + ((size_t)n * heat_ctot + 1 + j) * P + pbeg + 4 * q);      // channel 0 = background
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = __expf(h[k] - m) * inv;
-        }
+        if (j < 24) v = *reinterpret_cast<const f32x4*>(heat + ((size_t)n * heat_ctot + 1 + j) * P + pbeg + 4 * q);      // channel 0 = background
         *reinterpret_cast<f32x4*>(prob + j * kPoolStride + 4 * q) = v;
+    }
+    __syncthreads();
+    for (int j = (tid >> 6) * 4; j < (tid >> 6) * 4 + 4; ++j) {
+        float* row = prob + j * kPoolStride;
+        float hv[kPoolChunk / 64], m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < kPoolChunk / 64; ++i) { hv[i] = row[lane + 64 * i]; m = fmaxf(m, hv[i]); }
+        m = wave_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < kPoolChunk / 64; ++i) { const float e = __expf(hv[i] - m); row[lane + 64 * i] = e; sum += e; }
+        sum = wave_sum(sum);
+        if (lane == 0 && blockIdx.y == 0) {
+            float* st = stats + (((size_t)n * kPoolSplit + blockIdx.z) * 24 + j) * 2;      // [n][range][joint][max, sum]
+            st[0] = m;
+            st[1] = sum;
+        }
     }
     const int ct = blockIdx.y * 6 + (tid >> 6);                         // row tile: channels 16 ct .. 16 ct + 15 of [featA | featB]
     const int c = ct * 16 + l15;
@@ -347,14 +338,13 @@ __global__ __launch_bounds__(384) void attn_pool_kernel(const float* __restrict_
     }
 }
 
-size_t softmax_pool_ws_floats(int N) { return (size_t)N * 48 + (size_t)N * kPoolSplit * 192 * 24; }
+size_t softmax_pool_ws_floats(int N) { return (size_t)N * kPoolStatsFloats + (size_t)N * kPoolSplit * 192 * 24; }
 
 hipError_t launch_softmax_pool(const float* heat, int heat_ctot, const float* featA, int CA, const float* featB, int CB,
                                float* outA, float* outB, float* stats_ws, int N, int P, hipStream_t s) {
     (void)outA; (void)outB;                                  // written by head_tail_kernel from the partial sums
     if (CA != 128 || CB != 64 || P != kPoolChunk * kPoolSplit) return hipErrorInvalidValue;      // 56 x 56 = 7 ranges x 7 rounds of 4 groups of 16 positions
-    float* part = stats_ws + (size_t)N * 48;
-    GRK_TRY(launch_k(softmax_stats_kernel, dim3(N * 24), dim3(256), 0, s, heat, heat_ctot, stats_ws, P));
+    float* part = stats_ws + (size_t)N * kPoolStatsFloats;
     GRK_TRY(launch_k(attn_pool_kernel, dim3(N, (CA + CB) / 96, kPoolSplit), dim3(384), 0, s, heat, heat_ctot, stats_ws, featA, CA, featB,
                        CB, part, P));
     return hipGetLastError();
@@ -408,8 +398,10 @@ __device__ __forceinline__ void rotmat_to_aa_dev(const float* R, float* aa) {
 
 // FROM_PARTS: plf / csf are produced here from the pooling partials (first head pass); otherwise they are INPUTS (the second
 // head pass of the use_gait_feat branch, grnet.py:165, and the single-op parity hook).
+// zstats != nullptr: the partials are sums of feat * exp(h - range max) and zstats holds each range's (max, sum of exp) per joint; the
+// softmax over all positions is finished here: weight of range z = exp(max_z - max over ranges), divided by the weighted sum of sums.
 template <bool FROM_PARTS>
-__global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict__ part, float* __restrict__ plf, float* __restrict__ csf, TailWeights w,
+__global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict__ part, const float* __restrict__ zstats, float* __restrict__ plf, float* __restrict__ csf, TailWeights w,
                                                           float* __restrict__ rot6d, float* __restrict__ shape,
                                                           float* __restrict__ cam, float* __restrict__ rotmat,
                                                           float* __restrict__ theta) {
@@ -419,7 +411,27 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
     __shared__ float s_sc[13];
     __shared__ float s_pp[4][144];
     __shared__ float s_sp[13][8];
+    __shared__ float s_zw[kPoolSplit + 1][24];                // range weights; row kPoolSplit: 1 / (weighted sum of the ranges' sums)
     const int n = blockIdx.x, tid = threadIdx.x;
+    if constexpr (FROM_PARTS) {
+        if (tid < 24) {
+            float m[kPoolSplit], sm[kPoolSplit], M = -INFINITY, S = 0.f;
+#pragma unroll
+            for (int z = 0; z < kPoolSplit; ++z) {
+                m[z] = zstats ? zstats[(((size_t)n * kPoolSplit + z) * 24 + tid) * 2] : 0.f;
+                sm[z] = zstats ? zstats[(((size_t)n * kPoolSplit + z) * 24 + tid) * 2 + 1] : 0.f;
+                M = fmaxf(M, m[z]);
+            }
+#pragma unroll
+            for (int z = 0; z < kPoolSplit; ++z) {
+                const float wz = zstats ? __expf(m[z] - M) : 1.f;
+                s_zw[z][tid] = wz;
+                S += sm[z] * wz;
+            }
+            s_zw[kPoolSplit][tid] = zstats ? 1.f / S : 1.f;
+        }
+        __syncthreads();
+    }
     // add the pixel-range partials of the pooling in a fixed order; 6 elements x 7 partials of loads in flight per thread
     // (one block per frame: nothing else hides the L2 latency of this kernel, which sits on the critical path)
     static_assert((192 * 24) % (256 * 6) == 0, "partials loop");
@@ -436,9 +448,11 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
             const int e = e0 + u * 256;
+            const int j = e % 24;
             float acc = 0.f;
 #pragma unroll
-            for (int sp = 0; sp < kPoolSplit; ++sp) acc += v[u][sp];
+            for (int sp = 0; sp < kPoolSplit; ++sp) acc += v[u][sp] * s_zw[sp][j];
+            acc *= s_zw[kPoolSplit][j];
             if (e < 128 * 24) { s_plf[e] = acc; plf[(size_t)n * 128 * 24 + e] = acc; }
             else { s_csf[e - 128 * 24] = acc; csf[(size_t)n * 64 * 24 + e - 128 * 24] = acc; }
         }
@@ -512,15 +526,16 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
     }
 }
 
-hipError_t launch_head_tail(const float* pool_ws, float* plf, float* csf, TailWeights w, float* rot6d, float* shape, float* cam,
+hipError_t launch_head_tail(const float* pool_ws, bool range_stats, float* plf, float* csf, TailWeights w, float* rot6d, float* shape, float* cam,
                             float* rotmat, float* theta, int N, hipStream_t s) {
-    GRK_TRY(launch_k(head_tail_kernel<true>, dim3(N), dim3(256), 0, s, pool_ws + (size_t)N * 48, plf, csf, w, rot6d, shape, cam, rotmat, theta));
+    GRK_TRY(launch_k(head_tail_kernel<true>, dim3(N), dim3(256), 0, s, pool_ws + (size_t)N * kPoolStatsFloats, range_stats ? pool_ws : (const float*)nullptr, plf, csf,
+                     w, rot6d, shape, cam, rotmat, theta));
     return hipGetLastError();
 }
 
 hipError_t launch_head_tail_from_feats(const float* plf, const float* csf, TailWeights w, float* rot6d, float* shape, float* cam, float* rotmat,
                                        float* theta, int N, hipStream_t s) {
-    GRK_TRY(launch_k(head_tail_kernel<false>, dim3(N), dim3(256), 0, s, (const float*)nullptr, const_cast<float*>(plf), const_cast<float*>(csf), w,
+    GRK_TRY(launch_k(head_tail_kernel<false>, dim3(N), dim3(256), 0, s, (const float*)nullptr, (const float*)nullptr, const_cast<float*>(plf), const_cast<float*>(csf), w,
                      rot6d, shape, cam, rotmat, theta));
     return hipGetLastError();
 }
@@ -571,22 +586,22 @@ hipError_t launch_rotmat_to_aa(const float* R, float* aa, int m, hipStream_t s) 
 //   kernel 4 (one block per frame): the 29 "spin2" joints (smpl.py:113-118) incl. the thorax row
 //     of J_regressor_extra, weak-perspective -> perspective camera, projection / 112
 //     (geometry.py:427-479, smpl.py:172-186).
-__global__ __launch_bounds__(64) void smpl_chain_kernel(const float* __restrict__ betas, const float* __restrict__ rotmat, SmplTables t,
-                                                          float* __restrict__ A_ws, float* __restrict__ kp3d, float* __restrict__ feat) {
+__global__ __launch_bounds__(320) void smpl_chain_kernel(const float* __restrict__ betas, const float* __restrict__ rotmat, SmplTables t,
+                                                           float* __restrict__ A_ws, float* __restrict__ kp3d, float* __restrict__ feat) {
     __shared__ float J[24][3];
     __shared__ float G[24][12];
-    __shared__ float Rs[216];                                    // the frame's rotations and the parent table in LDS: the serial chain below
-    __shared__ int par[24];                                      // used to fetch both from global memory joint by joint (13.7 us per call)
+    __shared__ float Rs[216];                                    // the frame's rotations, the parent table and the joints' depths in LDS
+    __shared__ int par[24], depth[24];
     const int n = blockIdx.x, tid = threadIdx.x;
-    for (int e = tid; e < 216; e += 64) Rs[e] = rotmat[(size_t)n * 216 + e];
+    for (int e = tid; e < 216; e += 320) Rs[e] = rotmat[(size_t)n * 216 + e];
     if (tid < 24) par[tid] = t.parents[tid];
-    for (int e = tid; e < 72; e += 64) {
+    for (int e = tid; e < 72; e += 320) {
         float v = t.J_template[e];
 #pragma unroll
         for (int l = 0; l < 10; ++l) v += t.J_shapedirs[e * 10 + l] * betas[(size_t)n * 10 + l];
         J[e / 3][e % 3] = v;
     }
-    for (int e = tid; e < kBlendK; e += 64) {                    // this frame's row of the blend-shape GEMM
+    for (int e = tid; e < kBlendK; e += 320) {                   // this frame's row of the blend-shape GEMM
         float v = 0.f;
         if (e < 207) v = rotmat[(size_t)n * 216 + 9 + e] - ((e % 9 == 0 || e % 9 == 4 || e % 9 == 8) ? 1.f : 0.f);   // (R[1:] - I).flatten
         else if (e < 217) v = betas[(size_t)n * 10 + e - 207];
@@ -594,39 +609,42 @@ __global__ __launch_bounds__(64) void smpl_chain_kernel(const float* __restrict_
         feat[(size_t)n * kBlendK + e] = v;
     }
     __syncthreads();
-    if (tid == 0) {
-        const float* R = Rs;
-        for (int i = 0; i < 24; ++i) {
-            const int p = par[i];
-            float tl[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) tl[k] = J[i][k] - (i > 0 ? J[p][k] : 0.f);
-            if (i == 0) {
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) G[0][r * 4 + c] = R[r * 3 + c];
-                    G[0][r * 4 + 3] = tl[r];
-                }
+    if (tid < 24) {
+        int d = 0;
+        for (int p = par[tid]; p >= 0 && d < 24; p = par[p]) ++d;                 // parents[i] < i, parents[0] < 0
+        depth[tid] = d;
+    }
+    __syncthreads();
+    // The kinematic chain level by level: thread (joint i, entry r, c) of G_i = G_parent . [R_i | J_i - J_parent] once its parent's level
+    // is done -- 8 levels for the SMPL tree instead of 24 joints one after another on one thread (13.6 us per call; same arithmetic per
+    // entry, so the same results).
+    const int ji = tid / 12, rc = tid - ji * 12, r = rc >> 2, c = rc & 3;
+    const bool mine = tid < 288;
+    const int myd = mine ? depth[ji] : -1, p = mine ? par[ji] : 0;
+    for (int d = 0; d < 24; ++d) {
+        if (mine && myd == d) {
+            if (d == 0) {
+                G[ji][rc] = c < 3 ? Rs[ji * 9 + r * 3 + c] : J[ji][r];
             } else {
-                const float* Ri = R + i * 9;
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    const float g0 = G[p][r * 4 + 0], g1 = G[p][r * 4 + 1], g2 = G[p][r * 4 + 2];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) G[i][r * 4 + c] = g0 * Ri[c] + g1 * Ri[3 + c] + g2 * Ri[6 + c];
-                    G[i][r * 4 + 3] = g0 * tl[0] + g1 * tl[1] + g2 * tl[2] + G[p][r * 4 + 3];
+                const float g0 = G[p][r * 4 + 0], g1 = G[p][r * 4 + 1], g2 = G[p][r * 4 + 2];
+                if (c < 3) {
+                    const float* Ri = Rs + ji * 9;
+                    G[ji][rc] = g0 * Ri[c] + g1 * Ri[3 + c] + g2 * Ri[6 + c];
+                } else {
+                    const float t0 = J[ji][0] - J[p][0], t1 = J[ji][1] - J[p][1], t2 = J[ji][2] - J[p][2];
+                    G[ji][rc] = g0 * t0 + g1 * t1 + g2 * t2 + G[p][r * 4 + 3];
                 }
             }
         }
+        __syncthreads();
+        if (d >= 1 && __syncthreads_count(mine && myd > d) == 0) break;     // nobody is deeper
     }
-    __syncthreads();
-    for (int e = tid; e < 24 * 12; e += 64) {
-        const int i = e / 12, rc = e % 12, r = rc / 4, c = rc % 4;
-        float v = G[i][rc];
-        if (c == 3) {
-            kp3d[((size_t)n * 29 + i) * 3 + r] = v;                  // posed joint = translation of G_i
-            v -= G[i][r * 4 + 0] * J[i][0] + G[i][r * 4 + 1] * J[i][1] + G[i][r * 4 + 2] * J[i][2];
+    for (int e = tid; e < 24 * 12; e += 320) {
+        const int i = e / 12, rc2 = e % 12, r2 = rc2 / 4, c2 = rc2 % 4;
+        float v = G[i][rc2];
+        if (c2 == 3) {
+            kp3d[((size_t)n * 29 + i) * 3 + r2] = v;                 // posed joint = translation of G_i
+            v -= G[i][r2 * 4 + 0] * J[i][0] + G[i][r2 * 4 + 1] * J[i][1] + G[i][r2 * 4 + 2] * J[i][2];
         }
         A_ws[(size_t)n * 288 + e] = v;
     }
@@ -771,7 +789,7 @@ __global__ __launch_bounds__(256) void smpl_joints_kernel(const float* __restric
 hipError_t launch_smpl(const float* betas, const float* rotmat, const float* cam, SmplTables t, float* A_ws, float* verts,
                        float* kp3d, float* kp2d, int N, hipStream_t s) {
     float* feat = A_ws + (size_t)N * 288;                    // the workspace holds (N,288) skinning matrices + (N,220) GEMM rows
-    GRK_TRY(launch_k(smpl_chain_kernel, dim3(N), dim3(64), 0, s, betas, rotmat, t, A_ws, kp3d, feat));
+    GRK_TRY(launch_k(smpl_chain_kernel, dim3(N), dim3(320), 0, s, betas, rotmat, t, A_ws, kp3d, feat));
     GRK_TRY(launch_k(smpl_blend_mfma_kernel, dim3((kBlendCols + 63) / 64), dim3(256), 0, s, (const float*)feat, t.blend, verts, N));
     GRK_TRY(launch_k(smpl_skin_kernel, dim3((kNumVerts + 255) / 256, N), dim3(256), 0, s, t, (const float*)A_ws, verts));
     GRK_TRY(launch_k(smpl_joints_kernel, dim3(N), dim3(256), 0, s, verts, cam, t, kp3d, kp2d));

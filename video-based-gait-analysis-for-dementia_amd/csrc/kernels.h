@@ -102,6 +102,10 @@ int conv_wino4_blocks(int cout, int map_width);   // 16-channel blocks per workg
 
 void wino4_transform_filter(const double* g33, double* u36);   // U = G g G^T of F(4x4,3x3) in fp64
 // ---- register-resident F(4x4,3x3) for the small maps (conv_wino4s.hip): 128 -> 128 @14x14, 256 -> 256 @7x7 (HR branches 2, 3), 256 -> 256 @14x14
+// ---- the stem's first convolution (3 -> 64, 3x3, stride 2) with K = (channel, tap) flattened to 7 k-steps (conv_stem.hip)
+bool conv_stem_eligible(int cin, int cout, int ks, int stride, int h, int w, int n_add);
+hipError_t launch_conv_stem(ConvArgs a, hipStream_t s);                   // a.w = pack_stem_weights
+void pack_stem_weights(const double* w_folded /* (64,3,3,3) */, float* out /* 7*4*64 */);
 bool conv_wino4s_eligible(int cin, int cout, int ks, int stride, int h, int w, int n_add);
 hipError_t launch_conv_wino4s(ConvArgs a, hipStream_t s, int ksplit);      // a.w = pack_wino4r_weights; ksplit 0: the shape's default
 void pack_wino4r_weights(const double* w_folded /* (cout,cin,3,3) */, int cout, int cin, float* out /* 36*cin*cout */);
@@ -139,7 +143,7 @@ struct TailWeights {
 };
 // plf (N,128,24), csf (N,64,24) -> rot6d (N,24,6), shape (N,10), cam (N,3), rotmat (N,24,9), theta (N,85)
 // pool_ws: the workspace launch_softmax_pool filled (per-range partial sums); plf / csf are WRITTEN here
-hipError_t launch_head_tail(const float* pool_ws, float* plf, float* csf, TailWeights w, float* rot6d, float* shape, float* cam,
+hipError_t launch_head_tail(const float* pool_ws, bool range_stats /* fp32 path: per-range (max, sum) pairs to merge; bf16 path: partials already normalised */, float* plf, float* csf, TailWeights w, float* rot6d, float* shape, float* cam,
                             float* rotmat, float* theta, int N, hipStream_t s);
 // the same tail from given features (second head pass of the use_gait_feat branch, grnet.py:165; plf / csf are inputs)
 hipError_t launch_head_tail_from_feats(const float* plf, const float* csf, TailWeights w, float* rot6d, float* shape, float* cam, float* rotmat,
@@ -147,6 +151,7 @@ hipError_t launch_head_tail_from_feats(const float* plf, const float* csf, TailW
 hipError_t launch_rot6d_to_rotmat(const float* x, float* R, int m, hipStream_t s);      // geometry.py:395-410
 hipError_t launch_rotmat_to_aa(const float* R, float* aa, int m, hipStream_t s);        // geometry.py:68-97,159-293
 size_t softmax_pool_ws_floats(int N);
+constexpr int kPoolStatsFloats = 7 * 24 * 2;    // per frame, in front of the partial sums: fp32 path [range][joint][max, sum]; bf16 path [joint][max, 1/sum]
 constexpr int kPoolSplit = 7;                 // pixel ranges of the attention pooling (3136 = 7 x 448): ONE constant for the fp32 and bf16 paths
 
 constexpr int kBlendK = 220;       // rows of the blend-shape table: 207 pose + 10 shape + 1 template + 2 of padding (k-steps of 4)
