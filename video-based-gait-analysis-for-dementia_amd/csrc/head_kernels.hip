@@ -296,7 +296,7 @@ __global__ __launch_bounds__(384) void attn_pool_kernel(const float* __restrict_
         m = wave_max(m);
         float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < kPoolChunk / 64; ++i) { const float e = __expf(hv[i] - m); row[lane + 64 * i] = e; sum += e; }
+        for (int i = 0; i < kPoolChunk / 64; ++i) { const float e = expf(hv[i] - m); row[lane + 64 * i] = e; sum += e; }
         sum = wave_sum(sum);
         if (lane == 0 && blockIdx.y == 0) {
             float* st = stats + (((size_t)n * kPoolSplit + blockIdx.z) * 24 + j) * 2;      // [n][range][joint][max, sum]
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
             }
 #pragma unroll
             for (int z = 0; z < kPoolSplit; ++z) {
-                const float wz = zstats ? __expf(m[z] - M) : 1.f;
+                const float wz = zstats ? expf(m[z] - M) : 1.f;
                 s_zw[z][tid] = wz;
                 S += sm[z] * wz;
             }
