@@ -26,7 +26,7 @@ def bmodel(pkg):
 
 CASES = [(3, 64, 3, 2, 224), (64, 64, 3, 2, 112), (64, 256, 1, 1, 56), (256, 64, 1, 1, 56), (32, 32, 3, 1, 56), (64, 64, 3, 1, 28),
          (128, 128, 3, 1, 14), (256, 256, 3, 1, 7), (32, 64, 3, 2, 56), (128, 256, 3, 2, 14), (256, 32, 1, 1, 7), (128, 25, 1, 1, 56),
-         (480, 256, 3, 1, 56)]
+         (480, 256, 3, 1, 56), (64, 64, 3, 1, 56), (32, 32, 3, 1, 28)]
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c)))

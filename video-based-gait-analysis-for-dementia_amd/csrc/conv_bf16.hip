@@ -328,12 +328,152 @@ void conv_bf16_nhwc(const ConvArgs a) {
 #endif
 }
 
-// (N,C,H,W) f32 -> (N,H,W,Cp) bf16, channels C..Cp-1 zero.  The caller's frames (C = 3 -> 8) and the test hooks.
+// ---- Register-resident kernel for the narrow 3x3 stride-1 layers with as many output as input channels (C = 32 on 56x56 maps, C = 64
+// on 28x28 and 56x56 maps: the BasicBlocks of HR branches 0 and 1 and of layer1's bottlenecks).  An ablation of conv_bf16_nhwc on
+// these layers (patch DMA from a zero block, stores skipped: tools/bf16_micro.py on the diagnostic build) leaves 80-90 % of their
+// time standing: they are bound by that kernel's per-workgroup structure -- slot table, barrier, LDS-DMA issue loop, wait, LDS reads
+// with a wait in front of every MFMA group, output through LDS with two barriers -- not by HBM.  Here nothing goes through the LDS
+// and there is no barrier:
+//   wave  = one output row of one frame x 32 output channels; its weights of ALL taps (9 x C/32 x 2 fragments = 72 / 144 registers)
+//           are loaded once and stay in registers for the row;
+//   tile  = 16 loaded pixels xs .. xs+15 of an input row, of which the middle 14 are outputs (a 56- / 28-wide row is 4 / 2 tiles):
+//           lane (pixel l15, k-group lq) loads the 16 bytes = 8 channels of ITS pixel once per filter row and 32-channel chunk; that
+//           IS the B operand of the centre tap (NHWC: K = 8 consecutive channels per lane), and the left / right taps are the same
+//           registers shifted by one lane within the 16-lane row (DPP row_shr / row_shl: 4 moves per operand);
+//   zero padding: rows outside the image are not loaded (wave-uniform), pixels -1 and W are a select on lanes 0 / 15 of the edge tiles;
+//   output: D[row = channel 4 lq + r][col = pixel l15] -> bias, residual (8 bytes per lane), ReLU, 8-byte stores of 4 channels;
+//           lanes 0 and 15 hold no output.  The next tile's loads are requested before the current tile's MFMAs.
+//   A wave walks a strip of R consecutive output rows with the three input rows it needs in registers: after tile t of row y is
+//   done, the registers of its TOP row (y - 1, not needed again) are re-requested with row y + 2, which is the bottom row of output
+//   row y + 1 -- one new row of loads per output row instead of three, requested a whole row of work ahead, and the weights are
+//   loaded once per strip instead of once per row (a first version, one row per wave with the next TILE's loads in flight, ran at
+//   the LDS kernel's speed: 18 KB of weights per 3.5 KB row and a 0.2 us prefetch distance).  The roles of the three row buffers
+//   rotate, so the row loop is unrolled by three.
+template <int C, int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 32 ? 3 : 2))) void conv_bf16_direct(const ConvArgs a, int R, int strips_per_frame) {
+    constexpr int NCH = C / 32, HALVES = C / 32;
+    constexpr bool RES_AHEAD = C == 32;                    // residual of row y + 1 requested during row y (8 registers; the 64-channel variant has none to spare)
+    const int lane = threadIdx.x & 63, l15 = lane & 15, lq = lane >> 4;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), half = gw % HALVES, strip = gw / HALVES;
+    const int cols = a.W / (14 * NT);                      // column parts of a row: a strip is R rows x NT tiles (56-wide maps with NT = 2: two parts)
+    const int n = strip / (strips_per_frame * cols), sr = strip - n * strips_per_frame * cols;
+    const int y0 = (sr / cols) * R, t0 = (sr % cols) * NT;
+    if (n >= a.N || y0 >= a.H) return;
+    const int y1 = y0 + R < a.H ? y0 + R : a.H, co0 = half * 32;
+    const u16* wg = reinterpret_cast<const u16*>(a.w);
+    bf16x8 wq[NCH][9][2];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                wq[ch][tap][mt] = *reinterpret_cast<const bf16x8*>(wg + ((size_t)(ch * 9 + tap) * a.CoutPad + co0 + mt * 16 + l15) * 32 + lq * 8);
+    f32x4 biasv[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) biasv[mt] = *reinterpret_cast<const f32x4*>(a.bias + co0 + mt * 16 + lq * 4);
+    const u16* inb = reinterpret_cast<const u16*>(a.in) + (size_t)n * a.H * a.W * a.in_ctot + a.in_coff + lq * 8;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    typedef u32x4 RowBuf[NT][NCH];
+    auto load_tile = [&](int yin, int t, u32x4 (&dst)[NCH]) {     // this lane's 8 channels of pixel 14 t - 1 + l15 of input row yin, per chunk
+        const int x = 14 * (t0 + t) - 1 + l15;
+        const bool ok = yin >= 0 && yin < a.H && x >= 0 && x < a.W;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            dst[ch] = zero4;
+            if (ok) dst[ch] = *reinterpret_cast<const u32x4*>(inb + ((size_t)yin * a.W + x) * a.in_ctot + ch * 32);
+        }
+    };
+    u16* outb = reinterpret_cast<u16*>(a.out) + (size_t)n * a.H * a.W * a.out_ctot + a.out_coff + co0 + lq * 4;
+    const u16* addb = a.n_add ? reinterpret_cast<const u16*>(a.add[0]) + (size_t)n * a.H * a.W * a.add_ctot[0] + a.add_coff[0] + co0 + lq * 4 : nullptr;
+    const bool olane = l15 >= 1 && l15 <= 14;
+    u32x2 resrow[RES_AHEAD ? NT : 1][2];                   // RES_AHEAD: the residual of the row about to be computed
+    auto load_res = [&](int y, int t, u32x2 (&dst)[2]) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            dst[mt] = u32x2{0u, 0u};
+            if (addb && olane && y < y1) dst[mt] = *reinterpret_cast<const u32x2*>(addb + ((size_t)y * a.W + 14 * (t0 + t) - 1 + l15) * a.add_ctot[0] + mt * 16);
+        }
+    };
+    if (RES_AHEAD) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) load_res(y0, t, resrow[t]);
+    }
+    auto do_row = [&](int y, RowBuf& top, RowBuf& mid, RowBuf& bot) {
+        u32x2 res[2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (RES_AHEAD) { res[0] = resrow[t][0]; res[1] = resrow[t][1]; load_res(y + 1, t, resrow[t]); }
+            else load_res(y, t, res);                        // under this tile's 36 MFMAs
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    const u32x4 c = ky == 0 ? top[t][ch] : ky == 1 ? mid[t][ch] : bot[t][ch];
+                    u32x4 lft, rgt;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        lft[k] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)c[k], 0x111, 0xf, 0xf, true);      // row_shr:1: pixel x - 1
+                        rgt[k] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)c[k], 0x101, 0xf, 0xf, true);      // row_shl:1: pixel x + 1
+                    }
+                    const bf16x8 b0 = __builtin_bit_cast(bf16x8, lft), b1 = __builtin_bit_cast(bf16x8, c), b2 = __builtin_bit_cast(bf16x8, rgt);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ch][ky * 3 + 0][mt], b0, acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ch][ky * 3 + 1][mt], b1, acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ch][ky * 3 + 2][mt], b2, acc[mt], 0, 0, 0);
+                    }
+                }
+            if (y + 1 < y1) load_tile(y + 2, t, top[t]);           // row y - 1 is done with: its registers take the bottom row of output row y + 1
+            if (olane) {
+                const int x = 14 * (t0 + t) - 1 + l15;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    f32x4 v = acc[mt] + biasv[mt];
+                    v[0] += bf2f((u16)(res[mt][0] & 0xffffu)); v[1] += bf2f((u16)(res[mt][0] >> 16));
+                    v[2] += bf2f((u16)(res[mt][1] & 0xffffu)); v[3] += bf2f((u16)(res[mt][1] >> 16));
+                    if (a.relu) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
+                    *reinterpret_cast<u32x2*>(outb + ((size_t)y * a.W + x) * a.out_ctot + mt * 16) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+                }
+            }
+        }
+    };
+    RowBuf A, B, Cb;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { load_tile(y0 - 1, t, A[t]); load_tile(y0, t, B[t]); load_tile(y0 + 1, t, Cb[t]); }
+    for (int y = y0; y < y1; y += 3) {
+        do_row(y, A, B, Cb);
+        if (y + 1 < y1) do_row(y + 1, B, Cb, A);
+        if (y + 2 < y1) do_row(y + 2, Cb, A, B);
+    }
+}
+
+bool bf16_direct_eligible(const ConvArgs& a) {
+    return a.ks == 3 && a.stride == 1 && a.Cin == a.Cout && (a.Cin == 32 || a.Cin == 64) && a.CinPad == a.Cin && a.CoutPad >= a.Cout && (a.W == 28 || (a.W == 56 && a.Cin == 32)) &&
+           a.Ho == a.H && a.Wo == a.W && a.n_add <= 1 && (a.n_add == 0 || a.add_shift[0] == 0) && a.out_ctot - a.out_coff >= a.Cout &&
+           a.in_ctot % 8 == 0 && a.in_coff % 8 == 0 && a.out_ctot % 4 == 0 && a.out_coff % 4 == 0 && (a.n_add == 0 || (a.add_ctot[0] % 4 == 0 && a.add_coff[0] % 4 == 0));
+}
+
+// (N,C,H,W) f32 -> (N,H,W,Cp) bf16, channels C..Cp-1 zero.  The caller's frames (C = 3 -> 8) and the test hooks.  A thread owns 8 stored
+// channels of one pixel: its reads walk each channel plane with the lanes (coalesced), its write is one 16-byte store.
 __global__ __launch_bounds__(256) void nchw_f32_to_nhwc_bf16_kernel(const float* __restrict__ in, u16* __restrict__ out, int C, int HW, int Cp, long total) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % Cp);
-        const long p = i / Cp, n = p / HW, hw = p - n * HW;
-        out[i] = c < C ? f2bf(in[(n * C + c) * HW + hw]) : (u16)0;
+    const int c8n = Cp / 8;                                            // 16-byte groups per pixel
+    const long units = total / 8;                                      // (n, pixel, group)
+    for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long)gridDim.x * 256) {
+        long px = u, g = 0;
+        if (c8n > 1) { px = u / c8n; g = u - px * c8n; }
+        const long n = px / HW, hw = px - n * HW;
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = (int)g * 8 + k;
+            v[k] = c < C ? in[(n * C + c) * HW + hw] : 0.f;
+        }
+        *reinterpret_cast<u32x4*>(out + u * 8) = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
     }
 }
 // (N,H,W,ctot)[coff .. coff+C) bf16 -> (N,C,H,W) f32 (debug taps, test hooks)
@@ -345,23 +485,26 @@ __global__ __launch_bounds__(256) void nhwc_bf16_to_nchw_f32_kernel(const u16* _
     }
 }
 
-// nn.Upsample(scale_factor=2, bilinear, align_corners=True) on NHWC bf16 (hrnet.py:443); one thread = 8 channels of one output pixel.
+// nn.Upsample(scale_factor=2, bilinear, align_corners=True) on NHWC bf16 (hrnet.py:443); one workgroup = one output row of one frame,
+// one thread = 8 channels of one output pixel (32-bit index arithmetic: the flat 64-bit index cost four 64-bit divisions per thread).
 __global__ __launch_bounds__(256) void bilinear2x_bf16_kernel(const u16* __restrict__ in, u16* __restrict__ out, int N, int C, int H, int W) {
     const int Ho = 2 * H, Wo = 2 * W, C8 = C / 8;
-    const long total = (long)N * Ho * Wo * C8;
+    const int n = blockIdx.x / Ho, yo = blockIdx.x - n * Ho;
     const float sy = (float)(H - 1) / (float)(Ho - 1), sx = (float)(W - 1) / (float)(Wo - 1);
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c8 = (int)(i % C8);
-        long p = i / C8;
-        const int xo = (int)(p % Wo);
-        p /= Wo;
-        const int yo = (int)(p % Ho), n = (int)(p / Ho);
-        const float fy = __fmul_rn((float)yo, sy), fx = __fmul_rn((float)xo, sx);
-        const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1 < H ? y0 + 1 : H - 1, x1 = x0 + 1 < W ? x0 + 1 : W - 1;
-        const float wy = fy - (float)y0, wx = fx - (float)x0;
-        const u16* b = in + (size_t)n * H * W * C + c8 * 8;
-        const u32x4 v00 = *reinterpret_cast<const u32x4*>(b + ((size_t)y0 * W + x0) * C), v01 = *reinterpret_cast<const u32x4*>(b + ((size_t)y0 * W + x1) * C);
-        const u32x4 v10 = *reinterpret_cast<const u32x4*>(b + ((size_t)y1 * W + x0) * C), v11 = *reinterpret_cast<const u32x4*>(b + ((size_t)y1 * W + x1) * C);
+    const float fy = __fmul_rn((float)yo, sy);
+    const int y0 = (int)fy, y1 = y0 + 1 < H ? y0 + 1 : H - 1;
+    const float wy = fy - (float)y0;
+    const u16* r0 = in + ((size_t)n * H + y0) * W * C;
+    const u16* r1 = in + ((size_t)n * H + y1) * W * C;
+    u16* orow = out + ((size_t)n * Ho + yo) * Wo * C;
+    const float inv_c8 = 1.0f / (float)C8;
+    for (int i = threadIdx.x; i < Wo * C8; i += 256) {
+        const int xo = fdiv(i, inv_c8), c8 = i - xo * C8;
+        const float fx = __fmul_rn((float)xo, sx);
+        const int x0 = (int)fx, x1 = x0 + 1 < W ? x0 + 1 : W - 1;
+        const float wx = fx - (float)x0;
+        const u32x4 v00 = *reinterpret_cast<const u32x4*>(r0 + (size_t)x0 * C + c8 * 8), v01 = *reinterpret_cast<const u32x4*>(r0 + (size_t)x1 * C + c8 * 8);
+        const u32x4 v10 = *reinterpret_cast<const u32x4*>(r1 + (size_t)x0 * C + c8 * 8), v11 = *reinterpret_cast<const u32x4*>(r1 + (size_t)x1 * C + c8 * 8);
         u32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -375,21 +518,19 @@ __global__ __launch_bounds__(256) void bilinear2x_bf16_kernel(const u16* __restr
             }
             o[k] = pack2(r[0], r[1]);
         }
-        *reinterpret_cast<u32x4*>(out + (((size_t)n * Ho + yo) * Wo + xo) * C + c8 * 8) = o;
+        *reinterpret_cast<u32x4*>(orow + (size_t)i * 8) = o;
     }
 }
 
-// out = relu?( sum_k nearest_up(add_k) ) on NHWC bf16 (hrnet.py:258-265, output 0 of a fuse layer); one thread = 8 channels of a pixel.
+// out = relu?( sum_k nearest_up(add_k) ) on NHWC bf16 (hrnet.py:258-265, output 0 of a fuse layer); one workgroup = one row of one
+// frame, one thread = 8 channels of a pixel (32-bit index arithmetic).
 __global__ __launch_bounds__(256) void fuse_sum_bf16_kernel(const SumArgs a) {
     const int C8 = a.C / 8;
-    const long total = (long)a.N * a.H * a.W * C8;
+    const int n = blockIdx.x / a.H, y = blockIdx.x - n * a.H;
     u16* out = reinterpret_cast<u16*>(a.out);
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c8 = (int)(i % C8);
-        long p = i / C8;
-        const int x = (int)(p % a.W);
-        p /= a.W;
-        const int y = (int)(p % a.H), n = (int)(p / a.H);
+    const float inv_c8 = 1.0f / (float)C8;
+    for (int i = threadIdx.x; i < a.W * C8; i += 256) {
+        const int x = fdiv(i, inv_c8), c8 = i - x * C8;
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -556,6 +697,17 @@ hipError_t launch_conv_bf16(ConvArgs a, hipStream_t s, int tile_hint) {
     if (!((a.ks == 1 && a.stride == 1) || (a.ks == 3 && (a.stride == 1 || a.stride == 2)))) return hipErrorInvalidValue;
     if (a.CinPad % kCK != 0 || a.CoutPad % 32 != 0 || a.in_ctot % 8 != 0 || a.in_coff % 8 != 0 || a.out_ctot % 8 != 0 || a.out_coff % 8 != 0)
         return hipErrorInvalidValue;
+    static const int direct_env = getenv("GRNET_BF16_DIRECT") ? atoi(getenv("GRNET_BF16_DIRECT")) : 1;
+    if (direct_env && tile_hint == 0 && bf16_direct_eligible(a)) {
+        // rows per strip: enough strips to give every SIMD about two waves, at most 8 rows (weights and the first rows are a strip's fixed cost)
+        const int halves = a.Cin / 32, cols = a.W / 28;       // a strip is R rows x 28 pixels (2 tiles) x 32 output channels
+        int R = (int)((long)a.N * a.H * halves * cols / (a.Cin == 64 ? 2048 : 3072));      // 64 channels: 36 KB of weights per strip, fewer and longer strips
+        R = R < 2 ? 2 : (R > 8 ? 8 : R);
+        const int spf = (a.H + R - 1) / R, waves = a.N * spf * cols * halves;
+        const dim3 grid((waves + 3) / 4);
+        if (a.Cin == 32) return launch_k(conv_bf16_direct<32, 2>, grid, dim3(256), 0, s, a, R, spf);
+        return launch_k(conv_bf16_direct<64, 2>, grid, dim3(256), 0, s, a, R, spf);
+    }
     const int tc = a.CoutPad % 64 == 0 ? 64 : 32;          // measured at 256 frames: 32 everywhere is 1.5x slower
     // 224-pixel tiles for the 56-wide maps, 112 otherwise (measured: 224 everywhere ties at 256 frames and loses 13 % at 16; 112 everywhere loses 28 %)
     int tps = (tile_hint == 7 || tile_hint == 14) ? tile_hint : (a.Wo >= 56 ? 14 : 7);
@@ -583,8 +735,9 @@ hipError_t launch_conv_bf16(ConvArgs a, hipStream_t s, int tile_hint) {
 }
 
 hipError_t launch_nchw_f32_to_nhwc_bf16(const float* in, void* out, int N, int C, int H, int W, int Cp, hipStream_t s) {
+    if (Cp % 8 != 0) return hipErrorInvalidValue;
     const long total = (long)N * H * W * Cp;
-    return launch_k(nchw_f32_to_nhwc_bf16_kernel, dim3(blocks_for(total)), dim3(256), 0, s, in, reinterpret_cast<u16*>(out), C, H * W, Cp, total);
+    return launch_k(nchw_f32_to_nhwc_bf16_kernel, dim3(blocks_for(total / 8)), dim3(256), 0, s, in, reinterpret_cast<u16*>(out), C, H * W, Cp, total);
 }
 hipError_t launch_nhwc_bf16_to_nchw_f32(const void* in, float* out, int N, int C, int H, int W, int ctot, int coff, hipStream_t s) {
     const long total = (long)N * C * H * W;
@@ -592,13 +745,11 @@ hipError_t launch_nhwc_bf16_to_nchw_f32(const void* in, float* out, int N, int C
 }
 hipError_t launch_bilinear2x_bf16(const void* in, void* out, int N, int C, int H, int W, hipStream_t s) {
     if (C % 8 != 0) return hipErrorInvalidValue;
-    const long total = (long)N * 4 * H * W * (C / 8);
-    return launch_k(bilinear2x_bf16_kernel, dim3(blocks_for(total)), dim3(256), 0, s, reinterpret_cast<const u16*>(in), reinterpret_cast<u16*>(out), N, C, H, W);
+    return launch_k(bilinear2x_bf16_kernel, dim3(N * 2 * H), dim3(256), 0, s, reinterpret_cast<const u16*>(in), reinterpret_cast<u16*>(out), N, C, H, W);
 }
 hipError_t launch_fuse_sum_bf16(const SumArgs& a, hipStream_t s) {
     if (a.C % 8 != 0 || a.n_add < 1 || a.n_add > 4) return hipErrorInvalidValue;
-    const long total = (long)a.N * a.H * a.W * (a.C / 8);
-    return launch_k(fuse_sum_bf16_kernel, dim3(blocks_for(total)), dim3(256), 0, s, a);
+    return launch_k(fuse_sum_bf16_kernel, dim3(a.N * a.H), dim3(256), 0, s, a);
 }
 // heat (N,P,hc) with channel 0 = background; featA / featB: first channel of the view, ctA / ctB channels per pixel in memory;
 // pool_ws as launch_softmax_pool fills it.
