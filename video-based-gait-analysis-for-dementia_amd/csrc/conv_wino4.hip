@@ -246,12 +246,27 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
         meet(false);
         chunk(ch & 1, true, ch + 1);
     }
+    const bool has_add = a.n_add == 1;
     meet(nchunks > 1);
+    // thread (channel c of the pass's 16, tile t): 4 output rows of 4 pixels.  The residual rows of a pass are requested a pass ahead
+    // (pass 0's before the accumulators go to LDS): their round trip used to sit between the inverse transform and the stores of every
+    // pass -- twice per launch of the 32-channel branch layers, which are the longest dependency chain of stages 2-4.
+    const int ec = tid / 14, et = tid - ec * 14, etro = et / TPR, etx = et - etro * TPR, eorow = 4 * (TRG * r + etro);
+    const bool ethread = tid < 14 * 16 && eorow < a.H;
+    f32x4 radd[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    auto fetch_res = [&](int nt) {
+        const int co = co0 + (nb0 + nt) * 16 + ec;
+        if (has_add && ethread && co < a.Cout) {
+            const float* ap = a.add[0] + ((size_t)img * a.add_ctot[0] + a.add_coff[0] + co) * HW + eorow * WD + 4 * etx;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) radd[i] = *reinterpret_cast<const f32x4*>(ap + i * WD);
+        }
+    };
+    fetch_res(0);                                       // under the last chunk's MFMAs
     chunk((nchunks - 1) & 1, false, 0);
 
     // ---- epilogue: inverse transform A^T M A (A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]), + bias, + residual, ReLU
     float* Mx = smem;                                    // [36 points][16 channels][20]
-    const bool has_add = a.n_add == 1;
     for (int nt = 0; nt < NB; ++nt) {
         __syncthreads();
 #pragma unroll
@@ -262,10 +277,12 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
             *reinterpret_cast<f32x4*>(Mx + ((wave * 9 + pi) * 16 + l15) * kMrow + lq * 4) = v;
         }
         __syncthreads();
-        if (tid < 14 * 16) {
-            const int c = tid / 14, t = tid - c * 14, tro = t / TPR, tx = t - tro * TPR;
-            const int co = co0 + (nb0 + nt) * 16 + c, orow = 4 * (TRG * r + tro);
-            if (co < a.Cout && orow < a.H) {
+        const f32x4 rcur[4] = {radd[0], radd[1], radd[2], radd[3]};
+        if (nt + 1 < NB) fetch_res(nt + 1);
+        if (ethread) {
+            const int c = ec, t = et, tx = etx;
+            const int co = co0 + (nb0 + nt) * 16 + c, orow = eorow;
+            if (co < a.Cout) {
                 float s[4][6];                           // A^T M: rows of the 4x6 intermediate
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
@@ -285,7 +302,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
                     const float* q = s[i];
                     const float p12 = q[1] + q[2], m12 = q[1] - q[2], p34 = q[3] + q[4], m34 = q[3] - q[4];
                     f32x4 y = f32x4{q[0] + p12 + p34 + b, fmaf(2.f, m34, m12) + b, fmaf(4.f, p34, p12) + b, fmaf(8.f, m34, m12) + q[5] + b};
-                    if (has_add) y += *reinterpret_cast<const f32x4*>(a.add[0] + ((size_t)img * a.add_ctot[0] + a.add_coff[0] + co) * HW + (orow + i) * WD + 4 * tx);
+                    if (has_add) y += rcur[i];
                     if (a.relu) { y[0] = fmaxf(y[0], 0.f); y[1] = fmaxf(y[1], 0.f); y[2] = fmaxf(y[2], 0.f); y[3] = fmaxf(y[3], 0.f); }
                     *reinterpret_cast<f32x4*>(a.out + obase + i * WD) = y;
                 }
