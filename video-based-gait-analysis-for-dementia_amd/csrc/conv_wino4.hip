@@ -14,12 +14,22 @@
 // 16-byte load straight from L2, requested a chunk ahead.
 #include "kernels.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace grk {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GRNET_LDS_AS __attribute__((address_space(3)))
 
 namespace {
+
+#ifdef GRNET_ABLATION
+__device__ unsigned long long g_w4phase[8];      // diagnostic build, dbg bit 3: ticks summed over workgroups (tools/wino_phases.py)
+#define W4_TICK(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define W4_TICK(var) do { } while (0)
+#endif
 
 constexpr int kCK = 8;                       // input channels per chunk
 constexpr int kRaw = 6 * 56;                 // raw floats per channel: 6 input rows
@@ -172,6 +182,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
 
     const int nchunks = a.CinPad / kCK;
     bfrag bq[NLD];                                       // B fragments of the 18 MFMA groups (PAIR: of the 9 points); each is re-requested for the next chunk behind its group
+    W4_TICK(t_start);
     issue_raw(0);
     if (nchunks > 1) issue_raw(1);
 #pragma unroll
@@ -179,6 +190,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
     if constexpr (PAIR) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // the raw rows (requested before the weight loads) have landed
     else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
     __syncthreads();
+    W4_TICK(t_first);
     {
         Tf t;
         tf_read(t, raw + rpos);
@@ -186,6 +198,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
         tf_rows(t);
         tf_cols(t, V + vpos);
     }
+    W4_TICK(t_tf0);
     // ---- the chunk loop: three clusters of 24 MFMAs (three points x two k-steps x four channel blocks)
     float av[2][6];
     auto load_a = [&](int buf, int c, int set) {         // A fragments of cluster c: points 3c .. 3c+2 of this wave, both k-steps
@@ -265,6 +278,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
     fetch_res(0);                                       // under the last chunk's MFMAs
     chunk((nchunks - 1) & 1, false, 0);
 
+    W4_TICK(t_loop);
     // ---- epilogue: inverse transform A^T M A (A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]), + bias, + residual, ReLU
     float* Mx = smem;                                    // [36 points][16 channels][20]
     for (int nt = 0; nt < NB; ++nt) {
@@ -309,10 +323,18 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
             }
         }
     }
+#ifdef GRNET_ABLATION
+    if ((a.dbg & 8) && tid == 0) {
+        W4_TICK(t_end);
+        atomicAdd(&g_w4phase[0], t_first - t_start); atomicAdd(&g_w4phase[1], t_tf0 - t_first); atomicAdd(&g_w4phase[2], t_loop - t_tf0);
+        atomicAdd(&g_w4phase[3], t_end - t_loop); atomicAdd(&g_w4phase[4], 1ull);
+    }
+#endif
 }
 
 template <int NB, int WD = 56, int ABL = 0, bool WSPLIT = false>
 __global__ __launch_bounds__(256) void conv_wino4_f32(const ConvArgs a) { conv_wino4_body<NB, WD, ABL, WSPLIT>(a); }
+
 
 }  // namespace
 
@@ -375,12 +397,27 @@ hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s, int* n_launches) {
         auto set = [&](auto kern) { if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsB); };
         set(conv_wino4_f32<4, 56>); set(conv_wino4_f32<2, 56>); set(conv_wino4_f32<4, 28>); set(conv_wino4_f32<2, 28>);
         set(conv_wino4_f32<2, 56, 0, true>); set(conv_wino4_f32<2, 28, 0, true>);
+
         if (e != hipSuccess) return e;
         attr_done[dev] = true;
     }
     const int nb = conv_wino4_blocks(a.Cout, a.W);
     if (!conv_wino4_eligible(a.Cin, a.Cout, a.ks, a.stride, a.H, a.W, a.n_add) || a.CinPad % kCK != 0 || a.CoutPad % (nb * 16) != 0) return hipErrorInvalidValue;
     if (a.n_add == 1 && a.add_shift[0] != 0) return hipErrorInvalidValue;
+#ifdef GRNET_ABLATION
+    if (getenv("GRNET_W4_PHASES")) {
+        a.dbg |= 8;
+        const hipError_t e = a.W == 56 ? launch_wino4_w<56>(a, s, nb, n_launches) : launch_wino4_w<28>(a, s, nb, n_launches);
+        unsigned long long h[8] = {}, z[8] = {};
+        hipStreamSynchronize(s);
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_w4phase), sizeof(h));
+        hipMemcpyToSymbol(HIP_SYMBOL(g_w4phase), z, sizeof(z));
+        const double n = h[4] ? (double)h[4] : 1.0;
+        fprintf(stderr, "[wino4 phases] %d->%d @%d N%d add %d nb %d wgs %llu: per WG ticks  prologue %.0f  first transform %.0f  chunk loop %.0f (%d chunks)  epilogue %.0f\n",
+                a.Cin, a.Cout, a.W, a.N, a.n_add, nb, h[4], h[0] / n, h[1] / n, h[2] / n, a.CinPad / kCK, h[3] / n);
+        return e;
+    }
+#endif
     return a.W == 56 ? launch_wino4_w<56>(a, s, nb, n_launches) : launch_wino4_w<28>(a, s, nb, n_launches);
 }
 
