@@ -418,12 +418,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 32 ? 3
                         rgt[k] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)c[k], 0x101, 0xf, 0xf, true);      // row_shl:1: pixel x + 1
                     }
                     const bf16x8 b0 = __builtin_bit_cast(bf16x8, lft), b1 = __builtin_bit_cast(bf16x8, c), b2 = __builtin_bit_cast(bf16x8, rgt);
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ch][ky * 3 + 0][mt], b0, acc[mt], 0, 0, 0);
-                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ch][ky * 3 + 1][mt], b1, acc[mt], 0, 0, 0);
-                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ch][ky * 3 + 2][mt], b2, acc[mt], 0, 0, 0);
-                    }
+                    // the two channel blocks alternate: back-to-back MFMAs into one accumulator wait for each other
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ch][ky * 3 + 0][0], b0, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ch][ky * 3 + 0][1], b0, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ch][ky * 3 + 1][0], b1, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ch][ky * 3 + 1][1], b1, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ch][ky * 3 + 2][0], b2, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ch][ky * 3 + 2][1], b2, acc[1], 0, 0, 0);
                 }
             if (y + 1 < y1) load_tile(y + 2, t, top[t]);           // row y - 1 is done with: its registers take the bottom row of output row y + 1
             if (olane) {
