@@ -150,7 +150,7 @@ def roofline_object(fps_per_gpu, dtype, conv_flops_per_frame, conv_ms, conv_ms_s
          "kernel": ("conv_wino4_f32 (Winograd F(4x4,3x3) on the fp32 matrix cores: the 3x3 stride-1 layers on 56x56 and 28x28 maps) + conv_wino4s_f32 "
                     "(the same on 14x14 / 7x7 maps, register-resident) + conv_mfma_f32 / conv_splitk_f32 (fp32 MFMA implicit-GEMM convolution: "
                     "1x1, stride-2 and stem layers), all launches of a step" if dtype == "f32"
-                    else "conv_bf16_nhwc (bf16 MFMA implicit-GEMM convolution on NHWC activations, all launches of a step)"),
+                    else "conv_bf16_nhwc (bf16 MFMA implicit-GEMM convolution on NHWC activations) + conv_bf16_direct (register-resident kernel of the 32 ch @56x56 / 64 ch @28x28 layers), all launches of a step"),
          "conv_launches_per_step": n_conv, "conv_gflop_per_step": round(conv_flops / 1e9, 3),
          "gflop_per_launch": round(conv_flops / 1e9 / max(n_conv, 1), 4)}
     if executed_flops_per_frame and executed_flops_per_frame != conv_flops_per_frame:

@@ -552,58 +552,98 @@ __global__ __launch_bounds__(256) void fuse_sum_bf16_kernel(const SumArgs a) {
     }
 }
 
-// Attention pooling on NHWC bf16 maps (keypoint_attention.py:42-48): the spatial softmax of heat channel 1+j weights the
-// features.  Pass 1: per (image, joint) max and sum of exp over the P positions.  Pass 2: partial sums over a range of
-// positions, written in the fp32 path's workspace layout so head_tail_kernel finishes both paths alike.
-constexpr int kPoolSplitB = kPoolSplit;   // shared with the fp32 path: both feed head_tail_kernel through softmax_pool_ws_floats()
-__global__ __launch_bounds__(256) void softmax_stats_bf16_kernel(const u16* __restrict__ heat, int hc, float* __restrict__ stats, int P) {
-    __shared__ float red[256];
-    const int n = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
-    const u16* h = heat + (size_t)n * P * hc + 1 + j;
-    float m = -INFINITY;
-    for (int p = tid; p < P; p += 256) m = fmaxf(m, bf2f(h[(size_t)p * hc]));
-    red[tid] = m;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]); __syncthreads(); }
-    m = red[0];
-    __syncthreads();
-    float sum = 0.f;
-    for (int p = tid; p < P; p += 256) sum += expf(bf2f(h[(size_t)p * hc]) - m);
-    red[tid] = sum;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
-    if (tid == 0) { stats[(n * 24 + j) * 2] = m; stats[(n * 24 + j) * 2 + 1] = 1.0f / red[0]; }
+// Attention pooling on NHWC bf16 maps (keypoint_attention.py:42-48): per frame the GEMM out[c][j] = sum_p feat[p][c] * prob[p][j] on the
+// fp32 matrix cores, the structure of the fp32 path's attn_pool_kernel (head_kernels.hip): workgroup = (frame, 96 channels, one of
+// kPoolSplit position ranges) = 6 waves; the range's exp(h - range max) is built once per workgroup in LDS (fp32) and the softmax over
+// all positions is finished by head_tail_kernel from the (max, sum) pairs of the ranges.  NHWC makes the position axis the slow one, so
+// a lane's A operand of a k-step is ONE bf16 (channel l15 of position p0 + 4 lq + s: 16 lanes = 32 contiguous bytes of a pixel), widened
+// to fp32 in the register; the products are exact and the sums fp32, as in the vector-ALU kernel this replaces (284 + 137 us for the
+// pooling and its statistics pass at 256 frames).
+constexpr int kPoolChunkB = 448, kPoolStrideB = kPoolChunkB + 4;
+__device__ __forceinline__ float wave_max_b(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
 }
-// grid (N, kPoolSplitB); thread c < CA+CB owns one feature channel and 24 accumulators.
-__global__ __launch_bounds__(256) void attn_pool_bf16_kernel(const u16* __restrict__ heat, int hc, const u16* __restrict__ featA, int CA, int ctA,
-                                                               const u16* __restrict__ featB, int CB, int ctB, const float* __restrict__ stats,
+__device__ __forceinline__ float wave_sum_b(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+constexpr int kPoolFS = 96 + 8;                            // bf16 per staged position: 96 channels + 16 bytes (the four positions of a k-step land on different banks)
+__global__ __launch_bounds__(384) void attn_pool_bf16_kernel(const u16* __restrict__ heat, int hc, const u16* __restrict__ featA, int CA, int ctA,
+                                                               const u16* __restrict__ featB, int CB, int ctB, float* __restrict__ stats,
                                                                float* __restrict__ part, int P) {
-    __shared__ float wgt[32][24];
-    const int n = blockIdx.x, sp = blockIdx.y, tid = threadIdx.x;
-    const int per = (P + kPoolSplitB - 1) / kPoolSplitB, p0 = sp * per, p1 = p0 + per < P ? p0 + per : P;
-    float acc[24];
+    __shared__ __align__(16) float prob[24 * kPoolStrideB];
+    __shared__ __align__(16) u16 fst[2][32 * kPoolFS];    // two buffers of 32 positions x 96 channels, as they lie in memory (NHWC); 57 KB of LDS in all
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int pbeg = blockIdx.z * kPoolChunkB, cb = blockIdx.y * 96;      // first channel of this workgroup in [featA | featB]
+    // staging: 32 positions x 12 units of 16 bytes = one unit per thread; a unit lies entirely in featA or in featB (128 = 8 x 16)
+    const int spp = tid / 12, sq = tid - spp * 12, sc = cb + sq * 8;
+    const u16* ssrc = sc < CA ? featA + ((size_t)n * P + pbeg + spp) * ctA + sc : featB + ((size_t)n * P + pbeg + spp) * ctB + (sc - CA);
+    const size_t sstride = sc < CA ? ctA : ctB;
+    auto stage = [&](int p0, int buf) {
+        *reinterpret_cast<u32x4*>(&fst[buf][spp * kPoolFS + sq * 8]) = *reinterpret_cast<const u32x4*>(ssrc + (size_t)p0 * sstride);
+    };
+    stage(0, 0);
+    // heat rows of the range -> LDS: thread = (position, 8 joints)
+    for (int u = tid; u < kPoolChunkB * 3; u += 384) {
+        const int p = u / 3, jg = u - p * 3;
+        const u32x4 h8 = *reinterpret_cast<const u32x4*>(heat + ((size_t)n * P + pbeg + p) * hc + jg * 8);      // channels 8 jg .. 8 jg + 7 (channel 0 = background)
+        const u16 nx = heat[((size_t)n * P + pbeg + p) * hc + jg * 8 + 8];                                          // channel 8 jg + 8 = joint 8 jg + 7
 #pragma unroll
-    for (int j = 0; j < 24; ++j) acc[j] = 0.f;
-    const u16* src = tid < CA ? featA + (size_t)n * P * ctA + tid : featB + (size_t)n * P * ctB + (tid - CA);
-    const int cs = tid < CA ? ctA : ctB;
-    for (int pb = p0; pb < p1; pb += 32) {
-        __syncthreads();
-        for (int u = tid; u < 32 * 24; u += 256) {
-            const int pp = u / 24, j = u - pp * 24, p = pb + pp;
-            wgt[pp][j] = p < p1 ? expf(bf2f(heat[((size_t)n * P + p) * hc + 1 + j]) - stats[(n * 24 + j) * 2]) * stats[(n * 24 + j) * 2 + 1] : 0.f;
+        for (int k = 0; k < 8; ++k) {
+            const int ch = k + 1;                                                                                   // joint 8 jg + k is channel 8 jg + k + 1
+            const u16 v = ch < 8 ? (u16)(h8[ch >> 1] >> (16 * (ch & 1))) : nx;
+            prob[(jg * 8 + k) * kPoolStrideB + p] = bf2f(v);
         }
-        __syncthreads();
-        if (tid < CA + CB) {
-            for (int pp = 0; pp < 32 && pb + pp < p1; ++pp) {
-                const float f = bf2f(src[(size_t)(pb + pp) * cs]);
+    }
+    __syncthreads();
+    for (int j = (tid >> 6) * 4; j < (tid >> 6) * 4 + 4; ++j) {
+        float* row = prob + j * kPoolStrideB;
+        float hv[kPoolChunkB / 64], m = -INFINITY;
 #pragma unroll
-                for (int j = 0; j < 24; ++j) acc[j] = fmaf(wgt[pp][j], f, acc[j]);
+        for (int i = 0; i < kPoolChunkB / 64; ++i) { hv[i] = row[lane + 64 * i]; m = fmaxf(m, hv[i]); }
+        m = wave_max_b(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < kPoolChunkB / 64; ++i) { const float e = expf(hv[i] - m); row[lane + 64 * i] = e; sum += e; }
+        sum = wave_sum_b(sum);
+        if (lane == 0 && blockIdx.y == 0) {
+            float* st = stats + (((size_t)n * kPoolSplit + blockIdx.z) * 24 + j) * 2;      // [n][range][joint][max, sum]
+            st[0] = m;
+            st[1] = sum;
+        }
+    }
+    const int wv = tid >> 6;                                            // row tile of this wave: channels cb + 16 wv .. + 15
+    const float* b0 = prob + l15 * kPoolStrideB + 4 * lq;
+    const float* b1 = prob + (16 + (l15 & 7)) * kPoolStrideB + 4 * lq;  // joints 16..23; lanes 8..15 of the second column tile are zero columns
+    const bool j1 = l15 < 8;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int p0 = 0; p0 < kPoolChunkB; p0 += 32) {
+        const int buf = (p0 >> 5) & 1;
+        __syncthreads();                                                // buffer `buf` is staged (and the probabilities are final); the other one is free
+        if (p0 + 32 < kPoolChunkB) stage(p0 + 32, buf ^ 1);
+        const u16* fs = &fst[buf][(4 * lq) * kPoolFS + wv * 16 + l15];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const f32x4 u = *reinterpret_cast<const f32x4*>(b0 + p0 + 16 * g);
+            f32x4 v = *reinterpret_cast<const f32x4*>(b1 + p0 + 16 * g);
+            if (!j1) v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float f = bf2f(fs[(16 * g + k) * kPoolFS]);       // channel l15 of position p0 + 16 g + 4 lq + k
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(f, u[k], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f, v[k], acc1, 0, 0, 0);
             }
         }
     }
-    if (tid < CA + CB) {
+    const int ct = blockIdx.y * 6 + wv;
+    float* o = part + (((size_t)n * kPoolSplit + blockIdx.z) * (CA + CB) + ct * 16 + 4 * lq) * 24;      // [n][split][192][24]
 #pragma unroll
-        for (int j = 0; j < 24; ++j) part[(((size_t)n * kPoolSplitB + sp) * (CA + CB) + tid) * 24 + j] = acc[j];
+    for (int r = 0; r < 4; ++r) {
+        o[r * 24 + l15] = acc0[r];
+        if (l15 < 8) o[r * 24 + 16 + l15] = acc1[r];
     }
 }
 
@@ -756,12 +796,10 @@ hipError_t launch_fuse_sum_bf16(const SumArgs& a, hipStream_t s) {
 // pool_ws as launch_softmax_pool fills it.
 hipError_t launch_softmax_pool_bf16(const void* heat, int hc, const void* featA, int CA, int ctA, const void* featB, int CB, int ctB, float* pool_ws, int N,
                                     int P, hipStream_t s) {
-    if (CA != 128 || CB != 64) return hipErrorInvalidValue;
-    float* stats = pool_ws;
+    if (CA != 128 || CB != 64 || P != kPoolChunkB * kPoolSplit || hc < 32 || hc % 8 != 0 || ctA % 8 != 0 || ctB % 8 != 0) return hipErrorInvalidValue;
     float* part = pool_ws + (size_t)N * kPoolStatsFloats;
-    GRK_TRY(launch_k(softmax_stats_bf16_kernel, dim3(N, 24), dim3(256), 0, s, reinterpret_cast<const u16*>(heat), hc, stats, P));
-    return launch_k(attn_pool_bf16_kernel, dim3(N, kPoolSplitB), dim3(256), 0, s, reinterpret_cast<const u16*>(heat), hc, reinterpret_cast<const u16*>(featA), CA, ctA,
-                    reinterpret_cast<const u16*>(featB), CB, ctB, stats, part, P);
+    return launch_k(attn_pool_bf16_kernel, dim3(N, (CA + CB) / 96, kPoolSplit), dim3(384), 0, s, reinterpret_cast<const u16*>(heat), hc, reinterpret_cast<const u16*>(featA),
+                    CA, ctA, reinterpret_cast<const u16*>(featB), CB, ctB, pool_ws, part, P);
 }
 
 }  // namespace grk

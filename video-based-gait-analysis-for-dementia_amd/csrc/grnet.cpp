@@ -1207,10 +1207,10 @@ struct grnet {
                                                          v_csmap.ctot, d_stats, n, 56 * 56, s));
                     else
                         HIP_TRY(launch_softmax_pool(v_heat.p, 25, v_smpl_feats.p, 128, v_csmap.p, 64, plf, csf, d_stats, n, 56 * 56, s));
-                    launches += 2;
+                    ++launches;
                     break;
                 case Op::TAIL:
-                    HIP_TRY(launch_head_tail(d_stats, dtype == 0, plf, csf, tailw, rot6d, d_shape, d_cam, rotmat, theta, n, s));
+                    HIP_TRY(launch_head_tail(d_stats, true, plf, csf, tailw, rot6d, d_shape, d_cam, rotmat, theta, n, s));
                     ++launches;
                     break;
                 case Op::SMPL:

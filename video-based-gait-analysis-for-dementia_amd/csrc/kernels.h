@@ -143,7 +143,7 @@ struct TailWeights {
 };
 // plf (N,128,24), csf (N,64,24) -> rot6d (N,24,6), shape (N,10), cam (N,3), rotmat (N,24,9), theta (N,85)
 // pool_ws: the workspace launch_softmax_pool filled (per-range partial sums); plf / csf are WRITTEN here
-hipError_t launch_head_tail(const float* pool_ws, bool range_stats /* fp32 path: per-range (max, sum) pairs to merge; bf16 path: partials already normalised */, float* plf, float* csf, TailWeights w, float* rot6d, float* shape, float* cam,
+hipError_t launch_head_tail(const float* pool_ws, bool range_stats /* per-range (max, sum) pairs in front of the partials: the softmax is finished here (both paths) */, float* plf, float* csf, TailWeights w, float* rot6d, float* shape, float* cam,
                             float* rotmat, float* theta, int N, hipStream_t s);
 // the same tail from given features (second head pass of the use_gait_feat branch, grnet.py:165; plf / csf are inputs)
 hipError_t launch_head_tail_from_feats(const float* plf, const float* csf, TailWeights w, float* rot6d, float* shape, float* cam, float* rotmat,
@@ -151,7 +151,7 @@ hipError_t launch_head_tail_from_feats(const float* plf, const float* csf, TailW
 hipError_t launch_rot6d_to_rotmat(const float* x, float* R, int m, hipStream_t s);      // geometry.py:395-410
 hipError_t launch_rotmat_to_aa(const float* R, float* aa, int m, hipStream_t s);        // geometry.py:68-97,159-293
 size_t softmax_pool_ws_floats(int N);
-constexpr int kPoolStatsFloats = 7 * 24 * 2;    // per frame, in front of the partial sums: fp32 path [range][joint][max, sum]; bf16 path [joint][max, 1/sum]
+constexpr int kPoolStatsFloats = 7 * 24 * 2;    // per frame, in front of the partial sums: [range][joint][max, sum of exp]
 constexpr int kPoolSplit = 7;                 // pixel ranges of the attention pooling (3136 = 7 x 448): ONE constant for the fp32 and bf16 paths
 
 constexpr int kBlendK = 220;       // rows of the blend-shape table: 207 pose + 10 shape + 1 template + 2 of padding (k-steps of 4)
