@@ -526,11 +526,12 @@ __global__ __launch_bounds__(256) void bilinear2x_bf16_kernel(const u16* __restr
 // out = relu?( sum_k nearest_up(add_k) ) on NHWC bf16 (hrnet.py:258-265, output 0 of a fuse layer); one workgroup = one row of one
 // frame, one thread = 8 channels of a pixel (32-bit index arithmetic).
 __global__ __launch_bounds__(256) void fuse_sum_bf16_kernel(const SumArgs a) {
-    const int C8 = a.C / 8;
-    const int n = blockIdx.x / a.H, y = blockIdx.x - n * a.H;
+    const int C8 = a.C / 8, rpb = a.H % 4 == 0 ? 4 : 1;        // rows per workgroup (a 32-channel row of 56 pixels is only 224 units)
+    const int n = (blockIdx.x * rpb) / a.H, yb = blockIdx.x * rpb - n * a.H;
     u16* out = reinterpret_cast<u16*>(a.out);
-    const float inv_c8 = 1.0f / (float)C8;
-    for (int i = threadIdx.x; i < a.W * C8; i += 256) {
+    const float inv_c8 = 1.0f / (float)C8, inv_wc = 1.0f / (float)(a.W * C8);
+    for (int i0 = threadIdx.x; i0 < rpb * a.W * C8; i0 += 256) {
+        const int yr = fdiv(i0, inv_wc), i = i0 - yr * a.W * C8, y = yb + yr;
         const int x = fdiv(i, inv_c8), c8 = i - x * C8;
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -790,7 +791,7 @@ hipError_t launch_bilinear2x_bf16(const void* in, void* out, int N, int C, int H
 }
 hipError_t launch_fuse_sum_bf16(const SumArgs& a, hipStream_t s) {
     if (a.C % 8 != 0 || a.n_add < 1 || a.n_add > 4) return hipErrorInvalidValue;
-    return launch_k(fuse_sum_bf16_kernel, dim3(a.N * a.H), dim3(256), 0, s, a);
+    return launch_k(fuse_sum_bf16_kernel, dim3(a.N * a.H / (a.H % 4 == 0 ? 4 : 1)), dim3(256), 0, s, a);
 }
 // heat (N,P,hc) with channel 0 = background; featA / featB: first channel of the view, ctA / ctB channels per pixel in memory;
 // pool_ws as launch_softmax_pool fills it.
