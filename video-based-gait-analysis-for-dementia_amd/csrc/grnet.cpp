@@ -1694,7 +1694,7 @@ double grnet_conv_executed_flops_per_frame(grnet_t* h) {
     double m = 0;
     // F(4x4,3x3): 36 multiplies per 4x4 tile instead of 144; the small maps pay for their padding (14 -> 16, 7 -> 8 per side)
     for (auto& L : h->convs)
-        m += L.macs_per_frame * (h->wino_mode && h->dtype == 0 ? (h->wino4s_runs(L, h->last_n) ? 0.25 * (L.in.w == 14 ? 256.0 / 196.0 : 64.0 / 49.0) : L.wino4_dev ? 0.25 : 1.0) : 1.0);
+        m += L.macs_per_frame * (h->wino_mode && h->dtype == 0 && !h->conv_tile_hint ? (h->wino4s_runs(L, h->last_n) ? 0.25 * (L.in.w == 14 ? 256.0 / 196.0 : 64.0 / 49.0) : L.wino4_dev ? 0.25 : 1.0) : 1.0);
     return 2.0 * m;
 }
 
