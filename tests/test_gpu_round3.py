@@ -91,3 +91,26 @@ def test_stem_kernel_with_flattened_reduction(model, oracle, case):
     assert np.array_equal(got, model.op_conv2d(xd, w, None, stride=2, relu=False, tile_hint=3001).cpu().numpy())
     with pytest.raises(Exception):
         model.op_conv2d(torch.zeros(1, 4, 64, 64).cuda(), np.zeros((64, 4, 3, 3), np.float32), None, stride=2, relu=False, tile_hint=3001)
+
+
+@pytest.mark.parametrize("case", [(1, 64, 256), (3, 64, 256), (16, 64, 256), (2, 64, 64), (5, 64, 128)], ids=lambda c: "x".join(map(str, c)))
+def test_pointwise_kernel_of_layer1(model, oracle, case):
+    """conv_pw_f32 (the 64 -> 256 1x1 convolutions of layer1 on 56 x 56 maps, both operands straight from global memory, weights
+    resident in registers) vs the oracle: 64 -> 256 / 128 / 64 at 1 - 16 frames; bias + ReLU, + residual, linear form, bit-identical
+    repeats."""
+    n, cin, cout = case
+    g = np.random.Generator(np.random.Philox(key=[94, n * 100000 + cin * 10 + cout]))
+    x = g.standard_normal((n, cin, 56, 56)).astype(np.float32)
+    w = (g.standard_normal((cout, cin, 1, 1)) * np.sqrt(2.0 / cin)).astype(np.float32)
+    b = (g.standard_normal((cout,)) * 0.1).astype(np.float32)
+    r = g.standard_normal((n, cout, 56, 56)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    conv = oracle.conv2d(x, w, stride=1, bias=b)
+    got = model.op_conv2d(xd, w, b, stride=1, relu=True, tile_hint=3002).cpu().numpy()
+    assert got.shape == conv.shape and rel_err(got, torch.relu(conv).numpy()) < 1e-5
+    got = model.op_conv2d(xd, w, b, stride=1, relu=True, add=torch.from_numpy(r).cuda(), tile_hint=3002).cpu().numpy()
+    assert rel_err(got, torch.relu(conv + torch.from_numpy(r)).numpy()) < 1e-5
+    lin = oracle.conv2d(x, w, stride=1).numpy()
+    got = model.op_conv2d(xd, w, None, stride=1, relu=False, tile_hint=3002).cpu().numpy()
+    assert rel_err(got, lin) < 1e-5
+    assert np.array_equal(got, model.op_conv2d(xd, w, None, stride=1, relu=False, tile_hint=3002).cpu().numpy())

@@ -946,6 +946,12 @@ struct grnet {
     // 16-32 workgroups whose waves each walk 16 k-steps, and the direct split-K kernel with its 8-wave workgroups is the shorter chain
     // link (measured at 1 / 2 / 4 / 8 / 12 frames: -4 % / -3 % / -5 % / -4 % / +0.5 % with the 7x7 layers on it; 14x14: +2 ... +4 % throughout)
     bool wino4s_runs(const ConvLayer& L, int n) const { return L.wino4s_dev && wino_mode && (L.in.w != 7 || n >= 12); }
+    // layer1's 64 -> 256 1x1 convolutions on 56x56 maps: the register-resident kernel of conv_pw.hip (fp32 handles; GRNET_PW=0: the generic kernel)
+    bool pw_on(const ConvLayer& L) const {
+        static const int pw_env = getenv("GRNET_PW") ? atoi(getenv("GRNET_PW")) : 1;
+        return pw_env && dtype == 0 && L.in.w == 56 && L.cout >= 128 && L.segs.size() == 1 && L.cin_w == L.in.c && (L.adds.empty() || L.adds[0].shift == 0) &&
+               conv_pw_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size());
+    }
     int last_n = 16;                   // frame count of the latest forward (grnet_conv_executed_flops_per_frame reports for it)
     std::map<int, int> tuned_mode;     // n -> bit 0: measured per-shape configurations (else cost model), bit 2: eager launches on the lane streams even if graphs are enabled
     int tune(int n, hipStream_t s, int level = 1) {
@@ -1164,6 +1170,8 @@ struct grnet {
                         static const int w4s_prio = getenv("GRNET_WINO4S_PRIO") ? atoi(getenv("GRNET_WINO4S_PRIO")) : 3;   // bit 0: 14x14 layers, bit 1: 7x7 layers at wave priority 1
                         wa.prio = (w4s_prio & (L.in.w == 7 ? 2 : 1)) ? 1 : 0;
                         HIP_TRY(launch_conv_wino4s(wa, s, w4s_ks));
+                    } else if (pw_on(L) && !conv_tile_hint) {
+                        HIP_TRY(launch_conv_pw(conv_args(L, frames, n), s));
                     } else if (L.stem_dev && !conv_tile_hint) {
                         ConvArgs wa = conv_args(L, frames, n);
                         wa.w = L.stem_dev;
@@ -1782,6 +1790,10 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
         }
         a.w = ud;
     }
+    if (tile_hint == 3002 && !conv_pw_eligible(cin, cout, ks, stride, hgt, wid, add_dev ? 1 : 0)) {   // the register-resident 1x1 kernel on this one convolution
+        hipFree(wd); hipFree(bd);
+        return h->fail(GRNET_EINVAL, "shape not eligible for the 1x1 kernel");
+    }
     if (tile_hint == 3001) {                                   // the flattened-K stem kernel on this one convolution
         if (!conv_stem_eligible(cin, cout, ks, stride, hgt, wid, add_dev ? 1 : 0)) {
             hipFree(wd); hipFree(bd);
@@ -1815,7 +1827,7 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
         a.w = ud;
     }
     auto launch_one = [&]() {
-        return w4s_on ? launch_conv_wino4s(a, s, w4s_ks) : tile_hint == 2001 ? launch_conv_wino4(a, s) : tile_hint == 3001 ? launch_conv_stem(a, s) : launch_conv(a, s, tile_hint);
+        return w4s_on ? launch_conv_wino4s(a, s, w4s_ks) : tile_hint == 2001 ? launch_conv_wino4(a, s) : tile_hint == 3001 ? launch_conv_stem(a, s) : tile_hint == 3002 ? launch_conv_pw(a, s) : launch_conv(a, s, tile_hint);
     };
     hipError_t e = launch_one();
     if (const char* r = getenv("GRNET_CONV_REPS")) {           // timing loop for tools/conv_micro.py

@@ -102,6 +102,9 @@ int conv_wino4_blocks(int cout, int map_width);   // 16-channel blocks per workg
 
 void wino4_transform_filter(const double* g33, double* u36);   // U = G g G^T of F(4x4,3x3) in fp64
 // ---- register-resident F(4x4,3x3) for the small maps (conv_wino4s.hip): 128 -> 128 @14x14, 256 -> 256 @7x7 (HR branches 2, 3), 256 -> 256 @14x14
+// ---- layer1's 1x1 convolutions (64 -> 64 / 256, 256 -> 64 on 56x56 maps) with both operands straight from global memory (conv_pw.hip)
+bool conv_pw_eligible(int cin, int cout, int ks, int stride, int h, int w, int n_add);
+hipError_t launch_conv_pw(ConvArgs a, hipStream_t s);                     // a.w = the direct kernels' packing
 // ---- the stem's first convolution (3 -> 64, 3x3, stride 2) with K = (channel, tap) flattened to 7 k-steps (conv_stem.hip)
 bool conv_stem_eligible(int cin, int cout, int ks, int stride, int h, int w, int n_add);
 hipError_t launch_conv_stem(ConvArgs a, hipStream_t s);                   // a.w = pack_stem_weights
