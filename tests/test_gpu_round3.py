@@ -93,11 +93,11 @@ def test_stem_kernel_with_flattened_reduction(model, oracle, case):
         model.op_conv2d(torch.zeros(1, 4, 64, 64).cuda(), np.zeros((64, 4, 3, 3), np.float32), None, stride=2, relu=False, tile_hint=3001)
 
 
-@pytest.mark.parametrize("case", [(1, 64, 256), (3, 64, 256), (16, 64, 256), (2, 64, 64), (5, 64, 128)], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("case", [(1, 64, 256), (3, 64, 256), (16, 64, 256), (2, 64, 64), (16, 64, 64), (5, 64, 128), (16, 128, 25), (3, 128, 25)], ids=lambda c: "x".join(map(str, c)))
 def test_pointwise_kernel_of_layer1(model, oracle, case):
-    """conv_pw_f32 (the 64 -> 256 1x1 convolutions of layer1 on 56 x 56 maps, both operands straight from global memory, weights
-    resident in registers) vs the oracle: 64 -> 256 / 128 / 64 at 1 - 16 frames; bias + ReLU, + residual, linear form, bit-identical
-    repeats."""
+    """conv_pw_f32 (layer1's 64 -> 256 1x1 convolutions and the PARE head's 128 -> 25 heat-map layer on 56 x 56 maps, both operands
+    straight from global memory, weights resident in registers) vs the oracle: 64 -> 256 / 128 / 64 and 128 -> 25 (a partial last
+    channel block) at 1 - 16 frames (long and short runs of tiles per wave); bias + ReLU, + residual, linear form, bit-identical repeats."""
     n, cin, cout = case
     g = np.random.Generator(np.random.Philox(key=[94, n * 100000 + cin * 10 + cout]))
     x = g.standard_normal((n, cin, 56, 56)).astype(np.float32)

@@ -946,11 +946,14 @@ struct grnet {
     // 16-32 workgroups whose waves each walk 16 k-steps, and the direct split-K kernel with its 8-wave workgroups is the shorter chain
     // link (measured at 1 / 2 / 4 / 8 / 12 frames: -4 % / -3 % / -5 % / -4 % / +0.5 % with the 7x7 layers on it; 14x14: +2 ... +4 % throughout)
     bool wino4s_runs(const ConvLayer& L, int n) const { return L.wino4s_dev && wino_mode && (L.in.w != 7 || n >= 12); }
-    // layer1's 64 -> 256 1x1 convolutions on 56x56 maps: the register-resident kernel of conv_pw.hip (fp32 handles; GRNET_PW=0: the generic kernel)
+    // layer1's 64 -> 256 1x1 convolutions and the PARE head's 128 -> 25 heat-map layer on 56x56 maps: the register-resident kernel of
+    // conv_pw.hip (fp32 handles; GRNET_PW: bit 0 64 -> 256, bit 1 128 -> 25, bit 2 the rest of the eligible shapes -- 64 -> 64 and
+    // 128 -> 64 measure within 1 us of the generic kernel either way and stay on it; 0: the generic kernel everywhere)
     bool pw_on(const ConvLayer& L) const {
-        static const int pw_env = getenv("GRNET_PW") ? atoi(getenv("GRNET_PW")) : 1;
-        return pw_env && dtype == 0 && L.in.w == 56 && L.cout >= 128 && L.segs.size() == 1 && L.cin_w == L.in.c && (L.adds.empty() || L.adds[0].shift == 0) &&
-               conv_pw_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size());
+        static const int pw_env = getenv("GRNET_PW") ? atoi(getenv("GRNET_PW")) : 3;
+        return dtype == 0 && L.in.w == 56 && L.segs.size() == 1 && L.cin_w == L.in.c && (L.adds.empty() || L.adds[0].shift == 0) &&
+               conv_pw_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size()) && L.cout_pad >= (L.cout > 32 ? (L.cout + 63) / 64 * 64 : 32) &&
+               (pw_env & (L.in.c == 64 && L.cout >= 128 ? 1 : L.in.c == 128 && L.cout <= 32 ? 2 : 4));
     }
     int last_n = 16;                   // frame count of the latest forward (grnet_conv_executed_flops_per_frame reports for it)
     std::map<int, int> tuned_mode;     // n -> bit 0: measured per-shape configurations (else cost model), bit 2: eager launches on the lane streams even if graphs are enabled
