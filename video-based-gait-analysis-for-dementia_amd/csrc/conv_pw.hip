@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 }  // namespace
 
 bool conv_pw_eligible(int cin, int cout, int ks, int stride, int h, int w, int n_add) {
-    return ks == 1 && stride == 1 && n_add <= 1 && (h * w) % 16 == 0 && ((cin == 64 && cout >= 17) || (cin == 128 && cout >= 17 && cout <= 32));      // 128 -> 64 would need 128 weight registers + operands: spills
+    return ks == 1 && stride == 1 && n_add <= 1 && (h * w) % (16 * 14) == 0 && ((cin == 64 && cout >= 17) || (cin == 128 && cout >= 17 && cout <= 32));      // 128 -> 64 would need 128 weight registers + operands: spills
 }
 
 // a.w: the direct kernels' packing [CinPad][CoutPad] (one tap)
