@@ -114,3 +114,27 @@ def test_pointwise_kernel_of_layer1(model, oracle, case):
     got = model.op_conv2d(xd, w, None, stride=1, relu=False, tile_hint=3002).cpu().numpy()
     assert rel_err(got, lin) < 1e-5
     assert np.array_equal(got, model.op_conv2d(xd, w, None, stride=1, relu=False, tile_hint=3002).cpu().numpy())
+
+
+@pytest.mark.parametrize("scale", [0.0, 1.0, 60.0], ids=["uniform", "as_is", "peaked"])
+def test_attention_pooling_merges_range_softmaxes(pkg, oracle, synth_smpl, scale):
+    """The attention pooling computes exp(h - max) per RANGE of 448 positions and head_tail_kernel finishes the softmax over all 3136
+    from the seven (max, sum) pairs.  Heat maps scaled to the extremes: all-equal (every range weighs the same), as the synthetic
+    weights give them, and x 60 (a few positions carry the whole mass: most ranges' weights underflow to zero) -- pooled features and
+    the outputs that follow, against the oracle with the same weights."""
+    sd = {k: v.copy() for k, v in pkg.synth.make_state_dict().items()}
+    keys = [k for k in sd if "keypoint_final_layer" in k]
+    assert len(keys) == 2, keys
+    for k in keys:
+        sd[k] = (sd[k] * np.float32(scale)).astype(np.float32)
+    m = pkg.GRNet(max_frames=4)
+    m.load_state_dict(sd, strict=True)
+    m.load_smpl(synth_smpl)
+    m.finalize()
+    frames = pkg.synth.make_frames(3)
+    out = m(torch.from_numpy(frames).cuda(), extras=("point_local_feat", "cam_shape_feats"))[-1]
+    ref = oracle.grnet_forward(frames, sd, synth_smpl, return_intermediates=True)
+    for k in ("point_local_feat", "cam_shape_feats", "theta", "kp_3d"):
+        a = out[k].cpu().numpy()
+        assert rel_err(a, np.asarray(ref[k]).reshape(a.shape)) < 2e-4, (k, rel_err(a, np.asarray(ref[k]).reshape(a.shape)))
+    m.close()
