@@ -121,7 +121,7 @@ int grnet_set_tuning(grnet_t* h, int n_frames, const char* text);
 
 /* Introspection used by bench.py / tests. */
 int grnet_num_kernel_launches(grnet_t* h);      /* launches enqueued by one grnet_forward */
-int grnet_num_conv_launches(grnet_t* h);        /* convolution launches of one grnet_forward */
+int grnet_num_conv_launches(grnet_t* h);        /* convolution launches of one grnet_forward (incl. the grouped fuse-term launch of each HR module) */
 double grnet_conv_flops_per_frame(grnet_t* h);  /* 2 * MACs of all convolutions on the path */
 /* The same with the layers that run a Winograd F(4x4,3x3) kernel counted at the 1/4 of their multiplies it executes (x 256/196 on 14x14 and
  * x 64/49 on 7x7 maps, whose tiles are padded), under the kernel choice of the handle's latest forward (that of a 16-frame call before the
@@ -134,6 +134,16 @@ double grnet_conv_executed_flops_per_frame(grnet_t* h);
  * info[0..11] = Cin, Cout, kernel, stride, Hin, Win, Hout, Wout, fused addends, relu, lane, addend elements per
  * frame; name = state_dict key of its weight (hrnet.py / pare.py module path).  Returns 0 or GRNET_EINVAL. */
 int grnet_describe_conv(grnet_t* h, int pos, int32_t* info /* 12 */, char* name, int name_size);
+/* fp32 handles run the 1x1 "up" terms of an HR module's fuse layer (hrnet.py:199-210 as summed at :258-265) as ONE launch per module
+ * (csrc/hr_fuse.hip); grnet_describe_conv lists it in its place with Cin = 0, Cout = the channels it writes (32 [+ 64 [+ 128]]), kernel 1,
+ * the 56x56 map of output 0, "fused addends" = the module's branch count, addend elements = the floats it reads per frame, and the name
+ * "<module>.fuse_layers(up)".  Multiply-accumulates per frame of the pos-th launch of that list (either kind; < 0: bad position): */
+double grnet_describe_conv_macs(grnet_t* h, int pos);
+/* Diagnostic: ONE eager forward on the lane streams with a HIP timing event in front of and behind every op (placed after the op's
+ * cross-lane waits), after two untimed warm passes; no profiler involved.  Writes one text line per op in enqueue order --
+ * "index lane start_us end_us label", times relative to the first op's start -- into buf and returns the text's length (< 0: error;
+ * GRNET_EINVAL if buf_size is too small).  Synchronises the stream.  tools/op_timeline.py prints concurrency and per-section sums. */
+int grnet_op_timeline(grnet_t* h, const float* frames_dev, int n_frames, void* stream, char* buf, int buf_size);
 /* Re-enqueue ONLY the convolution launches of the last forward, bracketed by HIP events on
  * `stream`; returns elapsed ms in *ms_out (synchronises the stream). */
 int grnet_time_convs(grnet_t* h, int n_frames, void* stream, float* ms_out);
@@ -201,10 +211,20 @@ int grnet_crop_normalise(grnet_t* h, const unsigned char* images_dev, int n, int
  * (DESIGN.md), the uint8 patch is bit-identical to the oracle's restatement of the same arithmetic. */
 int grnet_crop_normalise_cv(grnet_t* h, const unsigned char* images_dev, int n, int height, int width, int one_image_for_all,
                             const double* inv_affine_dev, int bgr, float* out_dev, void* stream);
+/* The same for ANY box, as generate_patch_image_cv crops it (lib/data_utils/img_utils.py:90-113): maps_dev is (n,10) float64 --
+ * [0..5] the inverse affine map of the (first) warp, [6] iw, [7] ih, [8] tx, [9] ty.  iw = 0: a square box, one warp, as above.
+ * iw > 0: bb_width != bb_height (:97-106) -- the first warp resizes the scaled box, aspect kept, to an iw x ih 8-bit image
+ * (iw, ih = int(s*w), int(s*h), s = 224 / max(w, h)), a second warpAffine moves it by (224/2 - iw/2, 224/2 - ih/2) into the patch;
+ * (tx, ty) is the inverse translation.  Same fixed-point arithmetic for both warps, the intermediate image rounded to 8 bits as
+ * OpenCV returns it (it is computed on the fly, never stored).  The host forms the records: pipeline.cv_crop_maps.  This is the crop
+ * GRNet.crop_normalise / demo.py / batch_generation.py use. */
+int grnet_crop_normalise_cv_maps(grnet_t* h, const unsigned char* images_dev, int n, int height, int width, int one_image_for_all,
+                                 const double* maps_dev, int bgr, float* out_dev, void* stream);
 
 /* Copy a named intermediate of the LAST forward (first n_frames images) into out_dev as a dense
  * (n,C,H,W) tensor; shape_out[3] receives C,H,W (out_dev may be NULL to query the shape).  Names:
- * stem_conv1, stem_conv2, layer1, stage{2,3,4}.{branch}, up{2,3,4}.{layer}.{bilinear,conv}.
+ * stem_conv1, stem_conv2, layer1, stage{2,3,4}.{branch}, up{2,3,4}.{layer}.{bilinear,conv}, and per HR module
+ * stage{2,3,4}.{module}.x{branch} (the branch outputs = the fuse layer's inputs) / .y{branch} (the module's outputs).
  * Parity tests compare these with the oracle's taps of hrnet.py:469-536. */
 int grnet_debug_tensor(grnet_t* h, const char* name, int n_frames, float* out_dev, int64_t* shape_out, void* stream);
 

@@ -153,13 +153,11 @@ def bottleneck(x, sd, p, has_down):
     return conv_bn(y, sd, p + "conv3.weight", p + "bn3", relu=True, residual=res)
 
 
-def hr_module(xs, sd, p):
-    """HighResolutionModule.forward (hrnet.py:249-267); fuse terms per hrnet.py:199-241."""
+def hr_fuse(xs, sd, p):
+    """The fuse layer of HighResolutionModule.forward (hrnet.py:258-265) on the branch outputs xs; fuse terms per hrnet.py:199-241:
+    j > i: conv1x1 + BN + nearest upsample, j == i: identity, j < i: i-j stride-2 conv3x3 + BN (ReLU between them); summed in the
+    reference's order j = 0 .. nb-1, then ReLU."""
     nb = len(xs)
-    xs = list(xs)
-    for b in range(nb):
-        for k in range(4):
-            xs[b] = basic_block(xs[b], sd, f"{p}branches.{b}.{k}.")
     outs = []
     for i in range(nb):
         y = None
@@ -176,6 +174,16 @@ def hr_module(xs, sd, p):
             y = t if y is None else y + t
         outs.append(_q(torch.relu_(y)))
     return outs
+
+
+def hr_module(xs, sd, p):
+    """HighResolutionModule.forward (hrnet.py:249-267): four BasicBlocks per branch, then the fuse layer."""
+    nb = len(xs)
+    xs = list(xs)
+    for b in range(nb):
+        for k in range(4):
+            xs[b] = basic_block(xs[b], sd, f"{p}branches.{b}.{k}.")
+    return hr_fuse(xs, sd, p)
 
 
 def backbone(x, sd, p="backbone.", taps=None):
@@ -503,18 +511,19 @@ def cv_round(v):
 
 
 def warp_affine_u8(img_u8, inv_m, size=224):
-    """cv2.warpAffine(img, M, (size,size), flags=INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=0) for an 8-bit image, given
-    the INVERSE map `inv_m` (6 doubles) that warpAffine derives from M.  OpenCV 4.1.2 imgwarp.cpp restated (third-party source, absent
-    offline -- restated from its published algorithm): WarpAffineInvoker computes 1/32-pixel fixed-point positions (AB_BITS = 10,
-    INTER_BITS = 5, round_delta = 16), remapBilinear blends the four taps with the 15-bit table of initInterTab2D and
-    FixedPtCast<int, uchar, 15>.  Returns the uint8 patch (size,size,C)."""
+    """cv2.warpAffine(img, M, (w,h), flags=INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=0) for an 8-bit image, given
+    the INVERSE map `inv_m` (6 doubles) that warpAffine derives from M; `size`: an int (square) or (width, height).  OpenCV 4.1.2
+    imgwarp.cpp restated (third-party source, absent offline -- restated from its published algorithm): WarpAffineInvoker computes
+    1/32-pixel fixed-point positions (AB_BITS = 10, INTER_BITS = 5, round_delta = 16), remapBilinear blends the four taps with the
+    15-bit table of initInterTab2D and FixedPtCast<int, uchar, 15>.  Returns the uint8 patch (height,width,C)."""
     img = np.asarray(img_u8)
     H, W = img.shape[:2]
+    ow, oh = (size, size) if np.isscalar(size) else (int(size[0]), int(size[1]))
     m0, m1, m2, m3, m4, m5 = [float(v) for v in inv_m]
-    x = np.arange(size)
+    x, y = np.arange(ow), np.arange(oh)
     adelta, bdelta = cv_round(m0 * x * 1024.0), cv_round(m3 * x * 1024.0)
-    X0 = cv_round((m1 * x + m2) * 1024.0) + 16               # indexed by the row y
-    Y0 = cv_round((m4 * x + m5) * 1024.0) + 16
+    X0 = cv_round((m1 * y + m2) * 1024.0) + 16               # indexed by the row y
+    Y0 = cv_round((m4 * y + m5) * 1024.0) + 16
     X = (X0[:, None] + adelta[None, :]) >> 5
     Y = (Y0[:, None] + bdelta[None, :]) >> 5
     sx, sy = np.clip(X >> 5, -32768, 32767), np.clip(Y >> 5, -32768, 32767)
@@ -536,6 +545,59 @@ def warp_affine_u8(img_u8, inv_m, size=224):
 def crop_normalise_cv(img_u8, inv_m, crop=224):
     """warp_affine_u8 + ToTensor + Normalize (img_utils.py:355-363): (3,crop,crop) float32."""
     val = warp_affine_u8(img_u8, inv_m, crop).astype(np.float32) / np.float32(255.0)
+    return np.ascontiguousarray(((val - IMAGENET_MEAN) / IMAGENET_STD).transpose(2, 0, 1)).astype(np.float32)
+
+
+def invert_affine_cv(m):
+    """The inversion cv2.warpAffine applies to M when WARP_INVERSE_MAP is not set (imgwarp.cpp, in double)."""
+    m = [float(v) for v in m]
+    d = m[0] * m[4] - m[1] * m[3]
+    d = 1.0 / d if d != 0 else 0.0
+    a11, a22 = m[4] * d, m[0] * d
+    m0, m1, m3, m4 = a11, m[1] * -d, m[3] * -d, a22
+    return np.array([m0, m1, -m0 * m[2] - m1 * m[5], m3, m4, -m3 * m[2] - m4 * m[5]], np.float64)
+
+
+def gen_trans_from_patch(c_x, c_y, src_width, src_height, dst_width, dst_height, scale):
+    """gen_trans_from_patch_cv with rot = 0, inv = False (img_utils.py:54-88): the two triangles as FLOAT32 points, then
+    cv2.getAffineTransform = the 6x6 system of the three point pairs solved in double.  Returns M (6 doubles)."""
+    src_w, src_h = float(src_width) * float(scale), float(src_height) * float(scale)
+    centre = np.array([c_x, c_y], np.float64)
+    src = np.zeros((3, 2), np.float32)
+    src[0] = centre
+    src[1] = centre + np.array([0, src_h * 0.5], np.float32)
+    src[2] = centre + np.array([src_w * 0.5, 0], np.float32)
+    dst_center = np.array([dst_width * 0.5, dst_height * 0.5], np.float32)
+    dst = np.zeros((3, 2), np.float32)
+    dst[0] = dst_center
+    dst[1] = dst_center + np.array([0, dst_height * 0.5], np.float32)
+    dst[2] = dst_center + np.array([dst_width * 0.5, 0], np.float32)
+    a, b = np.zeros((6, 6), np.float64), np.zeros(6, np.float64)
+    for k in range(3):
+        a[2 * k, 0:2], a[2 * k, 2] = src[k], 1.0
+        a[2 * k + 1, 3:5], a[2 * k + 1, 5] = src[k], 1.0
+        b[2 * k], b[2 * k + 1] = dst[k]
+    return np.linalg.solve(a, b)
+
+
+def patch_image_cv(img_u8, bbox, scale=1.0, patch=224):
+    """generate_patch_image_cv (img_utils.py:90-113) with do_flip = False, rot = 0, as get_single_image_crop_demo calls it (:266-277):
+    a square box is ONE warp into the patch; a box with bb_width != bb_height is TWO (:97-106) -- an aspect-preserving resize of the
+    scaled box to (int(s*w), int(s*h)), s = patch / max(w, h), then a translation by (patch/2 - width/2, patch/2 - height/2) into the
+    patch, whose border stays 0.  The uint8 result of the first warp is what the second one samples.  Returns the uint8 patch."""
+    c_x, c_y, bw, bh = [float(v) for v in bbox]
+    if bw != bh:
+        s = patch / max(bh, bw)
+        iw, ih = int(s * bw), int(s * bh)
+        first = warp_affine_u8(img_u8, invert_affine_cv(gen_trans_from_patch(c_x, c_y, bw, bh, iw, ih, scale)), (iw, ih))
+        dx, dy = patch / 2 - first.shape[1] / 2, patch / 2 - first.shape[0] / 2
+        return warp_affine_u8(first, invert_affine_cv([1.0, 0.0, dx, 0.0, 1.0, dy]), patch)
+    return warp_affine_u8(img_u8, invert_affine_cv(gen_trans_from_patch(c_x, c_y, bw, bh, patch, patch, scale)), patch)
+
+
+def crop_normalise_box_cv(img_u8, bbox, scale=1.0, crop=224):
+    """patch_image_cv + ToTensor + Normalize (img_utils.py:279, 355-363): (3,crop,crop) float32."""
+    val = patch_image_cv(img_u8, bbox, scale, crop).astype(np.float32) / np.float32(255.0)
     return np.ascontiguousarray(((val - IMAGENET_MEAN) / IMAGENET_STD).transpose(2, 0, 1)).astype(np.float32)
 
 

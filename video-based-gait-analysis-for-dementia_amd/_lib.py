@@ -45,6 +45,8 @@ EXPORTS = {
     "grnet_conv_flops_per_frame": (C.c_double, [C.c_void_p]),
     "grnet_conv_executed_flops_per_frame": (C.c_double, [C.c_void_p]),
     "grnet_describe_conv": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_char_p, C.c_int]),
+    "grnet_describe_conv_macs": (C.c_double, [C.c_void_p, C.c_int]),
+    "grnet_op_timeline": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_char_p, C.c_int]),
     "grnet_time_convs": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "grnet_op_conv2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
@@ -54,6 +56,8 @@ EXPORTS = {
     "grnet_crop_normalise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_int,
                                        C.c_void_p, C.c_void_p]),
     "grnet_crop_normalise_cv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                          C.c_void_p]),
+    "grnet_crop_normalise_cv_maps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                           C.c_void_p]),
     "grnet_head_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Outputs), C.c_void_p]),
     "grnet_gait_correct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

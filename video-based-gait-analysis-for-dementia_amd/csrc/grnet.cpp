@@ -71,14 +71,27 @@ struct ConvLayer {
     std::map<int, int> tuned;   // n_frames -> launch configuration (tile hint) measured fastest by grnet_tune
 };
 
+// The up half of one HR module's fuse layer (hr_fuse.hip): outputs 0 .. nb-2 in one launch.
+struct FuseUpPlan {
+    int nb = 0;
+    std::string prefix;                  // "backbone.stage3.1."
+    std::vector<View> xs;                // the module's branch outputs (nb)
+    std::vector<View> outs;              // outputs 0 .. nb-2 (final)
+    std::vector<std::vector<View>> extra; // per output: the finished down chains D_ij, j < i, added by the grouped launch
+    float* w_dev[3][3] = {};             // [output i][source j - i - 1], pack_fuse_up_weights
+    float* b_dev[3] = {};                // [output i]: sum over j of the folded BatchNorm shifts
+    double macs_per_frame = 0;
+};
+
 struct Op {
-    enum Kind { CONV, SUM, BILINEAR, POOL, TAIL, SMPL, CONVERT } kind;
+    enum Kind { CONV, SUM, BILINEAR, POOL, TAIL, SMPL, CONVERT, FUSEUP } kind;
     int conv_idx = -1;
     SumArgs sum{};
     View bin, bout;   // bilinear
     // multi-lane execution: independent branches of the HR modules run on parallel HIP streams
     // (captured as parallel branches of the hipGraph); cross-lane read-after-write edges are events
     int lane = 0;
+    int follow = -1;          // plan index of an op this one depends on and whose stream it must share (the lane scheduler keeps them together)
     std::vector<int> waits;   // ops (on other lanes) whose completion event this op waits for
     bool record = false;      // some op on another lane consumes this op's output
 };
@@ -167,6 +180,9 @@ struct grnet {
     int cur_lane = 0;
     bool multi_lane = true;
     int launches_last = 0;
+    // diagnostic (grnet_op_timeline): timing events around every op of one eager forward
+    std::vector<hipEvent_t>* tl_start = nullptr;
+    std::vector<hipEvent_t>* tl_end = nullptr;
 
     int fail(int code, const std::string& msg) {
         err = msg;
@@ -272,9 +288,10 @@ struct grnet {
     }
 
     // HighResolutionModule (hrnet.py:249-267).  out0 (optional) receives fused output 0.
-    // Every convolution is its own launch on the lane of its branch; schedule_lanes() places the fuse layer's launches.
+    // Every branch convolution is its own launch on the lane of its branch; schedule_lanes() places the fuse layer's launches.
     std::vector<View> hr_module(std::vector<View> xs, const std::string& p, const View* out0) {
         const int nb = (int)xs.size();
+        std::vector<int> branch_tail(nb, -1);                               // plan index of the launch that writes x_b
         cur_lane = 0;
         for (int k = 0; k < 4; ++k) {
             std::vector<View> y(nb);
@@ -287,8 +304,97 @@ struct grnet {
                 cur_lane = b;
                 const std::string q = p + "branches." + std::to_string(b) + "." + std::to_string(k) + ".";
                 xs[b] = conv_bn(y[b], q + "conv2.weight", q + "bn2", kBranchCh[b], 3, 1, true, {AddRef{xs[b], 0}});
+                branch_tail[b] = (int)ops.size() - 1;
             }
         }
+        const std::string tag = p.substr(p.find("stage"));                  // "stage3.1."
+        for (int b = 0; b < nb; ++b) name_view(tag + "x" + std::to_string(b), xs[b]);
+        // GRNET_FUSE_UP=0: the round-3 fuse layer (one 1x1 launch per up term, an elementwise launch for output 0); the bf16 path keeps it
+        static const int fuse_up_env = getenv("GRNET_FUSE_UP") ? atoi(getenv("GRNET_FUSE_UP")) : 1;
+        std::vector<View> outs = (dtype == 0 && fuse_up_env) ? hr_fuse_grouped(xs, p, out0, branch_tail) : hr_fuse_separate(xs, p, out0);
+        for (int i = 0; i < nb; ++i) name_view(tag + "y" + std::to_string(i), outs[i]);
+        cur_lane = 0;
+        return outs;
+    }
+
+    // Fuse layer, round 4 (hrnet.py:189-244 as used by :258-265).  Output i = relu(sum_j term_ij) with term_ij = x_i (j == i),
+    // nearest_up(BN(conv1x1(x_j))) (j > i), a chain of i-j stride-2 3x3 convolutions (j < i).  The branches of a module end at
+    // different times -- the 56x56 branch ~50 us before the 7x7 / 14x14 ones, which are the long pole of stages 3 and 4 -- so the
+    // layer is split by WHEN its inputs exist:
+    //   early: every down chain that starts at a branch b <= nb-3 runs to its end on that branch's own stream, right behind the
+    //          branch's last convolution (no cross-stream hop), as plain convolutions D_ij (no addend, no ReLU after the last one);
+    //          the first convolutions of the chains (i,0), i >= 2 (32 -> 32, ReLU) share their input and are one launch;
+    //   late:  ONE grouped launch (Op::FUSEUP, hr_fuse.hip) finishes outputs 0 .. nb-2 -- all 1x1 up terms, x_i, the D_ij, ReLU --
+    //          and ONE stride-2 convolution from branch nb-2 finishes output nb-1 (adds x_{nb-1} and the D_{nb-1,j}, ReLU).
+    // After the last branch output exists, every output of the module is ONE launch away (round 3: 1x1 launch -> sum / finishing
+    // convolution, up to four dependent launches with a cross-stream event between each pair).
+    // Stage 4: 10 launches per fuse layer (round 3: 17), stage 3: 5 (8), stage 2: 2 (3).
+    std::vector<View> hr_fuse_grouped(const std::vector<View>& xs, const std::string& p, const View* out0, const std::vector<int>& branch_tail) {
+        const int nb = (int)xs.size();
+        std::vector<View> outs(nb);
+        auto key = [&](int i, int j, int level) { return p + "fuse_layers." + std::to_string(i) + "." + std::to_string(j) + "." + std::to_string(level) + "."; };
+        std::vector<std::vector<View>> d(nb, std::vector<View>(nb));       // running tensor of chain (i,j)
+        std::vector<std::vector<int>> d_op(nb, std::vector<int>(nb, -1));  // its latest launch
+        for (int i = 1; i < nb; ++i)
+            for (int j = 0; j < i; ++j) { d[i][j] = xs[j]; d_op[i][j] = branch_tail[j]; }
+        auto follow_last = [&](int op_idx) { ops.back().follow = op_idx; };
+        // early: chains from branches 0 .. nb-3 (and, for outputs < nb-1, from branch nb-2 too: D_{i,i-1} with i <= nb-2 starts at a branch <= nb-3)
+        for (int j = 0; j < nb - 1; ++j)
+            for (int level = 0; level < nb - 1 - j; ++level) {
+                const bool merged = level == 0 && j == 0 && nb >= 4;
+                if (merged) {
+                    std::vector<ConvSeg> segs;
+                    for (int i = 2; i < nb; ++i) segs.push_back(ConvSeg{key(i, 0, 0) + "0.weight", key(i, 0, 0) + "1", "", kBranchCh[0]});
+                    cur_lane = 0;
+                    View m = add_conv(xs[0], segs, 3, 2, true);
+                    follow_last(branch_tail[0]);
+                    for (int i = 2; i < nb; ++i) { d[i][0] = slice(m, (i - 2) * kBranchCh[0], kBranchCh[0]); d_op[i][0] = (int)ops.size() - 1; }
+                }
+                for (int i = j + 1; i < nb; ++i) {
+                    const int len = i - j;
+                    if (level >= len || (merged && i >= 2)) continue;
+                    if (i == nb - 1 && j == nb - 2) continue;                // the finishing convolution of the last output: late
+                    const bool last = level == len - 1;
+                    cur_lane = j;
+                    d[i][j] = conv_bn(d[i][j], key(i, j, level) + "0.weight", key(i, j, level) + "1", last ? kBranchCh[i] : kBranchCh[j], 3, 2, !last);
+                    follow_last(d_op[i][j]);
+                    d_op[i][j] = (int)ops.size() - 1;
+                }
+            }
+        // late: the grouped launch for outputs 0 .. nb-2 ...
+        FuseUpPlan fp;
+        fp.nb = nb; fp.prefix = p; fp.xs = xs;
+        for (int i = 0; i < nb - 1; ++i) {
+            outs[i] = (i == 0 && out0) ? *out0 : new_buffer(kBranchCh[i], xs[i].h, xs[i].w);
+            fp.outs.push_back(outs[i]);
+            fp.extra.push_back({});
+            for (int j = 0; j < i; ++j) fp.extra.back().push_back(d[i][j]);
+            for (int j = i + 1; j < nb; ++j) fp.macs_per_frame += (double)xs[j].h * xs[j].w * kBranchCh[j] * kBranchCh[i];
+        }
+        fuse_ups.push_back(fp);
+        Op op;
+        op.kind = Op::FUSEUP;
+        op.conv_idx = (int)fuse_ups.size() - 1;
+        op.lane = cur_lane = nb - 1;
+        op.follow = branch_tail[nb - 1];
+        ops.push_back(op);
+        // ... and the stride-2 convolution from branch nb-2 that finishes output nb-1
+        {
+            const int i = nb - 1;
+            std::vector<AddRef> adds;
+            adds.push_back(AddRef{xs[i], 0});
+            for (int j = 0; j < i - 1; ++j) adds.push_back(AddRef{d[i][j], 0});
+            cur_lane = nb - 2;
+            outs[i] = conv_bn(xs[i - 1], key(i, i - 1, 0) + "0.weight", key(i, i - 1, 0) + "1", kBranchCh[i], 3, 2, true, adds);
+            follow_last(branch_tail[i - 1]);
+        }
+        return outs;
+    }
+    std::vector<FuseUpPlan> fuse_ups;
+
+    // Fuse layer as launched until round 3 (kept for the bf16 path and for A/B runs)
+    std::vector<View> hr_fuse_separate(std::vector<View> xs, const std::string& p, const View* out0) {
+        const int nb = (int)xs.size();
         // up terms t[i][j], j > i: conv1x1 + BN at the resolution of branch j (nearest upsample is
         // applied where the term is consumed: it commutes with the per-pixel conv/BN)
         std::vector<std::vector<View>> t(nb, std::vector<View>(nb));
@@ -471,24 +577,17 @@ struct grnet {
         }
         for (auto& op : ops) { resolve(op.bin); resolve(op.bout); }
         for (auto& sv : sum_views) { resolve(sv.first); for (auto& a : sv.second) resolve(a.v); }
+        for (auto& fp : fuse_ups) {
+            for (auto& v : fp.xs) resolve(v);
+            for (auto& v : fp.outs) resolve(v);
+            for (auto& e : fp.extra) for (auto& v : e) resolve(v);
+        }
         for (auto& nv : named) resolve(nv.second);
         resolve(v_cat); resolve(v_heat); resolve(v_smpl_feats); resolve(v_csmap);
         if (dtype == 1) resolve(v_in8);
-        ops_flat = ops;
-        static const int sched_env = getenv("GRNET_LANE_SCHED") ? atoi(getenv("GRNET_LANE_SCHED")) : 1;   // 0: lanes as written in the plan
-        if (sched_env) schedule_lanes(ops_flat, max_frames);
-        analyze_dependencies(ops_flat, op_events_flat);
         // streams / events of the parallel lanes are created here, never inside a stream capture
         if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return fail(GRNET_EHIP, "hipEventCreate failed");
-        lanes_used = 1;                                        // only the streams the two schedules really use are created / forked / joined
-        for (const Op& op : ops_flat) lanes_used = std::max(lanes_used, op.lane + 1);
-        for (int l = 1; l < lanes_used; ++l) {
-            if (hipStreamCreateWithFlags(&side[l], hipStreamNonBlocking) != hipSuccess) return fail(GRNET_EHIP, "hipStreamCreate failed");
-            if (hipEventCreateWithFlags(&ev_join[l], hipEventDisableTiming) != hipSuccess) return fail(GRNET_EHIP, "hipEventCreate failed");
-        }
-        for (size_t i = 0; i < ops_flat.size(); ++i)
-            if (ops_flat[i].record && hipEventCreateWithFlags(&op_events_flat[i], hipEventDisableTiming) != hipSuccess)
-                return fail(GRNET_EHIP, "hipEventCreate failed");
+        if (int rc = install_schedule(max_frames)) return rc;
         if (hipStreamCreateWithFlags(&capture_stream, hipStreamNonBlocking) != hipSuccess) return fail(GRNET_EHIP, "hipStreamCreate failed");
         const size_t n = max_frames;
         int rc;
@@ -524,16 +623,21 @@ struct grnet {
                 for (auto& a : sum_views[op.conv_idx].second) r.push_back(a.v.p);
                 break;
             case Op::BILINEAR: r.push_back(op.bin.p); break;
+            case Op::FUSEUP:
+                for (auto& v : fuse_ups[op.conv_idx].xs) r.push_back(v.p);
+                for (auto& e : fuse_ups[op.conv_idx].extra) for (auto& v : e) r.push_back(v.p);
+                break;
             case Op::POOL: r.push_back(v_heat.p); r.push_back(v_smpl_feats.p); r.push_back(v_csmap.p); break;
-            default: break;
+            default: break;                                     // TAIL / SMPL follow POOL on lane 0
         }
     }
-    const float* op_writes(const Op& op) const {
-        if (op.kind == Op::CONV) return convs[op.conv_idx].out.p;
-        if (op.kind == Op::SUM) return sum_views[op.conv_idx].first.p;
-        if (op.kind == Op::BILINEAR) return op.bout.p;
-        if (op.kind == Op::CONVERT) return v_in8.p;
-        return nullptr;
+    void op_writes(const Op& op, std::vector<const float*>& w) const {
+        w.clear();
+        if (op.kind == Op::CONV) w.push_back(convs[op.conv_idx].out.p);
+        else if (op.kind == Op::SUM) w.push_back(sum_views[op.conv_idx].first.p);
+        else if (op.kind == Op::BILINEAR) w.push_back(op.bout.p);
+        else if (op.kind == Op::CONVERT) w.push_back(v_in8.p);
+        else if (op.kind == Op::FUSEUP) for (auto& v : fuse_ups[op.conv_idx].outs) w.push_back(v.p);
     }
 
     // Static list scheduling of the op list onto the kLanes streams.  The plan writes "branch b on lane b",
@@ -543,12 +647,37 @@ struct grnet {
     // that lets them start first, preferring the lane of their latest producer (no cross-lane event).  Streams are FIFO,
     // so the resulting list is both the enqueue order and a topological order; analyze_dependencies() then derives
     // the cross-lane events from it exactly as for the hand-written lanes.
+    // Build ops_flat from the plan: lane placement, cross-lane events, the streams the schedule uses.
+    // (Round 4 also re-placed the lanes at tune time from the durations grnet_op_timeline measures in company: 3.728 -> 3.784 ms and
+    // 3.735 -> 3.757 ms per step, i.e. no better than the calibrated estimates below; removed.)
+    int install_schedule(int n) {
+        drop_graphs();
+        seen_once.clear();
+        for (hipEvent_t e : op_events_flat) if (e) (void)hipEventDestroy(e);
+        op_events_flat.clear();
+        ops_flat = ops;
+        static const int sched_env = getenv("GRNET_LANE_SCHED") ? atoi(getenv("GRNET_LANE_SCHED")) : 1;   // 0: lanes as written in the plan
+        if (sched_env) schedule_lanes(ops_flat, n);
+        analyze_dependencies(ops_flat, op_events_flat);
+        int used = 1;                                          // only the streams the schedule really uses are forked / joined
+        for (const Op& op : ops_flat) used = std::max(used, op.lane + 1);
+        for (int l = 1; l < used; ++l) {
+            if (!side[l] && hipStreamCreateWithFlags(&side[l], hipStreamNonBlocking) != hipSuccess) return fail(GRNET_EHIP, "hipStreamCreate failed");
+            if (!ev_join[l] && hipEventCreateWithFlags(&ev_join[l], hipEventDisableTiming) != hipSuccess) return fail(GRNET_EHIP, "hipEventCreate failed");
+        }
+        lanes_used = used;
+        for (size_t i = 0; i < ops_flat.size(); ++i)
+            if (ops_flat[i].record && hipEventCreateWithFlags(&op_events_flat[i], hipEventDisableTiming) != hipSuccess)
+                return fail(GRNET_EHIP, "hipEventCreate failed");
+        return 0;
+    }
+
     void schedule_lanes(std::vector<Op>& list, int n) const {
         const int m = (int)list.size();
         std::vector<double> est(m), blevel(m, 0.0);
         std::vector<std::vector<int>> deps(m), users(m);
         std::map<const float*, std::vector<int>> writers;
-        std::vector<const float*> r;
+        std::vector<const float*> r, wr;
         int prev_tail = -1;
         static const double fix_us = getenv("GRNET_SCHED_FIX") ? atof(getenv("GRNET_SCHED_FIX")) : 6.0;
         static const double hop_us = getenv("GRNET_SCHED_HOP") ? atof(getenv("GRNET_SCHED_HOP")) : 4.0;
@@ -558,8 +687,17 @@ struct grnet {
                 case Op::CONV: {
                     const double gf = 2.0 * convs[op.conv_idx].macs_per_frame * n / 1e9;
                     est[i] = fix_us + gf / (gf > 20 ? 0.105 : gf > 3 ? 0.085 : 0.060);     // us; GFLOP per us = TFLOP/s / 1000
+                    // launches that run beside three others (everything between transition1 and the heads): measured in company at 16
+                    // frames (grnet_op_timeline) the four branch convolutions of a module take 19 / 23 / 22 / 32 us for the SAME FLOPs
+                    // (56x56 ... 7x7: the 7x7 chain is the long pole of stage 4), the stride-2 and small launches 17-23 us
+                    if (!convs[op.conv_idx].solo && gf < 3) {
+                        const ConvLayer& L = convs[op.conv_idx];
+                        est[i] = std::max(est[i], 17.0);
+                        if (L.ks == 3 && L.stride == 1 && L.in.c == L.cout) est[i] *= L.in.w == 7 ? 1.45 : L.in.w == 56 ? 0.9 : 1.05;
+                    }
                     break;
                 }
+                case Op::FUSEUP: est[i] = 18; break;
                 case Op::POOL: est[i] = 50; break;
                 case Op::TAIL: est[i] = 50; break;
                 case Op::SMPL: est[i] = 60; break;
@@ -576,7 +714,8 @@ struct grnet {
                 if (prev_tail >= 0) deps[i].push_back(prev_tail);
                 prev_tail = i;
             }
-            if (const float* o = op_writes(op)) writers[o].push_back(i);
+            op_writes(op, wr);
+            for (const float* o : wr) writers[o].push_back(i);
         }
         for (int i = 0; i < m; ++i)
             for (int d : deps[i]) users[d].push_back(i);
@@ -604,7 +743,10 @@ struct grnet {
                 const bool pinned = list[i].kind == Op::POOL || list[i].kind == Op::TAIL || list[i].kind == Op::SMPL;
                 int lane = 0;
                 double start = std::max(ready, lane_free[0]);
-                if (!pinned) {
+                if (!pinned && list[i].follow >= 0) {             // shares the stream of the op it follows
+                    lane = lane_of[list[i].follow];
+                    start = std::max(ready, lane_free[lane]);
+                } else if (!pinned) {
                     const int pref = from >= 0 ? lane_of[from] : 0;
                     lane = pref;
                     start = std::max(ready, lane_free[pref]);
@@ -640,27 +782,10 @@ struct grnet {
 
     void analyze_dependencies(std::vector<Op>& ops, std::vector<hipEvent_t>& op_events) {
         std::map<const float*, std::vector<int>> writers;      // buffer base -> ops that wrote (part of) it
-        auto reads_of = [&](const Op& op, std::vector<const float*>& r) {
-            r.clear();
-            switch (op.kind) {
-                case Op::CONV: {
-                    const ConvLayer& L = convs[op.conv_idx];
-                    r.push_back(L.in.p);
-                    for (auto& a : L.adds) r.push_back(a.v.p);
-                    break;
-                }
-                case Op::SUM:
-                    for (auto& a : sum_views[op.conv_idx].second) r.push_back(a.v.p);
-                    break;
-                case Op::BILINEAR: r.push_back(op.bin.p); break;
-                case Op::POOL: r.push_back(v_heat.p); r.push_back(v_smpl_feats.p); r.push_back(v_csmap.p); break;
-                    default: break;                                 // TAIL / SMPL follow POOL on lane 0
-            }
-        };
-        std::vector<const float*> r;
+        std::vector<const float*> r, wr;
         for (int i = 0; i < (int)ops.size(); ++i) {
             Op& op = ops[i];
-            reads_of(op, r);
+            op_reads(op, r);
             for (const float* buf : r) {
                 auto it = writers.find(buf);
                 if (it == writers.end()) continue;              // the caller's frames
@@ -672,12 +797,8 @@ struct grnet {
                         ops[w].record = true;
                     }
             }
-            const float* out = nullptr;
-            if (op.kind == Op::CONV) out = convs[op.conv_idx].out.p;
-            else if (op.kind == Op::SUM) out = sum_views[op.conv_idx].first.p;
-            else if (op.kind == Op::BILINEAR) out = op.bout.p;
-            else if (op.kind == Op::CONVERT) out = v_in8.p;
-            if (out) writers[out].push_back(i);
+            op_writes(op, wr);
+            for (const float* out : wr) writers[out].push_back(i);
         }
         op_events.assign(ops.size(), nullptr);
         if (getenv("GRNET_TRACE")) {
@@ -896,10 +1017,45 @@ struct grnet {
         return 0;
     }
 
+    // The 1x1 fuse terms of one HR module (hrnet.py:199-210: Conv2d 1x1 + BatchNorm2d; the nearest upsampling commutes with both):
+    // BatchNorm folded in fp64, weights in the MFMA B-fragment order of hr_fuse.hip, the shifts of an output's terms summed into one bias.
+    int pack_fuse_up(FuseUpPlan& fp) {
+        for (int i = 0; i < fp.nb - 1; ++i) {
+            const int co = kBranchCh[i];
+            std::vector<double> bias(co, 0.0);
+            for (int j = i + 1; j < fp.nb; ++j) {
+                const int ci = kBranchCh[j];
+                const std::string q = fp.prefix + "fuse_layers." + std::to_string(i) + "." + std::to_string(j) + ".";
+                const HostTensor* w = find(q + "0.weight");
+                if (!w) return fail(GRNET_ENOENT, "missing tensor " + q + "0.weight");
+                if (w->shape.size() != 4 || w->shape[0] != co || w->shape[1] != ci || w->shape[2] != 1 || w->shape[3] != 1) return fail(GRNET_EINVAL, "bad shape for " + q + "0.weight");
+                const HostTensor *g = find(q + "1.weight"), *be = find(q + "1.bias"), *m = find(q + "1.running_mean"), *v = find(q + "1.running_var");
+                if (!g || !be || !m || !v) return fail(GRNET_ENOENT, "missing BatchNorm tensors " + q + "1.*");
+                if ((int)g->numel() != co || (int)be->numel() != co || (int)m->numel() != co || (int)v->numel() != co) return fail(GRNET_EINVAL, "bad BatchNorm size " + q + "1");
+                std::vector<double> wf((size_t)co * ci);
+                for (int c = 0; c < co; ++c) {
+                    const double sc = (double)g->data[c] / std::sqrt((double)v->data[c] + kBnEps);
+                    bias[c] += (double)be->data[c] - (double)m->data[c] * sc;
+                    for (int k = 0; k < ci; ++k) wf[(size_t)c * ci + k] = (double)w->data[(size_t)c * ci + k] * sc;
+                }
+                std::vector<float> packed((size_t)co * ci);
+                pack_fuse_up_weights(wf.data(), co, ci, packed.data());
+                if (int rc = upload(packed, &fp.w_dev[i][j - i - 1])) return rc;
+            }
+            std::vector<float> bf(bias.begin(), bias.end());
+            if (int rc = upload(bf, &fp.b_dev[i])) return rc;
+        }
+        return 0;
+    }
+
     int finalize() {
         if (finalized) return fail(GRNET_ESTATE, "weights already finalized");
         for (auto& L : convs) {
             int rc = pack_conv(L);
+            if (rc) return rc;
+        }
+        for (auto& fp : fuse_ups) {
+            int rc = pack_fuse_up(fp);
             if (rc) return rc;
         }
         int rc;
@@ -1145,17 +1301,36 @@ struct grnet {
         hipStream_t caller = s;
         for (size_t oi = 0; oi < ops.size(); ++oi) {
             const Op& op = ops[oi];
-            if (convs_only && op.kind != Op::CONV) continue;
+            if (convs_only && op.kind != Op::CONV && op.kind != Op::FUSEUP) continue;
             s = lane_stream[op.lane];
             const int lane = multi_lane ? op.lane : 0;
             if (lanes)
                 for (int w : op.waits) HIP_TRY(hipStreamWaitEvent(s, op_events[w], 0));
+            if (tl_start && !rec) HIP_TRY(hipEventRecord((*tl_start)[oi], s));
             if (rec) {                                            // dependencies: previous node of the lane + cross-lane producers
                 rec->deps.clear();
                 if (lane_last[lane]) rec->deps.push_back(lane_last[lane]);
                 if (multi_lane)
                     for (int w : op.waits)
                         if (op_node[w]) rec->deps.push_back(op_node[w]);
+            }
+            // timing-only ablation (results are garbage): GRNET_ABL_SKIP=<substring of a weight key>[,<substring>...] drops the matching
+            // convolution launches and "fuse_up" the grouped fuse launches, events and dependencies stay -- what is a group of launches worth?
+            static const char* abl_skip = getenv("GRNET_ABL_SKIP");
+            if (abl_skip && (op.kind == Op::CONV || op.kind == Op::FUSEUP)) {
+                const std::string lbl = op_label(op);
+                bool skip = false;
+                for (const char* q = abl_skip; *q;) {
+                    const char* e = strchr(q, ',');
+                    const std::string pat = e ? std::string(q, e) : std::string(q);
+                    if (!pat.empty() && lbl.find(pat) != std::string::npos) skip = true;
+                    q = e ? e + 1 : q + strlen(q);
+                }
+                if (skip) {
+                    if (tl_end && !rec) HIP_TRY(hipEventRecord((*tl_end)[oi], s));
+                    if (lanes && op.record) HIP_TRY(hipEventRecord(op_events[oi], s));
+                    continue;
+                }
             }
             switch (op.kind) {
                 case Op::CONVERT:
@@ -1207,6 +1382,24 @@ struct grnet {
                     ++launches;
                     break;
                 }
+                case Op::FUSEUP: {
+                    const FuseUpPlan& fp = fuse_ups[op.conv_idx];
+                    FuseUpArgs a{};
+                    a.N = n; a.nb = fp.nb;
+                    for (int i = 0; i < fp.nb - 1; ++i) {
+                        FuseUpOut& fo = a.o[i];
+                        fo.out = fp.outs[i].p; fo.out_ctot = fp.outs[i].ctot; fo.out_coff = fp.outs[i].coff;
+                        fo.base = fp.xs[i].p; fo.base_ctot = fp.xs[i].ctot; fo.base_coff = fp.xs[i].coff;
+                        fo.bias = fp.b_dev[i];
+                        fo.relu = 1;
+                        fo.n_extra = (int)fp.extra[i].size();
+                        for (int k = 0; k < fo.n_extra; ++k) { fo.extra[k] = fp.extra[i][k].p; fo.extra_ctot[k] = fp.extra[i][k].ctot; fo.extra_coff[k] = fp.extra[i][k].coff; }
+                        for (int j = i + 1; j < fp.nb; ++j) fo.src[j - i - 1] = FuseUpSrc{fp.xs[j].p, fp.xs[j].ctot, fp.xs[j].coff, fp.w_dev[i][j - i - 1]};
+                    }
+                    HIP_TRY(launch_hr_fuse_up(a, s));
+                    ++launches;
+                    break;
+                }
                 case Op::BILINEAR:
                     if (dtype == 1) HIP_TRY(launch_bilinear2x_bf16(op.bin.p, op.bout.p, n, op.bin.c, op.bin.h, op.bin.w, s));
                     else HIP_TRY(launch_bilinear2x(op.bin.p, op.bout.p, n, op.bin.c, op.bin.h, op.bin.w, s));
@@ -1229,6 +1422,7 @@ struct grnet {
                     launches += 4;
                     break;
             }
+            if (tl_end && !rec) HIP_TRY(hipEventRecord((*tl_end)[oi], s));
             if (lanes && op.record) HIP_TRY(hipEventRecord(op_events[oi], s));
             if (rec && !rec->deps.empty()) lane_last[lane] = op_node[oi] = rec->deps[0];
         }
@@ -1386,6 +1580,60 @@ struct grnet {
             oc.rotmat = o.rotmat ? o.rotmat + s0 * 216 : nullptr;
             oc.pred_rot6d = o.pred_rot6d ? o.pred_rot6d + s0 * 144 : nullptr;
             if (int rc = head_from_feats(new_plf + s0 * 3072, csf + s0 * 1536, m, oc, s)) return rc;
+        }
+        return 0;
+    }
+
+    std::string op_label(const Op& op) const {
+        switch (op.kind) {
+            case Op::CONV: {
+                const ConvLayer& L = convs[op.conv_idx];
+                char b[256];
+                snprintf(b, sizeof b, "conv %dx%d s%d %d->%d @%d %s", L.ks, L.ks, L.stride, L.in.c, L.cout, L.in.w, L.segs.empty() ? "" : L.segs[0].wkey.c_str());
+                return b;
+            }
+            case Op::FUSEUP: return "fuse_up " + fuse_ups[op.conv_idx].prefix;
+            case Op::SUM: return "fuse_sum";
+            case Op::BILINEAR: return "bilinear2x c" + std::to_string(op.bin.c) + " @" + std::to_string(op.bin.w);
+            case Op::POOL: return "attn_pool";
+            case Op::TAIL: return "head_tail";
+            case Op::SMPL: return "smpl";
+            case Op::CONVERT: return "convert";
+        }
+        return "?";
+    }
+
+    // Diagnostic: one eager forward on the lane streams with a timing event in front of and behind every op (after its cross-lane waits),
+    // un-traced -- rocprofv3's per-dispatch cost distorts a step of ~300 launches of 5-25 us.  Text: one line per op in enqueue order,
+    // "index lane start_us end_us label", times relative to the first op's start.  The events cost ~1 us of queue time each.
+    int op_timeline(const float* frames, int n, hipStream_t s, std::string& text) {
+        if (!finalized) return fail(GRNET_ESTATE, "grnet_op_timeline before grnet_finalize_weights");
+        if (!frames || n < 1 || n > max_frames) return fail(GRNET_EINVAL, "n_frames outside [1, max_frames]");
+        if (!multi_lane) return fail(GRNET_ESTATE, "grnet_op_timeline needs GRNET_OPT_MULTI_LANE");
+        const size_t m = ops_flat.size();
+        std::vector<hipEvent_t> st(m, nullptr), en(m, nullptr);
+        struct Cleanup {
+            grnet* g; std::vector<hipEvent_t>*a, *b;
+            ~Cleanup() { g->tl_start = g->tl_end = nullptr; for (auto e : *a) if (e) (void)hipEventDestroy(e); for (auto e : *b) if (e) (void)hipEventDestroy(e); }
+        } cleanup{this, &st, &en};
+        for (size_t i = 0; i < m; ++i) { HIP_TRY(hipEventCreate(&st[i])); HIP_TRY(hipEventCreate(&en[i])); }
+        grnet_outputs_t o{};
+        for (int rep = 0; rep < 3; ++rep) {                      // two warm passes, the third is reported
+            tl_start = rep == 2 ? &st : nullptr;
+            tl_end = rep == 2 ? &en : nullptr;
+            int rc = enqueue(frames, n, o, s);
+            tl_start = tl_end = nullptr;
+            if (rc) return rc;
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+        text.clear();
+        for (size_t i = 0; i < m; ++i) {
+            float a = 0, b = 0;
+            HIP_TRY(hipEventElapsedTime(&a, st[0], st[i]));
+            HIP_TRY(hipEventElapsedTime(&b, st[0], en[i]));
+            char line[400];
+            snprintf(line, sizeof line, "%zu %d %.2f %.2f %s\n", i, ops_flat[i].lane, a * 1e3f, b * 1e3f, op_label(ops_flat[i]).c_str());
+            text += line;
         }
         return 0;
     }
@@ -1691,12 +1939,13 @@ int grnet_set_tuning(grnet_t* h, int n_frames, const char* text) {
 
 int grnet_num_kernel_launches(grnet_t* h) { return h ? h->launches_last : GRNET_EINVAL; }
 
-int grnet_num_conv_launches(grnet_t* h) { return h ? (int)h->convs.size() : GRNET_EINVAL; }
+int grnet_num_conv_launches(grnet_t* h) { return h ? (int)(h->convs.size() + h->fuse_ups.size()) : GRNET_EINVAL; }
 
 double grnet_conv_flops_per_frame(grnet_t* h) {
     if (!h) return 0;
     double m = 0;
     for (auto& L : h->convs) m += L.macs_per_frame;
+    for (auto& fp : h->fuse_ups) m += fp.macs_per_frame;            // the 1x1 fuse terms computed by hr_fuse_up_f32
     return 2.0 * m;
 }
 
@@ -1706,6 +1955,7 @@ double grnet_conv_executed_flops_per_frame(grnet_t* h) {
     // F(4x4,3x3): 36 multiplies per 4x4 tile instead of 144; the small maps pay for their padding (14 -> 16, 7 -> 8 per side)
     for (auto& L : h->convs)
         m += L.macs_per_frame * (h->wino_mode && h->dtype == 0 && !h->conv_tile_hint ? (h->wino4s_runs(L, h->last_n) ? 0.25 * (L.in.w == 14 ? 256.0 / 196.0 : 64.0 / 49.0) : L.wino4_dev ? 0.25 : 1.0) : 1.0);
+    for (auto& fp : h->fuse_ups) m += fp.macs_per_frame;
     return 2.0 * m;
 }
 
@@ -1713,8 +1963,19 @@ int grnet_describe_conv(grnet_t* h, int pos, int32_t* info, char* name, int name
     if (!h || !info || !h->finalized || pos < 0) return GRNET_EINVAL;
     int seen = 0;
     for (const Op& op : h->ops_flat) {
-        if (op.kind != Op::CONV) continue;
+        if (op.kind != Op::CONV && op.kind != Op::FUSEUP) continue;
         if (seen++ != pos) continue;
+        if (op.kind == Op::FUSEUP) {                       // the grouped 1x1 up terms of one HR module: Cin = 0 marks the entry
+            const FuseUpPlan& fp = h->fuse_ups[op.conv_idx];
+            int cout = 0;
+            int64_t rd = 0;
+            for (int i = 0; i < fp.nb - 1; ++i) cout += kBranchCh[i];
+            for (int j = 0; j < fp.nb; ++j) rd += (int64_t)kBranchCh[j] * fp.xs[j].h * fp.xs[j].w;       // every branch output is read once
+            const int32_t v[12] = {0, cout, 1, 1, fp.xs[0].h, fp.xs[0].w, fp.xs[0].h, fp.xs[0].w, fp.nb, 1, op.lane, (int32_t)rd};
+            memcpy(info, v, sizeof(v));
+            if (name && name_size > 0) snprintf(name, name_size, "%sfuse_layers(up)", fp.prefix.c_str());
+            return 0;
+        }
         const ConvLayer& L = h->convs[op.conv_idx];
         int64_t add_elems = 0;
         for (const AddRef& r : L.adds) add_elems += (int64_t)L.cout * (L.out.h >> r.shift) * (L.out.w >> r.shift);
@@ -1725,6 +1986,27 @@ int grnet_describe_conv(grnet_t* h, int pos, int32_t* info, char* name, int name
         return 0;
     }
     return GRNET_EINVAL;
+}
+
+double grnet_describe_conv_macs(grnet_t* h, int pos) {
+    if (!h || pos < 0) return -1.0;
+    int seen = 0;
+    for (const Op& op : h->ops_flat) {
+        if (op.kind != Op::CONV && op.kind != Op::FUSEUP) continue;
+        if (seen++ != pos) continue;
+        return op.kind == Op::FUSEUP ? h->fuse_ups[op.conv_idx].macs_per_frame : h->convs[op.conv_idx].macs_per_frame;
+    }
+    return -1.0;
+}
+
+int grnet_op_timeline(grnet_t* h, const float* frames_dev, int n_frames, void* stream, char* buf, int buf_size) {
+    if (!h || !buf || buf_size < 1) return GRNET_EINVAL;
+    DeviceGuard guard(h->device);
+    std::string text;
+    if (int rc = h->op_timeline(frames_dev, n_frames, static_cast<hipStream_t>(stream), text)) return rc;
+    if ((int)text.size() + 1 > buf_size) return h->fail(GRNET_EINVAL, "grnet_op_timeline: buffer too small (" + std::to_string(text.size() + 1) + " bytes needed)");
+    memcpy(buf, text.c_str(), text.size() + 1);
+    return (int)text.size();
 }
 
 int grnet_time_convs(grnet_t* h, int n_frames, void* stream, float* ms_out) {
@@ -1912,9 +2194,19 @@ int grnet_crop_normalise_cv(grnet_t* h, const unsigned char* images_dev, int n, 
                             const double* inv_affine_dev, int bgr, float* out_dev, void* stream) {
     if (!h || !images_dev || !inv_affine_dev || !out_dev || n < 1 || height < 1 || width < 1) return GRNET_EINVAL;
     DeviceGuard guard(h->device);
-    hipError_t e = launch_crop_normalise_cv(images_dev, height, width, one_image_for_all ? 0 : 1, inv_affine_dev, bgr, out_dev, n,
+    hipError_t e = launch_crop_normalise_cv(images_dev, height, width, one_image_for_all ? 0 : 1, inv_affine_dev, 6, bgr, out_dev, n,
                                             static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("crop_normalise_cv: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int grnet_crop_normalise_cv_maps(grnet_t* h, const unsigned char* images_dev, int n, int height, int width, int one_image_for_all,
+                                 const double* maps_dev, int bgr, float* out_dev, void* stream) {
+    if (!h || !images_dev || !maps_dev || !out_dev || n < 1 || height < 1 || width < 1) return GRNET_EINVAL;
+    DeviceGuard guard(h->device);
+    hipError_t e = launch_crop_normalise_cv(images_dev, height, width, one_image_for_all ? 0 : 1, maps_dev, 10, bgr, out_dev, n,
+                                            static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("crop_normalise_cv_maps: ") + hipGetErrorString(e));
     return 0;
 }
 

@@ -220,36 +220,67 @@ __global__ __launch_bounds__(256) void crop_normalise_kernel(const unsigned char
 // Integer arithmetic end to end: the uint8 patch is bit-identical to the oracle's.  cv2 itself is absent offline, so agreement
 // with a real OpenCV build is argued from its source, not measured.
 __device__ __forceinline__ int cv_round(double v) { return (int)__builtin_rint(v); }
+// one destination pixel (x, y) of warpAffine from an interleaved 8-bit image of H x W x 3: the three channel values
+__device__ __forceinline__ void cv_warp_px(const unsigned char* __restrict__ src, int H, int W, const double* m, int x, int y, int v[3]) {
+    const int X0 = cv_round((m[1] * y + m[2]) * 1024.0) + 16, Y0 = cv_round((m[4] * y + m[5]) * 1024.0) + 16;
+    const int X = (X0 + cv_round(m[0] * x * 1024.0)) >> 5, Y = (Y0 + cv_round(m[3] * x * 1024.0)) >> 5;
+    const int sx = min(max(X >> 5, -32768), 32767), sy = min(max(Y >> 5, -32768), 32767);
+    const int ax = X & 31, ay = Y & 31;
+    const int w00 = (32 - ax) * (32 - ay), w01 = ax * (32 - ay), w10 = (32 - ax) * ay, w11 = ax * ay;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        auto px = [&](int yy, int xx) -> int { return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (int)src[((size_t)yy * W + xx) * 3 + c] : 0; };
+        const int sum = px(sy, sx) * w00 + px(sy, sx + 1) * w01 + px(sy + 1, sx) * w10 + px(sy + 1, sx + 1) * w11;
+        v[c] = (sum * 32 + 16384) >> 15;
+    }
+}
+// maps: per frame `mstride` doubles -- [0..5] the inverse affine map of the (first) warp; with mstride = 10 also [6] iw, [7] ih, [8] tx,
+// [9] ty: iw > 0 is the reference's TWO-warp crop of a non-square box (img_utils.py:97-106): the first warp makes an iw x ih 8-bit
+// image, the second moves it by (-tx, -ty) into the patch.  The intermediate image is never stored: a patch pixel blends the (up to
+// four) intermediate pixels its second warp samples, each computed from the source on the fly -- same integers as two passes.
 __global__ __launch_bounds__(256) void crop_normalise_cv_kernel(const unsigned char* __restrict__ img, int H, int W, int per_image,
-                                                                const double* __restrict__ inv_m, int bgr, float* __restrict__ out) {
+                                                                const double* __restrict__ maps, int mstride, int bgr, float* __restrict__ out) {
     const int n = blockIdx.y;
     const unsigned char* src = img + (size_t)(per_image ? n : 0) * H * W * 3;
-    const double m0 = inv_m[n * 6 + 0], m1 = inv_m[n * 6 + 1], m2 = inv_m[n * 6 + 2];
-    const double m3 = inv_m[n * 6 + 3], m4 = inv_m[n * 6 + 4], m5 = inv_m[n * 6 + 5];
+    double m[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) m[k] = maps[(size_t)n * mstride + k];
+    const int iw = mstride >= 10 ? (int)maps[(size_t)n * mstride + 6] : 0, ih = mstride >= 10 ? (int)maps[(size_t)n * mstride + 7] : 0;
+    const double t2[6] = {1.0, 0.0, iw > 0 ? maps[(size_t)n * mstride + 8] : 0.0, 0.0, 1.0, iw > 0 ? maps[(size_t)n * mstride + 9] : 0.0};
     const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
     for (int i = blockIdx.x * 256 + threadIdx.x; i < 224 * 224; i += gridDim.x * 256) {
         const int y = i / 224, x = i - y * 224;
-        const int X0 = cv_round((m1 * y + m2) * 1024.0) + 16, Y0 = cv_round((m4 * y + m5) * 1024.0) + 16;
-        const int X = (X0 + cv_round(m0 * x * 1024.0)) >> 5, Y = (Y0 + cv_round(m3 * x * 1024.0)) >> 5;
-        const int sx = min(max(X >> 5, -32768), 32767), sy = min(max(Y >> 5, -32768), 32767);
-        const int ax = X & 31, ay = Y & 31;
-        const int w00 = (32 - ax) * (32 - ay), w01 = ax * (32 - ay), w10 = (32 - ax) * ay, w11 = ax * ay;
+        int val[3];
+        if (iw <= 0) {
+            cv_warp_px(src, H, W, m, x, y, val);
+        } else {
+            const int X0 = cv_round((t2[1] * y + t2[2]) * 1024.0) + 16, Y0 = cv_round((t2[4] * y + t2[5]) * 1024.0) + 16;
+            const int X = (X0 + cv_round(t2[0] * x * 1024.0)) >> 5, Y = (Y0 + cv_round(t2[3] * x * 1024.0)) >> 5;
+            const int sx = min(max(X >> 5, -32768), 32767), sy = min(max(Y >> 5, -32768), 32767);
+            const int ax = X & 31, ay = Y & 31;
+            const int wt[4] = {(32 - ax) * (32 - ay), ax * (32 - ay), (32 - ax) * ay, ax * ay};
+            int sum[3] = {0, 0, 0};
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int cs = bgr ? 2 - c : c;
-            auto px = [&](int yy, int xx) -> int {
-                return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (int)src[((size_t)yy * W + xx) * 3 + cs] : 0;
-            };
-            const int sum = px(sy, sx) * w00 + px(sy, sx + 1) * w01 + px(sy + 1, sx) * w10 + px(sy + 1, sx + 1) * w11;
-            const int val = (sum * 32 + 16384) >> 15;
-            out[((size_t)n * 3 + c) * (224 * 224) + i] = ((float)val / 255.f - mean[c]) / stdv[c];
+            for (int t = 0; t < 4; ++t) {
+                const int ix = sx + (t & 1), iy = sy + (t >> 1);
+                if (wt[t] != 0 && ix >= 0 && ix < iw && iy >= 0 && iy < ih) {
+                    int v[3];
+                    cv_warp_px(src, H, W, m, ix, iy, v);
+                    sum[0] += v[0] * wt[t]; sum[1] += v[1] * wt[t]; sum[2] += v[2] * wt[t];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) val[c] = (sum[c] * 32 + 16384) >> 15;
         }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[((size_t)n * 3 + c) * (224 * 224) + i] = ((float)val[bgr ? 2 - c : c] / 255.f - mean[c]) / stdv[c];
     }
 }
 
-hipError_t launch_crop_normalise_cv(const unsigned char* img, int H, int W, int per_image, const double* inv_m, int bgr, float* out, int N,
+hipError_t launch_crop_normalise_cv(const unsigned char* img, int H, int W, int per_image, const double* maps, int mstride, int bgr, float* out, int N,
                                     hipStream_t s) {
-    GRK_TRY(launch_k(crop_normalise_cv_kernel, dim3(49, N), dim3(256), 0, s, img, H, W, per_image, inv_m, bgr, out));
+    if (mstride != 6 && mstride != 10) return hipErrorInvalidValue;
+    GRK_TRY(launch_k(crop_normalise_cv_kernel, dim3(49, N), dim3(256), 0, s, img, H, W, per_image, maps, mstride, bgr, out));
     return hipSuccess;
 }
 

@@ -120,6 +120,22 @@ struct SumArgs {
 };
 hipError_t launch_fuse_sum(const SumArgs& a, hipStream_t s);
 
+// The up half of an HR module's fuse layer in one launch (hr_fuse.hip; hrnet.py:249-267, fuse layers hrnet.py:189-244):
+// out_i = act(x_i + bias_i + sum_{j > i} nearest_up(W_ij . x_j) + sum_k extra_k) for outputs i = 0 .. nb-2 of a module with nb
+// branches (branch b: 32 << b channels on a (56 >> b)^2 map); extra_k: the finished stride-2 chains D_ij, j < i (same shape as out_i).
+struct FuseUpSrc { const float* x; int ctot, coff; const float* w; };      // x_j as a View, W_ij packed by pack_fuse_up_weights
+struct FuseUpOut {
+    float* out; int out_ctot, out_coff;
+    const float* base; int base_ctot, base_coff;     // x_i
+    const float* bias;                               // sum over j of the folded BatchNorm shifts, [32 << i]
+    int relu, n_extra;
+    const float* extra[2]; int extra_ctot[2], extra_coff[2];
+    FuseUpSrc src[3];                                // j = i+1 .. nb-1
+};
+struct FuseUpArgs { int N, nb; FuseUpOut o[3]; };
+hipError_t launch_hr_fuse_up(const FuseUpArgs& a, hipStream_t s);
+void pack_fuse_up_weights(const double* w_folded /* (cout, cin) */, int cout, int cin, float* out /* cout * cin */);
+
 // nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (hrnet.py:443)
 hipError_t launch_bilinear2x(const float* in, float* out, int N, int C, int H, int W, hipStream_t s);
 
@@ -127,8 +143,9 @@ hipError_t launch_bilinear2x(const float* in, float* out, int N, int C, int H, i
 hipError_t launch_crop_normalise(const unsigned char* img, int H, int W, int per_image, const float* bbox, float scale, int bgr,
                                  float* out, int N, hipStream_t s);
 
-// the same with OpenCV's fixed-point warpAffine arithmetic; inv_m: (N,6) doubles, the inverse affine map of each frame
-hipError_t launch_crop_normalise_cv(const unsigned char* img, int H, int W, int per_image, const double* inv_m, int bgr, float* out, int N,
+// the same with OpenCV's fixed-point warpAffine arithmetic; maps: (N,mstride) doubles -- mstride 6: the inverse affine map of each frame;
+// mstride 10: + iw, ih, tx, ty of the two-warp crop of a non-square box (iw = 0: one warp)
+hipError_t launch_crop_normalise_cv(const unsigned char* img, int H, int W, int per_image, const double* maps, int mstride, int bgr, float* out, int N,
                                     hipStream_t s);
 
 // PARE head tail ---------------------------------------------------------------------------

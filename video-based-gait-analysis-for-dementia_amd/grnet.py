@@ -291,7 +291,8 @@ class GRNet:
         return self._lib.grnet_conv_executed_flops_per_frame(self._h)
 
     def describe_convs(self):
-        """The convolution launches of one forward in launch order: list of dicts (shape, fused addends, weight key)."""
+        """The convolution launches of one forward in launch order: list of dicts (shape, fused addends, weight key, MACs per frame).
+        An entry with cin == 0 is the grouped launch of an HR module's 1x1 fuse terms (csrc/hr_fuse.hip)."""
         self.finalize()
         keys = ("cin", "cout", "ks", "stride", "hin", "win", "hout", "wout", "n_add", "relu", "lane", "add_elems")
         out = []
@@ -300,8 +301,24 @@ class GRNet:
             _lib.check(self._lib, self._h, self._lib.grnet_describe_conv(self._h, pos, info, name, 160), "grnet_describe_conv")
             d = dict(zip(keys, list(info)))
             d["name"] = name.value.decode()
+            d["macs"] = int(self._lib.grnet_describe_conv_macs(self._h, pos))
             out.append(d)
         return out
+
+    def op_timeline(self, frames):
+        """Diagnostic (grnet_op_timeline): [(index, lane, start_us, end_us, label)] of one eager forward on `frames` (n,3,224,224)."""
+        self.finalize()
+        x = frames.to(self.device, torch.float32).contiguous()
+        buf = C.create_string_buffer(1 << 18)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = self._lib.grnet_op_timeline(self._h, x.data_ptr(), x.shape[0], stream, buf, len(buf))
+        if rc < 0:
+            _lib.check(self._lib, self._h, rc, "grnet_op_timeline")
+        rows = []
+        for line in buf.value.decode().splitlines():
+            i, lane, a, b, label = line.split(" ", 4)
+            rows.append((int(i), int(lane), float(a), float(b), label))
+        return rows
 
     def time_convs(self, n_frames):
         ms = C.c_float()
@@ -331,8 +348,9 @@ class GRNet:
 
     def crop_normalise(self, images, bboxes, scale=1.0, bgr=False, mode="cv2"):
         """uint8 frames (n,H,W,3) [or one (H,W,3) frame] + boxes (n,4) -> (n,3,224,224) normalised crops, on the GPU.
-        mode "cv2" (default): OpenCV's fixed-point warpAffine arithmetic (grnet_crop_normalise_cv; the inverse affine maps are
-        computed on the host as the reference's gen_trans_from_patch_cv / getAffineTransform / warpAffine do);
+        mode "cv2" (default): OpenCV's fixed-point warpAffine arithmetic (grnet_crop_normalise_cv_maps; the maps are computed on the
+        host as the reference's gen_trans_from_patch_cv / getAffineTransform / warpAffine do -- pipeline.cv_crop_maps; a box with
+        w != h takes the reference's two-warp, aspect-preserving branch, img_utils.py:97-106);
         mode "ideal": exact bilinear sampling in float (grnet_crop_normalise), kept for A/B."""
         shared = images.dim() == 3
         if images.dtype != torch.uint8 or images.shape[-1] != 3 or not images.is_cuda:
@@ -346,11 +364,11 @@ class GRNet:
         out = torch.empty(n, 3, 224, 224, dtype=torch.float32, device=images.device)
         stream = C.c_void_p(torch.cuda.current_stream(images.device).cuda_stream)
         if mode == "cv2":
-            from .pipeline import cv_inverse_affine
-            inv = torch.from_numpy(cv_inverse_affine(bb_host, scale)).to(images.device, non_blocking=True)
-            rc = self._lib.grnet_crop_normalise_cv(self._h, images.data_ptr(), n, hgt, wid, int(shared), inv.data_ptr(), int(bgr),
-                                                   out.data_ptr(), stream)
-            _lib.check(self._lib, self._h, rc, "grnet_crop_normalise_cv")
+            from .pipeline import cv_crop_maps
+            maps = torch.from_numpy(cv_crop_maps(bb_host, scale)).to(images.device, non_blocking=True)
+            rc = self._lib.grnet_crop_normalise_cv_maps(self._h, images.data_ptr(), n, hgt, wid, int(shared), maps.data_ptr(), int(bgr),
+                                                        out.data_ptr(), stream)
+            _lib.check(self._lib, self._h, rc, "grnet_crop_normalise_cv_maps")
             return out
         if mode != "ideal":
             raise ValueError("mode must be 'cv2' or 'ideal'")

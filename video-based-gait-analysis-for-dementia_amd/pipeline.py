@@ -143,44 +143,69 @@ def smooth_pose(model, pred_pose, pred_betas, min_cutoff=0.004, beta=0.7, kinect
 
 
 # ----------------------------------------------------------------------------- the crop's affine map, as the reference forms it
-def cv_inverse_affine(bboxes, scale=1.0, crop_size=224):
-    """(n,4) boxes [cx,cy,w,h] -> (n,6) float64: the INVERSE affine map cv2.warpAffine evaluates for the crop of
-    get_single_image_crop_demo (img_utils.py:252-285 -> generate_patch_image_cv :90-113 with bb_width == bb_height handled like any
-    box: the reference's own boxes are square -> gen_trans_from_patch_cv :54-88, rot = 0).  Steps restated:
+def _affine_from_box(cx, cy, w, h, dst_w, dst_h, scale):
+    """gen_trans_from_patch_cv (img_utils.py:54-88, rot = 0) + cv2.getAffineTransform, then the inversion cv2.warpAffine applies:
       * src_w = w*scale, src_h = h*scale in double (numpy 1.18 promotes float32-scalar * Python float to float64);
-      * the two triangles as FLOAT32 points: centre, centre + (0, src_h/2), centre + (src_w/2, 0) and (112,112), (112,224), (224,112);
-      * cv2.getAffineTransform: the 6x6 system of the three point pairs solved in double (LU with partial pivoting);
+      * the two triangles as FLOAT32 points: centre, centre + (0, src_h/2), centre + (src_w/2, 0) and (dst_w/2, dst_h/2), + (0, dst_h/2), + (dst_w/2, 0);
+      * getAffineTransform: the 6x6 system of the three point pairs solved in double (LU with partial pivoting);
       * warpAffine (no WARP_INVERSE_MAP) inverts the 2x3 matrix in double: D = 1/(M0*M4 - M1*M3), ...
     The LU's last-bit rounding can differ between LAPACK and OpenCV; it matters only where cvRound(x*1024) sits on an exact tie."""
+    src_w, src_h = float(w) * float(scale), float(h) * float(scale)
+    centre = np.array([cx, cy], np.float64)
+    src = np.zeros((3, 2), np.float32)
+    src[0] = centre
+    src[1] = centre + np.array([0, src_h * 0.5], np.float32)
+    src[2] = centre + np.array([src_w * 0.5, 0], np.float32)
+    dc = np.array([dst_w * 0.5, dst_h * 0.5], np.float32)
+    dst = np.zeros((3, 2), np.float32)
+    dst[0] = dc
+    dst[1] = dc + np.array([0, dst_h * 0.5], np.float32)
+    dst[2] = dc + np.array([dst_w * 0.5, 0], np.float32)
+    a = np.zeros((6, 6), np.float64)
+    b = np.zeros(6, np.float64)
+    for k in range(3):
+        a[2 * k, 0:2], a[2 * k, 2] = src[k], 1.0
+        a[2 * k + 1, 3:5], a[2 * k + 1, 5] = src[k], 1.0
+        b[2 * k], b[2 * k + 1] = dst[k]
+    m = np.linalg.solve(a, b)                              # [M0 M1 M2 M3 M4 M5]
+    d = m[0] * m[4] - m[1] * m[3]
+    d = 1.0 / d if d != 0 else 0.0
+    a11, a22 = m[4] * d, m[0] * d
+    m0, m1, m3, m4 = a11, m[1] * -d, m[3] * -d, a22
+    return (m0, m1, -m0 * m[2] - m1 * m[5], m3, m4, -m3 * m[2] - m4 * m[5])
+
+
+def cv_crop_maps(bboxes, scale=1.0, crop_size=224):
+    """(n,4) boxes [cx,cy,w,h] -> (n,10) float64 records for grnet_crop_normalise_cv_maps: what generate_patch_image_cv
+    (img_utils.py:90-113, called by get_single_image_crop_demo :252-285 with do_flip = False, rot = 0) makes cv2.warpAffine evaluate.
+      * w == h (what the tracker path of demo.py produces): ONE warp into the patch -- record = [inverse map (6), 0, 0, 0, 0];
+      * w != h (:97-106; precomputed annotations may hold such boxes): TWO warps -- the scaled box resized, aspect kept, to
+        (iw, ih) = (int(s*w), int(s*h)) with s = crop/max(w, h), whose uint8 result is then moved by (crop/2 - iw/2, crop/2 - ih/2)
+        into the patch (the letterbox stays 0; a half-pixel offset blends neighbours) -- record = [inverse of the first map (6), iw, ih,
+        tx, ty] with (tx, ty) the inverse translation.  The comparison is exact, as the reference's `bb_width != bb_height` is."""
     bboxes = np.asarray(bboxes)
-    out = np.empty((bboxes.shape[0], 6), np.float64)
-    half = np.float32(crop_size * 0.5)
-    dst = np.array([[half, half], [half, half + half], [half + half, half]], np.float32)
+    out = np.zeros((bboxes.shape[0], 10), np.float64)
     for i, (cx, cy, w, h) in enumerate(bboxes):
         if float(w) != float(h):
-            # generate_patch_image_cv (img_utils.py:97-106) crops a non-square box in TWO warps (aspect-preserving resize to
-            # (int(s*w), int(s*h)), then a translation into the patch): two resamplings, which this single map cannot reproduce
-            raise ValueError(f"box {i} is {float(w)} x {float(h)}: the OpenCV-exact crop models the reference's single-warp path (square boxes, "
-                             "what demo.py and batch_generation.py produce); GRNet.crop_normalise(mode='ideal') samples any box in one exact bilinear pass")
-        src_w, src_h = float(w) * float(scale), float(h) * float(scale)
-        centre = np.array([cx, cy], np.float64)
-        src = np.zeros((3, 2), np.float32)
-        src[0] = centre
-        src[1] = centre + np.array([0, src_h * 0.5], np.float32)
-        src[2] = centre + np.array([src_w * 0.5, 0], np.float32)
-        a = np.zeros((6, 6), np.float64)
-        b = np.zeros(6, np.float64)
-        for k in range(3):
-            a[2 * k, 0:2], a[2 * k, 2] = src[k], 1.0
-            a[2 * k + 1, 3:5], a[2 * k + 1, 5] = src[k], 1.0
-            b[2 * k], b[2 * k + 1] = dst[k]
-        m = np.linalg.solve(a, b)                              # [M0 M1 M2 M3 M4 M5]
-        d = m[0] * m[4] - m[1] * m[3]
-        d = 1.0 / d if d != 0 else 0.0
-        a11, a22 = m[4] * d, m[0] * d
-        m0, m1, m3, m4 = a11, m[1] * -d, m[3] * -d, a22
-        out[i] = (m0, m1, -m0 * m[2] - m1 * m[5], m3, m4, -m3 * m[2] - m4 * m[5])
+            s = crop_size / max(float(h), float(w))
+            iw, ih = int(s * float(w)), int(s * float(h))
+            if iw < 1 or ih < 1:
+                raise ValueError(f"box {i} is {float(w)} x {float(h)}: its aspect-preserving resize has an empty side ({iw} x {ih}); the reference's cv2.warpAffine refuses that size too")
+            out[i, :6] = _affine_from_box(cx, cy, w, h, iw, ih, scale)
+            dx, dy = crop_size / 2 - iw / 2, crop_size / 2 - ih / 2
+            out[i, 6:] = (iw, ih, -1.0 * dx - (-0.0) * dy, -(-0.0) * dx - 1.0 * dy)      # warpAffine's inversion of [[1,0,dx],[0,1,dy]]
+        else:
+            out[i, :6] = _affine_from_box(cx, cy, w, h, crop_size, crop_size, scale)
     return out
+
+
+def cv_inverse_affine(bboxes, scale=1.0, crop_size=224):
+    """(n,4) SQUARE boxes -> (n,6) float64: the inverse affine map of the single-warp crop (the first six entries of cv_crop_maps).
+    A box with w != h takes the reference's two-warp branch, which one map cannot describe: ValueError -- use cv_crop_maps."""
+    maps = cv_crop_maps(bboxes, scale, crop_size)
+    if np.any(maps[:, 6] != 0):
+        raise ValueError(f"box {int(np.nonzero(maps[:, 6])[0][0])} is not square: the reference crops it in two warps (img_utils.py:97-106); cv_crop_maps describes both")
+    return np.ascontiguousarray(maps[:, :6])
 
 
 # ----------------------------------------------------------------------------- frame sources
