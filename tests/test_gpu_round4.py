@@ -2,11 +2,16 @@
 the stride-2 chains run early as plain convolutions on the streams of the branches they start from, ONE grouped launch
 (csrc/hr_fuse.hip) finishes outputs 0 .. nb-2 (all 1x1 "up" terms, the identity, the finished chains, ReLU) and one stride-2
 convolution finishes the last output -- against the oracle's fuse layer fed the SAME branch outputs the GPU produced."""
+import importlib
+import os
+import sys
+
+import joblib
 import numpy as np
 import pytest
 import torch
 
-from .conftest import rel_err
+from .conftest import CALL_SIZE_NOISE, ROOT, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -54,4 +59,114 @@ def test_fuse_layer_launch_count_and_macs(pkg):
     assert len(convs) == m.num_conv_launches() == 290
     assert sum(c["macs"] for c in convs) == 15441563648
     assert not any(c["ks"] == 1 and "fuse_layers" in c["name"] and c["cin"] for c in convs)      # no separate 1x1 fuse launch is left
+    m.close()
+
+
+# ----------------------------------------------------------------------------- row f1: the crop of ANY box, and the real-data path
+def _u8_image(h, w, seed):
+    """A smooth, structured 8-bit RGB image (sums of a few sinusoids + noise): bilinear resampling of it is not degenerate."""
+    g = np.random.Generator(np.random.Philox(key=[57, seed]))
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.zeros((h, w, 3))
+    for c in range(3):
+        for _ in range(4):
+            fx, fy, ph = g.uniform(0.01, 0.12), g.uniform(0.01, 0.12), g.uniform(0, 6.28)
+            img[..., c] += np.sin(fx * xx + fy * yy + ph)
+    img = (img - img.min()) / (img.max() - img.min()) * 235 + g.uniform(0, 20, (h, w, 3))
+    return img.astype(np.uint8)
+
+
+def test_crop_kernel_two_warp_boxes_bit_exact(model, pkg, oracle):
+    """grnet_crop_normalise_cv_maps on NON-SQUARE boxes (the reference's two-warp branch, img_utils.py:97-106) and square ones mixed in
+    one call, boxes hanging over every border, an odd intermediate width (half-pixel second warp), float32 / float64 boxes,
+    per-frame images and one shared image, RGB / BGR: bit-identical to the oracle's patch_image_cv + normalisation."""
+    imgs = np.stack([_u8_image(260, 340, s) for s in range(6)])
+    boxes = np.array([[170.0, 130.0, 300.0, 150.0], [30.25, 240.5, 101.0, 224.0], [320.0, 20.0, 90.0, 160.0], [100.0, 100.0, 180.0, 180.0],
+                      [5.5, 250.0, 260.0, 130.0], [200.0, 128.0, 223.0, 111.0]], np.float32)
+    for bb in (boxes, boxes.astype(np.float64)):
+        for scale in (1.0, 1.1):
+            got = model.crop_normalise(torch.from_numpy(imgs).cuda(), torch.from_numpy(bb), scale=scale).cpu().numpy()
+            for i in range(len(bb)):
+                assert np.array_equal(got[i], oracle.crop_normalise_box_cv(imgs[i], bb[i], scale)), (i, scale)
+    one = model.crop_normalise(torch.from_numpy(imgs[1]).cuda(), torch.from_numpy(boxes), scale=1.1).cpu().numpy()
+    for i in range(len(boxes)):
+        assert np.array_equal(one[i], oracle.crop_normalise_box_cv(imgs[1], boxes[i], 1.1))
+    bgr = model.crop_normalise(torch.from_numpy(imgs[:, :, :, ::-1].copy()).cuda(), torch.from_numpy(boxes), scale=1.1, bgr=True).cpu().numpy()
+    assert np.array_equal(bgr[0], oracle.crop_normalise_box_cv(imgs[0], boxes[0], 1.1))
+    # the letterbox of the 2:1 box is exactly the normalised zero
+    zero = ((0.0 - np.array([0.485, 0.456, 0.406], np.float32)) / np.array([0.229, 0.224, 0.225], np.float32)).astype(np.float32)
+    wide = model.crop_normalise(torch.from_numpy(imgs[:1]).cuda(), torch.from_numpy(boxes[:1]), scale=1.0).cpu().numpy()[0]
+    assert np.array_equal(wide[:, :56], np.broadcast_to(zero[:, None, None], (3, 56, 224))) and np.array_equal(wide[:, 168:], np.broadcast_to(zero[:, None, None], (3, 56, 224)))
+
+
+def _write_png(folder, images):
+    from PIL import Image
+    os.makedirs(folder, exist_ok=True)
+    for i, im in enumerate(images):
+        Image.fromarray(im).save(os.path.join(folder, f"{i:06d}.png"))
+
+
+def test_demo_on_png_frames_matches_oracle_crops(pkg, oracle, tmp_path):
+    """demo.py's real-data path (BASELINE configs[0] in its image form): 8-bit PNG frames are decoded, uploaded, cropped + normalised by
+    the HIP kernel (InferenceFrames.batches -> GRNet.crop_normalise) and run through the model in batches of 16; compared frame by
+    frame with the model fed the ORACLE's crops of the same frames (bit-exact crop => only the call-size bound remains).  Square
+    tracker boxes that hang over the image border; two tracks."""
+    sys.path.insert(0, ROOT)
+    demo = importlib.import_module("demo")
+    n = 28
+    imgs = [_u8_image(240, 320, 100 + i) for i in range(n)]
+    img_dir = str(tmp_path / "clip")
+    _write_png(img_dir, imgs)
+    t = np.arange(n, dtype=np.float32)
+    box1 = np.stack([40 + 8 * t, 60 + 5 * t, 150 + 2 * t, 150 + 2 * t], 1).astype(np.float32)        # drifts from the top-left corner outwards
+    box2 = np.stack([300 - 2 * t, 200 + t, np.full(n, 180.0), np.full(n, 180.0)], 1).astype(np.float32)   # hangs over the right / bottom border
+    tp = str(tmp_path / "tracking.pkl")
+    joblib.dump({7: {"bbox": box1.copy(), "frames": np.arange(n)}, 9: {"bbox": box2[2:].copy(), "frames": np.arange(2, n)}}, tp)
+    args = demo.parser().parse_args(["--img_folder", img_dir, "--tracking_path", tp, "--output_folder", str(tmp_path / "out"),
+                                     "--synthetic_weights", "--grnet_batch_size", "16", "--max_frames", "16"])
+    res = joblib.load(demo.main(args))
+    assert sorted(res) == [7, 9]
+    m = pkg.build_synthetic_model(max_frames=32, with_gru=False)
+    for pid, bb, fr in ((7, box1, np.arange(n)), (9, box2[2:], np.arange(2, n))):
+        crops = np.stack([oracle.crop_normalise_box_cv(imgs[f], b, 1.0) for f, b in zip(fr, bb)])
+        direct = m(torch.from_numpy(crops).cuda())[-1]
+        torch.cuda.synchronize()
+        r = res[pid]
+        assert r["joints3d"].shape == (len(fr), 29, 3) and np.array_equal(r["frame_ids"], fr) and np.array_equal(r["bboxes"], bb)
+        assert rel_err(r["joints3d"], direct["kp_3d"][0].cpu().numpy()) < CALL_SIZE_NOISE
+        assert rel_err(r["pose"], direct["theta"][0, :, 3:75].cpu().numpy()) < CALL_SIZE_NOISE
+        assert rel_err(r["verts"], direct["verts"][0].cpu().numpy()) < CALL_SIZE_NOISE
+    m.close()
+
+
+def test_batch_generation_on_png_frames_incl_non_square_annotations(pkg, oracle, tmp_path):
+    """batch_generation.prepare_data on image files (run_on_frames -> GPU crop): two videos with frames of DIFFERENT sizes; the
+    second video's precomputed annotations are NON-SQUARE boxes (batch_generation.py:39-93 produces such boxes from 2D joints), which
+    take the reference's aspect-preserving two-warp crop.  joints3D vs the model on the oracle's crops, boxes scaled by 1.1 in place
+    and by 1.1 again in the crop (inference.py:48,80), kinectv2 order."""
+    sys.path.insert(0, ROOT)
+    bg = importlib.import_module("batch_generation")
+    vids = {"S001C001P001R001A001": ([_u8_image(200, 300, 200 + i) for i in range(7)],
+                                     np.tile(np.array([[150.0, 100.0, 170.0, 170.0]], np.float32), (7, 1)) + np.arange(7, dtype=np.float32)[:, None] * np.array([3, 2, 1, 1], np.float32)),
+            "S001C001P001R001A002": ([_u8_image(260, 180, 300 + i) for i in range(5)],
+                                     np.tile(np.array([[90.0, 130.0, 100.0, 210.0]], np.float32), (5, 1)) + np.arange(5, dtype=np.float32)[:, None] * np.array([2, -3, 1, 2], np.float32))}
+    annos = {}
+    for name, (imgs, bb) in vids.items():
+        _write_png(str(tmp_path / "vids" / name), imgs)
+        annos[name] = bb.copy()
+    bp = str(tmp_path / "bbox.pkl")
+    joblib.dump(annos, bp)
+    written = bg.prepare_data(fv=bp, vid_folder=str(tmp_path / "vids"), outpath=str(tmp_path / "db.json"), synthetic_weights=True, max_frames=8)
+    db = joblib.load(written[0])
+    assert db["joints3D"].shape == (12, 25, 3) and list(db["vid_name"][:7]) == ["S001C001P001R001A001"] * 7
+    m = pkg.build_synthetic_model(max_frames=8, with_gru=False)
+    row = 0
+    for name, (imgs, bb) in vids.items():
+        scaled = bb.copy()
+        scaled[:, 2:] *= np.float32(1.1)                                        # Inference.__init__, in place, float32
+        assert np.array_equal(db["bbox"][row:row + len(bb)], scaled)
+        crops = np.stack([oracle.crop_normalise_box_cv(im, b, 1.1) for im, b in zip(imgs, scaled)])
+        kp = m(torch.from_numpy(crops).cuda())[-1]["kp_3d"][0].cpu().numpy()
+        assert rel_err(db["joints3D"][row:row + len(bb)], pkg.pipeline.spin2_to_kinectv2(kp)) < CALL_SIZE_NOISE, name
+        row += len(bb)
     m.close()
