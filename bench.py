@@ -43,8 +43,8 @@ F_FRAME_FLOP = 2 * 15441563648     # algorithmic conv FLOPs of one 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 300; 3 for --workload batchgen, whose step is a whole job)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default: 20; 1 for --workload batchgen)")
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step (default: configs[1])")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -55,7 +55,18 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32", help="f32: the headline (BASELINE configs[1]); bf16: bf16 storage / "
                     "fp32 accumulation on the bf16 matrix cores (configs[2] with --frames 256), errors vs the fp32 oracle reported in `parity`")
     ap.add_argument("--tune-cache", default=None, help="tuning table file written by a previous run (default: none, grnet_tune measures)")
-    return ap.parse_args(argv)
+    ap.add_argument("--workload", choices=("clip", "batchgen"), default="clip", help="clip: the headline, one 16-frame clip per GPU per step (weak scaling); "
+                    "batchgen: BASELINE configs[3] -- ONE job of --total-frames frames sharded over the GPUs in calls of <= --chunk frames, one all-gather of the "
+                    "per-frame records, then the temporal branch (GRU + attention + second head pass) on the whole sequence; a step is the whole job (strong scaling)")
+    ap.add_argument("--total-frames", type=int, default=10000, help="batchgen: frames of the whole job")
+    ap.add_argument("--chunk", type=int, default=128, help="batchgen: frames per grnet_forward call")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the bf16 256-frame leg (BASELINE configs[2]) that the default 1-GPU fp32 run appends as `secondary`")
+    a = ap.parse_args(argv)
+    if a.steps is None:
+        a.steps = 3 if a.workload == "batchgen" else 300
+    if a.warmup is None:
+        a.warmup = 1 if a.workload == "batchgen" else 20
+    return a
 
 
 # ------------------------------------------------------------------------------------------- launching
@@ -137,34 +148,38 @@ def timed_steps(do_step, device_sync, steps, warmup, dist, reduce_device):
 
 # ------------------------------------------------------------------------------------------- the JSON line
 def roofline_object(fps_per_gpu, dtype, conv_flops_per_frame, conv_ms, conv_ms_serial, n_conv, n, extra=None, executed_flops_per_frame=None):
-    """achieved = frames/s per GPU x F_frame; the conv-only figure (same FLOPs / wall time of the conv launches
-    alone) and the serial per-launch average (what rocprofv3 --stats averages add up to) sit beside it."""
+    """`achieved` / `frac`: the multiplies the matrix cores EXECUTE per second over the dense peak of the dtype -- the whole step (pooling,
+    tail, SMPL, launch gaps) charged to the convolutions.  `effective_*`: SURVEY 8(d)'s figure, frames/s per GPU x F_frame with F_frame the
+    ALGORITHMIC (direct-convolution) count; on the fp32 path 92 % of F_frame runs as Winograd F(4x4,3x3) at a quarter of the multiplies,
+    so the effective figure can exceed the peak of the fp32 matrix cores (1.1 at 256 frames per call) and is not a utilisation.  The
+    conv-only figures (same FLOPs / wall time of the conv launches alone) and the serial per-launch average (what rocprofv3 --stats
+    averages add up to) sit beside them."""
     peak = PEAK_BF16_MFMA_TFLOPS if dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
-    achieved = fps_per_gpu * conv_flops_per_frame / 1e12
+    executed = executed_flops_per_frame or conv_flops_per_frame
+    effective = fps_per_gpu * conv_flops_per_frame / 1e12
+    achieved = fps_per_gpu * executed / 1e12
     conv_flops = conv_flops_per_frame * n
-    r = {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-         "definition": "frames/s per GPU x F_frame (SURVEY 8d: 30.883 GFLOP of convolutions per frame = the ALGORITHMIC, direct-convolution "
-                       "count); the whole step -- pooling, tail, SMPL, launch gaps -- is charged to the convolutions.  On the fp32 path the Winograd "
-                       "layers (92 % of F_frame) execute 4x fewer multiplies than counted here (F(4x4,3x3)), in fp32 throughout",
+    floor_ms = executed * n / (peak * 1e12) * 1e3
+    r = {"bound": "mfma (executed multiplies)", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+         "definition": "frames/s per GPU x the FLOPs the matrix cores execute per frame (Winograd F(4x4,3x3) layers at 1/4 of their direct-convolution "
+                       "count, x 256/196 on 14x14 and x 64/49 on 7x7 maps whose tiles are padded; every other layer at its direct count) / dense peak of "
+                       "the dtype; the whole step -- pooling, tail, SMPL, launch gaps -- is charged to the convolutions",
+         "executed_gflop_per_step": round(executed * n / 1e9, 3),
+         "floor_ms": round(floor_ms, 4), "step_over_floor": round(n / fps_per_gpu * 1e3 / floor_ms, 3),
+         "effective_achieved": round(effective, 3), "effective_frac": round(effective / peak, 4),
+         "effective_is": "SURVEY 8d: frames/s per GPU x F_frame (30.883 GFLOP of convolutions per frame = the ALGORITHMIC, direct-convolution count). "
+                         "An equivalent-work rate, NOT a share of the peak: the fp32 path executes 0.32 of F_frame, so this figure passes 1.0 at large calls",
          "traffic": None,
          "kernel": ("conv_wino4_f32 (Winograd F(4x4,3x3) on the fp32 matrix cores: the 3x3 stride-1 layers on 56x56 and 28x28 maps) + conv_wino4s_f32 "
                     "(the same on 14x14 / 7x7 maps, register-resident) + conv_mfma_f32 / conv_splitk_f32 (fp32 MFMA implicit-GEMM convolution: "
-                    "1x1, stride-2 and stem layers), all launches of a step" if dtype == "f32"
+                    "1x1, stride-2 and stem layers) + hr_fuse_up_f32 (the 1x1 fuse terms of an HR module, grouped), all launches of a step" if dtype == "f32"
                     else "conv_bf16_nhwc (bf16 MFMA implicit-GEMM convolution on NHWC activations) + conv_bf16_direct (register-resident kernel of the 32 ch @56x56 / 64 ch @28x28 layers), all launches of a step"),
          "conv_launches_per_step": n_conv, "conv_gflop_per_step": round(conv_flops / 1e9, 3),
          "gflop_per_launch": round(conv_flops / 1e9 / max(n_conv, 1), 4)}
-    if executed_flops_per_frame and executed_flops_per_frame != conv_flops_per_frame:
-        ex = fps_per_gpu * executed_flops_per_frame / 1e12
-        floor_ms = executed_flops_per_frame * n / (peak * 1e12) * 1e3
-        r.update(frac_is="effective (direct-convolution-equivalent) utilisation, NOT the share of peak the matrix cores executed: that is executed_frac",
-                 executed_gflop_per_step=round(executed_flops_per_frame * n / 1e9, 3), executed_achieved=round(ex, 3), executed_frac=round(ex / peak, 4),
-                 floor_ms=round(floor_ms, 4), step_over_floor=round(n / fps_per_gpu * 1e3 / floor_ms, 3),
-                 executed_note="the multiplies the matrix cores were asked to do: F(4x4,3x3) layers at 1/4 of their direct-convolution count (x 256/196 on "
-                               "14x14 and x 64/49 on 7x7 maps, whose tiles are padded to 16x16 / 8x8); floor_ms = that work at the "
-                               "fp32 matrix peak, step_over_floor = ms_per_step / floor_ms")
     if conv_ms:
-        r.update(conv_only_ms_per_step=round(conv_ms, 4), conv_only_achieved=round(conv_flops / (conv_ms * 1e-3) / 1e12, 3),
-                 conv_only_frac=round(conv_flops / (conv_ms * 1e-3) / 1e12 / peak, 4),
+        r.update(conv_only_ms_per_step=round(conv_ms, 4), conv_only_achieved=round(executed * n / (conv_ms * 1e-3) / 1e12, 3),
+                 conv_only_frac=round(executed * n / (conv_ms * 1e-3) / 1e12 / peak, 4),
+                 conv_only_effective_frac=round(conv_flops / (conv_ms * 1e-3) / 1e12 / peak, 4),
                  avg_launch_us=round(conv_ms * 1e3 / max(n_conv, 1), 3))
     if conv_ms_serial:
         r.update(conv_ms_per_step_serial=round(conv_ms_serial, 4), avg_launch_us_serial=round(conv_ms_serial * 1e3 / max(n_conv, 1), 3),
@@ -173,6 +188,33 @@ def roofline_object(fps_per_gpu, dtype, conv_flops_per_frame, conv_ms, conv_ms_s
     if extra:
         r.update(extra)
     return r
+
+
+LAYER_TABLE_FILE = "r04_layer_traffic.json"   # per-kernel counter / algorithmic bytes of this round (tools/layer_table.py), optional
+
+
+def kernel_objects(table, dtype):
+    """`dominant_kernel` (the kernel family whose launches add up to the most time when each runs alone) and the top of the table, from
+    GRNet.kernel_table: durations measured live with HIP events (grnet_time_conv), FLOPs from the launch list."""
+    peak = PEAK_BF16_MFMA_TFLOPS if dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
+    ratios, why = {}, f"none: profiles/{LAYER_TABLE_FILE} is missing (the per-launch counter passes of this round were not taken)"
+    try:
+        with open(os.path.join(ROOT, "profiles", LAYER_TABLE_FILE)) as f:
+            ratios = json.load(f).get("counter_over_algorithmic_by_kernel", {})
+        why = f"profiles/{LAYER_TABLE_FILE}"
+    except (OSError, ValueError):
+        pass
+
+    def obj(r):
+        return {"name": r["name"], "launches": r["launches"], "us": round(r["avg_us"], 2), "total_us": round(r["total_us"], 1),
+                "frac_executed": round(r["executed_gflop"] / r["total_us"] * 1e3 / peak, 4),
+                "frac_effective": round(r["gflop"] / r["total_us"] * 1e3 / peak, 4),
+                "counter_over_algorithmic": ratios.get(r["name"])}
+
+    top = [obj(r) for r in table[:6]]
+    dom = dict(top[0], traffic_source=why, measured="each distinct layer shape launched alone, 20 back-to-back launches between two HIP events "
+               "on the launch stream (grnet_time_conv); frac_* = FLOPs of the family's launches / their summed durations / dense peak")
+    return dom, top
 
 
 TRAFFIC_FILE = "r03_pmc_traffic.json"      # THIS round's counter passes (tools/gpu_profile_r03.sh -> tools/summarize_profiles.py r03)
@@ -314,17 +356,22 @@ class GpuWorkload:
     def roofline(self, fps_per_gpu):
         model, n, pkg = self.model, self.n, self.pkg
         conv_ms = min(model.time_convs(n) for _ in range(5))
-        model.set_option(pkg._lib.OPT_MULTI_LANE, 0)          # the same launches one after another on one stream
-        conv_ms_serial = min(model.time_convs(n) for _ in range(3))
-        model.set_option(pkg._lib.OPT_MULTI_LANE, 1)
+        conv_ms_serial = None
+        if not getattr(self.args, "light", False):
+            model.set_option(pkg._lib.OPT_MULTI_LANE, 0)      # the same launches one after another on one stream
+            conv_ms_serial = min(model.time_convs(n) for _ in range(3))
+            model.set_option(pkg._lib.OPT_MULTI_LANE, 1)
         alg_bytes = None
         if self.args.dtype == "f32":                          # input + fused addends + weights read once, output written once, fp32
             alg_bytes = 0
             for c in model.describe_convs():
                 alg_bytes += 4 * (n * (c["cin"] * c["hin"] * c["win"] + c["cout"] * c["hout"] * c["wout"] + c["add_elems"]) + c["ks"] * c["ks"] * c["cin"] * c["cout"])
+        extra = stored_traffic(n, self.args.dtype, alg_bytes)
+        if self.rank == 0 and not getattr(self.args, "light", False):
+            extra["dominant_kernel"], extra["kernels_by_time_alone"] = kernel_objects(model.kernel_table(n), self.args.dtype)
         return roofline_object(fps_per_gpu, self.args.dtype, model.conv_flops_per_frame(), conv_ms, conv_ms_serial,
-                               model.num_conv_launches(), n, stored_traffic(n, self.args.dtype, alg_bytes),
-                               executed_flops_per_frame=model.conv_executed_flops_per_frame())
+                               model.num_conv_launches(), n, extra,
+                               executed_flops_per_frame=model.conv_executed_flops_per_frame(n))
 
     def extras(self, line):
         """cpu_baseline + parity: rank 0 at N = 1 only, after the timed region."""
@@ -347,30 +394,105 @@ class GpuWorkload:
             r.model.close()
 
 
+class BatchgenWorkload:
+    """BASELINE configs[3] (`--workload batchgen`): harness.ShardedSequenceRunner over this rank's shard of a --total-frames job."""
+
+    def __init__(self, args, world, rank, local_rank, dist):
+        import torch
+        self.torch, self.args, self.world, self.rank, self.dist = torch, args, world, rank, dist
+        pkg = self.pkg = importlib.import_module(PKG)
+        chunk = self.chunk = min(args.chunk, args.total_frames)
+        self.model = pkg.build_synthetic_model(max_frames=chunk, device_id=local_rank, dtype=args.dtype, use_gait_feat=True)
+        lo, hi = pkg.harness.shard_range(args.total_frames, world, rank)
+        base = torch.from_numpy(pkg.synth.make_frames(min(chunk, max(hi - lo, 1)), start=lo)).cuda()
+        reps = -(-(hi - lo) // base.shape[0])
+        frames = base.repeat(reps, 1, 1, 1)[:hi - lo].contiguous()               # the shard resident in HBM: (hi-lo) x 602 KB
+        self.model.finalize()                                                    # eager lane streams: every call has its own output pointers
+        if args.tune_level:
+            self.model.tune(chunk, level=args.tune_level)
+            if (hi - lo) % chunk:
+                self.model.tune((hi - lo) % chunk, level=args.tune_level)
+        self.runner = pkg.harness.ShardedSequenceRunner(self.model, frames, args.total_frames, world, rank, dist, chunk=chunk)
+
+    def step(self):
+        self.runner.step()
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def config(self):
+        a = self.args
+        return {"workload": f"batch_generation over ONE {a.total_frames}-frame synthetic video: per-frame path on ceil({a.total_frames}/{self.world}) frames per GPU in calls of <= "
+                            f"{self.chunk} frames, one all-gather of the per-frame records (19.4 KB per frame), then cparams + GRU gait encoder + corrector / attention "
+                            "block + second head pass on the whole sequence (replicated); seed-defined synthetic weights",
+                "total_frames": a.total_frames, "frames_per_gpu": self.runner.n_local, "chunk": self.chunk, "calls_per_gpu": len(self.runner.calls),
+                "exchange": "none (1 GPU)" if self.world == 1 else
+                            (("RCCL" if os.environ.get("GRNET_BENCH_BACKEND", "nccl") == "nccl" else os.environ["GRNET_BENCH_BACKEND"] + " (rehearsal backend)") +
+                             f" all-gather of {self.runner.packed.numel() * 4 / 1e6:.1f} MB per rank, once per job")}
+
+    def roofline(self, fps_per_gpu):
+        model, n = self.model, self.chunk
+        return roofline_object(fps_per_gpu, self.args.dtype, model.conv_flops_per_frame(), None, None, model.num_conv_launches(), n,
+                               {"note": "frames/s per GPU of the WHOLE job (per-frame path + exchange + replicated temporal branch) x the convolution FLOPs of a frame"},
+                               executed_flops_per_frame=model.conv_executed_flops_per_frame(n))
+
+    def extras(self, line):
+        pass
+
+    def close(self):
+        self.model.close()
+
+
 def run_rank(args, make_workload=GpuWorkload, out=None):
     """Everything one rank does; returns the JSON object on rank 0 (None elsewhere).  `make_workload` is the seam the CPU
     tests use to drive the rank logic (barrier, MAX over ranks, rank-0 line) with a stand-in workload under gloo."""
     world, rank, local_rank = rank_env()
     dist, local_rank, reduce_device = init_dist(world, rank, local_rank)
+    batchgen = getattr(args, "workload", "clip") == "batchgen"
+    if batchgen and make_workload is GpuWorkload:
+        make_workload = BatchgenWorkload
     wl = make_workload(args, world, rank, local_rank, dist)
     elapsed = timed_steps(wl.step, wl.sync, args.steps, args.warmup, dist, reduce_device)
     line = None
     n = args.frames
-    total_frames = n * world * args.steps
+    total_frames = (args.total_frames if batchgen else n * world) * args.steps
     fps = total_frames / elapsed
     roof = wl.roofline(fps / world)                            # every rank runs it (keeps the ranks in step), rank 0 reports
     if rank == 0:
-        line = {"metric": f"frames/sec (224x224, seq={n})", "value": round(fps, 2), "unit": "frames/s",
+        line = {"metric": f"frames/sec (224x224, {args.total_frames}-frame video directory, all-gather before the GRU)" if batchgen else f"frames/sec (224x224, seq={n})",
+                "value": round(fps, 2), "unit": "frames/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                "higher_is_better": True, "scaling": "strong" if batchgen else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                 "config": wl.config(), "roofline": roof}
         wl.extras(line)
-        print(json.dumps(line), file=out or sys.stdout, flush=True)
     wl.close()
+    if rank == 0:
+        if world == 1 and make_workload is GpuWorkload and args.dtype == "f32" and args.frames == FRAMES_PER_GPU and not args.no_secondary and not batchgen:
+            line["secondary"] = secondary_leg(args)
+        print(json.dumps(line), file=out or sys.stdout, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     return line
+
+
+def secondary_leg(args, frames=256, steps=20, warmup=5):
+    """BASELINE configs[2] under the same clock as the headline: 8 clips x 32 frames = 256 frames per call, bf16 storage / fp32 accumulation on the
+    bf16 matrix cores, timed right after the headline in the same process (a few seconds, no CPU leg: the bf16 path's distance from the
+    fp32 oracle is covered by tests/test_gpu_bf16.py and by `bench.py --dtype bf16`)."""
+    import copy
+    a = copy.copy(args)
+    a.dtype, a.frames, a.steps, a.warmup, a.inflight, a.light, a.tune_cache = "bf16", frames, steps, warmup, 1, True, None
+    try:
+        wl = GpuWorkload(a, 1, 0, 0, None)
+        elapsed = timed_steps(wl.step, wl.sync, steps, warmup, None, "cuda")
+        fps = frames * steps / elapsed
+        obj = {"config": wl.config(), "metric": f"frames/sec (224x224, 8 clips x seq=32)", "dtype": "bf16", "value": round(fps, 2), "unit": "frames/s",
+               "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4), "roofline": wl.roofline(fps)}
+        wl.close()
+        return obj
+    except Exception as e:                                     # the headline line must not be lost to the second leg
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def main(argv=None):

@@ -129,6 +129,7 @@ double grnet_conv_flops_per_frame(grnet_t* h);  /* 2 * MACs of all convolutions 
  * grnet_conv_flops_per_frame otherwise.  Reporting only: the roofline figure is quoted on the algorithmic count above, this one says what
  * the matrix cores were actually asked to do. */
 double grnet_conv_executed_flops_per_frame(grnet_t* h);
+double grnet_conv_executed_flops_per_frame_n(grnet_t* h, int n_frames);   /* the same for a call of n_frames frames, stated explicitly */
 /* The pos-th convolution launch of one forward in the un-grouped launch order (the dispatch order of a
  * GRNET_OPT_MULTI_LANE=0, un-tuned run -- what tools/layer_table.py joins per-dispatch profiler rows on):
  * info[0..11] = Cin, Cout, kernel, stride, Hin, Win, Hout, Wout, fused addends, relu, lane, addend elements per
@@ -139,6 +140,12 @@ int grnet_describe_conv(grnet_t* h, int pos, int32_t* info /* 12 */, char* name,
  * the 56x56 map of output 0, "fused addends" = the module's branch count, addend elements = the floats it reads per frame, and the name
  * "<module>.fuse_layers(up)".  Multiply-accumulates per frame of the pos-th launch of that list (either kind; < 0: bad position): */
 double grnet_describe_conv_macs(grnet_t* h, int pos);
+/* Per-launch figures for bench.py's kernel table (positions as in grnet_describe_conv): the kernel that runs the pos-th launch in a call
+ * of n_frames frames (family<shape> name) and the multiply-accumulates per frame the matrix cores execute for it; and the average
+ * duration, in microseconds, of `reps` back-to-back launches of it ALONE on `stream` (HIP events around the repetitions, two warm launches
+ * first; the launch reads and writes its own planned buffers, whose contents are garbage afterwards like after any forward). */
+int grnet_conv_kernel_info(grnet_t* h, int pos, int n_frames, char* name, int name_size, double* executed_macs_per_frame);
+int grnet_time_conv(grnet_t* h, int pos, int n_frames, int reps, void* stream, float* us_out);
 /* Diagnostic: ONE eager forward on the lane streams with a HIP timing event in front of and behind every op (placed after the op's
  * cross-lane waits), after two untimed warm passes; no profiler involved.  Writes one text line per op in enqueue order --
  * "index lane start_us end_us label", times relative to the first op's start -- into buf and returns the text's length (< 0: error;

@@ -108,6 +108,62 @@ def test_allgather_reassembles_sequence_world2(n_total):
         assert shape == (n_total, 29, 3)
 
 
+def _sharded_worker(rank, world, port, n_total, chunk, q):
+    """ShardedSequenceRunner (BASELINE configs[3], `bench.py --workload batchgen`) under gloo with a stand-in per-frame model: every
+    call writes, through the Outputs pointers it was given, field f of GLOBAL frame i = i + f/1000 (+ element / 1e6)."""
+    import ctypes as C
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    h = importlib.import_module(PKG_NAME).harness
+    lo, hi = h.shard_range(n_total, world, rank)
+    frames = torch.zeros(hi - lo, 3, 2, 2)                             # only the count matters to the stand-in
+    calls, seen = [], {}
+
+    def forward_chunk(c0, c1, out):
+        calls.append((c0, c1))
+        for fi, (name, sz) in enumerate(h.POSE_RECORD_GAIT):
+            ptr = getattr(out, name)
+            vals = (torch.arange(lo + c0, lo + c1, dtype=torch.float32)[:, None] + fi / 1000.0 + torch.arange(sz)[None] / 1e6).reshape(-1).contiguous()
+            C.memmove(ptr, vals.data_ptr(), vals.numel() * 4)
+
+    def temporal(seq):
+        seen.update({k: v.clone() for k, v in seq.items()})
+        return {"frames": seq["theta"].shape[0]}
+
+    r = h.ShardedSequenceRunner(None, frames, n_total, world, rank, dist, chunk=chunk, forward_chunk=forward_chunk, temporal=temporal)
+    res = r.step()
+    ok = res == {"frames": n_total} and calls == [(c, min(hi - lo, c + chunk)) for c in range(0, hi - lo, chunk)]
+    for fi, (name, sz) in enumerate(h.POSE_RECORD_GAIT):
+        want = torch.arange(n_total, dtype=torch.float32)[:, None] + fi / 1000.0 + torch.arange(sz)[None] / 1e6
+        ok = ok and torch.equal(seen[name].reshape(n_total, sz), want)
+    q.put((rank, ok, len(calls), r.n_local))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total,chunk", [(37, 8), (64, 128)])
+def test_sharded_sequence_runner_world2(n_total, chunk):
+    """Two gloo ranks: shards of ceil(n/2) frames in calls of <= chunk, each call's output pointers aimed at its frames' slots of the send
+    block, ONE all-gather, the whole sequence in frame order on every rank handed to the temporal step (37 frames: rank 1's shard is one
+    frame short and its padding row is dropped)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, n_total, chunk, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    per = -(-n_total // 2)
+    for rank, ok, n_calls, n_local in res:
+        assert ok, f"rank {rank}: wrong calls or a wrong reassembled sequence"
+        assert n_local == per and n_calls == -(-(min(n_total, (rank + 1) * per) - rank * per) // chunk)
+
+
 def test_synth_is_deterministic(pkg):
     a = pkg.synth.make_state_dict()
     b = pkg.synth.make_state_dict()

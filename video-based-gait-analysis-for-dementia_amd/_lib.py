@@ -46,6 +46,9 @@ EXPORTS = {
     "grnet_conv_executed_flops_per_frame": (C.c_double, [C.c_void_p]),
     "grnet_describe_conv": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_char_p, C.c_int]),
     "grnet_describe_conv_macs": (C.c_double, [C.c_void_p, C.c_int]),
+    "grnet_conv_executed_flops_per_frame_n": (C.c_double, [C.c_void_p, C.c_int]),
+    "grnet_conv_kernel_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double)]),
+    "grnet_time_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "grnet_op_timeline": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_char_p, C.c_int]),
     "grnet_time_convs": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "grnet_op_conv2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

@@ -285,10 +285,39 @@ class GRNet:
     def conv_flops_per_frame(self):
         return self._lib.grnet_conv_flops_per_frame(self._h)
 
-    def conv_executed_flops_per_frame(self):
-        """Winograd layers counted at the 1/4 (F(4x4,3x3)) or 4/9 (F(2x2,3x3)) of their multiplies they execute (reporting only)."""
+    def conv_executed_flops_per_frame(self, n_frames=None):
+        """Winograd F(4x4,3x3) layers counted at the 1/4 of their multiplies they execute (x the tile padding on 14x14 / 7x7 maps), for a
+        call of n_frames frames (default: the handle's latest forward).  Reporting only."""
         self.finalize()
-        return self._lib.grnet_conv_executed_flops_per_frame(self._h)
+        if n_frames is None:
+            return self._lib.grnet_conv_executed_flops_per_frame(self._h)
+        return self._lib.grnet_conv_executed_flops_per_frame_n(self._h, int(n_frames))
+
+    def kernel_table(self, n_frames, reps=20):
+        """Per kernel (family<shape>) of the conv-class launches of one forward of n_frames frames: launches, time of each distinct layer
+        shape measured ALONE (grnet_time_conv: HIP events around `reps` back-to-back launches), algorithmic and executed FLOPs.
+        Returns a list of dicts sorted by total time: name, launches, total_us, avg_us, gflop (algorithmic, per step), executed_gflop."""
+        self.finalize()
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        convs = self.describe_convs()
+        timed, rows = {}, {}
+        for pos, c in enumerate(convs):
+            name, ex = C.create_string_buffer(96), C.c_double()
+            _lib.check(self._lib, self._h, self._lib.grnet_conv_kernel_info(self._h, pos, int(n_frames), name, 96, C.byref(ex)), "grnet_conv_kernel_info")
+            key = (name.value, c["cin"], c["cout"], c["ks"], c["stride"], c["hin"], c["n_add"], c["macs"])
+            if key not in timed:
+                us = C.c_float()
+                _lib.check(self._lib, self._h, self._lib.grnet_time_conv(self._h, pos, int(n_frames), int(reps), stream, C.byref(us)), "grnet_time_conv")
+                timed[key] = us.value
+            r = rows.setdefault(name.value.decode(), {"name": name.value.decode(), "launches": 0, "total_us": 0.0, "gflop": 0.0, "executed_gflop": 0.0})
+            r["launches"] += 1
+            r["total_us"] += timed[key]
+            r["gflop"] += 2.0 * c["macs"] * n_frames / 1e9
+            r["executed_gflop"] += 2.0 * ex.value * n_frames / 1e9
+        out = sorted(rows.values(), key=lambda r: -r["total_us"])
+        for r in out:
+            r["avg_us"] = r["total_us"] / r["launches"]
+        return out
 
     def describe_convs(self):
         """The convolution launches of one forward in launch order: list of dicts (shape, fused addends, weight key, MACs per frame).

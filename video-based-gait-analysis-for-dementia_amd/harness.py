@@ -159,3 +159,55 @@ class ClipRunner:
         """Whole-clip results in frame order (after step())."""
         g = self.gathered.view(self.world, -1) if self.world > 1 else self.packed.view(1, -1)
         return unpack_sequence(g, self.n, n_total if n_total is not None else self.n * self.world, self.record)
+
+
+class ShardedSequenceRunner:
+    """BASELINE configs[3] as one job: a sequence of ``n_total`` frames (a 10 000-frame video directory) sharded over the ranks
+    (shard_range: ceil(n/world) frames each), every rank running the per-frame path on its shard in calls of <= ``chunk`` frames
+    (batch_generation.py:289-329; 128 is where the kernels are efficient and what --max_frames sizes the activation arena for),
+    ONE all-gather of the per-frame records (theta, kp_3d, kp_2d, point_local_feat, cam_shape_feats: 19.4 KB per frame, written by
+    the kernels straight into the send block -- every call's output pointers aim at its frames' slots, no packing kernel), then
+    the temporal branch (grnet.py:154-173: cparams, GRU gait encoder, corrector + attention block, second head pass) on the whole
+    reassembled sequence, replicated on every rank (temporal_after_gather).  Strong scaling: the job is fixed, the shards shrink.
+
+    ``frames``: this rank's shard, (count, 3, 224, 224) on the device, count = hi - lo of shard_range.  ``forward_chunk(lo, hi, out)``
+    and ``temporal(seq)`` are the seams of the CPU tests (a stand-in model under gloo); by default they call grnet_forward /
+    temporal_after_gather."""
+
+    def __init__(self, model, frames, n_total, world=1, rank=0, dist=None, chunk=128, forward_chunk=None, temporal=None, bbox=None, cimg=None):
+        self.model, self.frames, self.n_total, self.world, self.rank, self.dist = model, frames, int(n_total), world, rank, dist
+        self.n_local = -(-self.n_total // world)
+        lo, hi = shard_range(self.n_total, world, rank)
+        self.count = hi - lo
+        assert frames.shape[0] == self.count, (frames.shape, lo, hi)
+        dev = frames.device
+        self.record = POSE_RECORD_GAIT
+        layout, block = pack_layout(self.n_local, self.record)
+        self.packed = torch.zeros(block, dtype=torch.float32, device=dev)       # a short last shard leaves its padding rows zero
+        self.gathered = torch.empty(world * block, dtype=torch.float32, device=dev)
+        self.calls = []
+        for c0 in range(0, self.count, chunk):
+            c1 = min(self.count, c0 + chunk)
+            out = _lib.Outputs()
+            for name, (off, sz) in layout.items():
+                setattr(out, name, self.packed[off + sz * c0:off + sz * c1].data_ptr())
+            self.calls.append((c0, c1, out))
+        self.bbox = bbox if bbox is not None else torch.tensor([112.0, 112.0, 224.0, 224.0], device=dev).repeat(1, self.n_total, 1)
+        self.cimg = cimg if cimg is not None else torch.full((1, self.n_total, 2), 112.0, device=dev)
+        self._forward_chunk = forward_chunk or self._grnet_forward
+        self._temporal = temporal or (lambda seq: temporal_after_gather(self.model, seq, self.bbox, self.cimg, 1, self.n_total))
+        self.result = None
+
+    def _grnet_forward(self, c0, c1, out):
+        m = self.model
+        stream = C.c_void_p(torch.cuda.current_stream(self.frames.device).cuda_stream)
+        rc = m._lib.grnet_forward(m._h, C.c_void_p(self.frames[c0:c1].data_ptr()), c1 - c0, C.byref(out), stream)
+        _lib.check(m._lib, m._h, rc, "grnet_forward")
+
+    def step(self):
+        for c0, c1, out in self.calls:
+            self._forward_chunk(c0, c1, out)
+        g = gather_pose_records(self.packed, self.n_local, self.world, self.dist, out=self.gathered)
+        self.seq = unpack_sequence(g, self.n_local, self.n_total, self.record)
+        self.result = self._temporal(self.seq)
+        return self.result
