@@ -217,7 +217,7 @@ def kernel_objects(table, dtype):
     return dom, top
 
 
-TRAFFIC_FILE = "r03_pmc_traffic.json"      # THIS round's counter passes (tools/gpu_profile_r03.sh -> tools/summarize_profiles.py r03)
+TRAFFIC_FILE = "r04_pmc_traffic.json"      # THIS round's counter passes (tools/gpu_profile.sh -> tools/summarize_profiles.py r04)
 
 
 def stored_traffic(n, dtype, algorithmic_bytes=None):

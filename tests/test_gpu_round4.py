@@ -170,3 +170,22 @@ def test_batch_generation_on_png_frames_incl_non_square_annotations(pkg, oracle,
         assert rel_err(db["joints3D"][row:row + len(bb)], pkg.pipeline.spin2_to_kinectv2(kp)) < CALL_SIZE_NOISE, name
         row += len(bb)
     m.close()
+
+
+def test_attention_block_large_lds_branch_17000_frames(pkg, oracle):
+    """The temporal attention keeps one softmax row over the clip's frames in LDS; beyond ~15 800 frames that is more than 64 KB and the
+    launcher raises the kernel's dynamic-LDS limit (up to the 160 KB of gfx950, from which the 32 768-frame limit follows; both read from
+    the device).  A 17 000-frame clip made of a 50-frame pattern repeated 340 times: every distinct key appears 340 times with the same
+    logit, so each frame's attention output -- and the clip means of the gate -- equal those of the 50-frame clip, which the CPU oracle
+    computes in a moment.  Covers the large-LDS launch, which no test ran before (round-3 advisor)."""
+    m = pkg.build_synthetic_model(max_frames=2, with_gru=True, with_tsattn=True, use_gait_feat=False)
+    tsd = pkg.synth.make_tsattn_state_dict()
+    x, xs = pkg.synth.make_tsattn_inputs(1, 50)
+    reps = 340
+    xl, xsl = np.tile(x, (1, reps, 1, 1)), np.tile(xs, (1, reps, 1, 1))
+    y = m.tsattn_forward(torch.from_numpy(xl).cuda(), torch.from_numpy(xsl).cuda()).cpu().numpy()
+    ref = oracle.ts_attn_block(x, xs, tsd)
+    assert y.shape == (1, 50 * reps) + ref.shape[2:]
+    assert rel_err(y[:, :50], ref) < 5e-5 and rel_err(y[:, -50:], ref) < 5e-5
+    assert rel_err(y.reshape(reps, 50, -1), np.broadcast_to(ref.reshape(1, 50, -1), (reps, 50, ref[0, 0].size))) < 5e-5
+    m.close()

@@ -24,7 +24,7 @@ stats = os.path.join(src, "prof", "bench_kernel_stats.csv")
 if os.path.isfile(stats):
     shutil.copy(stats, os.path.join(dst, f"{rnd}_kernel_stats.csv"))
     rows = list(csv.DictReader(open(stats)))
-    conv = [r for r in rows if "conv_" in r["Name"]]
+    conv = [r for r in rows if "conv_" in r["Name"] or "hr_fuse_up" in r["Name"]]
     tot = sum(float(r["TotalDurationNs"]) for r in conv)
     calls = sum(int(r["Calls"]) for r in conv)
     print(f"conv kernels: {calls} launches, {tot / 1e6:.2f} ms total, avg {tot / calls / 1e3:.2f} us/launch")
@@ -36,7 +36,7 @@ serial = os.path.join(src, "prof_serial", "bench_kernel_stats.csv")
 if os.path.isfile(serial):                      # GRNET_MULTI_LANE=0: launches strictly one after another
     shutil.copy(serial, os.path.join(dst, f"{rnd}_kernel_stats_serial.csv"))
     rows = list(csv.DictReader(open(serial)))
-    conv = [r for r in rows if "conv_" in r["Name"]]
+    conv = [r for r in rows if "conv_" in r["Name"] or "hr_fuse_up" in r["Name"]]
     tot = sum(float(r["TotalDurationNs"]) for r in conv)
     calls = sum(int(r["Calls"]) for r in conv)
     print(f"serial run: conv kernels {calls} launches, {tot / 1e6:.2f} ms total, avg {tot / calls / 1e3:.2f} us/launch")
@@ -55,11 +55,12 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         n = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         per_kernel[n][0] += float(r["Counter_Value"])
         per_kernel[n][1] += 1
-    conv_launches_total = sum(v[1] for k, v in per_kernel.items() if "conv_" in k)
-    per_fw = int(os.environ.get("CONV_DISPATCHES_PER_FORWARD", "318"))   # 316 convolutions, two of them with a half-size last round (2 dispatches)
+    is_conv = lambda k: "conv_" in k or "hr_fuse_up" in k
+    conv_launches_total = sum(v[1] for k, v in per_kernel.items() if is_conv(k))
+    per_fw = int(os.environ.get("CONV_DISPATCHES_PER_FORWARD", "292"))   # 290 conv-class launches, two of them with a half-size last round (2 dispatches)
     n_forwards = max(1, round(conv_launches_total / per_fw))
-    conv_kb = sum(v[0] for k, v in per_kernel.items() if "conv_" in k)
-    conv_launches = sum(v[1] for k, v in per_kernel.items() if "conv_" in k)
+    conv_kb = sum(v[0] for k, v in per_kernel.items() if is_conv(k))
+    conv_launches = sum(v[1] for k, v in per_kernel.items() if is_conv(k))
     all_kb = sum(v[0] for v in per_kernel.values())
     out[c] = {"unit": "KB (rocprofv3 derived counter)", "forwards_in_run": n_forwards,
               "conv_kernels_kb_per_forward": conv_kb / n_forwards, "all_kernels_kb_per_forward": all_kb / n_forwards,
@@ -72,7 +73,7 @@ if out:
         out["correction"] = "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B for 16 B/lane streaming reads), WRITE_SIZE x1"
         out["note"] = ("memory-side (fabric) requests of the L2: Infinity-Cache hits are counted, so this is an upper bound on HBM "
                        "bytes; the 16-frame working set (~1.7 GB of activations) does not fit the 256 MiB cache")
-    lt = os.path.join(dst, f"{rnd}_layer_traffic.json")          # tools/layer_table_r03.py: the same counters joined per launch (THIS round's only)
+    lt = os.path.join(dst, f"{rnd}_layer_traffic.json")          # tools/layer_table.py: the same counters joined per launch (THIS round's only)
     if os.path.isfile(lt):
         t = json.load(open(lt))
         out["algorithmic_bytes_per_step_conv_kernels"] = t["algorithmic_bytes"]

@@ -370,11 +370,8 @@ static hipError_t launch_wino4_w(ConvArgs a, hipStream_t s, int nb, int* n_launc
     if (nb == 2) return launch_k(conv_wino4_f32<2, WD>, dim3(total), dim3(256), kLdsB, s, a);
     // a last round of workgroups that is at most half full runs as twice as many half-size workgroups
     static const int split_env = getenv("GRNET_WINO_SPLIT") ? atoi(getenv("GRNET_WINO_SPLIT")) : 1;
-    static int cu_count[64] = {};                        // workgroups per round = CUs of this device (one workgroup fits a CU)
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!cu_count[dev] && hipDeviceGetAttribute(&cu_count[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return hipErrorInvalidDevice;
-    const int kCUs = cu_count[dev];
+    int kCUs = 0;                                        // workgroups per round = CUs of this device (one workgroup fits a CU)
+    if (hipError_t e = device_cu_count(&kCUs); e != hipSuccess) return e;
     const int full = total / kCUs * kCUs, rest = total - full;
     if (split_env && full > 0 && rest > 0 && 2 * rest <= kCUs && (!a.xcd || full % 8 == 0)) {
         hipError_t e = launch_k(conv_wino4_f32<4, WD>, dim3(full), dim3(256), kLdsB, s, a);
@@ -389,18 +386,16 @@ static hipError_t launch_wino4_w(ConvArgs a, hipStream_t s, int nb, int* n_launc
 
 // a.w: transformed weights [36][CinPad][CoutPad] (pack_wino4_weights), CoutPad % 64 == 0 (or 32: the 32-channel variant)
 hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s, int* n_launches) {
-    static bool attr_done[64] = {};
+    static PerDeviceOnce attr;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_done[dev]) {
-        hipError_t e = hipSuccess;
-        auto set = [&](auto kern) { if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsB); };
-        set(conv_wino4_f32<4, 56>); set(conv_wino4_f32<2, 56>); set(conv_wino4_f32<4, 28>); set(conv_wino4_f32<2, 28>);
-        set(conv_wino4_f32<2, 56, 0, true>); set(conv_wino4_f32<2, 28, 0, true>);
-
-        if (e != hipSuccess) return e;
-        attr_done[dev] = true;
-    }
+    if (hipError_t e = current_device(&dev); e != hipSuccess) return e;
+    if (hipError_t e = once_per_device(attr, dev, [](int*) {
+            hipError_t e = hipSuccess;
+            auto set = [&](auto kern) { if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsB); };
+            set(conv_wino4_f32<4, 56>); set(conv_wino4_f32<2, 56>); set(conv_wino4_f32<4, 28>); set(conv_wino4_f32<2, 28>);
+            set(conv_wino4_f32<2, 56, 0, true>); set(conv_wino4_f32<2, 28, 0, true>);
+            return e;
+        }); e != hipSuccess) return e;
     const int nb = conv_wino4_blocks(a.Cout, a.W);
     if (!conv_wino4_eligible(a.Cin, a.Cout, a.ks, a.stride, a.H, a.W, a.n_add) || a.CinPad % kCK != 0 || a.CoutPad % (nb * 16) != 0) return hipErrorInvalidValue;
     if (a.n_add == 1 && a.add_shift[0] != 0) return hipErrorInvalidValue;

@@ -246,14 +246,12 @@ __global__ __launch_bounds__(64 * KS) void conv_wino4s_f32(const ConvArgs a) {
 template <int WD, int C, int KS>
 hipError_t launch_s(const ConvArgs& a, hipStream_t s) {
     typedef GeoS<WD, KS> G;
-    static bool attr_done[64] = {};
+    static PerDeviceOnce attr;                           // one per instantiation
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_done[dev]) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4s_f32<WD, C, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes);
-        if (e != hipSuccess) return e;
-        attr_done[dev] = true;
-    }
+    if (hipError_t e = current_device(&dev); e != hipSuccess) return e;
+    if (hipError_t e = once_per_device(attr, dev, [](int*) {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4s_f32<WD, C, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes);
+        }); e != hipSuccess) return e;
     const int groups = (a.N + G::IPW - 1) / G::IPW;
     return launch_k(conv_wino4s_f32<WD, C, KS>, dim3(groups * (C / 16)), dim3(64 * KS), G::lds_bytes, s, a);
 }

@@ -563,6 +563,8 @@ struct grnet {
             size_t fl = pr.second * (size_t)max_frames;
             total += (fl + 63) / 64 * 64;               // 256-byte aligned buffers
         }
+        total += 64;                                    // 256 bytes of tail: conv_wino4s_f32's 16-byte row loads on 7-wide maps touch (and mask) one float past a row,
+                                                        // i.e. 4 bytes past the LAST buffer's end for its last row -- they stay inside the arena
         arena_floats = total;
         void* q = nullptr;
         if (hipMalloc(&q, total * sizeof(float)) != hipSuccess)
@@ -1911,11 +1913,11 @@ int grnet_gru_forward(grnet_t* h, const float* x, const float* cp, int b, int T,
 
 int grnet_tsattn_forward(grnet_t* h, const float* x, const float* xs, int b, int n, float* y, void* stream) {
     if (!h || !x || !xs || !y || b < 1 || n < 1) return GRNET_EINVAL;
-    if (n > kTsAttnMaxFrames) return h->fail(GRNET_EINVAL, "a clip of " + std::to_string(n) + " frames exceeds the attention block's limit of " + std::to_string(kTsAttnMaxFrames) +
+    DeviceGuard guard(h->device);                          // the limit below is the handle's device's
+    if (n > tsattn_max_frames()) return h->fail(GRNET_EINVAL, "a clip of " + std::to_string(n) + " frames exceeds the attention block's limit of " + std::to_string(tsattn_max_frames()) +
                                                              " frames per clip (its softmax row over the clip lives in LDS): split the sequence into clips");
     if (!h->tsattn_ready)
         return h->fail(GRNET_ESTATE, "attention-block weights were not loaded (keys tsattn.* or pfeat_corrector.featTencoder.0.*)");
-    DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* ws = nullptr;                                   // handle-owned scratch, like the GRU's
     if (int rc = h->temporal_scratch(kGemmWsFloats + tsattn_ws_floats(b, n), &ws)) return rc;
@@ -2327,9 +2329,9 @@ int grnet_gait_correct(grnet_t* h, const float* plf_dev, const float* csf_dev, c
     if (!h->gru_ready || !h->tsattn_ready || !h->featcorr_ready)
         return h->fail(GRNET_ESTATE, "pose-feature corrector weights were not loaded (keys pfeat_corrector.*)");
     if ((long)b * T > 65536) return h->fail(GRNET_EINVAL, "b*T exceeds 65536 frames");
-    if (T > kTsAttnMaxFrames) return h->fail(GRNET_EINVAL, "a clip of " + std::to_string(T) + " frames exceeds the attention block's limit of " + std::to_string(kTsAttnMaxFrames) +
+    DeviceGuard guard(h->device);                          // the limit below is the handle's device's
+    if (T > tsattn_max_frames()) return h->fail(GRNET_EINVAL, "a clip of " + std::to_string(T) + " frames exceeds the attention block's limit of " + std::to_string(tsattn_max_frames()) +
                                                              " frames per clip: split the sequence into clips (b, T)");
-    DeviceGuard guard(h->device);
     grnet_gait_outputs_t g{};
     if (gait) g = *gait;
     return h->gait_correct(plf_dev, csf_dev, cam_dev, cam_ld, bbox_dev, cimg_dev, b, T, *out, g, static_cast<hipStream_t>(stream));

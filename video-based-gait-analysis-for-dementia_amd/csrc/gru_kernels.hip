@@ -334,11 +334,9 @@ hipError_t launch_gru(const float* x, const float* cparams, GruWeights w, GruWor
         // the 8 slices of a (sequence, direction) spin on each other: every workgroup of the grid must be resident at once, i.e. the
         // grid may not exceed one 512-thread workgroup per CU of THIS device (256 on MI355X; fewer on a partitioned or smaller part)
         const int split_grid = 64 * ((2 * b + 7) / 8);
-        static int cu_count[64] = {};
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-        if (!cu_count[dev]) GRK_TRY(hipDeviceGetAttribute(&cu_count[dev], hipDeviceAttributeMultiprocessorCount, dev));
-        if (split_env && ws.xbuf && b <= 16 && T >= 8 && split_grid <= cu_count[dev]) {
+        int cus = 0;
+        GRK_TRY(device_cu_count(&cus));
+        if (split_env && ws.xbuf && b <= 16 && T >= 8 && split_grid <= cus) {
             // W_hh resident in registers, split over 8 workgroups per (sequence, direction); the exchange buffer starts zeroed
             GRK_TRY(hipMemsetAsync(ws.xbuf, 0, (size_t)b * 2 * 2 * kH * sizeof(unsigned long long), s));
             GRK_TRY(launch_k(gru_recurrent_split_kernel, dim3(split_grid), dim3(512), 0, s, (const float*)ws.gi, w.w_hh[layer][0], w.w_hh[layer][1],

@@ -6,11 +6,38 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <tuple>
 #include <utility>
 #include <vector>
 
 namespace grk {
+
+// One-time work per device (kernel attributes, device queries) that launchers used to cache in plain function-local statics: two host
+// threads driving two handles raced on those (a thread could see the flag set before the other's hipFuncSetAttribute had finished).
+// call_once per device id; the first result (error code, value) is kept.
+struct PerDeviceOnce {
+    std::once_flag flag[64];
+    hipError_t err[64];
+    int val[64];
+};
+inline hipError_t current_device(int* dev) {
+    return (hipGetDevice(dev) != hipSuccess || *dev < 0 || *dev >= 64) ? hipErrorInvalidDevice : hipSuccess;
+}
+template <typename F>
+hipError_t once_per_device(PerDeviceOnce& c, int dev, F&& f) {      // f(int* value) -> hipError_t
+    std::call_once(c.flag[dev], [&] { c.val[dev] = 0; c.err[dev] = f(&c.val[dev]); });
+    return c.err[dev];
+}
+inline hipError_t device_cu_count(int* cus) {                        // CUs of the current device
+    static PerDeviceOnce c;
+    int dev = 0;
+    hipError_t e = current_device(&dev);
+    if (e != hipSuccess) return e;
+    e = once_per_device(c, dev, [&](int* v) { return hipDeviceGetAttribute(v, hipDeviceAttributeMultiprocessorCount, dev); });
+    *cus = c.val[dev];
+    return e;
+}
 
 // Every kernel launch of the library goes through launch_k().  Normally it is a plain launch on the
 // given stream; while a GraphRecorder is installed (grnet.cpp builds the per-forward hipGraph with the
@@ -235,7 +262,7 @@ struct TsAttnWeights {
 size_t tsattn_ws_floats(int b, int n);
 // longest clip the temporal attention takes: its softmax row over the clip's frames lives in LDS ((512 + n) floats <= 160 KB)
 constexpr int kTsAttnMaxFrames = 32768;
-int tsattn_max_frames();
+int tsattn_max_frames();        // min(kTsAttnMaxFrames, what the CURRENT device's LDS per workgroup holds): the up-front refusal matches the device
 // x (b,n,3072) index c*24+j, xs (b,n,3200) index c*25+t -> y (b,n,3072); ws: tsattn_ws_floats(b, n) floats of scratch.
 hipError_t launch_tsattn(const float* x, const float* xs, const TsAttnWeights& w, float* ws, float* y, int b, int n, hipStream_t s);
 

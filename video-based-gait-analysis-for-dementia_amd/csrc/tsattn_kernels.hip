@@ -13,6 +13,8 @@
 // Everything is fp32; reductions run in a fixed order (deterministic).
 #include "kernels.h"
 
+#include <algorithm>
+
 namespace grk {
 
 #define GRK_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return _e; } while (0)
@@ -196,20 +198,37 @@ size_t tsattn_ws_floats(int b, int n) {
     return 2 * R * 3 * kE + 2 * R * kE + 2 * (size_t)b * 2 * kE + 3 * R * kD + 64;
 }
 
-int tsattn_max_frames() { return kTsAttnMaxFrames; }
+// The longest clip the attention kernel takes on the CURRENT device: its query row + softmax row + reduction scratch ((512 + n) floats) must
+// fit the LDS one workgroup may have (160 KB on gfx950 -> kTsAttnMaxFrames; 64 KB parts: 15 872 frames).  Both entry points ask this BEFORE
+// anything is enqueued, so a clip that cannot run is refused with the remedy instead of failing inside the launch.
+static hipError_t device_lds_per_block(int* bytes) {
+    static PerDeviceOnce c;
+    int dev = 0;
+    hipError_t e = current_device(&dev);
+    if (e != hipSuccess) return e;
+    e = once_per_device(c, dev, [&](int* v) { return hipDeviceGetAttribute(v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev); });
+    *bytes = c.val[dev];
+    return e;
+}
+int tsattn_max_frames() {
+    int lds = 0;
+    if (device_lds_per_block(&lds) != hipSuccess || lds <= 0) return 0;
+    const long fit = (long)lds / (long)sizeof(float) - 512;
+    return (int)std::min<long>(kTsAttnMaxFrames, fit > 0 ? fit : 0);
+}
 
 hipError_t launch_tsattn(const float* x, const float* xs, const TsAttnWeights& w, float* ws, float* y, int b, int n, hipStream_t s) {
-    if (b < 1 || n < 1 || n > kTsAttnMaxFrames) return hipErrorInvalidValue;
+    if (b < 1 || n < 1 || n > tsattn_max_frames()) return hipErrorInvalidValue;
     const size_t attn_lds = (size_t)(256 + n + 256) * sizeof(float);       // query row + one softmax row over the n frames of the clip
     if (attn_lds > 64 * 1024) {                                             // clips beyond ~15 800 frames: raise the kernel's dynamic LDS limit once per device
-        static bool attr_done[64] = {};
+        static PerDeviceOnce attr;
         int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-        if (!attr_done[dev]) {
-            GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(temporal_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)((256 + kTsAttnMaxFrames + 256) * sizeof(float))));
-            attr_done[dev] = true;
-        }
+        GRK_TRY(current_device(&dev));
+        const int max_n = tsattn_max_frames();
+        GRK_TRY(once_per_device(attr, dev, [max_n](int*) {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(temporal_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)((256 + max_n + 256) * sizeof(float)));
+        }));
     }
     const size_t R = (size_t)b * n;
     float* qkv_t = ws;
