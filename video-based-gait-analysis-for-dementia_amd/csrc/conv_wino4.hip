@@ -335,6 +335,249 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a) {
 template <int NB, int WD = 56, int ABL = 0, bool WSPLIT = false>
 __global__ __launch_bounds__(256) void conv_wino4_f32(const ConvArgs a) { conv_wino4_body<NB, WD, ABL, WSPLIT>(a); }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv_wino4w_f32: the same F(4x4,3x3) convolution for the WIDE layers on 56x56 maps (output channels in 128s: 480 -> 256, 256 -> 256,
+// 128 -> 128 -- the upsample heads and the PARE head, 0.9 ms of a 3.7 ms step), round 4.  What the 4-wave kernel above loses on them is
+// not the matrix pipe (its chunk loop is ~53 % MFMA) but everything a workgroup does per 64 output channels: the input transform, the
+// raw-row DMA and the chunk skeleton are paid again by every 64-channel workgroup of the same tile row, and with one wave per SIMD every
+// LDS / L2 round trip is dead time.  Here a workgroup is EIGHT waves = 128 output channels on one tile row:
+//   * V (the transformed chunk) is built once and shared by both 64-channel halves: transform and DMA per output channel halve;
+//   * two waves per SIMD: wave w and wave w+4 share a SIMD (waves go to SIMDs cyclically) and run the two halves of an iteration in
+//     OPPOSITE order -- waves 0-3 transform chunk c+1, then multiply chunk c; waves 4-7 multiply first -- so a SIMD's two waves are in
+//     different phases and each one's LDS / memory latencies are covered by the other's MFMAs;
+//   * chunks of 16 input channels (all 512 threads transform: thread = (channel, tile, half of the patch)), one barrier per 16 channels;
+//   * at most 256 registers per wave (two waves per SIMD): hipcc then keeps the 144 accumulators in ordinary VGPRs (no AGPR split), the
+//     B fragments live in a ring of two clusters (48 registers) instead of a whole chunk (72), re-requested right behind their MFMAs.
+// Wave w: points 9 (w & 3) .. + 8, output channels 64 (w >> 2) .. + 63 of the workgroup's 128 (4 accumulator tiles per point).
+// LDS: raw rows [2][16][336] + V [2][36][16][16] = 116.7 KB (one workgroup per CU); the epilogue's [2 halves][36][16][20] reuses it.
+constexpr int kCKW = 16;                              // input channels per chunk
+constexpr int kVW = 36 * kCKW * 16;                   // V[point][channel][16 tile slots]
+constexpr size_t kLdsW = sizeof(float) * (2 * kCKW * kRaw + 2 * kVW);      // 116 736 B
+static_assert(sizeof(float) * 2 * 36 * 16 * kMrow <= kLdsW, "the epilogue tiles reuse the staging area");
+
+__global__ __launch_bounds__(512) void conv_wino4w_f32(const ConvArgs a) {
+    constexpr int WD = 56, TPR = 14, kRawW = kRaw, UPC = kRawW / 4;       // one tile row of 14 tiles, 6 raw rows of 56 per channel
+    extern __shared__ __align__(16) float smem[];
+    float* raw = smem;                                  // [2][16][336]
+    float* V = raw + 2 * kCKW * kRawW;                  // [2][36][16][16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, lq = lane >> 4;
+    const int pg = wave & 3, hf = wave >> 2;            // point group; half of the workgroup's 128 output channels = half of the patch it transforms
+
+    const int id = blockIdx.x;
+    int bx, by;
+    if (a.xcd) {
+        const int j = id >> 3, x = id & 7, q = j / a.gy;
+        by = j - q * a.gy;
+        bx = x * (a.gx >> 3) + q;
+    } else {
+        bx = id / a.gy;
+        by = id - bx * a.gy;
+    }
+    const int groups = a.H >> 2;                        // tile rows per image (14)
+    const int img = bx / groups, r = bx - img * groups;
+    const int co0 = by * 128 + hf * 64;                 // first output channel of this wave; channel n*16 + l sits at l*4 + n of its 64-block
+    const int HW = a.H * a.W;
+    const float* inb = a.in + ((size_t)img * a.in_ctot + a.in_coff) * HW;
+    const int g0 = (4 * r - 1) * WD;                    // plane index of raw[.][0]
+
+    const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, 36 * a.CinPad * a.CoutPad * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, a.Cin * HW * 4, 0x00020000);
+    const int ub = ((pg * 9 * a.CinPad + lq) * a.CoutPad + co0 + l15 * 4) * 4;       // a lane's part of a B-fragment address (bytes)
+    const int u_point = a.CinPad * a.CoutPad * 4, u_kstep = 4 * a.CoutPad * 4, u_chunk = kCKW * a.CoutPad * 4;
+    // B fragments of cluster q of a chunk: q = 2 * (point third t) + (k-step pair kp); entry e = 2 * (point in third) + (k-step in pair)
+    auto load_u = [&](int chunk, int q, int e) -> f32x4 {
+        const int soff = chunk * u_chunk + (3 * (q >> 1) + (e >> 1)) * u_point + (2 * (q & 1) + (e & 1)) * u_kstep;
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, ub, soff, 0));
+    };
+    int roff[3];                                         // raw rows: 1344 units of 16 bytes per chunk; -1 = no unit or a row outside the image
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int u = i * 512 + tid, ch = u / UPC, k = u - ch * UPC, gi = g0 + 4 * k;
+        const bool unit = u < kCKW * UPC, inside = gi >= 0 && gi < HW;
+        roff[i] = unit && inside ? (ch * HW + gi) * 4 : -1;
+        if (unit && !inside) {                           // rows above / below the image: zero once in both buffers, the DMA never writes there
+            *reinterpret_cast<f32x4*>(raw + u * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(raw + kCKW * kRawW + u * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const int cin_real = a.Cin;                          // channels past Cin (480 = 30 chunks exactly; padded layers read zeros through the range check)
+    (void)cin_real;
+    auto issue_raw = [&](int chunk) {
+        const int soff = chunk * (kCKW * 4) * HW;
+        float* dst = raw + (chunk & 1) * (kCKW * kRawW);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (roff[i] >= 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (GRNET_LDS_AS void*)(dst + (i * 512 + wave * 64) * 4), 16, roff[i], soff, 0, 0);
+        asm volatile("" ::: "memory");
+    };
+
+    // ---- input transform: thread = (channel 0..15, tile 0..13 [+ 2 idle lanes], half).  As in the 4-wave kernel, but the column pass runs
+    // while the rows arrive (18 running values instead of the 36-value patch: registers are what two waves per SIMD are short of).
+    const int row16 = tid >> 4, px = tid & 15, chn = row16 & 15;
+    const bool real = px < TPR;
+    const int rpos = chn * kRawW + 4 * (real ? px : TPR - 1);
+    const int slot = real ? px : 14 + (px - 14);
+    const int vpos = (hf * 18) * (kCKW * 16) + chn * 16 + slot;            // + (rr * 6 + c) * 256 for row rr of the half, column c
+    auto transform = [&](const float* rp, float* vp) {
+        float e[3][6];
+        float d[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rp + i * WD);
+            d[i][1] = v[0]; d[i][2] = v[1]; d[i][3] = v[2]; d[i][4] = v[3];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            d[i][0] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d[i][4]), 0x111, 0xf, 0xf, true));                   // row_shr:1
+            d[i][5] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(real ? d[i][1] : 0.f), 0x101, 0xf, 0xf, true));     // row_shl:1
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float col[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
+            if (hf == 0) bt_lo(col, e[0][j], e[1][j], e[2][j]);
+            else bt_hi(col, e[0][j], e[1][j], e[2][j]);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            float o[6];
+            bt_lo(e[rr], o[0], o[1], o[2]);
+            bt_hi(e[rr], o[3], o[4], o[5]);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) vp[(rr * 6 + c) * (kCKW * 16)] = o[c];
+        }
+    };
+
+    f32x4 acc[9][4];                                     // [point of this wave][16-channel block of its 64]
+#pragma unroll
+    for (int p = 0; p < 9; ++p)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[p][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = a.CinPad / kCKW;
+    f32x4 bq[6];                                         // B fragments of ONE cluster; every entry is re-requested for the next cluster right behind its MFMAs
+    float av[2][6];
+    auto load_a = [&](int buf, int q, int set) {         // A fragments of cluster q: points 3 (q >> 1) .. + 2 of this wave, k-steps 2 (q & 1), + 1
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+            const int p = pg * 9 + 3 * (q >> 1) + (e >> 1), ks = 2 * (q & 1) + (e & 1);
+            av[set][e] = V[buf * kVW + p * (kCKW * 16) + (ks * 4 + lq) * 16 + l15];
+        }
+    };
+    // the six clusters of a chunk: 24 MFMAs each (three points x two k-steps x four channel blocks).  Entry e of bq is consumed by four
+    // MFMAs and re-requested at once for the next cluster (of the next chunk after cluster 5): five entries' MFMAs (640 cycles) and the
+    // SIMD's other wave cover the L2 round trip.
+    auto multiply = [&](int buf, int ch, bool more) {
+        load_a(buf, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+#pragma unroll
+            for (int e = 0; e < 6; ++e) landed(av[q & 1][e]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q < 5) load_a(buf, q + 1, (q + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                const int pi = 3 * (q >> 1) + (e >> 1);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[pi][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q & 1][e], bq[e][n], acc[pi][n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q < 5) bq[e] = load_u(ch, q + 1, e);
+                else if (more) bq[e] = load_u(ch + 1, 0, e);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    // thread (half h, channel c of the pass's 16, tile t) of the epilogue: 4 output rows of 4 pixels; the residual rows of a pass are requested a pass ahead
+    const bool has_add = a.n_add == 1;
+    const int eh = tid >> 8, et2 = tid & 255, ec = et2 / 14, et = et2 - ec * 14, eorow = 4 * r;
+    const bool ethread = et2 < 14 * 16;
+    f32x4 radd[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    auto fetch_res = [&](int nt) {
+        const int co = by * 128 + eh * 64 + nt * 16 + ec;
+        if (has_add && ethread && co < a.Cout) {
+            const float* ap = a.add[0] + ((size_t)img * a.add_ctot[0] + a.add_coff[0] + co) * HW + eorow * WD + 4 * et;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) radd[i] = *reinterpret_cast<const f32x4*>(ap + i * WD);
+        }
+    };
+
+    issue_raw(0);
+    if (nchunks > 1) issue_raw(1);
+#pragma unroll
+    for (int e = 0; e < 6; ++e) bq[e] = load_u(0, 0, e);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");        // this wave's shares of raw(0), raw(1) (requested before the 6 weight loads) have landed
+    __syncthreads();
+    // Barrier #k separates "every wave has transformed chunk k" from "any wave multiplies chunk k".  Between two barriers waves 0-3 run
+    // [transform k+1, multiply k] and waves 4-7 [multiply k, transform k+1]: the two waves of a SIMD are never both in their transform, and
+    // each one's LDS / memory latencies are covered by the other's MFMAs.  Written as ONE loop with ONE multiply -- waves 0-3 take the
+    // barrier in front of their transform, waves 4-7 behind it -- because with the two orders spelled out hipcc copied the 144 accumulators
+    // at every merge point and spilled 127 registers.  raw(k + 2) is requested right behind barrier #k (its buffer held chunk k, which every
+    // wave transformed before that barrier) and has landed when its requester reaches barrier #(k + 1).
+    if (hf == 0) transform(raw + rpos, V + vpos);
+    for (int k = 0; k < nchunks; ++k) {
+        if (hf == 0) {
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __syncthreads();
+            if (k + 2 < nchunks) issue_raw(k + 2);
+        }
+        const int tk = k + 1 - hf;                            // the chunk this wave transforms in this iteration
+        if (tk < nchunks) transform(raw + (tk & 1) * (kCKW * kRawW) + rpos, V + (tk & 1) * kVW + vpos);
+        if (hf != 0) {
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __syncthreads();
+            if (k + 2 < nchunks) issue_raw(k + 2);
+        }
+        if (k + 1 == nchunks) fetch_res(0);                  // under the last chunk's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(k & 1, k, k + 1 < nchunks);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue: inverse transform A^T M A, + bias, + residual, ReLU; both 64-channel halves go through LDS together, 16 channels each per pass
+    float* Mx = smem + hf * (36 * 16 * kMrow);           // this wave's half: [36 points][16 channels][20]
+    const float* Mr = smem + eh * (36 * 16 * kMrow);     // the half this thread reads
+    for (int nt = 0; nt < 4; ++nt) {
+        __syncthreads();
+#pragma unroll
+        for (int pi = 0; pi < 9; ++pi) {
+            const f32x4 v = nt == 0 ? acc[pi][0] : nt == 1 ? acc[pi][1] : nt == 2 ? acc[pi][2] : acc[pi][3];
+            *reinterpret_cast<f32x4*>(Mx + ((pg * 9 + pi) * 16 + l15) * kMrow + lq * 4) = v;
+        }
+        __syncthreads();
+        const f32x4 rcur[4] = {radd[0], radd[1], radd[2], radd[3]};
+        if (nt + 1 < 4) fetch_res(nt + 1);
+        if (ethread) {
+            const int co = by * 128 + eh * 64 + nt * 16 + ec;
+            if (co < a.Cout) {
+                float s4[4][6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    float m[6];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) m[i] = Mr[((i * 6 + j) * 16 + ec) * kMrow + et];
+                    const float p12 = m[1] + m[2], m12 = m[1] - m[2], p34 = m[3] + m[4], m34 = m[3] - m[4];
+                    s4[0][j] = m[0] + p12 + p34;
+                    s4[1][j] = fmaf(2.f, m34, m12);
+                    s4[2][j] = fmaf(4.f, p34, p12);
+                    s4[3][j] = fmaf(8.f, m34, m12) + m[5];
+                }
+                const float b = a.bias[co];
+                const size_t obase = ((size_t)img * a.out_ctot + a.out_coff + co) * HW + eorow * WD + 4 * et;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float* q = s4[i];
+                    const float p12 = q[1] + q[2], m12 = q[1] - q[2], p34 = q[3] + q[4], m34 = q[3] - q[4];
+                    f32x4 y = f32x4{q[0] + p12 + p34 + b, fmaf(2.f, m34, m12) + b, fmaf(4.f, p34, p12) + b, fmaf(8.f, m34, m12) + q[5] + b};
+                    if (has_add) y += rcur[i];
+                    if (a.relu) { y[0] = fmaxf(y[0], 0.f); y[1] = fmaxf(y[1], 0.f); y[2] = fmaxf(y[2], 0.f); y[3] = fmaxf(y[3], 0.f); }
+                    *reinterpret_cast<f32x4*>(a.out + obase + i * WD) = y;
+                }
+            }
+        }
+    }
+}
+
 
 }  // namespace
 
@@ -342,6 +585,8 @@ __global__ __launch_bounds__(256) void conv_wino4_f32(const ConvArgs a) { conv_w
 // 32-channel workgroups double a grid that would otherwise be 64 workgroups for 256 CUs (in context, 16 frames: 3 693 frames/s
 // against 3 310 with 64-channel workgroups there)
 int conv_wino4_blocks(int cout, int w) { return (cout % 64 == 0 && !(w == 28 && cout == 64)) ? 4 : 2; }
+// eight-wave workgroups of 128 output channels (conv_wino4w_f32): the 56x56 layers whose output channels come in 128s
+bool conv_wino4_wide(int cout, int w) { return w == 56 && cout % 128 == 0; }
 
 bool conv_wino4_eligible(int cin, int cout, int ks, int stride, int h, int w, int n_add) {
     return ks == 3 && stride == 1 && ((h == 56 && w == 56) || (h == 28 && w == 28)) && n_add <= 1 && cin % kCK == 0 && cout % 32 == 0 && cin >= 32;
@@ -394,11 +639,23 @@ hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s, int* n_launches) {
             auto set = [&](auto kern) { if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsB); };
             set(conv_wino4_f32<4, 56>); set(conv_wino4_f32<2, 56>); set(conv_wino4_f32<4, 28>); set(conv_wino4_f32<2, 28>);
             set(conv_wino4_f32<2, 56, 0, true>); set(conv_wino4_f32<2, 28, 0, true>);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4w_f32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsW);
             return e;
         }); e != hipSuccess) return e;
     const int nb = conv_wino4_blocks(a.Cout, a.W);
     if (!conv_wino4_eligible(a.Cin, a.Cout, a.ks, a.stride, a.H, a.W, a.n_add) || a.CinPad % kCK != 0 || a.CoutPad % (nb * 16) != 0) return hipErrorInvalidValue;
     if (a.n_add == 1 && a.add_shift[0] != 0) return hipErrorInvalidValue;
+    // the wide layers of the 56x56 maps (output channels in 128s): eight-wave workgroups, conv_wino4w_f32.  GRNET_WINO_WIDE=0: the 4-wave kernel (A/B)
+    static const int wide_env = getenv("GRNET_WINO_WIDE") ? atoi(getenv("GRNET_WINO_WIDE")) : 1;
+    if (wide_env && conv_wino4_wide(a.Cout, a.W) && a.CinPad % kCKW == 0 && a.CoutPad % 128 == 0 && !(a.dbg & 32)) {
+        a.gx = a.N * (a.H >> 2);
+        a.gy = a.CoutPad / 128;
+        a.xcd = a.gx % 8 == 0 && a.gx >= 16 ? 1 : 0;
+        a.blk0 = 0;
+        a.wsplit = 0;
+        if (n_launches) *n_launches = 1;
+        return launch_k(conv_wino4w_f32, dim3(a.gx * a.gy), dim3(512), kLdsW, s, a);
+    }
 #ifdef GRNET_ABLATION
     if (getenv("GRNET_W4_PHASES")) {
         a.dbg |= 8;

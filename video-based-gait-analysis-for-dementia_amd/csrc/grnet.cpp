@@ -1304,7 +1304,12 @@ struct grnet {
             case K_WINO4S: snprintf(b, sizeof b, "conv_wino4s_f32<%d,%d>", L.in.w, L.in.c); return b;
             case K_PW: snprintf(b, sizeof b, "conv_pw_f32<%d>", L.in.c); return b;
             case K_STEM: return "conv_stem_f32";
-            case K_WINO4: snprintf(b, sizeof b, "conv_wino4_f32<%d,%d>", conv_wino4_blocks(L.cout, L.in.w), L.in.w); return b;
+            case K_WINO4: {
+                static const int wide_env = getenv("GRNET_WINO_WIDE") ? atoi(getenv("GRNET_WINO_WIDE")) : 1;
+                if (wide_env && conv_wino4_wide(L.cout, L.in.w) && L.cin_pad % 16 == 0 && L.cout_pad % 128 == 0) return "conv_wino4w_f32";
+                snprintf(b, sizeof b, "conv_wino4_f32<%d,%d>", conv_wino4_blocks(L.cout, L.in.w), L.in.w);
+                return b;
+            }
             default: snprintf(b, sizeof b, "conv_direct_f32 %dx%d s%d", L.ks, L.ks, L.stride); return b;
         }
     }
@@ -2154,6 +2159,7 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
     if (const char* d = getenv("GRNET_CONV_DBG")) a.dbg = atoi(d);
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* ud = nullptr;
+    if (tile_hint == 2003) { tile_hint = 2001; a.dbg |= 32; }   // 2003: the 4-wave F(4x4,3x3) kernel also where the 8-wave one would run
     if (tile_hint == 2001) {                                   // the F(4x4,3x3) kernel on this one convolution
         if (!conv_wino4_eligible(cin, cout, ks, stride, hgt, wid, add_dev ? 1 : 0) || cin_pad % 8 != 0 || cout_pad % (cout % 64 == 0 ? 64 : 32) != 0) {
             hipFree(wd); hipFree(bd);
