@@ -191,19 +191,22 @@ def test_attention_block_large_lds_branch_17000_frames(pkg, oracle):
     m.close()
 
 
-@pytest.mark.parametrize("case", [(16, 480, 256), (3, 256, 256), (1, 128, 128), (5, 32, 256), (4, 48, 128), (2, 64, 384)], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("case", [(16, 480, 256, 56), (3, 256, 256, 56), (1, 128, 128, 56), (5, 32, 256, 56), (4, 48, 128, 56), (2, 64, 384, 56),
+                                  (4, 64, 64, 56), (16, 64, 64, 28), (5, 256, 256, 28)],
+                         ids=lambda c: "x".join(map(str, c)))
 def test_wide_winograd_kernel_eight_waves(model, oracle, case):
-    """conv_wino4w_f32 (F(4x4,3x3), eight waves = 128 output channels per workgroup sharing one transformed chunk, 16-channel chunks, the two
-    waves of a SIMD in opposite phases) vs the oracle's direct convolution: the three layer shapes it runs in the path (480 -> 256 at 16
-    frames = 448 workgroups, 256 -> 256, 128 -> 128), two chunks (32 channels), an odd chunk count (48), three channel blocks (384); bias
-    + ReLU, + residual, the linear form with the borders looked at separately, bit-identical repeats, and agreement with the 4-wave kernel
-    (hint 2003) to re-association noise.  Bound 1e-4 of the output scale as for the other F(4x4,3x3) kernels."""
-    n, cin, cout = case
-    g = np.random.Generator(np.random.Philox(key=[94, n * 100000 + cin * 1000 + cout]))
-    x = g.standard_normal((n, cin, 56, 56)).astype(np.float32)
+    """conv_wino4w_f32 (F(4x4,3x3), eight waves per workgroup sharing one transformed chunk, 16-channel chunks, the two waves of a SIMD in
+    opposite phases) vs the oracle's direct convolution.  128 output channels per workgroup: the three 56x56 layer shapes of the heads
+    (480 -> 256 at 16 frames = 448 workgroups, 256 -> 256, 128 -> 128), two chunks (32 channels), an odd chunk count (48), three channel
+    blocks (384).  The last three shapes run the eight-wave kernel only under GRNET_WINO_WIDE bits 1-3 (64 channels per workgroup, 28x28
+    maps: measured and left off, conv_wino4_wide) -- by default they repeat the 4-wave kernel's check on the same data.  Bias + ReLU, + residual, the linear form with the borders looked at separately, bit-identical repeats, and agreement with
+    the 4-wave kernel (hint 2003) to re-association noise.  Bound 1e-4 of the output scale as for the other F(4x4,3x3) kernels."""
+    n, cin, cout, hw = case
+    g = np.random.Generator(np.random.Philox(key=[94, n * 100000 + cin * 1000 + cout + hw]))
+    x = g.standard_normal((n, cin, hw, hw)).astype(np.float32)
     w = (g.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (cin * 9))).astype(np.float32)
     b = (g.standard_normal((cout,)) * 0.1).astype(np.float32)
-    r = g.standard_normal((n, cout, 56, 56)).astype(np.float32)
+    r = g.standard_normal((n, cout, hw, hw)).astype(np.float32)
     conv = oracle.conv2d(x, w, stride=1, bias=b)
     xd, rd = torch.from_numpy(x).cuda(), torch.from_numpy(r).cuda()
     got = model.op_conv2d(xd, w, b, stride=1, relu=True, tile_hint=2001).cpu().numpy()
@@ -216,6 +219,6 @@ def test_wide_winograd_kernel_eight_waves(model, oracle, case):
     lin = oracle.conv2d(x, w, stride=1).numpy()
     got = model.op_conv2d(xd, w, None, stride=1, relu=False, tile_hint=2001).cpu().numpy()
     assert rel_err(got, lin) < 1e-4
-    assert rel_err(got[:, :, [0, 55]], lin[:, :, [0, 55]]) < 1e-4 and rel_err(got[..., [0, 55]], lin[..., [0, 55]]) < 1e-4
+    assert rel_err(got[:, :, [0, hw - 1]], lin[:, :, [0, hw - 1]]) < 1e-4 and rel_err(got[..., [0, hw - 1]], lin[..., [0, hw - 1]]) < 1e-4
     again = model.op_conv2d(xd, w, None, stride=1, relu=False, tile_hint=2001).cpu().numpy()
     assert np.array_equal(got, again)

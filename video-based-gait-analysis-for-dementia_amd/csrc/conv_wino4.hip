@@ -352,16 +352,24 @@ __global__ __launch_bounds__(256) void conv_wino4_f32(const ConvArgs a) { conv_w
 // LDS: raw rows [2][16][336] + V [2][36][16][16] = 116.7 KB (one workgroup per CU); the epilogue's [2 halves][36][16][20] reuses it.
 constexpr int kCKW = 16;                              // input channels per chunk
 constexpr int kVW = 36 * kCKW * 16;                   // V[point][channel][16 tile slots]
-constexpr size_t kLdsW = sizeof(float) * (2 * kCKW * kRaw + 2 * kVW);      // 116 736 B
+constexpr size_t kLdsW = sizeof(float) * (2 * kCKW * kRaw + 2 * kVW);      // 116 736 B (56-wide maps; 28-wide ones need less and take the same)
 static_assert(sizeof(float) * 2 * 36 * 16 * kMrow <= kLdsW, "the epilogue tiles reuse the staging area");
 
-__global__ __launch_bounds__(512) void conv_wino4w_f32(const ConvArgs a) {
-    constexpr int WD = 56, TPR = 14, kRawW = kRaw, UPC = kRawW / 4;       // one tile row of 14 tiles, 6 raw rows of 56 per channel
+// WD: map width, 56 (one tile row of 14 tiles) or 28 (two tile rows of 7, as in the 4-wave kernel).  NPW: 16-channel blocks per wave:
+// 4 = 128 output channels per workgroup, 2 = 64 (the 64 -> 64 layers: HR branch 1 on 28x28 maps -- until round 4 two 32-channel
+// workgroups, each transforming the same input -- and layer1 / the first upsample head on 56x56 maps).  Weights are packed as for the
+// 4-wave kernel's 64-channel blocks: a lane's 16 bytes hold its channel of the four 16-channel blocks; with NPW = 2 a wave reads its 8.
+template <int WD, int NPW>
+__device__ __forceinline__ void conv_wino4w_body(const ConvArgs& a) {
+    constexpr int TPR = WD / 4, TRG = 14 / TPR, kRawW = (4 * TRG + 2) * WD, UPC = kRawW / 4;   // tiles per tile row, tile rows per workgroup, raw floats / units per channel
+    constexpr int COUTW = 2 * NPW * 16;                  // output channels per workgroup
+    static_assert((WD == 56 || WD == 28) && (NPW == 4 || NPW == 2), "geometry");
+    typedef float bfrag __attribute__((ext_vector_type(NPW)));
     extern __shared__ __align__(16) float smem[];
-    float* raw = smem;                                  // [2][16][336]
-    float* V = raw + 2 * kCKW * kRawW;                  // [2][36][16][16]
+    float* raw = smem;                                  // [2][16][kRawW]
+    float* V = raw + 2 * kCKW * kRaw;                   // [2][36][16][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, lq = lane >> 4;
-    const int pg = wave & 3, hf = wave >> 2;            // point group; half of the workgroup's 128 output channels = half of the patch it transforms
+    const int pg = wave & 3, hf = wave >> 2;            // point group; half of the workgroup's output channels = half of the patch it transforms
 
     const int id = blockIdx.x;
     int bx, by;
@@ -373,25 +381,31 @@ __global__ __launch_bounds__(512) void conv_wino4w_f32(const ConvArgs a) {
         bx = id / a.gy;
         by = id - bx * a.gy;
     }
-    const int groups = a.H >> 2;                        // tile rows per image (14)
+    const int groups = ((a.H >> 2) + TRG - 1) / TRG;     // tile-row groups per image (14 or 4)
     const int img = bx / groups, r = bx - img * groups;
-    const int co0 = by * 128 + hf * 64;                 // first output channel of this wave; channel n*16 + l sits at l*4 + n of its 64-block
+    // first output channel of this wave and where it sits in the packed weights: channel n*16 + l of a 64-block is at l*4 + n
+    const int co0 = by * COUTW + hf * (NPW * 16);
+    const int wpos = NPW == 4 ? co0 : (co0 & ~63) + ((co0 >> 5) & 1) * 2;
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (a.prio >= 2) __builtin_amdgcn_s_setprio(3);
     const int HW = a.H * a.W;
     const float* inb = a.in + ((size_t)img * a.in_ctot + a.in_coff) * HW;
-    const int g0 = (4 * r - 1) * WD;                    // plane index of raw[.][0]
+    const int g0 = (4 * TRG * r - 1) * WD;               // plane index of raw[.][0]
 
     const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, 36 * a.CinPad * a.CoutPad * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, a.Cin * HW * 4, 0x00020000);
-    const int ub = ((pg * 9 * a.CinPad + lq) * a.CoutPad + co0 + l15 * 4) * 4;       // a lane's part of a B-fragment address (bytes)
+    const int ub = ((pg * 9 * a.CinPad + lq) * a.CoutPad + wpos + l15 * 4) * 4;       // a lane's part of a B-fragment address (bytes)
     const int u_point = a.CinPad * a.CoutPad * 4, u_kstep = 4 * a.CoutPad * 4, u_chunk = kCKW * a.CoutPad * 4;
     // B fragments of cluster q of a chunk: q = 2 * (point third t) + (k-step pair kp); entry e = 2 * (point in third) + (k-step in pair)
-    auto load_u = [&](int chunk, int q, int e) -> f32x4 {
+    auto load_u = [&](int chunk, int q, int e) -> bfrag {
         const int soff = chunk * u_chunk + (3 * (q >> 1) + (e >> 1)) * u_point + (2 * (q & 1) + (e & 1)) * u_kstep;
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, ub, soff, 0));
+        if constexpr (NPW == 4) return __builtin_bit_cast(bfrag, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, ub, soff, 0));
+        else return __builtin_bit_cast(bfrag, __builtin_amdgcn_raw_buffer_load_b64(u_rsrc, ub, soff, 0));
     };
-    int roff[3];                                         // raw rows: 1344 units of 16 bytes per chunk; -1 = no unit or a row outside the image
+    constexpr int NRU = (kCKW * UPC + 511) / 512;        // 16-byte units of a chunk's raw rows per thread (3)
+    int roff[NRU];                                       // -1 = no unit or a row outside the image
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NRU; ++i) {
         const int u = i * 512 + tid, ch = u / UPC, k = u - ch * UPC, gi = g0 + 4 * k;
         const bool unit = u < kCKW * UPC, inside = gi >= 0 && gi < HW;
         roff[i] = unit && inside ? (ch * HW + gi) * 4 : -1;
@@ -400,23 +414,22 @@ __global__ __launch_bounds__(512) void conv_wino4w_f32(const ConvArgs a) {
             *reinterpret_cast<f32x4*>(raw + kCKW * kRawW + u * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
-    const int cin_real = a.Cin;                          // channels past Cin (480 = 30 chunks exactly; padded layers read zeros through the range check)
-    (void)cin_real;
     auto issue_raw = [&](int chunk) {
         const int soff = chunk * (kCKW * 4) * HW;
         float* dst = raw + (chunk & 1) * (kCKW * kRawW);
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < NRU; ++i)
             if (roff[i] >= 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (GRNET_LDS_AS void*)(dst + (i * 512 + wave * 64) * 4), 16, roff[i], soff, 0, 0);
         asm volatile("" ::: "memory");
     };
 
-    // ---- input transform: thread = (channel 0..15, tile 0..13 [+ 2 idle lanes], half).  As in the 4-wave kernel, but the column pass runs
-    // while the rows arrive (18 running values instead of the 36-value patch: registers are what two waves per SIMD are short of).
+    // ---- input transform: thread = (channel 0..15, tile slot 0..15, half), as in the 4-wave kernel (WD = 28: the 16 lanes are two tile rows of
+    // 7 tiles + 1 idle lane each; idle lanes supply the zero on both sides there)
     const int row16 = tid >> 4, px = tid & 15, chn = row16 & 15;
-    const bool real = px < TPR;
-    const int rpos = chn * kRawW + 4 * (real ? px : TPR - 1);
-    const int slot = real ? px : 14 + (px - 14);
+    const int pc = WD == 56 ? px : (px & 7), trl = WD == 56 ? 0 : (px >> 3);
+    const bool real = pc < TPR;
+    const int rpos = chn * kRawW + (4 * trl) * WD + 4 * (real ? pc : TPR - 1);
+    const int slot = real ? trl * TPR + pc : 14 + (WD == 56 ? px - 14 : trl);
     const int vpos = (hf * 18) * (kCKW * 16) + chn * 16 + slot;            // + (rr * 6 + c) * 256 for row rr of the half, column c
     auto transform = [&](const float* rp, float* vp) {
         float e[3][6];
@@ -428,8 +441,8 @@ __global__ __launch_bounds__(512) void conv_wino4w_f32(const ConvArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            d[i][0] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d[i][4]), 0x111, 0xf, 0xf, true));                   // row_shr:1
-            d[i][5] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(real ? d[i][1] : 0.f), 0x101, 0xf, 0xf, true));     // row_shl:1
+            d[i][0] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(WD == 56 || real ? d[i][4] : 0.f), 0x111, 0xf, 0xf, true));   // row_shr:1
+            d[i][5] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(real ? d[i][1] : 0.f), 0x101, 0xf, 0xf, true));               // row_shl:1
         }
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -447,14 +460,14 @@ __global__ __launch_bounds__(512) void conv_wino4w_f32(const ConvArgs a) {
         }
     };
 
-    f32x4 acc[9][4];                                     // [point of this wave][16-channel block of its 64]
+    f32x4 acc[9][NPW];                                   // [point of this wave][16-channel block of its half]
 #pragma unroll
     for (int p = 0; p < 9; ++p)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[p][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NPW; ++n) acc[p][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nchunks = a.CinPad / kCKW;
-    f32x4 bq[6];                                         // B fragments of ONE cluster; every entry is re-requested for the next cluster right behind its MFMAs
+    bfrag bq[6];                                         // B fragments of ONE cluster; every entry is re-requested for the next cluster right behind its MFMAs
     float av[2][6];
     auto load_a = [&](int buf, int q, int set) {         // A fragments of cluster q: points 3 (q >> 1) .. + 2 of this wave, k-steps 2 (q & 1), + 1
 #pragma unroll
@@ -463,9 +476,9 @@ __global__ __launch_bounds__(512) void conv_wino4w_f32(const ConvArgs a) {
             av[set][e] = V[buf * kVW + p * (kCKW * 16) + (ks * 4 + lq) * 16 + l15];
         }
     };
-    // the six clusters of a chunk: 24 MFMAs each (three points x two k-steps x four channel blocks).  Entry e of bq is consumed by four
-    // MFMAs and re-requested at once for the next cluster (of the next chunk after cluster 5): five entries' MFMAs (640 cycles) and the
-    // SIMD's other wave cover the L2 round trip.
+    // the six clusters of a chunk: 6 x NPW MFMAs each (three points x two k-steps x NPW channel blocks).  Entry e of bq is consumed by NPW
+    // MFMAs and re-requested at once for the next cluster (of the next chunk after cluster 5): the other entries' MFMAs and the SIMD's
+    // other wave cover the L2 round trip.
     auto multiply = [&](int buf, int ch, bool more) {
         load_a(buf, 0, 0);
 #pragma unroll
@@ -479,7 +492,7 @@ __global__ __launch_bounds__(512) void conv_wino4w_f32(const ConvArgs a) {
             for (int e = 0; e < 6; ++e) {
                 const int pi = 3 * (q >> 1) + (e >> 1);
 #pragma unroll
-                for (int n = 0; n < 4; ++n) acc[pi][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q & 1][e], bq[e][n], acc[pi][n], 0, 0, 0);
+                for (int n = 0; n < NPW; ++n) acc[pi][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q & 1][e], bq[e][n], acc[pi][n], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (q < 5) bq[e] = load_u(ch, q + 1, e);
                 else if (more) bq[e] = load_u(ch + 1, 0, e);
@@ -490,13 +503,13 @@ __global__ __launch_bounds__(512) void conv_wino4w_f32(const ConvArgs a) {
 
     // thread (half h, channel c of the pass's 16, tile t) of the epilogue: 4 output rows of 4 pixels; the residual rows of a pass are requested a pass ahead
     const bool has_add = a.n_add == 1;
-    const int eh = tid >> 8, et2 = tid & 255, ec = et2 / 14, et = et2 - ec * 14, eorow = 4 * r;
-    const bool ethread = et2 < 14 * 16;
+    const int eh = tid >> 8, et2 = tid & 255, ec = et2 / 14, et = et2 - ec * 14, etro = et / TPR, etx = et - etro * TPR, eorow = 4 * (TRG * r + etro);
+    const bool ethread = et2 < 14 * 16 && eorow < a.H;
     f32x4 radd[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     auto fetch_res = [&](int nt) {
-        const int co = by * 128 + eh * 64 + nt * 16 + ec;
+        const int co = by * COUTW + eh * (NPW * 16) + nt * 16 + ec;
         if (has_add && ethread && co < a.Cout) {
-            const float* ap = a.add[0] + ((size_t)img * a.add_ctot[0] + a.add_coff[0] + co) * HW + eorow * WD + 4 * et;
+            const float* ap = a.add[0] + ((size_t)img * a.add_ctot[0] + a.add_coff[0] + co) * HW + eorow * WD + 4 * etx;
 #pragma unroll
             for (int i = 0; i < 4; ++i) radd[i] = *reinterpret_cast<const f32x4*>(ap + i * WD);
         }
@@ -534,21 +547,23 @@ __global__ __launch_bounds__(512) void conv_wino4w_f32(const ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    // ---- epilogue: inverse transform A^T M A, + bias, + residual, ReLU; both 64-channel halves go through LDS together, 16 channels each per pass
+    // ---- epilogue: inverse transform A^T M A, + bias, + residual, ReLU; both halves go through LDS together, 16 channels each per pass
     float* Mx = smem + hf * (36 * 16 * kMrow);           // this wave's half: [36 points][16 channels][20]
     const float* Mr = smem + eh * (36 * 16 * kMrow);     // the half this thread reads
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int nt = 0; nt < NPW; ++nt) {
         __syncthreads();
 #pragma unroll
         for (int pi = 0; pi < 9; ++pi) {
-            const f32x4 v = nt == 0 ? acc[pi][0] : nt == 1 ? acc[pi][1] : nt == 2 ? acc[pi][2] : acc[pi][3];
+            f32x4 v;
+            if constexpr (NPW == 4) v = nt == 0 ? acc[pi][0] : nt == 1 ? acc[pi][1] : nt == 2 ? acc[pi][2] : acc[pi][3];
+            else v = nt == 0 ? acc[pi][0] : acc[pi][1];
             *reinterpret_cast<f32x4*>(Mx + ((pg * 9 + pi) * 16 + l15) * kMrow + lq * 4) = v;
         }
         __syncthreads();
         const f32x4 rcur[4] = {radd[0], radd[1], radd[2], radd[3]};
-        if (nt + 1 < 4) fetch_res(nt + 1);
+        if (nt + 1 < NPW) fetch_res(nt + 1);
         if (ethread) {
-            const int co = by * 128 + eh * 64 + nt * 16 + ec;
+            const int co = by * COUTW + eh * (NPW * 16) + nt * 16 + ec;
             if (co < a.Cout) {
                 float s4[4][6];
 #pragma unroll
@@ -563,7 +578,7 @@ __global__ __launch_bounds__(512) void conv_wino4w_f32(const ConvArgs a) {
                     s4[3][j] = fmaf(8.f, m34, m12) + m[5];
                 }
                 const float b = a.bias[co];
-                const size_t obase = ((size_t)img * a.out_ctot + a.out_coff + co) * HW + eorow * WD + 4 * et;
+                const size_t obase = ((size_t)img * a.out_ctot + a.out_coff + co) * HW + eorow * WD + 4 * etx;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float* q = s4[i];
@@ -578,15 +593,27 @@ __global__ __launch_bounds__(512) void conv_wino4w_f32(const ConvArgs a) {
     }
 }
 
+template <int WD, int NPW>
+__global__ __launch_bounds__(512) void conv_wino4w_f32(const ConvArgs a) { conv_wino4w_body<WD, NPW>(a); }
 
 }  // namespace
 
 // 16-channel blocks per workgroup: 4 where the output channels come in 64s -- except for exactly 64 channels on a 28x28 map, where
 // 32-channel workgroups double a grid that would otherwise be 64 workgroups for 256 CUs (in context, 16 frames: 3 693 frames/s
 // against 3 310 with 64-channel workgroups there)
-int conv_wino4_blocks(int cout, int w) { return (cout % 64 == 0 && !(w == 28 && cout == 64)) ? 4 : 2; }
-// eight-wave workgroups of 128 output channels (conv_wino4w_f32): the 56x56 layers whose output channels come in 128s
-bool conv_wino4_wide(int cout, int w) { return w == 56 && cout % 128 == 0; }
+// Eight-wave workgroups (conv_wino4w_f32): 16-channel blocks per wave, 0 = the 4-wave kernel.  GRNET_WINO_WIDE is a mask (default 1):
+// bit 0 the 56x56 layers whose output channels come in 128s (upsample heads, PARE head): 480 -> 256 459 -> 357 us, 256 -> 256 264 -> 202,
+// 128 -> 128 78 -> 57 at 16 frames, the step 3.71 -> 3.52 ms.  The other shapes the kernel is instantiated for were measured and stay off:
+// bit 1 the 64 -> 64 layers of HR branch 1 on 28x28 maps (64 workgroups instead of 128: 18.7 us alone against 15.6, the step 3.53 -> 3.74 ms --
+// the branch chains need the short launches), bit 2 the 28x28 layers with output channels in 128s (half the CUs: 95 / 51 us against 74 / 39,
+// step unchanged), bit 3 the 64-channel layers on 56x56 maps (21.6 us alone against 24.2, but 3.530 -> 3.549 ms in the step).
+int conv_wino4_wide(int cout, int w) {
+    static const int wide_env = getenv("GRNET_WINO_WIDE") ? atoi(getenv("GRNET_WINO_WIDE")) : 1;
+    if (w == 56) return cout % 128 == 0 ? ((wide_env & 1) ? 4 : 0) : cout == 64 ? ((wide_env & 8) ? 2 : 0) : 0;
+    if (w == 28) return cout % 128 == 0 ? ((wide_env & 4) ? 4 : 0) : cout == 64 ? ((wide_env & 2) ? 2 : 0) : 0;
+    return 0;
+}
+int conv_wino4_blocks(int cout, int w) { return (cout % 64 == 0 && !(w == 28 && cout == 64 && !conv_wino4_wide(cout, w))) ? 4 : 2; }
 
 bool conv_wino4_eligible(int cin, int cout, int ks, int stride, int h, int w, int n_add) {
     return ks == 3 && stride == 1 && ((h == 56 && w == 56) || (h == 28 && w == 28)) && n_add <= 1 && cin % kCK == 0 && cout % 32 == 0 && cin >= 32;
@@ -639,22 +666,26 @@ hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s, int* n_launches) {
             auto set = [&](auto kern) { if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsB); };
             set(conv_wino4_f32<4, 56>); set(conv_wino4_f32<2, 56>); set(conv_wino4_f32<4, 28>); set(conv_wino4_f32<2, 28>);
             set(conv_wino4_f32<2, 56, 0, true>); set(conv_wino4_f32<2, 28, 0, true>);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4w_f32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsW);
+            auto setw = [&](auto kern) { if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsW); };
+            setw(conv_wino4w_f32<56, 4>); setw(conv_wino4w_f32<56, 2>); setw(conv_wino4w_f32<28, 4>); setw(conv_wino4w_f32<28, 2>);
             return e;
         }); e != hipSuccess) return e;
     const int nb = conv_wino4_blocks(a.Cout, a.W);
     if (!conv_wino4_eligible(a.Cin, a.Cout, a.ks, a.stride, a.H, a.W, a.n_add) || a.CinPad % kCK != 0 || a.CoutPad % (nb * 16) != 0) return hipErrorInvalidValue;
     if (a.n_add == 1 && a.add_shift[0] != 0) return hipErrorInvalidValue;
-    // the wide layers of the 56x56 maps (output channels in 128s): eight-wave workgroups, conv_wino4w_f32.  GRNET_WINO_WIDE=0: the 4-wave kernel (A/B)
-    static const int wide_env = getenv("GRNET_WINO_WIDE") ? atoi(getenv("GRNET_WINO_WIDE")) : 1;
-    if (wide_env && conv_wino4_wide(a.Cout, a.W) && a.CinPad % kCKW == 0 && a.CoutPad % 128 == 0 && !(a.dbg & 32)) {
-        a.gx = a.N * (a.H >> 2);
-        a.gy = a.CoutPad / 128;
+    // eight-wave workgroups (conv_wino4w_f32) where the layer's shape has them; test hint 2003 (dbg bit 5) forces the 4-wave kernel
+    const int npw = conv_wino4_wide(a.Cout, a.W);
+    if (npw && a.CinPad % kCKW == 0 && a.CoutPad % (npw * 32) == 0 && !(a.dbg & 32)) {
+        const int trg = a.W == 56 ? 1 : 2;
+        a.gx = a.N * (((a.H >> 2) + trg - 1) / trg);
+        a.gy = a.CoutPad / (npw * 32);
         a.xcd = a.gx % 8 == 0 && a.gx >= 16 ? 1 : 0;
         a.blk0 = 0;
         a.wsplit = 0;
         if (n_launches) *n_launches = 1;
-        return launch_k(conv_wino4w_f32, dim3(a.gx * a.gy), dim3(512), kLdsW, s, a);
+        const dim3 grid(a.gx * a.gy);
+        if (a.W == 56) return npw == 4 ? launch_k(conv_wino4w_f32<56, 4>, grid, dim3(512), kLdsW, s, a) : launch_k(conv_wino4w_f32<56, 2>, grid, dim3(512), kLdsW, s, a);
+        return npw == 4 ? launch_k(conv_wino4w_f32<28, 4>, grid, dim3(512), kLdsW, s, a) : launch_k(conv_wino4w_f32<28, 2>, grid, dim3(512), kLdsW, s, a);
     }
 #ifdef GRNET_ABLATION
     if (getenv("GRNET_W4_PHASES")) {

@@ -1305,9 +1305,9 @@ struct grnet {
             case K_PW: snprintf(b, sizeof b, "conv_pw_f32<%d>", L.in.c); return b;
             case K_STEM: return "conv_stem_f32";
             case K_WINO4: {
-                static const int wide_env = getenv("GRNET_WINO_WIDE") ? atoi(getenv("GRNET_WINO_WIDE")) : 1;
-                if (wide_env && conv_wino4_wide(L.cout, L.in.w) && L.cin_pad % 16 == 0 && L.cout_pad % 128 == 0) return "conv_wino4w_f32";
-                snprintf(b, sizeof b, "conv_wino4_f32<%d,%d>", conv_wino4_blocks(L.cout, L.in.w), L.in.w);
+                const int npw = conv_wino4_wide(L.cout, L.in.w);
+                if (npw && L.cin_pad % 16 == 0 && L.cout_pad % (npw * 32) == 0) snprintf(b, sizeof b, "conv_wino4w_f32<%d,%d>", L.in.w, npw);
+                else snprintf(b, sizeof b, "conv_wino4_f32<%d,%d>", conv_wino4_blocks(L.cout, L.in.w), L.in.w);
                 return b;
             }
             default: snprintf(b, sizeof b, "conv_direct_f32 %dx%d s%d", L.ks, L.ks, L.stride); return b;
@@ -1339,7 +1339,7 @@ struct grnet {
                 static const int chain_prio4 = getenv("GRNET_WINO_PRIO") ? atoi(getenv("GRNET_WINO_PRIO")) : 1;
                 // the BasicBlock chains of the 56x56 and 28x28 HR branches (32-channel workgroups): wave priority 1.  Worth +1 % when
                 // only the 56x56 chain ran on a Winograd kernel; with both on F(4x4,3x3) every combination is within 0.5 %
-                wa.prio = (L.in.c == L.cout && conv_wino4_blocks(L.cout, L.in.w) == 2) ? chain_prio4 : 0;
+                wa.prio = (L.in.c == L.cout && L.cout <= 64 && !L.solo) ? chain_prio4 : 0;
                 HIP_TRY(launch_conv_wino4(wa, s, n_launches));
                 break;
             }

@@ -126,7 +126,8 @@ bool conv_wino4_eligible(int cin, int cout, int ks, int stride, int h, int w, in
 hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s, int* n_launches = nullptr);     // a.w = transformed weights [36][CinPad][CoutPad]
 void pack_wino4_weights(const double* w_folded /* (cout,cin,3,3) */, int cout, int cin, int cin_pad, int cout_pad, float* out, int map_width = 56);
 int conv_wino4_blocks(int cout, int map_width);   // 16-channel blocks per workgroup of that layer (4 or 2)
-bool conv_wino4_wide(int cout, int map_width);    // the layer runs conv_wino4w_f32 (eight waves, 128 output channels per workgroup; weights packed as for 4 blocks)
+int conv_wino4_wide(int cout, int map_width);     // > 0: the layer runs conv_wino4w_f32 (eight waves) with that many 16-channel blocks per wave (4: 128 output channels per
+                                                  // workgroup, 2: 64); weights packed as for 4 blocks
 
 void wino4_transform_filter(const double* g33, double* u36);   // U = G g G^T of F(4x4,3x3) in fp64
 // ---- register-resident F(4x4,3x3) for the small maps (conv_wino4s.hip): 128 -> 128 @14x14, 256 -> 256 @7x7 (HR branches 2, 3), 256 -> 256 @14x14
