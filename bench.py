@@ -60,6 +60,7 @@ def parse_args(argv=None):
                     "per-frame records, then the temporal branch (GRU + attention + second head pass) on the whole sequence; a step is the whole job (strong scaling)")
     ap.add_argument("--total-frames", type=int, default=10000, help="batchgen: frames of the whole job")
     ap.add_argument("--chunk", type=int, default=128, help="batchgen: frames per grnet_forward call")
+    ap.add_argument("--no-kernel-table", action="store_true", help="skip roofline.dominant_kernel (its per-shape timing launches would sit in a profiler's dispatch list)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the bf16 256-frame leg (BASELINE configs[2]) that the default 1-GPU fp32 run appends as `secondary`")
     a = ap.parse_args(argv)
     if a.steps is None:
@@ -367,7 +368,7 @@ class GpuWorkload:
             for c in model.describe_convs():
                 alg_bytes += 4 * (n * (c["cin"] * c["hin"] * c["win"] + c["cout"] * c["hout"] * c["wout"] + c["add_elems"]) + c["ks"] * c["ks"] * c["cin"] * c["cout"])
         extra = stored_traffic(n, self.args.dtype, alg_bytes)
-        if self.rank == 0 and not getattr(self.args, "light", False):
+        if self.rank == 0 and not getattr(self.args, "light", False) and not getattr(self.args, "no_kernel_table", False):
             extra["dominant_kernel"], extra["kernels_by_time_alone"] = kernel_objects(model.kernel_table(n), self.args.dtype)
         return roofline_object(fps_per_gpu, self.args.dtype, model.conv_flops_per_frame(), conv_ms, conv_ms_serial,
                                model.num_conv_launches(), n, extra,

@@ -11,8 +11,8 @@ export TMPDIR=/tmp
 DT=${1:-f32}
 if [ "$DT" = bf16 ]; then D=gpurun_out/bf16; EXTRA="--dtype bf16 --frames 256"; else D=gpurun_out; EXTRA=""; fi
 mkdir -p $D/prof $D/prof_serial $D/pmc_sq $D/pmc $D/layers
-ARGS="bench.py $EXTRA --steps 10 --warmup 3 --no-cpu-baseline --no-secondary"
-SER="bench.py $EXTRA --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-graph --tune-level 0"
+ARGS="bench.py $EXTRA --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-kernel-table"
+SER="bench.py $EXTRA --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-kernel-table --no-graph --tune-level 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $D/prof -o bench -- python3 $ARGS > $D/prof/bench_stdout.log 2>&1
 GRNET_MULTI_LANE=0 rocprofv3 --kernel-trace --stats --output-format csv -d $D/prof_serial -o bench -- python3 $SER > $D/prof_serial/bench_stdout.log 2>&1
 GRNET_MULTI_LANE=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $D/pmc_sq -o sq -- python3 $SER > $D/pmc_sq/log.txt 2>&1
