@@ -23,15 +23,16 @@ PKG = "video-based-gait-analysis-for-dementia_amd"
 N = 16
 
 
-def dump(path):
+def dump(path, dtype="f32"):
     sys.path.insert(0, ROOT)
     pkg = importlib.import_module(PKG)
     import ctypes as C
-    m = pkg.build_synthetic_model(max_frames=N, with_gru=False)
+    n = 256 if dtype == "bf16" else N                    # the lane scheduler orders the launches for max_frames: the SAME value as the profiled run
+    m = pkg.build_synthetic_model(max_frames=n, with_gru=False, dtype=dtype)
     convs = m.describe_convs()
     for pos, c in enumerate(convs):                      # the kernel family<shape> name bench.py's kernel table uses
         name = C.create_string_buffer(96)
-        m._lib.grnet_conv_kernel_info(m._h, pos, N, name, 96, None)
+        m._lib.grnet_conv_kernel_info(m._h, pos, n, name, 96, None)
         c["kernel_family"] = name.value.decode()
     json.dump(convs, open(path, "w"))
     m.close()
@@ -83,8 +84,13 @@ def stage_of(name):
     return "other"
 
 
-def main(rnd):
-    src = os.path.join(ROOT, "gpurun_out")
+def main(rnd, dtype="f32"):
+    global N
+    bf = dtype == "bf16"
+    if bf:
+        N = 256                                          # BASELINE configs[2]: 8 clips x 32 frames per call
+    esz, peak = (2.0, 2500.0) if bf else (4.0, 157.3)
+    src = os.path.join(ROOT, "gpurun_out", "bf16") if bf else os.path.join(ROOT, "gpurun_out")
     convs = json.load(open(os.path.join(src, "layers", "convs.json")))
     n_conv = len(convs)
     dur = per_position(conv_dispatches(os.path.join(src, "prof_serial", "bench_kernel_trace.csv"), lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3), n_conv)
@@ -94,8 +100,8 @@ def main(rnd):
     for c, (k, us, nd), (_, fb, _), (_, wb, _) in zip(convs, dur, fetch, write):
         flop = 2.0 * N * c["macs"]
         if c["cin"]:
-            alg_r = 4.0 * (N * (c["cin"] * c["hin"] * c["win"] + c["add_elems"]) + c["ks"] * c["ks"] * c["cin"] * c["cout"])
-            alg_w = 4.0 * N * c["cout"] * c["hout"] * c["wout"]
+            alg_r = esz * (N * (c["cin"] * c["hin"] * c["win"] + c["add_elems"]) + c["ks"] * c["ks"] * c["cin"] * c["cout"])
+            alg_w = esz * N * c["cout"] * c["hout"] * c["wout"]
         else:                                            # the grouped fuse launch: add_elems = floats read per frame; it writes outputs 0 .. nb-2
             nb = c["n_add"]
             alg_r = 4.0 * N * c["add_elems"]
@@ -112,16 +118,16 @@ def main(rnd):
         w.writeheader()
         w.writerows(rows)
     tot = dict(n=len(rows), us=sum(r["us"] for r in rows), gflop=sum(r["gflop"] for r in rows), alg=sum(r["alg_mb"] for r in rows), cnt=sum(r["counter_mb"] for r in rows))
-    lines = [f"# Per-launch table of the {n_conv} convolution-class launches of a 16-frame fp32 step ({rnd}), launched one after another (GRNET_MULTI_LANE=0)", "",
+    lines = [f"# Per-launch table of the {n_conv} convolution-class launches of a {N}-frame {dtype} step ({rnd}), launched one after another (GRNET_MULTI_LANE=0)", "",
              f"Total: {tot['us'] / 1e3:.3f} ms, {tot['gflop']:.1f} algorithmic GFLOP = {tot['gflop'] / tot['us'] * 1e3:.1f} TFLOP/s; counter bytes (FETCH_SIZE x 2 + WRITE_SIZE) "
              f"{tot['cnt'] / 1e3:.2f} GB vs {tot['alg'] / 1e3:.2f} GB algorithmic ({tot['cnt'] / tot['alg']:.2f} x).",
-             "Peak of the fp32 matrix cores: 157.3 TFLOP/s.  `exec` = the multiplies the kernel issues (F(4x4,3x3): 1/4 of the direct count, x 1.31 on the padded 14x14 / 7x7 maps).", "",
+             f"Peak of the {dtype} matrix cores: {peak} TFLOP/s.  `exec` = the multiplies the kernel issues (fp32: F(4x4,3x3) at 1/4 of the direct count, x 1.31 on the padded 14x14 / 7x7 maps; bf16: the direct count).", "",
              "## By stage", "", "| stage | launches | ms | algorithmic TFLOP/s | executed TFLOP/s | counter MB | algorithmic MB |", "|---|---|---|---|---|---|---|"]
     for k, t in by_stage.items():
         lines.append(f"| {k} | {t['n']} | {t['us'] / 1e3:.3f} | {t['gflop'] / t['us'] * 1e3:.1f} | {t['ex'] / t['us'] * 1e3:.1f} | {t['cnt']:.0f} | {t['alg']:.0f} |")
-    lines += ["", "## By kernel and shape", "", "| kernel, shape | launches | us each | ms | algorithmic TFLOP/s | executed TFLOP/s (of 157.3) | counter / algorithmic bytes |", "|---|---|---|---|---|---|---|"]
+    lines += ["", "## By kernel and shape", "", f"| kernel, shape | launches | us each | ms | algorithmic TFLOP/s | executed TFLOP/s (of {peak}) | counter / algorithmic bytes |", "|---|---|---|---|---|---|---|"]
     for k, t in sorted(by_kernel.items(), key=lambda kv: -kv[1]["us"]):
-        lines.append(f"| {k} | {t['n']} | {t['us'] / t['n']:.1f} | {t['us'] / 1e3:.3f} | {t['gflop'] / t['us'] * 1e3:.1f} | {t['ex'] / t['us'] * 1e3:.1f} ({t['ex'] / t['us'] * 1e3 / 157.3:.2f}) | {t['cnt'] / t['alg']:.2f} |")
+        lines.append(f"| {k} | {t['n']} | {t['us'] / t['n']:.1f} | {t['us'] / 1e3:.3f} | {t['gflop'] / t['us'] * 1e3:.1f} | {t['ex'] / t['us'] * 1e3:.1f} ({t['ex'] / t['us'] * 1e3 / peak:.2f}) | {t['cnt'] / t['alg']:.2f} |")
     open(os.path.join(dst, f"{rnd}_layer_table.md"), "w").write("\n".join(lines) + "\n")
     json.dump({"launches": n_conv, "serial_ms": tot["us"] / 1e3, "algorithmic_bytes": tot["alg"] * 1e6, "counter_bytes_fetch_x2_plus_write": tot["cnt"] * 1e6,
                "by_stage": by_stage,
@@ -132,6 +138,6 @@ def main(rnd):
 
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--dump":
-        dump(sys.argv[2])
+        dump(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "f32")
     else:
-        main(sys.argv[1] if len(sys.argv) > 1 else "r04")
+        main(sys.argv[1] if len(sys.argv) > 1 else "r04", sys.argv[2] if len(sys.argv) > 2 else "f32")
