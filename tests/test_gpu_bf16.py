@@ -107,3 +107,26 @@ def test_bf16_config3_shape(pkg):
 def test_bf16_is_a_separate_handle_dtype(pkg):
     with pytest.raises(ValueError):
         pkg.GRNet(max_frames=1, dtype="fp8")
+
+
+@pytest.mark.parametrize("n", [1, 3])
+def test_bf16_stem_kernel_reads_fp32_frames(bmodel, oracle, n):
+    """conv_bf16_stem (round 4): the stem's 3 -> 64 stride-2 convolution straight from fp32 NCHW frames, K = (channel, tap) flattened to one
+    32-wide MFMA k-step.  It rounds the frames to bf16 itself, so it must equal the fp32 oracle on bf16-rounded frames and weights up to
+    the one rounding of its bf16 output -- and the generic kernel (which the conversion launch used to feed) on the same data likewise.
+    The top row and the left column read the zero padding: looked at separately."""
+    g = np.random.Generator(np.random.Philox(key=[79, n]))
+    x32 = g.standard_normal((n, 3, 224, 224)).astype(np.float32)          # NOT pre-rounded: the kernel does the rounding
+    w = _rb(g.standard_normal((64, 3, 3, 3)) * np.sqrt(2.0 / 27))
+    b = (g.standard_normal((64,)) * 0.1).astype(np.float32)
+    ref = torch.relu(oracle.conv2d(_rb(x32), w, stride=2, bias=b)).numpy()
+    got = bmodel.op_conv2d(torch.from_numpy(x32).cuda(), w, b, stride=2, relu=True, tile_hint=3001).cpu().numpy()
+    assert got.shape == ref.shape == (n, 64, 112, 112)
+    assert np.array_equal(got, _rb(got))
+    assert np.all(np.abs(got - ref) <= np.abs(ref) * 2.0 ** -8 + 1e-5), float(np.abs(got - ref).max())
+    assert np.all(np.abs(got[:, :, 0] - ref[:, :, 0]) <= np.abs(ref[:, :, 0]) * 2.0 ** -8 + 1e-5) and np.all(np.abs(got[..., 0] - ref[..., 0]) <= np.abs(ref[..., 0]) * 2.0 ** -8 + 1e-5)
+    lin = oracle.conv2d(_rb(x32), w, stride=2).numpy()
+    got = bmodel.op_conv2d(torch.from_numpy(x32).cuda(), w, None, stride=2, relu=False, tile_hint=3001).cpu().numpy()
+    assert np.all(np.abs(got - lin) <= np.abs(lin) * 2.0 ** -8 + 1e-5)
+    gen = bmodel.op_conv2d(torch.from_numpy(_rb(x32)).cuda(), w, None, stride=2, relu=False, tile_hint=0).cpu().numpy()
+    assert np.mean(got != gen) < 0.02                                      # the same sums in another order: they differ on output-rounding ties only

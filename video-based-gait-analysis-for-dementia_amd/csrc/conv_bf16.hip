@@ -16,6 +16,8 @@
 // operand reads fall on distinct banks.
 #include "kernels.h"
 
+#include <cstring>
+
 #include <cstdio>
 #include <cstdlib>
 
@@ -453,6 +455,69 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 32 ? 3
     }
 }
 
+// ---- The stem's first convolution on the bf16 path (3 -> 64, 3x3, stride 2, 224 -> 112; hrnet.py:470-475), round 4.  Through the generic kernel
+// it read an NHWC image padded from 3 to 8 channels and multiplied 27 real of 288 K elements: 604 us at 256 frames (0.01 of the matrix peak, 4 % of
+// the step) behind a 55 us conversion launch.  Here K = (channel, tap) is flattened to ONE 32-wide MFMA k-step (27 real), and the kernel reads the
+// caller's fp32 NCHW frames itself (the conversion launch and its buffer are gone): lane (pixel l15, k-group lq) gathers its 8 K elements -- 4-byte
+// loads, 16 lanes covering 128 contiguous bytes of a row at stride 2 -- rounds them to bf16 (nearest even, as the conversion kernel did) and that
+// is the B operand; A = the 64 x 32 weight block in 16 registers; D -> bias, ReLU, NHWC bf16, 8 bytes per lane and channel block.  A wave owns one
+// output row (7 tiles of 16 pixels); the next tile's gathers are requested before the current tile's four MFMAs.  Memory-bound: 0.6 MB read and
+// 1.6 MB written per frame.
+__global__ __launch_bounds__(256) void conv_bf16_stem(const float* __restrict__ frames, const u16* __restrict__ wpk, const float* __restrict__ bias,
+                                                      u16* __restrict__ out, int out_ctot, int out_coff, int N, int relu) {
+    constexpr int H = 224, W = 224, HO = 112, WO = 112;
+    const int lane = threadIdx.x & 63, l15 = lane & 15, lq = lane >> 4;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);          // (frame, output row)
+    if (row >= N * HO) return;
+    const int n = row / HO, y = row - n * HO;
+    bf16x8 wq[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) wq[mt] = *reinterpret_cast<const bf16x8*>(wpk + ((size_t)mt * 64 + lane) * 8);
+    f32x4 biasv[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) biasv[mt] = *reinterpret_cast<const f32x4*>(bias + mt * 16 + lq * 4);
+    // this lane's 8 K elements: k = 8 lq + j = channel * 9 + ky * 3 + kx (k >= 27: zero)
+    int off[8];
+    bool rowok[8], real[8], left[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * lq + j, c = k / 9, tap = k - 9 * c, ky = tap / 3, kx = tap - 3 * ky;
+        real[j] = k < 27;
+        rowok[j] = real[j] && (2 * y + ky - 1 >= 0);               // the bottom row 2 * 111 + 1 = 223 exists; only the top row is padding
+        left[j] = kx == 0;                                         // column 2 x - 1 is padding for x = 0
+        off[j] = (c * H + (2 * y + ky - 1)) * W + (kx - 1);
+    }
+    const float* fb = frames + (size_t)n * 3 * H * W;
+    auto gather = [&](int t, float (&v)[8]) {
+        const int x = 16 * t + l15;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool ok = rowok[j] && !(left[j] && x == 0);
+            v[j] = ok ? fb[off[j] + 2 * x] : 0.f;
+        }
+    };
+    float cur[8], nxt[8];
+    gather(0, cur);
+    u16* ob = out + ((size_t)(n * HO + y) * WO) * out_ctot + out_coff + lq * 4;
+#pragma unroll 1
+    for (int t = 0; t < WO / 16; ++t) {
+        if (t + 1 < WO / 16) gather(t + 1, nxt);
+        const u32x4 bp = {pack2(cur[0], cur[1]), pack2(cur[2], cur[3]), pack2(cur[4], cur[5]), pack2(cur[6], cur[7])};
+        const bf16x8 b = __builtin_bit_cast(bf16x8, bp);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            f32x4 v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[mt], b, biasv[mt], 0, 0, 0);
+            if (relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            *reinterpret_cast<u32x2*>(ob + (size_t)(16 * t + l15) * out_ctot + mt * 16) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cur[j] = nxt[j];
+    }
+}
+
 bool bf16_direct_eligible(const ConvArgs& a) {
     return a.ks == 3 && a.stride == 1 && a.Cin == a.Cout && (a.Cin == 32 || a.Cin == 64) && a.CinPad == a.Cin && a.CoutPad >= a.Cout && (a.W == 28 || (a.W == 56 && a.Cin == 32)) &&
            a.Ho == a.H && a.Wo == a.W && a.n_add <= 1 && (a.n_add == 0 || a.add_shift[0] == 0) && a.out_ctot - a.out_coff >= a.Cout &&
@@ -774,6 +839,25 @@ hipError_t launch_conv_bf16(ConvArgs a, hipStream_t s, int tile_hint) {
     }
 #endif
     return e;
+}
+
+// weights (64, 3, 3, 3) folded, fp64 -> [4 channel blocks][64 lanes][8] bf16: lane (l15, lq) of block mt holds W[16 mt + l15][k = 8 lq .. + 7], k = c * 9 + tap
+void pack_stem_weights_bf16(const double* w, unsigned short* out) {
+    for (int mt = 0; mt < 4; ++mt)
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+                const int k = 8 * (l >> 4) + j, co = 16 * mt + (l & 15);
+                float f = k < 27 ? (float)w[(size_t)co * 27 + k] : 0.f;
+                unsigned u;
+                memcpy(&u, &f, 4);
+                u += 0x7fffu + ((u >> 16) & 1u);
+                out[((size_t)mt * 64 + l) * 8 + j] = (unsigned short)(u >> 16);
+            }
+}
+
+hipError_t launch_conv_bf16_stem(const float* frames, const void* wpk, const float* bias, void* out, int out_ctot, int out_coff, int N, int relu, hipStream_t s) {
+    if (N < 1 || out_ctot % 4 != 0 || out_coff % 4 != 0) return hipErrorInvalidValue;
+    return launch_k(conv_bf16_stem, dim3((N * 112 + 3) / 4), dim3(256), 0, s, frames, static_cast<const u16*>(wpk), bias, static_cast<u16*>(out), out_ctot, out_coff, N, relu);
 }
 
 hipError_t launch_nchw_f32_to_nhwc_bf16(const float* in, void* out, int N, int C, int H, int W, int Cp, hipStream_t s) {

@@ -128,7 +128,8 @@ struct DeviceGuard {
 struct grnet {
     int device = 0, max_frames = 0;
     int dtype = 0;               // 0: fp32 NCHW activations, 1: bf16 NHWC activations (conv_bf16.hip), fp32 tail either way
-    View v_in8;                  // bf16: the caller's frames converted to NHWC bf16 with 8 channels (3 real)
+    View v_in8;                  // bf16 without conv_bf16_stem: the caller's frames converted to NHWC bf16 with 8 channels (3 real)
+    bool bf16_stem = false;
     bool finalized = false, smpl_loaded = false, gru_ready = false, tsattn_ready = false, featcorr_ready = false;
     TsAttnWeights tsw{};
     FeatCorrWeights fcw{};
@@ -459,7 +460,11 @@ struct grnet {
         v_input.p = nullptr; v_input.ctot = 3; v_input.coff = 0; v_input.c = 3; v_input.h = 224; v_input.w = 224;
         View in = v_input;
         in.p = reinterpret_cast<float*>(~(uintptr_t)0);   // tag: caller's frames pointer
-        if (dtype == 1) {                                  // bf16: frames (N,3,224,224) f32 -> NHWC bf16, 8 channels per pixel
+        // bf16: the stem's first convolution reads the caller's fp32 frames itself (conv_bf16_stem, round 4); GRNET_BF16_STEM=0 restores the
+        // conversion launch -- frames (N,3,224,224) f32 -> NHWC bf16, 8 channels per pixel -- in front of the generic kernel
+        static const int bf16_stem_env = getenv("GRNET_BF16_STEM") ? atoi(getenv("GRNET_BF16_STEM")) : 1;
+        bf16_stem = dtype == 1 && bf16_stem_env;
+        if (dtype == 1 && !bf16_stem) {
             v_in8 = new_buffer(8, 224, 224);
             Op cv;
             cv.kind = Op::CONVERT;
@@ -586,7 +591,7 @@ struct grnet {
         }
         for (auto& nv : named) resolve(nv.second);
         resolve(v_cat); resolve(v_heat); resolve(v_smpl_feats); resolve(v_csmap);
-        if (dtype == 1) resolve(v_in8);
+        if (dtype == 1 && !bf16_stem) resolve(v_in8);
         // streams / events of the parallel lanes are created here, never inside a stream capture
         if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return fail(GRNET_EHIP, "hipEventCreate failed");
         if (int rc = install_schedule(max_frames)) return rc;
@@ -843,8 +848,9 @@ struct grnet {
         const bool wino4s = !bf && wino4_env && cin == L.in.c && conv_wino4s_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size()) &&
                             (L.adds.empty() || L.adds[0].shift == 0);          // the small maps: conv_wino4s.hip
         static const int stem_env = getenv("GRNET_STEM") ? atoi(getenv("GRNET_STEM")) : 1;
-        const bool stem = !bf && stem_env && cin == L.in.c && L.segs.size() == 1 && conv_stem_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size());
-        std::vector<double> wfold(wino4 || wino4s || stem ? (size_t)L.cout * cin * 9 : 0);     // BN-folded weights (cout, cin, 3, 3) for the filter transform
+        const bool stem_shape = stem_env && cin == L.in.c && L.segs.size() == 1 && conv_stem_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size());
+        const bool stem = !bf && stem_shape, stem_bf = bf && bf16_stem && stem_shape;
+        std::vector<double> wfold(wino4 || wino4s || stem || stem_bf ? (size_t)L.cout * cin * 9 : 0);     // BN-folded weights (cout, cin, 3, 3) for the filter transform
         int co0 = 0;
         for (auto& s : L.segs) {
             const HostTensor* w = find(s.wkey);
@@ -874,7 +880,7 @@ struct grnet {
                     for (int t = 0; t < taps; ++t) {
                         const double wv = (double)w->data[((size_t)co * cin + ci) * taps + t] * scale[co];
                         wp[bf ? ((((size_t)(ci / 32) * taps + t) * L.cout_pad + co0 + co) * 32 + ci % 32) : ((size_t)t * L.cin_pad + ci) * L.cout_pad + co0 + co] = (float)wv;
-                        if (wino4 || wino4s || stem) wfold[((size_t)(co0 + co) * cin + ci) * 9 + t] = wv;
+                        if (wino4 || wino4s || stem || stem_bf) wfold[((size_t)(co0 + co) * cin + ci) * 9 + t] = wv;
                     }
             }
             co0 += s.cout;
@@ -892,6 +898,11 @@ struct grnet {
         if (stem) {
             std::vector<float> sw(7 * 4 * 64);
             pack_stem_weights(wfold.data(), sw.data());
+            if ((rc = upload(sw, &L.stem_dev))) return rc;
+        }
+        if (stem_bf) {                                          // conv_bf16_stem: 4 x 64 x 8 bf16, two per float slot
+            std::vector<float> sw(4 * 64 * 8 / 2);
+            pack_stem_weights_bf16(wfold.data(), reinterpret_cast<unsigned short*>(sw.data()));
             if ((rc = upload(sw, &L.stem_dev))) return rc;
         }
         if (wino4s) {                                          // U = G g G^T of the folded filter, fp64 -> fp32
@@ -1277,10 +1288,10 @@ struct grnet {
 
     // Which kernel runs convolution L in a call of n frames: ONE place, used by the launcher, by the executed-FLOP report and by the
     // per-kernel table of bench.py (round-3 review: the report read a hidden "latest n" and ignored the environment masks).
-    enum ConvKernel { K_BF16, K_WINO4S, K_PW, K_STEM, K_WINO4, K_DIRECT };
+    enum ConvKernel { K_BF16, K_BF16_STEM, K_WINO4S, K_PW, K_STEM, K_WINO4, K_DIRECT };
     ConvKernel kernel_for(const ConvLayer& L, int n) const {
         static const int w4s_env = getenv("GRNET_WINO4S") ? atoi(getenv("GRNET_WINO4S")) : 7;      // bit 0: 128 @14x14, bit 1: 256 @7x7, bit 2: 256 @14x14
-        if (dtype == 1) return K_BF16;
+        if (dtype == 1) return L.stem_dev ? K_BF16_STEM : K_BF16;      // (a plan built for conv_bf16_stem has no NHWC copy of the frames for the generic kernel)
         if (conv_tile_hint) return K_DIRECT;                   // a forced tile also switches every special kernel off (tests / tuning)
         if (wino4s_runs(L, n) && (w4s_env & (L.in.w == 7 ? 2 : L.in.c == 128 ? 1 : 4))) return K_WINO4S;
         if (pw_on(L)) return K_PW;
@@ -1301,6 +1312,7 @@ struct grnet {
         char b[96];
         switch (kernel_for(L, n)) {
             case K_BF16: return "conv_bf16";
+            case K_BF16_STEM: return "conv_bf16_stem";
             case K_WINO4S: snprintf(b, sizeof b, "conv_wino4s_f32<%d,%d>", L.in.w, L.in.c); return b;
             case K_PW: snprintf(b, sizeof b, "conv_pw_f32<%d>", L.in.c); return b;
             case K_STEM: return "conv_stem_f32";
@@ -1318,6 +1330,7 @@ struct grnet {
         *n_launches = 1;
         switch (kernel_for(L, n)) {
             case K_BF16: HIP_TRY(launch_conv_bf16(conv_args(L, frames, n), s, hint_for(L, n))); break;
+            case K_BF16_STEM: HIP_TRY(launch_conv_bf16_stem(frames, L.stem_dev, L.b_dev, L.out.p, L.out.ctot, L.out.coff, n, L.relu, s)); break;
             case K_WINO4S: {
                 ConvArgs wa = conv_args(L, frames, n);
                 wa.w = L.wino4s_dev;
@@ -1530,6 +1543,25 @@ struct grnet {
             for (int ci = 0; ci < cin; ++ci)
                 for (int t = 0; t < taps; ++t)
                     wp[(((size_t)(ci / 32) * taps + t) * cout_pad + co) * 32 + ci % 32] = f32_to_bf16(w_host[((size_t)co * cin + ci) * taps + t]);
+        }
+        if (tile_hint == 3001) {                               // conv_bf16_stem on this one convolution: fp32 NCHW in, (n,cout,112,112) f32 out
+            if (!conv_stem_eligible(cin, cout, ks, stride, hgt, wid, add_dev ? 1 : 0)) return fail(GRNET_EINVAL, "shape not eligible for the bf16 stem kernel");
+            std::vector<double> wf((size_t)cout * cin * 9);
+            for (size_t i = 0; i < wf.size(); ++i) wf[i] = w_host[i];
+            std::vector<unsigned short> sw(4 * 64 * 8);
+            pack_stem_weights_bf16(wf.data(), sw.data());
+            std::vector<float> bh(64, 0.f);
+            if (bias_host) for (int c = 0; c < 64; ++c) bh[c] = bias_host[c];
+            void *swd = nullptr, *bhd = nullptr, *od = nullptr;
+            if (hipMalloc(&swd, sw.size() * 2) != hipSuccess || hipMalloc(&bhd, 256) != hipSuccess || hipMalloc(&od, (size_t)n * ho * wo * 64 * 2) != hipSuccess) return fail(GRNET_ENOMEM, "hipMalloc failed");
+            hipError_t e = hipMemcpy(swd, sw.data(), sw.size() * 2, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(bhd, bh.data(), 256, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = launch_conv_bf16_stem(in_dev, swd, static_cast<const float*>(bhd), od, 64, 0, n, relu, s);
+            if (e == hipSuccess) e = launch_nhwc_bf16_to_nchw_f32(od, out_dev, n, 64, ho, wo, 64, 0, s);
+            hipError_t e2 = hipStreamSynchronize(s);
+            hipFree(swd); hipFree(bhd); hipFree(od);
+            if (e != hipSuccess || e2 != hipSuccess) return fail(GRNET_EHIP, std::string("bf16 stem conv: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+            return 0;
         }
         void *wd = nullptr, *bd = nullptr, *xin = nullptr, *xadd = nullptr, *xout = nullptr;
         const size_t in_b = (size_t)n * hgt * wid * cin8 * 2, out_b = (size_t)n * ho * wo * cout8 * 2;

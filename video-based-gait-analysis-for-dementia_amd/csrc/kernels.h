@@ -242,6 +242,9 @@ struct GruWorkspace {
 hipError_t conv_bf16_init();
 hipError_t launch_conv_bf16(ConvArgs a, hipStream_t s, int tile_hint = 0);     // pointers in `a` address bf16 data (bias fp32)
 hipError_t launch_nchw_f32_to_nhwc_bf16(const float* in, void* out, int N, int C, int H, int W, int Cp, hipStream_t s);
+// the stem's 3 -> 64 stride-2 convolution straight from the caller's fp32 NCHW frames (N,3,224,224) to NHWC bf16 (N,112,112,out_ctot)
+hipError_t launch_conv_bf16_stem(const float* frames, const void* wpk, const float* bias, void* out, int out_ctot, int out_coff, int N, int relu, hipStream_t s);
+void pack_stem_weights_bf16(const double* w_folded /* (64,3,3,3) */, unsigned short* out /* 4*64*8 */);
 hipError_t launch_nhwc_bf16_to_nchw_f32(const void* in, float* out, int N, int C, int H, int W, int ctot, int coff, hipStream_t s);
 hipError_t launch_bilinear2x_bf16(const void* in, void* out, int N, int C, int H, int W, hipStream_t s);
 hipError_t launch_fuse_sum_bf16(const SumArgs& a, hipStream_t s);
