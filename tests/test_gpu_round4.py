@@ -30,7 +30,7 @@ def test_fuse_layer_of_every_hr_module_matches_oracle(model, pkg, oracle, synth_
     """For each of the 8 HR modules: the module's branch outputs x_b and outputs y_i are read back from the HIP forward
     (grnet_debug_tensor), the oracle's hr_fuse runs on those x_b with the same weights, and every y_i must agree to 2e-5 of its scale
     (fp32 sums re-associated: the grouped launch adds identity, chains, bias and up terms in its own order).  Covers stage 2 (one 1x1 term, one stride-2 convolution), stage 3 (3 + 3 incl. a two-convolution chain)
-    and stage 4 (6 terms, chains of one / two / three stride-2 convolutions, the merged first convolution of chains (2,0) and (3,0));
+    and stage 4 (6 terms, chains of one / two / three stride-2 convolutions, the merged first convolutions of the chains that start at one branch, linear and ReLU'd segments in one launch);
     1 / 3 / 16 frames."""
     frames = pkg.synth.make_frames(n)
     model(torch.from_numpy(frames).cuda().unsqueeze(0))
@@ -50,13 +50,13 @@ def test_fuse_layer_of_every_hr_module_matches_oracle(model, pkg, oracle, synth_
 
 def test_fuse_layer_launch_count_and_macs(pkg):
     """The grouped fuse launch replaces 31 1x1 convolution launches and 8 elementwise sums; the merged first convolution of the
-    stage-4 chains (2,0) / (3,0) three more launches: 282 convolutions + 8 grouped launches, and the MACs still add up to SURVEY
+    stage-4 chains (2,0) / (3,0) three more launches: 272 convolutions + 8 grouped launches, and the MACs still add up to SURVEY
     8(d)'s 15 441 563 648 per frame (the 1x1 terms are computed, not dropped)."""
     m = pkg.build_synthetic_model(max_frames=2, with_gru=False)
     convs = m.describe_convs()
     grouped = [c for c in convs if c["cin"] == 0]
     assert len(grouped) == 8 and all(c["name"].endswith("fuse_layers(up)") for c in grouped)
-    assert len(convs) == m.num_conv_launches() == 290
+    assert len(convs) == m.num_conv_launches() == 280
     assert sum(c["macs"] for c in convs) == 15441563648
     assert not any(c["ks"] == 1 and "fuse_layers" in c["name"] and c["cin"] for c in convs)      # no separate 1x1 fuse launch is left
     m.close()

@@ -142,7 +142,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const EpiCtx& e, f
                 }
             }
         }
-        if (a.relu) {
+        if (a.relu && co >= a.relu_from) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         }
@@ -165,7 +165,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const EpiCtx& e, f
                 const int y = fdiv(pix, e.inv_Wo), x = pix - y * a.Wo;
                 o += a.add[k][((size_t)img * a.add_ctot[k] + a.add_coff[k] + co) * (hs * ws) + (y >> sh) * ws + (x >> sh)];
             }
-            if (a.relu) o = fmaxf(o, 0.f);
+            if (a.relu && co >= a.relu_from) o = fmaxf(o, 0.f);
             a.out[((size_t)img * a.out_ctot + a.out_coff + co) * e.HoWo + pix] = o;
         }
     }

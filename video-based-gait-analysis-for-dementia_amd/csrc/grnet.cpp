@@ -57,6 +57,7 @@ struct ConvLayer {
     View in, out;
     std::vector<ConvSeg> segs;
     int cout = 0, ks = 1, stride = 1, relu = 0;
+    int relu_from = 0;          // relu applies to output channels >= relu_from (a merged launch whose first segment is linear)
     bool solo = false;          // runs with no other launch beside it (stem, layer1, PARE head): isolated timings predict it well
     int cin_w = 0;              // input channels of the weight tensor (< in.c only for the bf16 stem: 3 of the 8 stored)
     std::vector<AddRef> adds;
@@ -329,7 +330,7 @@ struct grnet {
     //          and ONE stride-2 convolution from branch nb-2 finishes output nb-1 (adds x_{nb-1} and the D_{nb-1,j}, ReLU).
     // After the last branch output exists, every output of the module is ONE launch away (round 3: 1x1 launch -> sum / finishing
     // convolution, up to four dependent launches with a cross-stream event between each pair).
-    // Stage 4: 10 launches per fuse layer (round 3: 17), stage 3: 5 (8), stage 2: 2 (3).
+    // Stage 4: 8 launches per fuse layer (round 3: 17), stage 3: 4 (8), stage 2: 2 (3).
     std::vector<View> hr_fuse_grouped(const std::vector<View>& xs, const std::string& p, const View* out0, const std::vector<int>& branch_tail) {
         const int nb = (int)xs.size();
         std::vector<View> outs(nb);
@@ -339,23 +340,46 @@ struct grnet {
         for (int i = 1; i < nb; ++i)
             for (int j = 0; j < i; ++j) { d[i][j] = xs[j]; d_op[i][j] = branch_tail[j]; }
         auto follow_last = [&](int op_idx) { ops.back().follow = op_idx; };
-        // early: chains from branches 0 .. nb-3 (and, for outputs < nb-1, from branch nb-2 too: D_{i,i-1} with i <= nb-2 starts at a branch <= nb-3)
+        // early: chains from branches 0 .. nb-3 (and, for outputs < nb-1, from branch nb-2 too: D_{i,i-1} with i <= nb-2 starts at a branch <= nb-3).
+        // The first convolutions of all chains that start at one branch share their input and are ONE launch: the linear one ((j+1, j): the whole chain
+        // of output j+1, no ReLU) first, then the ReLU'd first links of the longer chains (ConvLayer::relu_from)
         for (int j = 0; j < nb - 1; ++j)
             for (int level = 0; level < nb - 1 - j; ++level) {
-                const bool merged = level == 0 && j == 0 && nb >= 4;
-                if (merged) {
-                    std::vector<ConvSeg> segs;
-                    for (int i = 2; i < nb; ++i) segs.push_back(ConvSeg{key(i, 0, 0) + "0.weight", key(i, 0, 0) + "1", "", kBranchCh[0]});
-                    cur_lane = 0;
-                    View m = add_conv(xs[0], segs, 3, 2, true);
-                    follow_last(branch_tail[0]);
-                    for (int i = 2; i < nb; ++i) { d[i][0] = slice(m, (i - 2) * kBranchCh[0], kBranchCh[0]); d_op[i][0] = (int)ops.size() - 1; }
+                std::vector<int> members;                                   // outputs i whose chain (i, j) has a convolution at this level
+                for (int i = j + 1; i < nb; ++i)
+                    if (level < i - j && !(i == nb - 1 && j == nb - 2)) members.push_back(i);
+                // GRNET_FUSE_MERGE (A/B switch): 2 = all first convolutions of a branch in one launch, 1 = only the ReLU'd ones, 0 = none
+                static const int merge_env = getenv("GRNET_FUSE_MERGE") ? atoi(getenv("GRNET_FUSE_MERGE")) : 2;
+                std::vector<int> solo;
+                if (level == 0 && merge_env < 2) {
+                    std::vector<int> keep;
+                    for (int i : members) (merge_env == 1 && i - j >= 2 ? keep : solo).push_back(i);
+                    members.swap(keep);
                 }
-                for (int i = j + 1; i < nb; ++i) {
-                    const int len = i - j;
-                    if (level >= len || (merged && i >= 2)) continue;
-                    if (i == nb - 1 && j == nb - 2) continue;                // the finishing convolution of the last output: late
-                    const bool last = level == len - 1;
+                if (level == 0 && members.size() >= 2) {
+                    std::vector<ConvSeg> segs;
+                    int lin = 0;
+                    for (int i : members) {
+                        const bool last = i - j == 1;
+                        segs.push_back(ConvSeg{key(i, j, 0) + "0.weight", key(i, j, 0) + "1", "", last ? kBranchCh[i] : kBranchCh[j]});
+                        if (last) lin += kBranchCh[i];
+                    }
+                    cur_lane = j;
+                    View m = add_conv(xs[j], segs, 3, 2, true);
+                    convs.back().relu_from = lin;                            // members are in ascending i: the linear segment (i = j + 1), if any, comes first
+                    follow_last(branch_tail[j]);
+                    int off = 0;
+                    for (int i : members) {
+                        const int c = i - j == 1 ? kBranchCh[i] : kBranchCh[j];
+                        d[i][j] = slice(m, off, c);
+                        d_op[i][j] = (int)ops.size() - 1;
+                        off += c;
+                    }
+                    members.clear();
+                }
+                members.insert(members.begin(), solo.begin(), solo.end());
+                for (int i : members) {
+                    const bool last = level == i - j - 1;
                     cur_lane = j;
                     d[i][j] = conv_bn(d[i][j], key(i, j, level) + "0.weight", key(i, j, level) + "1", last ? kBranchCh[i] : kBranchCh[j], 3, 2, !last);
                     follow_last(d_op[i][j]);
@@ -1276,7 +1300,7 @@ struct grnet {
         a.out = L.out.p; a.out_ctot = L.out.ctot; a.out_coff = L.out.coff;
         a.Cout = L.cout; a.Ho = L.out.h; a.Wo = L.out.w;
         a.w = L.w_dev; a.bias = L.b_dev; a.CinPad = L.cin_pad; a.CoutPad = L.cout_pad;
-        a.ks = L.ks; a.stride = L.stride; a.relu = L.relu;
+        a.ks = L.ks; a.stride = L.stride; a.relu = L.relu; a.relu_from = L.relu_from;
         a.n_add = (int)L.adds.size();
         for (int k = 0; k < a.n_add; ++k) {
             a.add[k] = L.adds[k].v.p; a.add_ctot[k] = L.adds[k].v.ctot; a.add_coff[k] = L.adds[k].v.coff;

@@ -101,6 +101,7 @@ struct ConvArgs {
     const float* bias;         // [CoutPad], BN shift (+ conv bias) folded in
     int CinPad, CoutPad;
     int ks, stride, relu;
+    int relu_from;             // with relu: output channels >= relu_from get the ReLU (0: all) -- merged launches whose first segment is linear (direct kernels only)
     int n_add;
     const float* add[kMaxAdd]; int add_ctot[kMaxAdd], add_coff[kMaxAdd], add_shift[kMaxAdd];
     const float* zeros;        // >= 64 B of zeros in HBM: source for halo / padded-channel loads
