@@ -60,6 +60,8 @@ def parse_args(argv=None):
                     "per-frame records, then the temporal branch (GRU + attention + second head pass) on the whole sequence; a step is the whole job (strong scaling)")
     ap.add_argument("--total-frames", type=int, default=10000, help="batchgen: frames of the whole job")
     ap.add_argument("--chunk", type=int, default=128, help="batchgen: frames per grnet_forward call")
+    ap.add_argument("--exchange", choices=("auto", "capi", "torch"), default="auto", help="N > 1: who owns the all-gather. capi: the C ABI's own RCCL communicator "
+                    "(grnet_comm_create / grnet_allgather); torch: the launcher's process group; auto: capi on the nccl backend if every rank can bootstrap it, else torch")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip roofline.dominant_kernel (its per-shape timing launches would sit in a profiler's dispatch list)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the bf16 256-frame leg (BASELINE configs[2]) that the default 1-GPU fp32 run appends as `secondary`")
     a = ap.parse_args(argv)
@@ -120,6 +122,37 @@ def init_dist(world, rank, local_rank):
     else:
         dist.init_process_group(backend, rank=rank, world_size=world)
     return dist, local_rank, ("cuda" if backend == "nccl" else "cpu")
+
+
+def make_exchange(args, world, rank, local_rank, dist):
+    """(RcclComm or None, label for config.exchange).  `auto` uses the C ABI's communicator only when EVERY rank created it (a MIN over the ranks'
+    outcomes, so no rank waits in a collective the others never enter); both choices are RCCL on the nccl backend -- this is not a CPU fallback."""
+    backend = os.environ.get("GRNET_BENCH_BACKEND", "nccl")
+    choice = getattr(args, "exchange", "auto")
+    if world == 1:
+        return None, "none (1 GPU)"
+    if backend != "nccl":
+        if choice == "capi":
+            raise SystemExit("--exchange capi needs one GPU per rank (RCCL); the %s rehearsal shares a device" % backend)
+        return None, backend + " (rehearsal backend, torch.distributed)"
+    if choice == "torch":
+        return None, "RCCL via torch.distributed.all_gather_into_tensor"
+    import torch
+    harness = importlib.import_module(PKG).harness
+    comm, err = None, ""
+    try:
+        comm = harness.RcclComm(world, rank, torch.device("cuda", local_rank), dist=dist)
+    except Exception as e:                                      # noqa: BLE001 -- reported below, on every rank alike
+        err = f"{type(e).__name__}: {e}"
+    ok = torch.tensor([1 if comm is not None else 0], device=f"cuda:{local_rank}")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 1:
+        return comm, "RCCL via the C ABI (grnet_comm_create + grnet_allgather)"
+    if comm is not None:
+        comm.close()
+    if choice == "capi":
+        raise SystemExit("--exchange capi: grnet_comm_create failed on some rank" + (f" (this rank: {err})" if err else ""))
+    return None, "RCCL via torch.distributed.all_gather_into_tensor (the C ABI's communicator could not be created on every rank" + (f"; rank {rank}: {err}" if err else "") + ")"
 
 
 def timed_steps(do_step, device_sync, steps, warmup, dist, reduce_device):
@@ -314,8 +347,9 @@ class GpuWorkload:
         self.frames_np = pkg.synth.make_frames(n, start=rank * n)
         frames = torch.from_numpy(self.frames_np).cuda()
         cache = self.cache = args.tune_cache                  # a table exported by grnet_get_tuning; default: measure (grnet_tune)
+        self.comm, self.exchange = make_exchange(args, world, rank, local_rank, dist)
         mk = lambda m: harness.ClipRunner(m, frames, use_graph=not args.no_graph, world=world, rank=rank, dist=dist,
-                                          tune_level=args.tune_level, tune_cache=cache)
+                                          tune_level=args.tune_level, tune_cache=cache, comm=self.comm)
         self.runner = mk(self.model)
         self.runners, self.streams = [self.runner], [torch.cuda.current_stream()]
         for _ in range(1, max(1, args.inflight)):             # extra clips in flight: own buffers, own stream
@@ -350,9 +384,7 @@ class GpuWorkload:
                 "frames_per_gpu": n, "clips_in_flight": len(self.runners), "launch": launch_desc,
                 "kernel_launches_per_step": model.num_kernel_launches(),
                 "launch_configs": ("stored table " + os.path.relpath(self.cache, ROOT)) if self.cache else f"grnet_tune level {args.tune_level}",
-                "exchange": "none (1 GPU)" if self.world == 1 else
-                            (("RCCL" if os.environ.get("GRNET_BENCH_BACKEND", "nccl") == "nccl" else os.environ["GRNET_BENCH_BACKEND"] + " (rehearsal backend)") +
-                             " all-gather of per-frame pose results")}
+                "exchange": self.exchange + ("" if self.world == 1 else ": one all-gather of the per-frame pose records per step")}
 
     def roofline(self, fps_per_gpu):
         model, n, pkg = self.model, self.n, self.pkg
@@ -391,6 +423,9 @@ class GpuWorkload:
                                   "Gram-Schmidt with random synthetic weights; the emulation moves as far on the same frames: tools/bf16_outliers.py)")
 
     def close(self):
+        if self.comm is not None:
+            self.torch.cuda.synchronize()
+            self.comm.close()
         for r in self.runners:
             r.model.close()
 
@@ -413,7 +448,8 @@ class BatchgenWorkload:
             self.model.tune(chunk, level=args.tune_level)
             if (hi - lo) % chunk:
                 self.model.tune((hi - lo) % chunk, level=args.tune_level)
-        self.runner = pkg.harness.ShardedSequenceRunner(self.model, frames, args.total_frames, world, rank, dist, chunk=chunk)
+        self.comm, self.exchange = make_exchange(args, world, rank, local_rank, dist)
+        self.runner = pkg.harness.ShardedSequenceRunner(self.model, frames, args.total_frames, world, rank, dist, chunk=chunk, comm=self.comm)
 
     def step(self):
         self.runner.step()
@@ -427,9 +463,7 @@ class BatchgenWorkload:
                             f"{self.chunk} frames, one all-gather of the per-frame records (19.4 KB per frame), then cparams + GRU gait encoder + corrector / attention "
                             "block + second head pass on the whole sequence (replicated); seed-defined synthetic weights",
                 "total_frames": a.total_frames, "frames_per_gpu": self.runner.n_local, "chunk": self.chunk, "calls_per_gpu": len(self.runner.calls),
-                "exchange": "none (1 GPU)" if self.world == 1 else
-                            (("RCCL" if os.environ.get("GRNET_BENCH_BACKEND", "nccl") == "nccl" else os.environ["GRNET_BENCH_BACKEND"] + " (rehearsal backend)") +
-                             f" all-gather of {self.runner.packed.numel() * 4 / 1e6:.1f} MB per rank, once per job")}
+                "exchange": self.exchange + ("" if self.world == 1 else f": one all-gather of {self.runner.packed.numel() * 4 / 1e6:.1f} MB per rank, once per job")}
 
     def roofline(self, fps_per_gpu):
         model, n = self.model, self.chunk
@@ -441,6 +475,9 @@ class BatchgenWorkload:
         pass
 
     def close(self):
+        if self.comm is not None:
+            self.torch.cuda.synchronize()
+            self.comm.close()
         self.model.close()
 
 

@@ -17,6 +17,7 @@
 #ifndef GRNET_HIP_H
 #define GRNET_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -234,6 +235,26 @@ int grnet_crop_normalise_cv_maps(grnet_t* h, const unsigned char* images_dev, in
  * stage{2,3,4}.{module}.x{branch} (the branch outputs = the fuse layer's inputs) / .y{branch} (the module's outputs).
  * Parity tests compare these with the oracle's taps of hrnet.py:469-536. */
 int grnet_debug_tensor(grnet_t* h, const char* name, int n_frames, float* out_dev, int64_t* shape_out, void* stream);
+
+/* ---- the exchange: all-gather of the per-frame records of a sharded clip (SURVEY 8b `grnet_allgather`, 8e) -------------------------------------
+ * The reference has no counterpart (demo.py:126-188 and batch_generation.py:289-329 are one process on one device).  One process per GPU; every
+ * rank runs grnet_forward on its contiguous frame range with the output pointers aimed INTO its send block, then ONE grnet_allgather (RCCL
+ * ncclAllGather over xGMI, enqueued on `stream` like every other call) reassembles the sequence on every rank before anything temporal runs.
+ * RCCL is looked up at run time (librccl.so.1, the copy the process already holds if any): the library loads and runs on one GPU without it, the
+ * grnet_comm_* calls then fail with GRNET_ESTATE.  Bootstrap: rank 0 calls grnet_comm_unique_id and hands the 128 bytes to the other ranks over any host
+ * channel (the launcher's store, a file, MPI); all ranks then call grnet_comm_create together (it blocks until every rank has arrived).
+ * A host that already owns an ncclComm_t passes it to grnet_comm_adopt instead (not destroyed by grnet_comm_destroy).
+ * Errors of this group: grnet_comm_last_error() (per thread), since no grnet_t is involved. */
+typedef struct grnet_comm grnet_comm_t;
+#define GRNET_COMM_ID_BYTES 128
+int grnet_comm_unique_id(void* id_out, int id_size /* >= GRNET_COMM_ID_BYTES */);
+int grnet_comm_create(grnet_comm_t** out_comm, const void* id, int world, int rank, int device_id);
+int grnet_comm_adopt(grnet_comm_t** out_comm, void* nccl_comm /* ncclComm_t */, int world, int rank);
+/* recv_dev holds world * bytes_per_rank bytes; rank r's block lands at offset r * bytes_per_rank (send_dev may alias its own slot). */
+int grnet_allgather(grnet_comm_t* comm, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream);
+int grnet_comm_info(grnet_comm_t* comm, int* world, int* rank);
+void grnet_comm_destroy(grnet_comm_t* comm);
+const char* grnet_comm_last_error(void);
 
 const char* grnet_last_error(grnet_t* h);
 const char* grnet_version(void);

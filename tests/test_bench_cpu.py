@@ -93,3 +93,19 @@ def test_kernel_objects_pick_the_family_with_the_most_time():
     assert dom["name"] == "conv_wino4_f32<4,56>" and dom["launches"] == 10 and dom["us"] == 100.0
     assert abs(dom["frac_executed"] - 60.0 / 1000.0 * 1e3 / 157.3) < 1e-3 and abs(dom["frac_effective"] - 240.0 / 1000.0 * 1e3 / 157.3) < 1e-3
     assert len(top) == 2 and "traffic_source" in dom
+
+
+def test_make_exchange_picks_the_owner_of_the_all_gather(monkeypatch):
+    """--exchange: one GPU needs none; a rehearsal backend (ranks share a device) stays with the launcher's process group and refuses `capi`; `torch` on the
+    nccl backend never touches the C ABI's communicator.  (The capi leg itself needs one GPU per rank: tests/test_gpu_round4.py covers world 1.)"""
+    import argparse
+    a = argparse.Namespace(exchange="auto")
+    assert bench.make_exchange(a, 1, 0, 0, None) == (None, "none (1 GPU)")
+    monkeypatch.setenv("GRNET_BENCH_BACKEND", "gloo")
+    comm, label = bench.make_exchange(a, 2, 1, 0, None)
+    assert comm is None and "gloo" in label and "torch.distributed" in label
+    with pytest.raises(SystemExit):
+        bench.make_exchange(argparse.Namespace(exchange="capi"), 2, 0, 0, None)
+    monkeypatch.setenv("GRNET_BENCH_BACKEND", "nccl")
+    comm, label = bench.make_exchange(argparse.Namespace(exchange="torch"), 2, 0, 0, None)
+    assert comm is None and label.startswith("RCCL via torch.distributed")

@@ -222,3 +222,37 @@ def test_wide_winograd_kernel_eight_waves(model, oracle, case):
     assert rel_err(got[:, :, [0, hw - 1]], lin[:, :, [0, hw - 1]]) < 1e-4 and rel_err(got[..., [0, hw - 1]], lin[..., [0, hw - 1]]) < 1e-4
     again = model.op_conv2d(xd, w, None, stride=1, relu=False, tile_hint=2001).cpu().numpy()
     assert np.array_equal(got, again)
+
+
+def test_c_abi_exchange_world1(pkg):
+    """grnet_comm_create + grnet_allgather: RCCL bound at run time from the process's librccl.so.1, a communicator of ONE rank on this
+    box's one GPU; the all-gather of one rank is the identity, on the caller's stream, for the packed pose-record block of a 16-frame clip and for an
+    odd byte count.  (N > 1 needs one GPU per rank: the 8-GPU node of the round-end driver run, `bench.py --gpus N --exchange capi`.)"""
+    import ctypes as C
+    harness = pkg.harness
+    dev = torch.device("cuda", 0)
+    comm = harness.RcclComm(1, 0, dev)
+    w, r = C.c_int(), C.c_int()
+    assert comm._lib.grnet_comm_info(comm._h, C.byref(w), C.byref(r)) == 0 and (w.value, r.value) == (1, 0)
+    _, block = harness.pack_layout(16, harness.POSE_RECORD_GAIT)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    send = torch.randn(block, generator=g).to(dev)
+    recv = torch.zeros_like(send)
+    out = harness.gather_pose_records(send, 16, 1, None, out=recv)       # world 1: plain copy, no collective
+    assert torch.equal(out.view(-1), send)
+    recv.zero_()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        comm.all_gather(recv, send)
+    st.synchronize()
+    assert torch.equal(recv, send)
+    odd = torch.arange(1001, dtype=torch.uint8, device=dev)
+    got = torch.zeros_like(odd)
+    comm.all_gather(got, odd)
+    torch.cuda.synchronize()
+    assert torch.equal(got, odd)
+    with pytest.raises(AssertionError):
+        comm.all_gather(torch.zeros(3, device=dev), torch.zeros(2, device=dev))
+    comm.close()
+    comm.close()                                                         # idempotent

@@ -26,6 +26,23 @@ def test_library_exports_every_declared_symbol(pkg):
     assert b"gfx950" in lib.grnet_version()
 
 
+def test_exchange_entry_points_refuse_bad_arguments(pkg):
+    """grnet_comm_* / grnet_allgather (the C ABI's RCCL exchange): argument errors come back as GRNET_EINVAL with a message, before RCCL or the GPU is touched."""
+    import ctypes as C
+    lib = pkg._lib.load()
+    h = C.c_void_p()
+    ident = bytes(pkg._lib.COMM_ID_BYTES)
+    assert lib.grnet_comm_create(C.byref(h), ident, 2, 2, 0) == -22 and b"rank" in lib.grnet_comm_last_error()
+    assert lib.grnet_comm_create(C.byref(h), None, 1, 0, 0) == -22
+    assert lib.grnet_comm_unique_id(C.create_string_buffer(16), 16) == -22 and b"128" in lib.grnet_comm_last_error()
+    assert lib.grnet_allgather(None, None, None, 4, None) == -22
+    assert lib.grnet_comm_adopt(C.byref(h), None, 1, 0) == -22
+    assert lib.grnet_comm_info(None, None, None) == -22
+    lib.grnet_comm_destroy(None)                                         # a no-op, like free(NULL)
+    with pytest.raises(pkg._lib.GrnetError, match="grnet_comm_create"):
+        pkg._lib.check_comm(lib, lib.grnet_comm_create(C.byref(h), ident, 0, 0, 0), "grnet_comm_create")
+
+
 def test_outputs_struct_matches_header(pkg):
     header = open(os.path.join(ROOT, "include", "grnet_hip.h")).read()
     body = header[header.index("typedef struct grnet_outputs {"):header.index("} grnet_outputs_t;")]

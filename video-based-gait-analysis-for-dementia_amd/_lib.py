@@ -68,6 +68,13 @@ EXPORTS = {
     "grnet_op_rot6d_to_rotmat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "grnet_op_rotmat_to_aa": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "grnet_debug_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
+    "grnet_comm_unique_id": (C.c_int, [C.c_void_p, C.c_int]),
+    "grnet_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "grnet_comm_adopt": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),
+    "grnet_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "grnet_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "grnet_comm_destroy": (None, [C.c_void_p]),
+    "grnet_comm_last_error": (C.c_char_p, []),
     "grnet_last_error": (C.c_char_p, [C.c_void_p]),
     "grnet_version": (C.c_char_p, []),
     "grnet_destroy": (None, [C.c_void_p]),
@@ -99,6 +106,14 @@ def load():
 
 class GrnetError(RuntimeError):
     pass
+
+
+COMM_ID_BYTES = 128
+
+
+def check_comm(lib, rc, what):
+    if rc != 0:
+        raise GrnetError(f"{what} failed with code {rc}: {lib.grnet_comm_last_error().decode()}")
 
 
 def check(lib, handle, rc, what):

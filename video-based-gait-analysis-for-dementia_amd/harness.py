@@ -43,7 +43,7 @@ def plan_work_items(lengths, world, chunk=128):
     return items
 
 
-def gather_work_items(items, local_rows, row_floats, world, rank, dist, device):
+def gather_work_items(items, local_rows, row_floats, world, rank, dist, device, comm=None):
     """ONE all-gather for a whole window of videos: every rank contributes the rows (frames) of its items, concatenated in item
     order and padded to the largest per-rank count; returns {video index: (n_frames_of_the_video, row_floats) tensor} in frame
     order (on every rank).  ``local_rows``: (count_of_this_rank, row_floats) tensor on ``device``."""
@@ -58,7 +58,7 @@ def gather_work_items(items, local_rows, row_floats, world, rank, dist, device):
         recv = send.unsqueeze(0)
     else:
         flat = torch.empty(world * cap, row_floats, dtype=torch.float32, device=device)
-        dist.all_gather_into_tensor(flat, send)
+        _all_gather(flat, send, dist, comm)
         recv = flat.view(world, cap, row_floats)
     cursor = [0] * world
     per_video = {}
@@ -66,6 +66,66 @@ def gather_work_items(items, local_rows, row_floats, world, rank, dist, device):
         per_video.setdefault(vi, []).append(recv[r, cursor[r]:cursor[r] + hi - lo])
         cursor[r] += hi - lo
     return {vi: torch.cat(parts, 0) for vi, parts in per_video.items()}
+
+
+class RcclComm:
+    """The C ABI's own RCCL communicator (grnet_comm_*, include/grnet_hip.h): the exchange then needs PyTorch only for the device buffers.
+
+    Bootstrap: rank 0 draws the 128-byte id (grnet_comm_unique_id) and the launcher's process group -- any backend, it only carries 128 bytes over
+    the host -- broadcasts it; every rank then enters grnet_comm_create (collective: it returns when all ranks have arrived).  ``all_gather`` enqueues
+    ONE ncclAllGather on the caller's stream.  RCCL wants one GPU per rank: two ranks sharing a device (the gloo rehearsals) cannot use this class.
+    """
+
+    def __init__(self, world, rank, device, dist=None, unique_id=None):
+        self._lib = lib = _lib.load()
+        self.world, self.rank, self.device = world, rank, torch.device(device)
+        if unique_id is None:
+            buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+            if rank == 0:
+                _lib.check_comm(lib, lib.grnet_comm_unique_id(buf, _lib.COMM_ID_BYTES), "grnet_comm_unique_id")
+            if world > 1:
+                if dist is None:
+                    raise ValueError("RcclComm: pass the launcher's torch.distributed (or the 128-byte unique_id of rank 0) when world > 1")
+                box = [buf.raw if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                unique_id = box[0]
+            else:
+                unique_id = buf.raw
+        if len(unique_id) != _lib.COMM_ID_BYTES:
+            raise ValueError(f"RcclComm: the unique id has {len(unique_id)} bytes, not {_lib.COMM_ID_BYTES}")
+        h = C.c_void_p()
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.check_comm(lib, lib.grnet_comm_create(C.byref(h), unique_id, world, rank, index), "grnet_comm_create")
+        self._h = h
+
+    def all_gather(self, recv, send, stream=None):
+        """recv (world * send.numel() elements) <- every rank's ``send``, rank-major; both contiguous device tensors of one dtype."""
+        assert send.is_contiguous() and recv.is_contiguous() and recv.dtype == send.dtype
+        assert recv.numel() == self.world * send.numel(), (recv.shape, send.shape, self.world)
+        stream = stream if stream is not None else torch.cuda.current_stream(send.device)
+        rc = self._lib.grnet_allgather(self._h, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()),
+                                       send.numel() * send.element_size(), C.c_void_p(stream.cuda_stream))
+        _lib.check_comm(self._lib, rc, "grnet_allgather")
+        return recv
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.grnet_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _all_gather(out, send, dist, comm):
+    """The one collective of the path: the C ABI's communicator when the caller made one, else the launcher's process group."""
+    if comm is not None:
+        comm.all_gather(out, send)
+    else:
+        dist.all_gather_into_tensor(out, send)
 
 
 def pack_layout(n_local, record=POSE_RECORD):
@@ -77,8 +137,9 @@ def pack_layout(n_local, record=POSE_RECORD):
     return layout, off
 
 
-def gather_pose_records(packed_local, n_local, world, dist, out=None):
-    """One all-gather of every rank's packed block (RCCL over xGMI on GPUs, gloo in CPU tests).
+def gather_pose_records(packed_local, n_local, world, dist, out=None, comm=None):
+    """One all-gather of every rank's packed block (RCCL over xGMI on GPUs -- through the C ABI's grnet_allgather when ``comm`` is an
+    RcclComm, else through the launcher's process group -- gloo in CPU tests).
 
     ``packed_local``: 1-D tensor of ``n_local * POSE_RECORD_FLOATS`` floats laid out by ``pack_layout``;
     every rank must pass the same ``n_local`` (pad the last shard).  Returns the (world, block) tensor.
@@ -89,7 +150,7 @@ def gather_pose_records(packed_local, n_local, world, dist, out=None):
     if world == 1:
         out.copy_(packed_local)
     else:
-        dist.all_gather_into_tensor(out, packed_local)
+        _all_gather(out, packed_local, dist, comm)
     return out.view(world, block)
 
 
@@ -125,8 +186,8 @@ class ClipRunner:
     the exchange needs no packing kernel.  ``verts`` / ``rotmat`` stay sharded (rank-local).
     """
 
-    def __init__(self, model, frames, use_graph=True, world=1, rank=0, dist=None, tune_level=1, tune_cache=None, record=POSE_RECORD):
-        self.model, self.frames, self.world, self.rank, self.dist = model, frames.contiguous(), world, rank, dist
+    def __init__(self, model, frames, use_graph=True, world=1, rank=0, dist=None, tune_level=1, tune_cache=None, record=POSE_RECORD, comm=None):
+        self.model, self.frames, self.world, self.rank, self.dist, self.comm = model, frames.contiguous(), world, rank, dist, comm
         self.n = n = frames.shape[0]
         self.record = record
         dev = frames.device
@@ -153,7 +214,7 @@ class ClipRunner:
                                      C.c_void_p(self._stream.cuda_stream))
         _lib.check(self._lib, self._h, rc, "grnet_forward")
         if self.world > 1:
-            gather_pose_records(self.packed, self.n, self.world, self.dist, out=self.gathered)
+            gather_pose_records(self.packed, self.n, self.world, self.dist, out=self.gathered, comm=self.comm)
 
     def sequence(self, n_total=None):
         """Whole-clip results in frame order (after step())."""
@@ -174,8 +235,9 @@ class ShardedSequenceRunner:
     and ``temporal(seq)`` are the seams of the CPU tests (a stand-in model under gloo); by default they call grnet_forward /
     temporal_after_gather."""
 
-    def __init__(self, model, frames, n_total, world=1, rank=0, dist=None, chunk=128, forward_chunk=None, temporal=None, bbox=None, cimg=None):
-        self.model, self.frames, self.n_total, self.world, self.rank, self.dist = model, frames, int(n_total), world, rank, dist
+    def __init__(self, model, frames, n_total, world=1, rank=0, dist=None, chunk=128, forward_chunk=None, temporal=None, bbox=None, cimg=None,
+                 comm=None):
+        self.model, self.frames, self.n_total, self.world, self.rank, self.dist, self.comm = model, frames, int(n_total), world, rank, dist, comm
         self.n_local = -(-self.n_total // world)
         lo, hi = shard_range(self.n_total, world, rank)
         self.count = hi - lo
@@ -207,7 +269,7 @@ class ShardedSequenceRunner:
     def step(self):
         for c0, c1, out in self.calls:
             self._forward_chunk(c0, c1, out)
-        g = gather_pose_records(self.packed, self.n_local, self.world, self.dist, out=self.gathered)
+        g = gather_pose_records(self.packed, self.n_local, self.world, self.dist, out=self.gathered, comm=self.comm)
         self.seq = unpack_sequence(g, self.n_local, self.n_total, self.record)
         self.result = self._temporal(self.seq)
         return self.result
