@@ -52,23 +52,31 @@ def parse_args(argv=None):
                     "k > 1 alternates k independent model instances on k streams so consecutive clips overlap (throughput mode)")
     ap.add_argument("--tune-level", type=int, default=1, help="0: cost model only, 1: per-shape measurement (~0.1 s), "
                     "2: + in-context greedy refinement (~20 s, untimed)")
-    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32", help="f32: the headline (BASELINE configs[1]); bf16: bf16 storage / "
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default=None, help="default f32 (bf16 for --workload tracks, as configs[4] names it). f32: the headline (BASELINE configs[1]); bf16: bf16 storage / "
                     "fp32 accumulation on the bf16 matrix cores (configs[2] with --frames 256), errors vs the fp32 oracle reported in `parity`")
     ap.add_argument("--tune-cache", default=None, help="tuning table file written by a previous run (default: none, grnet_tune measures)")
-    ap.add_argument("--workload", choices=("clip", "batchgen"), default="clip", help="clip: the headline, one 16-frame clip per GPU per step (weak scaling); "
+    ap.add_argument("--workload", choices=("clip", "batchgen", "tracks"), default="clip", help="tracks: BASELINE configs[4] -- --tracks person tracks x --track-frames raw "
+                    "1080p uint8 frames per GPU per step, crop + normalise on a side HIP stream overlapped with the (hipGraph-replayed or lane-stream) forward of the previous "
+                    "track, bf16; clip: the headline, one 16-frame clip per GPU per step (weak scaling); "
                     "batchgen: BASELINE configs[3] -- ONE job of --total-frames frames sharded over the GPUs in calls of <= --chunk frames, one all-gather of the "
                     "per-frame records, then the temporal branch (GRU + attention + second head pass) on the whole sequence; a step is the whole job (strong scaling)")
     ap.add_argument("--total-frames", type=int, default=10000, help="batchgen: frames of the whole job")
     ap.add_argument("--chunk", type=int, default=128, help="batchgen: frames per grnet_forward call")
+    ap.add_argument("--tracks", type=int, default=4, help="tracks: person tracks per GPU")
+    ap.add_argument("--track-frames", type=int, default=64, help="tracks: frames per track")
+    ap.add_argument("--call-frames", type=int, default=None, help="tracks: frames per forward call (default: all tracks of a step in ONE call; --track-frames = one call per track)")
+    ap.add_argument("--no-overlap", action="store_true", help="tracks: crop and forward on ONE stream (the A/B of the side stream)")
     ap.add_argument("--exchange", choices=("auto", "capi", "torch"), default="auto", help="N > 1: who owns the all-gather. capi: the C ABI's own RCCL communicator "
                     "(grnet_comm_create / grnet_allgather); torch: the launcher's process group; auto: capi on the nccl backend if every rank can bootstrap it, else torch")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip roofline.dominant_kernel (its per-shape timing launches would sit in a profiler's dispatch list)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the bf16 256-frame leg (BASELINE configs[2]) that the default 1-GPU fp32 run appends as `secondary`")
     a = ap.parse_args(argv)
+    if a.dtype is None:
+        a.dtype = "bf16" if a.workload == "tracks" else "f32"
     if a.steps is None:
-        a.steps = 3 if a.workload == "batchgen" else 300
+        a.steps = {"batchgen": 3, "tracks": 30}.get(a.workload, 300)
     if a.warmup is None:
-        a.warmup = 1 if a.workload == "batchgen" else 20
+        a.warmup = {"batchgen": 1, "tracks": 5}.get(a.workload, 20)
     return a
 
 
@@ -481,6 +489,77 @@ class BatchgenWorkload:
         self.model.close()
 
 
+class TracksWorkload:
+    """BASELINE configs[4] (`--workload tracks`): harness.OverlappedTrackRunner over --tracks person tracks of --track-frames raw 1080p frames, resident in HBM."""
+    H, W = 1080, 1920
+
+    def __init__(self, args, world, rank, local_rank, dist):
+        import numpy as np
+        import torch
+        self.torch, self.args, self.world, self.rank = torch, args, world, rank
+        pkg = self.pkg = importlib.import_module(PKG)
+        nt, t = args.tracks, args.track_frames
+        self.call_frames = args.call_frames or nt * t
+        self.model = pkg.build_synthetic_model(max_frames=self.call_frames, device_id=local_rank, with_gru=False, dtype=args.dtype)
+        dev = torch.device("cuda", local_rank)
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        video = torch.randint(0, 256, (t, self.H, self.W, 3), dtype=torch.uint8, device=dev, generator=g)        # ONE video, every track crops its own person from it
+        rng = np.random.default_rng(77 + rank)
+        self.boxes = []
+        for k in range(nt):                                     # a person walking across the picture: centre drifts, box breathes, some hang over the border
+            cx = np.linspace(150 + 400 * k, 500 + 400 * k, t) + rng.normal(0, 2, t)
+            cy = 540 + 200 * np.sin(np.linspace(0, 3, t) + k) + rng.normal(0, 2, t)
+            side = 380 + 60 * np.cos(np.linspace(0, 2, t) + k)
+            self.boxes.append(np.stack([cx, cy, side, side], 1).astype(np.float32))
+        self.raw = [video] * nt
+        self.runner = pkg.harness.OverlappedTrackRunner(self.model, self.raw, self.boxes, use_graph=not args.no_graph, tune_level=args.tune_level,
+                                                        overlap=not args.no_overlap, call_frames=self.call_frames)
+        self.n = nt * t
+
+    def step(self):
+        self.runner.step()
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def config(self):
+        a, model = self.args, self.model
+        tm = model.tuned_mode(self.runner.call_n[0]) or {}
+        eager = a.no_graph or tm.get("eager", False)
+        return {"workload": f"{a.tracks} person tracks x {a.track_frames} frames per GPU per step, packed into {len(self.runner.calls)} forward call(s) of <= {self.call_frames} frames: raw {self.W}x{self.H} uint8 frames resident in HBM -> crop + normalise "
+                            "(OpenCV arithmetic, HIP kernel) -> MAX-GRNet per-frame path, "
+                            f"{'fp32' if a.dtype == 'f32' else 'bf16 storage / fp32 accumulation'}; video decode excluded (host, out of scope); seed-defined synthetic weights",
+                "tracks": a.tracks, "track_frames": a.track_frames, "frames_per_gpu": self.n,
+                "forward_calls_per_step": len(self.runner.calls),
+                "preprocess": "same stream as the forward" if a.no_overlap else "side HIP stream, two crop buffers, events both ways (overlaps the previous call's forward, across steps too)",
+                "launch": ("eager launches on 4 lane streams" if eager else "hipGraph replay (one captured forward per (crop buffer, track output block))") +
+                          (" (schedule picked by grnet_tune)" if tm else ""),
+                "kernel_launches_per_forward": model.num_kernel_launches(), "exchange": "none (tracks stay on their GPU)"}
+
+    def roofline(self, fps_per_gpu):
+        model, n = self.model, self.runner.call_n[0]
+        return roofline_object(fps_per_gpu, self.args.dtype, model.conv_flops_per_frame(), None, None, model.num_conv_launches(), n,
+                               {"note": "frames/s per GPU of the whole step (crops + forwards of all tracks) x the convolution FLOPs of a frame"},
+                               executed_flops_per_frame=model.conv_executed_flops_per_frame(n))
+
+    def extras(self, line):
+        """parity: the overlapped, fixed-buffer loop against crop + forward of each track one after another through the allocating host API."""
+        torch, model = self.torch, self.model
+        res = self.runner.step()
+        torch.cuda.synchronize()
+        worst = 0.0
+        for k, box in enumerate(self.boxes):
+            crop = model.crop_normalise(self.raw[k], torch.as_tensor(box), scale=1.1)
+            ref = model(crop.unsqueeze(0))[-1]
+            for name in ("theta", "kp_3d", "verts"):
+                a, b = res[k][name].reshape(-1), ref[name].reshape(-1)
+                worst = max(worst, float((a - b).abs().max() / b.abs().max()))
+        line["parity"] = {"max_rel_err_vs_sequential_calls": worst, "of": "theta, kp_3d, verts of every track: overlapped fixed-buffer loop vs crop_normalise + forward per track"}
+
+    def close(self):
+        self.model.close()
+
+
 def run_rank(args, make_workload=GpuWorkload, out=None):
     """Everything one rank does; returns the JSON object on rank 0 (None elsewhere).  `make_workload` is the seam the CPU
     tests use to drive the rank logic (barrier, MAX over ranks, rank-0 line) with a stand-in workload under gloo."""
@@ -489,15 +568,18 @@ def run_rank(args, make_workload=GpuWorkload, out=None):
     batchgen = getattr(args, "workload", "clip") == "batchgen"
     if batchgen and make_workload is GpuWorkload:
         make_workload = BatchgenWorkload
+    tracks = getattr(args, "workload", "clip") == "tracks"
+    if tracks and make_workload is GpuWorkload:
+        make_workload = TracksWorkload
     wl = make_workload(args, world, rank, local_rank, dist)
     elapsed = timed_steps(wl.step, wl.sync, args.steps, args.warmup, dist, reduce_device)
     line = None
-    n = args.frames
+    n = args.tracks * args.track_frames if tracks else args.frames
     total_frames = (args.total_frames if batchgen else n * world) * args.steps
     fps = total_frames / elapsed
     roof = wl.roofline(fps / world)                            # every rank runs it (keeps the ranks in step), rank 0 reports
     if rank == 0:
-        line = {"metric": f"frames/sec (224x224, {args.total_frames}-frame video directory, all-gather before the GRU)" if batchgen else f"frames/sec (224x224, seq={n})",
+        line = {"metric": f"frames/sec (224x224, {args.total_frames}-frame video directory, all-gather before the GRU)" if batchgen else f"frames/sec (224x224, {args.tracks} tracks x seq={args.track_frames}, crop overlapped with the forward)" if tracks else f"frames/sec (224x224, seq={n})",
                 "value": round(fps, 2), "unit": "frames/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
                 "higher_is_better": True, "scaling": "strong" if batchgen else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",

@@ -256,3 +256,41 @@ def test_c_abi_exchange_world1(pkg):
         comm.all_gather(torch.zeros(3, device=dev), torch.zeros(2, device=dev))
     comm.close()
     comm.close()                                                         # idempotent
+
+
+@pytest.mark.parametrize("dtype,use_graph,call_frames", [("f32", False, None), ("f32", True, 8), ("f32", True, 12), ("bf16", True, None)])
+def test_overlapped_track_runner_equals_sequential_calls(pkg, dtype, use_graph, call_frames):
+    """BASELINE configs[4]'s loop (harness.OverlappedTrackRunner: crops on a side stream into two alternating buffers, forwards -- graph replay or lane
+    streams -- on the caller's stream, tracks packed into calls of <= call_frames frames, the next step's first crop staged under this step's last forward,
+    no allocation per step) gives what crop_normalise + forward per track give through the allocating host API (bit for bit when a call is one track; to the
+    call-size noise of the kernels' different tilings when tracks share a call), for tracks of different lengths, boxes over the border, repeated steps (buffer reuse + captured graphs), and with the side stream switched off."""
+    harness = pkg.harness
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(3)
+    video = torch.randint(0, 256, (7, 360, 480, 3), dtype=torch.uint8, device=dev, generator=g)
+    lens = [7, 4, 7]
+    raws = [video[:t] for t in lens]
+    boxes = [np.stack([np.linspace(40 + 150 * k, 120 + 150 * k, t), np.linspace(60, 330, t), np.full(t, 180.0), np.full(t, 180.0)], 1).astype(np.float32)
+             for k, t in enumerate(lens)]
+    model = pkg.build_synthetic_model(max_frames=18, device_id=0, with_gru=False, dtype=dtype)
+    ref = []
+    for raw, box in zip(raws, boxes):
+        out = model(model.crop_normalise(raw, torch.as_tensor(box), scale=1.1).unsqueeze(0))[-1]
+        ref.append({k: out[k].clone() for k in ("theta", "kp_3d", "kp_2d", "verts")})
+    for overlap in (True, False):
+        runner = harness.OverlappedTrackRunner(model, raws, boxes, use_graph=use_graph, tune_level=0, overlap=overlap, call_frames=call_frames)
+        assert [[k for k, _ in c] for c in runner.calls] == {None: [[0, 1, 2]], 8: [[0], [1], [2]], 12: [[0, 1], [2]]}[call_frames]
+        for _ in range(3):
+            res = runner.step()
+        torch.cuda.synchronize()
+        for k in range(len(lens)):
+            for name in ref[k]:
+                a, b = res[k][name].reshape(-1), ref[k][name].reshape(-1)
+                if call_frames == 8:
+                    assert torch.equal(a, b), (overlap, k, name)
+                else:
+                    a, b = a.cpu().numpy(), b.cpu().numpy()
+                    assert rel_err(a, b) <= (CALL_SIZE_NOISE if dtype == "f32" else 2e-2), (overlap, k, name, rel_err(a, b))
+    with pytest.raises(ValueError):
+        harness.OverlappedTrackRunner(model, raws, boxes, call_frames=5)
+    model.close()

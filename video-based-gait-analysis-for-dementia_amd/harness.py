@@ -273,3 +273,94 @@ class ShardedSequenceRunner:
         self.seq = unpack_sequence(g, self.n_local, self.n_total, self.record)
         self.result = self._temporal(self.seq)
         return self.result
+
+
+class OverlappedTrackRunner:
+    """BASELINE configs[4] on one GPU: several person tracks of one video, each ``(raw uint8 frames (t,H,W,3) resident on the device, boxes (t,4))``.
+    Frames are independent on this path, so tracks are packed -- in order, whole -- into forward calls of <= ``call_frames`` frames (default: as many as
+    the handle's arena takes; 4 x 64 frames are ONE 256-frame call, where the kernels are 1.3x more efficient than at 64).  Per call: the boxes' crop maps
+    go up (80 B per frame, from pinned memory) and the crop + normalise kernel (row f1, OpenCV's arithmetic, grnet_crop_normalise_cv_maps, one launch per
+    track) fills one of TWO fixed crop buffers on a side HIP stream while the forward of the previous call (a replayed hipGraph when the tuned schedule
+    says so: fixed crop buffers and per-call output blocks make the pointers repeat, grnet.cpp's cache is keyed by them) runs on the caller's stream;
+    events order the hand-over in both directions, and the first call of the NEXT step is staged under the last forward of this one (the runner cycles
+    over the same tracks, as a bench does; a video loop would hand in the next tracks).  Same loop as pipeline.run_tracks_overlapped (demo.py:126-188 per
+    person), minus every per-step allocation.  Video decode is the host's (ffmpeg / PIL: out of scope)."""
+
+    def __init__(self, model, raw, boxes, scale=1.1, use_graph=True, tune_level=1, overlap=True, call_frames=None):
+        from .pipeline import cv_crop_maps
+        self.model, self.raw, self.overlap = model, [r.contiguous() for r in raw], overlap
+        dev = self.dev = raw[0].device
+        self.t = [int(r.shape[0]) for r in raw]
+        cap = int(call_frames or model.max_frames)
+        if max(self.t) > cap or cap > model.max_frames:
+            raise ValueError(f"a track has {max(self.t)} frames, a call takes {cap}, the handle {model.max_frames}")
+        self.calls, cur = [], []                                                                       # [[(track, offset in the call)], ...]
+        for k, t in enumerate(self.t):
+            if cur and cur[-1][1] + self.t[cur[-1][0]] + t > cap:
+                self.calls.append(cur)
+                cur = []
+            cur.append((k, cur[-1][1] + self.t[cur[-1][0]] if cur else 0))
+        self.calls.append(cur)
+        self.call_n = [c[-1][1] + self.t[c[-1][0]] for c in self.calls]
+        n_max = max(self.call_n)
+        self.maps_host = [torch.from_numpy(cv_crop_maps(b, scale)).pin_memory() for b in boxes]        # (t,10) float64 per track
+        self.maps_dev = [torch.empty(n_max, 10, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.bufs = [torch.empty(n_max, 3, 224, 224, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.results, self.outs = [None] * len(self.t), []
+        for c, n in zip(self.calls, self.call_n):                                                      # one output block per call; a track's results are slices of it
+            res = {"theta": torch.empty(n, 85, device=dev), "kp_3d": torch.empty(n, 29, 3, device=dev), "kp_2d": torch.empty(n, 29, 2, device=dev),
+                   "verts": torch.empty(n, 6890, 3, device=dev), "rotmat": torch.empty(n, 24, 3, 3, device=dev),
+                   "point_local_feat": torch.empty(n, 128, 24, device=dev)}
+            out = _lib.Outputs()
+            for name, ten in res.items():
+                setattr(out, name, ten.data_ptr())
+            self.outs.append(out)
+            for k, off in c:
+                self.results[k] = {name: ten[off:off + self.t[k]] for name, ten in res.items()}
+        model.finalize()
+        if use_graph:
+            model.set_option(_lib.OPT_USE_GRAPH, 1)
+        if tune_level:
+            for n in sorted(set(self.call_n)):
+                model.tune(n, level=tune_level)
+        self.side = torch.cuda.Stream(device=dev) if overlap else None
+        self.ready = [torch.cuda.Event() for _ in range(2)]                                            # the crops of a call have landed in bufs[slot]
+        self.free = [torch.cuda.Event() for _ in range(2)]                                             # the forward that read bufs[slot] is done
+        self._lib, self._h = model._lib, model._h
+        self._seq = 0                                                                                  # calls issued so far: call number -> slot = seq % 2
+        self._staged = False                                                                           # the crops of call number _seq are already enqueued
+
+    def _stage(self, c, slot, main):
+        st = self.side if self.overlap else main
+        with torch.cuda.stream(st):
+            if self.overlap:
+                st.wait_event(self.free[slot])
+            for k, off in self.calls[c]:
+                t, raw = self.t[k], self.raw[k]
+                self.maps_dev[slot][off:off + t].copy_(self.maps_host[k], non_blocking=True)
+                rc = self._lib.grnet_crop_normalise_cv_maps(self._h, raw.data_ptr(), t, raw.shape[1], raw.shape[2], 0, self.maps_dev[slot][off:].data_ptr(), 0,
+                                                            self.bufs[slot][off:].data_ptr(), C.c_void_p(st.cuda_stream))
+                _lib.check(self._lib, self._h, rc, "grnet_crop_normalise_cv_maps")
+            if self.overlap:
+                self.ready[slot].record(st)
+
+    def step(self):
+        main = torch.cuda.current_stream(self.dev)
+        nc = len(self.calls)
+        if self.overlap and self._seq == 0:
+            for e in self.free:
+                e.record(main)
+        for c in range(nc):
+            slot = self._seq % 2
+            if not self._staged:
+                self._stage(c, slot, main)
+            if self.overlap:
+                self._stage((c + 1) % nc, 1 - slot, main)                                              # overlaps the forward below; (nc-1) + 1 = the next step's first call
+                self._staged = True
+                main.wait_event(self.ready[slot])
+            rc = self._lib.grnet_forward(self._h, C.c_void_p(self.bufs[slot].data_ptr()), self.call_n[c], C.byref(self.outs[c]), C.c_void_p(main.cuda_stream))
+            _lib.check(self._lib, self._h, rc, "grnet_forward")
+            if self.overlap:
+                self.free[slot].record(main)
+            self._seq += 1
+        return self.results
