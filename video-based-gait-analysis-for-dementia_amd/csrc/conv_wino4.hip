@@ -619,9 +619,16 @@ bool conv_wino4_eligible(int cin, int cout, int ks, int stride, int h, int w, in
     return ks == 3 && stride == 1 && ((h == 56 && w == 56) || (h == 28 && w == 28)) && n_add <= 1 && cin % kCK == 0 && cout % 32 == 0 && cin >= 32;
 }
 
+// GRNET_WINO_LDS_PAD (diagnostic): extra bytes of LDS the 4-wave launches ask for -- how sensitive the step is to the workgroups per CU
+static size_t wino4_lds() {
+    static const size_t pad = getenv("GRNET_WINO_LDS_PAD") ? (size_t)atoi(getenv("GRNET_WINO_LDS_PAD")) : 0;
+    return kLdsB + pad;
+}
+
 template <int WD>
 static hipError_t launch_wino4_w(ConvArgs a, hipStream_t s, int nb, int* n_launches) {
     constexpr int TRG = 14 / (WD / 4);
+    const size_t kLdsB = wino4_lds();
     a.gx = a.N * (((a.H >> 2) + TRG - 1) / TRG);
     a.gy = a.CoutPad / (nb * 16);
     a.xcd = a.gx % 8 == 0 && a.gx >= 16 ? 1 : 0;
@@ -663,7 +670,7 @@ hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s, int* n_launches) {
     if (hipError_t e = current_device(&dev); e != hipSuccess) return e;
     if (hipError_t e = once_per_device(attr, dev, [](int*) {
             hipError_t e = hipSuccess;
-            auto set = [&](auto kern) { if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsB); };
+            auto set = [&](auto kern) { if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino4_lds()); };
             set(conv_wino4_f32<4, 56>); set(conv_wino4_f32<2, 56>); set(conv_wino4_f32<4, 28>); set(conv_wino4_f32<2, 28>);
             set(conv_wino4_f32<2, 56, 0, true>); set(conv_wino4_f32<2, 28, 0, true>);
             auto setw = [&](auto kern) { if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsW); };
