@@ -44,9 +44,11 @@ def flush_windows(n_videos, max_vid):
 
 
 def prepare_data(fv, vid_folder, outpath, pretrained_file=None, synthetic_weights=False, max_frames=128, dtype="f32", chunk=None,
-                 model_factory=None, backend="nccl"):
+                 model_factory=None, backend="nccl", exchange="torch"):
     """model_factory(local_rank) -> model and backend="gloo" are the seam of the CPU tests (tests/test_host_cpu.py): the window / plan /
-    run / gather / flush logic below then runs under two gloo ranks with a stand-in model and tensors on the CPU."""
+    run / gather / flush logic below then runs under two gloo ranks with a stand-in model and tensors on the CPU.
+    exchange: "torch" = the window's all-gather through the launcher's process group; "capi" = through the C ABI's own RCCL communicator
+    (harness.RcclComm: grnet_comm_create + grnet_allgather; needs one GPU per rank)."""
     import joblib
     import torch
     pkg = importlib.import_module(PKG)
@@ -79,6 +81,11 @@ def prepare_data(fv, vid_folder, outpath, pretrained_file=None, synthetic_weight
         model.finalize()
     chunk = int(chunk or max_frames)
     dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+    comm = None
+    if exchange == "capi" and world > 1:
+        if not on_gpu:
+            raise ValueError("exchange='capi' needs the nccl backend (one GPU per rank)")
+        comm = harness.RcclComm(world, rank, dev, dist=dist)
     db = pipe.BatchDb(outpath) if rank == 0 else None
     vidnames = sorted(os.listdir(vid_folder), key=vid_sort_key)
     start, n_done = time.time(), 0
@@ -108,7 +115,7 @@ def prepare_data(fv, vid_folder, outpath, pretrained_file=None, synthetic_weight
             kp = pipe.run_on_frames(model, vids[vi][1], np.arange(lo, hi), vids[vi][2][lo:hi].copy(), device=dev, batch_size=chunk, on_device=True)["kp_3d"]
             mine.append(kp.reshape(hi - lo, 75))
         local = torch.cat(mine, 0) if mine else torch.zeros(0, 75, device=dev)
-        per_video = harness.gather_work_items(items, local, 75, world, rank, dist, dev)
+        per_video = harness.gather_work_items(items, local, 75, world, rank, dist, dev, comm=comm)
         if rank == 0:
             for vi, (key, _, bboxes) in enumerate(vids):
                 # the reference's db holds the boxes AFTER Inference scaled w,h by 1.1 in place (batch_generation.py:263-266
@@ -121,6 +128,9 @@ def prepare_data(fv, vid_folder, outpath, pretrained_file=None, synthetic_weight
     if rank == 0:
         print(f"=====>>> Generation frame rate: {n_done / max(time.time() - start, 1e-9):.1f}")
         print(f"Save database to {db.flush()}.")
+    if comm is not None:
+        torch.cuda.synchronize()
+        comm.close()
     if hasattr(model, "close"):
         model.close()
     if dist is not None:
@@ -139,6 +149,7 @@ if __name__ == "__main__":
     p.add_argument("--max_frames", type=int, default=128, help="frames per grnet_forward call (activation buffers are sized for it)")
     p.add_argument("--chunk", type=int, default=None, help="frames per multi-GPU work item (default: --max_frames)")
     p.add_argument("--dtype", choices=("f32", "bf16"), default="f32")
+    p.add_argument("--exchange", choices=("torch", "capi"), default="torch", help="multi-GPU: the all-gather through torch.distributed or through the C ABI's grnet_allgather")
     a = p.parse_args()
     prepare_data(fv=a.bbox_path, vid_folder=a.vid_folder, outpath=a.outpath, pretrained_file=a.pretrained_file,
-                 synthetic_weights=a.synthetic_weights, max_frames=a.max_frames, dtype=a.dtype, chunk=a.chunk)
+                 synthetic_weights=a.synthetic_weights, max_frames=a.max_frames, dtype=a.dtype, chunk=a.chunk, exchange=a.exchange)
