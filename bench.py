@@ -66,8 +66,9 @@ def parse_args(argv=None):
     ap.add_argument("--track-frames", type=int, default=64, help="tracks: frames per track")
     ap.add_argument("--call-frames", type=int, default=None, help="tracks: frames per forward call (default: all tracks of a step in ONE call; --track-frames = one call per track)")
     ap.add_argument("--no-overlap", action="store_true", help="tracks: crop and forward on ONE stream (the A/B of the side stream)")
-    ap.add_argument("--exchange", choices=("auto", "capi", "torch"), default="auto", help="N > 1: who owns the all-gather. capi: the C ABI's own RCCL communicator "
-                    "(grnet_comm_create / grnet_allgather); torch: the launcher's process group; auto: capi on the nccl backend if every rank can bootstrap it, else torch")
+    ap.add_argument("--exchange", choices=("auto", "capi", "torch"), default="torch", help="N > 1: who owns the all-gather. torch (default): the launcher's process group "
+                    "(RCCL on the nccl backend); capi: the C ABI's own RCCL communicator (grnet_comm_create / grnet_allgather; a second communicator next to the launcher's, "
+                    "verified on one rank only so far); auto: capi if every rank can bootstrap it, else torch")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip roofline.dominant_kernel (its per-shape timing launches would sit in a profiler's dispatch list)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the bf16 256-frame leg (BASELINE configs[2]) that the default 1-GPU fp32 run appends as `secondary`")
     a = ap.parse_args(argv)
@@ -136,7 +137,7 @@ def make_exchange(args, world, rank, local_rank, dist):
     """(RcclComm or None, label for config.exchange).  `auto` uses the C ABI's communicator only when EVERY rank created it (a MIN over the ranks'
     outcomes, so no rank waits in a collective the others never enter); both choices are RCCL on the nccl backend -- this is not a CPU fallback."""
     backend = os.environ.get("GRNET_BENCH_BACKEND", "nccl")
-    choice = getattr(args, "exchange", "auto")
+    choice = getattr(args, "exchange", "torch")
     if world == 1:
         return None, "none (1 GPU)"
     if backend != "nccl":

@@ -100,6 +100,7 @@ def test_make_exchange_picks_the_owner_of_the_all_gather(monkeypatch):
     nccl backend never touches the C ABI's communicator.  (The capi leg itself needs one GPU per rank: tests/test_gpu_round4.py covers world 1.)"""
     import argparse
     a = argparse.Namespace(exchange="auto")
+    assert bench.parse_args([]).exchange == "torch"                     # the driver's N > 1 run goes through the launcher's process group
     assert bench.make_exchange(a, 1, 0, 0, None) == (None, "none (1 GPU)")
     monkeypatch.setenv("GRNET_BENCH_BACKEND", "gloo")
     comm, label = bench.make_exchange(a, 2, 1, 0, None)

@@ -125,6 +125,33 @@ def test_allgather_reassembles_sequence_world2(n_total):
         assert shape == (n_total, 29, 3)
 
 
+def _id_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    h = importlib.import_module(PKG_NAME).harness
+    raw = bytes(range(128)) if rank == 0 else bytes(128)
+    q.put((rank, h.share_unique_id(raw, dist, torch.device("cpu"))))
+    dist.destroy_process_group()
+
+
+def test_comm_id_reaches_every_rank_world2():
+    """The bootstrap of the C ABI's communicator (harness.RcclComm): rank 0's 128-byte id arrives on every rank through the launcher's process group."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_id_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res[0] == res[1] == bytes(range(128))
+
+
 def _sharded_worker(rank, world, port, n_total, chunk, q):
     """ShardedSequenceRunner (BASELINE configs[3], `bench.py --workload batchgen`) under gloo with a stand-in per-frame model: every
     call writes, through the Outputs pointers it was given, field f of GLOBAL frame i = i + f/1000 (+ element / 1e6)."""

@@ -68,6 +68,16 @@ def gather_work_items(items, local_rows, row_floats, world, rank, dist, device, 
     return {vi: torch.cat(parts, 0) for vi, parts in per_video.items()}
 
 
+def share_unique_id(raw, dist, device):
+    """Rank 0's 128-byte communicator id to every rank over the launcher's process group: a device tensor on the nccl backend (RCCL moves
+    device memory only), a host tensor otherwise.  ``raw``: the id on rank 0, any 128 bytes elsewhere.  Returns the id as bytes."""
+    t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone()
+    if dist.get_backend() == "nccl":
+        t = t.to(device)
+    dist.broadcast(t, src=0)
+    return bytes(t.cpu().tolist())
+
+
 class RcclComm:
     """The C ABI's own RCCL communicator (grnet_comm_*, include/grnet_hip.h): the exchange then needs PyTorch only for the device buffers.
 
@@ -86,9 +96,7 @@ class RcclComm:
             if world > 1:
                 if dist is None:
                     raise ValueError("RcclComm: pass the launcher's torch.distributed (or the 128-byte unique_id of rank 0) when world > 1")
-                box = [buf.raw if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                unique_id = box[0]
+                unique_id = share_unique_id(buf.raw, dist, self.device)
             else:
                 unique_id = buf.raw
         if len(unique_id) != _lib.COMM_ID_BYTES:
