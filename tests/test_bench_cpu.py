@@ -110,3 +110,15 @@ def test_make_exchange_picks_the_owner_of_the_all_gather(monkeypatch):
     monkeypatch.setenv("GRNET_BENCH_BACKEND", "nccl")
     comm, label = bench.make_exchange(argparse.Namespace(exchange="torch"), 2, 0, 0, None)
     assert comm is None and label.startswith("RCCL via torch.distributed")
+
+
+def test_workload_defaults():
+    """Each workload's defaults: the headline is fp32 / 300 steps; configs[3] is a whole job per step; configs[4] is bf16 (as BASELINE names it) with its four
+    tracks in one forward call unless --call-frames says otherwise."""
+    a = bench.parse_args([])
+    assert (a.workload, a.dtype, a.steps, a.warmup, a.frames) == ("clip", "f32", 300, 20, 16)
+    a = bench.parse_args(["--workload", "batchgen"])
+    assert (a.dtype, a.steps, a.warmup, a.total_frames, a.chunk) == ("f32", 3, 1, 10000, 128)
+    a = bench.parse_args(["--workload", "tracks"])
+    assert (a.dtype, a.steps, a.warmup, a.tracks, a.track_frames, a.call_frames) == ("bf16", 30, 5, 4, 64, None)
+    assert bench.parse_args(["--workload", "tracks", "--dtype", "f32"]).dtype == "f32"
