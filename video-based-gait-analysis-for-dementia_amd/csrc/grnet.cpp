@@ -1437,6 +1437,7 @@ struct grnet {
             if (tl_start && !rec) HIP_TRY(hipEventRecord((*tl_start)[oi], s));
             if (rec) {                                            // dependencies: previous node of the lane + cross-lane producers
                 rec->deps.clear();
+                rec->n_chain = lane_last[lane] ? 1 : 0;
                 if (lane_last[lane]) rec->deps.push_back(lane_last[lane]);
                 if (multi_lane)
                     for (int w : op.waits)
@@ -1785,11 +1786,24 @@ struct grnet {
             HIP_TRY(hipGraphCreate(&g, 0));
             GraphRecorder recorder;
             recorder.graph = g;
+            // GRNET_GRAPH_EDGES (diagnostic): 0 = dependencies given at node creation (edges in plan order; default), 1 = lane-chain edges first, 2 = cross-lane
+            // edges first.  The order changes how ROCm 7.2's executor deals the nodes over its queues (108 / 26 / 142 / 16, 105 / 20 / 159 / 8, 116 / 90 / 70 / 16)
+            // but none of them replays faster than 4.16 ms against 3.5 ms for the eager lane streams (profiles/r04_graph_vs_eager_timeline.txt)
+            static const int edges_env = getenv("GRNET_GRAPH_EDGES") ? atoi(getenv("GRNET_GRAPH_EDGES")) : 0;
+            recorder.edge_order = edges_env;
             g_recorder = &recorder;
             int rc = enqueue(frames, n, o, s);
             g_recorder = nullptr;
             if (rc) { hipGraphDestroy(g); return rc; }
-            hipError_t e;
+            hipError_t e = hipSuccess;
+            if (recorder.edge_order) {
+                auto add = [&](std::vector<hipGraphNode_t>& from, std::vector<hipGraphNode_t>& to) {
+                    if (e == hipSuccess && !from.empty()) e = hipGraphAddDependencies(g, from.data(), to.data(), from.size());
+                };
+                if (recorder.edge_order == 2) { add(recorder.cross_from, recorder.cross_to); add(recorder.chain_from, recorder.chain_to); }
+                else { add(recorder.chain_from, recorder.chain_to); add(recorder.cross_from, recorder.cross_to); }
+                if (e != hipSuccess) { hipGraphDestroy(g); return fail(GRNET_EHIP, std::string("hipGraphAddDependencies: ") + hipGetErrorString(e)); }
+            }
             hipGraphExec_t ge = nullptr;
             e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
             hipGraphDestroy(g);

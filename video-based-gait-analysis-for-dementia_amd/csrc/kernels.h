@@ -47,6 +47,12 @@ struct GraphRecorder {
     hipGraph_t graph = nullptr;
     std::vector<hipGraphNode_t> deps;
     int nodes = 0;
+    // edge_order != 0: nodes are created WITHOUT dependencies and the edges added afterwards, all lane-chain edges (a launch -> the next launch of its lane)
+    // before the cross-lane ones (1) or after them (2): ROCm's executor walks a node's children in insertion order and keeps the first one on the
+    // parent's stream, so the order decides whether a lane of the plan stays one stream of the replay
+    int edge_order = 0;
+    int n_chain = 0;                                   // how many of the leading entries of `deps` are lane-chain predecessors (0 or 1)
+    std::vector<hipGraphNode_t> chain_from, chain_to, cross_from, cross_to;
 };
 extern thread_local GraphRecorder* g_recorder;
 
@@ -67,10 +73,18 @@ hipError_t launch_k_impl(void (*kern)(KArgs...), dim3 grid, dim3 block, size_t s
     p.kernelParams = ptrs;
     p.extra = nullptr;
     hipGraphNode_t node = nullptr;
-    hipError_t e = hipGraphAddKernelNode(&node, g_recorder->graph, g_recorder->deps.data(), g_recorder->deps.size(), &p);
+    GraphRecorder& r = *g_recorder;
+    hipError_t e = r.edge_order ? hipGraphAddKernelNode(&node, r.graph, nullptr, 0, &p) : hipGraphAddKernelNode(&node, r.graph, r.deps.data(), r.deps.size(), &p);
     if (e != hipSuccess) return e;
-    g_recorder->deps.assign(1, node);
-    ++g_recorder->nodes;
+    if (r.edge_order)
+        for (size_t i = 0; i < r.deps.size(); ++i) {
+            const bool chain = (int)i < r.n_chain;
+            (chain ? r.chain_from : r.cross_from).push_back(r.deps[i]);
+            (chain ? r.chain_to : r.cross_to).push_back(node);
+        }
+    r.deps.assign(1, node);                            // a second launch of the same op follows the first on its lane
+    r.n_chain = 1;
+    ++r.nodes;
     return hipSuccess;
 }
 template <typename... KArgs, typename... Args>
