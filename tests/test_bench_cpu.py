@@ -122,3 +122,28 @@ def test_workload_defaults():
     a = bench.parse_args(["--workload", "tracks"])
     assert (a.dtype, a.steps, a.warmup, a.tracks, a.track_frames, a.call_frames) == ("bf16", 30, 5, 4, 64, None)
     assert bench.parse_args(["--workload", "tracks", "--dtype", "f32"]).dtype == "f32"
+
+
+def test_committed_bench_lines_carry_the_contract():
+    """The lines kept under profiles/ (what DESIGN.md quotes) have the driver's keys, the two extra objects, and fractions that are fractions."""
+    must = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"}
+    for name, workload_key in (("r04_bench_default.json", "clip"), ("r04_bench_batchgen_n1.json", "batch_generation"), ("r04_bench_tracks_n1.json", "person tracks")):
+        path = os.path.join(ROOT, "profiles", name)
+        line = json.loads(open(path).read().strip().splitlines()[-1])
+        assert must <= set(line), (name, must - set(line))
+        assert workload_key in line["config"]["workload"] and line["vs_baseline"] is None and line["data"] == "synthetic"
+        roof = line["roofline"]
+        assert roof["bound"].startswith("mfma") and 0 < roof["frac"] <= 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    head = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_default.json")).read().strip().splitlines()[-1])
+    assert head["dtype"] == "f32" and head["config"]["frames_per_gpu"] == 16 and head["scaling"] == "weak"
+    assert head["cpu_baseline"]["kind"] == "port" and head["cpu_baseline"]["cores"] >= 1
+    assert head["secondary"]["dtype"] == "bf16" and head["roofline"]["dominant_kernel"]["name"]
+    assert head["parity"]["ok"] and max(head["parity"]["max_rel_err"].values()) < 1e-3 and max(head["parity"]["elementwise_worst_ratio"].values()) <= 1
+
+
+def test_tools_compile():
+    import py_compile
+    tools = os.path.join(ROOT, "tools")
+    for f in sorted(os.listdir(tools)):
+        if f.endswith(".py"):
+            py_compile.compile(os.path.join(tools, f), doraise=True)
