@@ -134,8 +134,11 @@ def init_dist(world, rank, local_rank):
 
 
 def make_exchange(args, world, rank, local_rank, dist):
-    """(RcclComm or None, label for config.exchange).  `auto` uses the C ABI's communicator only when EVERY rank created it (a MIN over the ranks'
-    outcomes, so no rank waits in a collective the others never enter); both choices are RCCL on the nccl backend -- this is not a CPU fallback."""
+    """(RcclComm or None, label for config.exchange).  `auto` uses the C ABI's communicator only when EVERY rank created it.  The bootstrap inside
+    harness.RcclComm is the same on every rank (local probe -> MIN over the ranks -> rank 0 always enters the id broadcast, with a status byte):
+    a rank that cannot bind RCCL, or rank 0 failing to draw the id, makes ALL ranks raise before any rank enters grnet_comm_create, and the MIN
+    below then sends every rank to torch's all-gather.  Both choices are RCCL on the nccl backend -- this is not a CPU fallback.  The default
+    stays `torch` until a run on >= 2 GPUs has exercised `capi` (it has run with one rank only)."""
     backend = os.environ.get("GRNET_BENCH_BACKEND", "nccl")
     choice = getattr(args, "exchange", "torch")
     if world == 1:

@@ -109,7 +109,10 @@ int grnet_tsattn_forward(grnet_t* h, const float* x_dev, const float* xs_dev, in
                                    * re-associated: ~1e-5 of the output scale from the direct kernel per layer, <= 3.5e-5 on the path's outputs); 0: every
                                    * convolution is the direct implicit GEMM.  grnet_op_conv2d tile hints 2001 / 2020 (+ K split) run the two kernels on
                                    * one convolution.  (Options 4, 5, 6 -- grouped launches, the persistent dataflow launch and its fence -- were removed
-                                   * in round 3 after losing every measurement; their sources are kept under tools/experiments/.) */
+                                   * in round 3 after losing every measurement; their sources are in the history: commit 8d3a931.) */
+#define GRNET_OPT_BF16_CHAIN 8    /* bf16 handles: which HR branches run their four BasicBlocks (8 convolutions, lib/models/hrnet.py:141-187) as ONE launch with
+                                   * the frame resident in LDS (csrc/conv_bf16_chain.hip) in calls of >= 64 frames -- bit 0: 64 ch @28x28, bit 1: 128 ch @14x14,
+                                   * bit 2: 256 ch @7x7 (default 7; environment GRNET_BF16_CHAIN); 0: one launch per convolution at every call size */
 int grnet_set_option(grnet_t* h, int option, int value);
 
 /* Optional, once per distinct n_frames after grnet_finalize_weights: times every launch configuration of every
@@ -162,6 +165,13 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
                     const float* bias_host, int cout, int ks, int stride, int relu, const float* add_dev,
                     float* out_dev, int tile_hint, void* stream);
 int grnet_op_bilinear2x(grnet_t* h, const float* in_dev, int n, int c, int hgt, int wid, float* out_dev, void* stream);
+/* bf16 handles: a chain of nconv (even, <= 8) 3x3 stride-1 convolutions c -> c on (n,c,wid,wid) maps as ONE launch with the frame resident in LDS
+ * (csrc/conv_bf16_chain.hip) -- convolutions 2k, 2k+1 are conv1 / conv2 of BasicBlock k (lib/models/hrnet.py:43-59: conv-BN-ReLU, conv-BN, + block
+ * input, ReLU; four of them are one branch of a HighResolutionModule, hrnet.py:141-187).  (c, wid) in {(64,28), (128,14), (256,7)}.
+ * in_dev / out_dev: f32 NCHW device buffers (rounded to / from NHWC bf16 around the launch); w_host: nconv x (c,c,3,3) folded weights,
+ * bias_host: nconv x (c).  reps > 0 and us_out != NULL: `reps` more launches are timed with HIP events (us per launch).  Synchronises. */
+int grnet_op_conv_chain(grnet_t* h, const float* in_dev, int n, int c, int wid, int nconv, const float* w_host, const float* bias_host,
+                        float* out_dev, int reps, float* us_out, void* stream);
 
 /* SMPL(...) forward with rotation matrices -- lib/models/smpl.py:108-130 (smplx LBS + the 29 "spin2" joints) and, when
  * cam_dev != NULL, the projection of smpl.py:172-186.  Used by the --smooth step (lib/utils/smooth_pose.py:59-100), which
@@ -247,6 +257,10 @@ int grnet_debug_tensor(grnet_t* h, const char* name, int n_frames, float* out_de
  * Errors of this group: grnet_comm_last_error() (per thread), since no grnet_t is involved. */
 typedef struct grnet_comm grnet_comm_t;
 #define GRNET_COMM_ID_BYTES 128
+/* Local and non-collective: 0 when RCCL could be bound in this process (librccl.so.1, or the one library named by the environment variable
+ * GRNET_RCCL_LIB), GRNET_ESTATE otherwise.  Every rank calls it FIRST and the ranks agree on the minimum over a host channel before any of them
+ * enters grnet_comm_unique_id / grnet_comm_create, so that no rank waits inside a collective the others never enter. */
+int grnet_comm_probe(void);
 int grnet_comm_unique_id(void* id_out, int id_size /* >= GRNET_COMM_ID_BYTES */);
 int grnet_comm_create(grnet_comm_t** out_comm, const void* id, int world, int rank, int device_id);
 int grnet_comm_adopt(grnet_comm_t** out_comm, void* nccl_comm /* ncclComm_t */, int world, int rank);

@@ -149,7 +149,70 @@ def test_comm_id_reaches_every_rank_world2():
     res = dict(q.get(timeout=120) for _ in procs)
     for p in procs:
         p.join(timeout=60)
-    assert res[0] == res[1] == bytes(range(128))
+    assert res[0] == res[1] == (0, bytes(range(128)))
+
+
+def _missing_rccl_child(q):
+    import ctypes as C
+    os.environ["GRNET_RCCL_LIB"] = "libno_such_rccl_anywhere.so.9"
+    lib = importlib.import_module(PKG_NAME)._lib.load()
+    out = [lib.grnet_comm_probe(), lib.grnet_comm_last_error()]
+    out += [lib.grnet_comm_unique_id(C.create_string_buffer(128), 128), lib.grnet_comm_last_error()]
+    h = C.c_void_p()
+    out += [lib.grnet_comm_create(C.byref(h), bytes(128), 1, 0, 0), lib.grnet_comm_last_error()]
+    q.put(out)
+
+
+def test_exchange_without_rccl_reports_estate_instead_of_crashing():
+    """Round-4 advice: with no RCCL to bind, the first grnet_comm_* call built its message from a second dlerror() call (NULL: undefined behaviour,
+    a crash).  A process that points the lookup at a library that does not exist must get GRNET_ESTATE (-1 ... the header's code) and a message."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_missing_rccl_child, args=(q,))
+    p.start()
+    out = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    estate = importlib.import_module(PKG_NAME)._lib.ESTATE
+    for rc, msg in zip(out[0::2], out[1::2]):
+        assert rc == estate and b"libno_such_rccl_anywhere.so.9 not found" in msg, (rc, msg)
+
+
+def _bootstrap_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if rank == 1:
+        os.environ["GRNET_RCCL_LIB"] = "libno_such_rccl_anywhere.so.9"      # ONE rank cannot bind RCCL
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    h = importlib.import_module(PKG_NAME).harness
+    try:
+        h.RcclComm(world, rank, torch.device("cpu"), dist=dist)
+        q.put((rank, "created"))
+    except RuntimeError as e:
+        q.put((rank, str(e)))
+    dist.barrier()                                                            # the process group is still usable: nobody is stuck in a collective
+    dist.destroy_process_group()
+
+
+def test_comm_bootstrap_is_symmetric_world2():
+    """Round-4 advice: rank 0 failing to draw the id skipped the broadcast the other ranks sat in.  Now every rank probes locally, the ranks agree
+    on the minimum, and ALL of them raise before any collective of the bootstrap -- here rank 1 cannot bind RCCL and rank 0 can (or cannot: no
+    GPU library is needed for the probe's answer to be consistent)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bootstrap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert "cannot be bound on every rank" in res[0] and "cannot be bound on every rank" in res[1], res
+    assert "libno_such_rccl_anywhere" in res[1]
 
 
 def _sharded_worker(rank, world, port, n_total, chunk, q):

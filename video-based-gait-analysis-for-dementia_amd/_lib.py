@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("GRNET_LIB_PATH") or os.path.join(_HERE, "libgrnet_hip
 
 OK, EINVAL, ENOENT, ENOMEM, EHIP, ESTATE = 0, -22, -2, -12, -5, -1
 DTYPE_F32, DTYPE_I64 = 0, 1
-OPT_USE_GRAPH, OPT_CONV_TILE, OPT_MULTI_LANE, OPT_WINOGRAD = 1, 2, 3, 7
+OPT_USE_GRAPH, OPT_CONV_TILE, OPT_MULTI_LANE, OPT_WINOGRAD, OPT_BF16_CHAIN = 1, 2, 3, 7, 8
 
 
 class Outputs(C.Structure):
@@ -53,6 +53,8 @@ EXPORTS = {
     "grnet_time_convs": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "grnet_op_conv2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "grnet_op_conv_chain": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.POINTER(C.c_float), C.c_void_p]),
     "grnet_op_bilinear2x": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "grnet_smpl_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
@@ -68,6 +70,7 @@ EXPORTS = {
     "grnet_op_rot6d_to_rotmat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "grnet_op_rotmat_to_aa": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "grnet_debug_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
+    "grnet_comm_probe": (C.c_int, []),
     "grnet_comm_unique_id": (C.c_int, [C.c_void_p, C.c_int]),
     "grnet_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "grnet_comm_adopt": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),

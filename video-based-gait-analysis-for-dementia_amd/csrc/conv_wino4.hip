@@ -1,6 +1,6 @@
 // Winograd F(4x4, 3x3) on the fp32 matrix cores for the widest 3x3 stride-1 layers on 56x56 maps (upsample head 256 -> 256, PARE head
 // 480 -> 256: hrnet.py:444-451, pare.py:197-210 -- Conv2d 3x3 pad 1 + BatchNorm2d(eval) + ReLU).  A 4x4 output tile is 36 independent
-// products instead of 144 multiplies: 2.25 per output against 4 for F(2x2, 3x3) (round 2: tools/experiments/conv_wino.hip) and 9 for the direct kernel.  The
+// products instead of 144 multiplies: 2.25 per output against 4 for F(2x2, 3x3) (round 2; source in the history: commit 8d3a931) and 9 for the direct kernel.  The
 // transforms have non-trivial coefficients (4, 5, 2, 8 and sixths in the filter transform, which is applied in fp64 at load):
 // measured on a 256-channel layer in fp32 the result is 7.8e-6 of the output rms away from the exact sum (F(2x2,3x3): 8e-7, the
 // direct fma chain: 1.9e-6) -- two orders of magnitude inside the 1e-3 bar, covered by the same parity tests.

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -44,12 +45,19 @@ Rccl& rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
+        // GRNET_RCCL_LIB: look THIS library up and nothing else (a deployment's own build of RCCL; the tests point it at a name that does not exist)
+        const char* forced = getenv("GRNET_RCCL_LIB");
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        std::string last;
         for (const char* n : names) {
+            if (forced) n = forced;
             r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
             if (r.lib) break;
+            const char* e = dlerror();                                       // ONE call: dlerror() clears the message it returns
+            last = e ? e : "?";
+            if (forced) break;
         }
-        if (!r.lib) { r.why = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : "?"); return; }
+        if (!r.lib) { r.why = std::string(forced ? forced : "librccl.so.1") + " not found: " + last; return; }
         r.get_unique_id = (GetUniqueIdFn)dlsym(r.lib, "ncclGetUniqueId");
         r.comm_init_rank = (CommInitRankFn)dlsym(r.lib, "ncclCommInitRank");
         r.all_gather = (AllGatherFn)dlsym(r.lib, "ncclAllGather");
@@ -79,6 +87,11 @@ struct grnet_comm {
 };
 
 extern "C" {
+
+int grnet_comm_probe(void) {
+    Rccl& r = rccl();
+    return r.lib ? 0 : fail(GRNET_ESTATE, r.why);
+}
 
 int grnet_comm_unique_id(void* id_out, int id_size) {
     if (!id_out || id_size < kUniqueIdBytes) return fail(GRNET_EINVAL, "grnet_comm_unique_id: the buffer must hold GRNET_COMM_ID_BYTES (128) bytes");

@@ -69,6 +69,7 @@ struct ConvLayer {
     int cin_pad = 0, cout_pad = 0;
     double macs_per_frame = 0;
     int lane_hint = 0;          // lane of this convolution when it is launched on its own (not as a group member)
+    int chain = -1, chain_pos = 0;   // bf16: member chain_pos of BasicBlock chain `chain` (conv_bf16_chain.hip); position 0 launches the whole chain in large calls
     std::map<int, int> tuned;   // n_frames -> launch configuration (tile hint) measured fastest by grnet_tune
 };
 
@@ -82,6 +83,12 @@ struct FuseUpPlan {
     float* w_dev[3][3] = {};             // [output i][source j - i - 1], pack_fuse_up_weights
     float* b_dev[3] = {};                // [output i]: sum over j of the folded BatchNorm shifts
     double macs_per_frame = 0;
+};
+
+// The 8 convolutions (4 BasicBlocks) of one branch of one HR module, runnable as ONE launch on the bf16 path (conv_bf16_chain.hip).
+struct ChainPlan {
+    std::vector<int> convs;              // indices into grnet::convs, in execution order
+    int c = 0, w = 0;
 };
 
 struct Op {
@@ -295,20 +302,40 @@ struct grnet {
         const int nb = (int)xs.size();
         std::vector<int> branch_tail(nb, -1);                               // plan index of the launch that writes x_b
         cur_lane = 0;
+        std::vector<std::vector<int>> branch_ops(nb);                       // plan indices of the branch's convolutions, in order
         for (int k = 0; k < 4; ++k) {
             std::vector<View> y(nb);
             for (int b = 0; b < nb; ++b) {
                 cur_lane = b;
                 const std::string q = p + "branches." + std::to_string(b) + "." + std::to_string(k) + ".";
                 y[b] = conv_bn(xs[b], q + "conv1.weight", q + "bn1", kBranchCh[b], 3, 1, true);
+                branch_ops[b].push_back((int)ops.size() - 1);
             }
             for (int b = 0; b < nb; ++b) {
                 cur_lane = b;
                 const std::string q = p + "branches." + std::to_string(b) + "." + std::to_string(k) + ".";
                 xs[b] = conv_bn(y[b], q + "conv2.weight", q + "bn2", kBranchCh[b], 3, 1, true, {AddRef{xs[b], 0}});
                 branch_tail[b] = (int)ops.size() - 1;
+                branch_ops[b].push_back((int)ops.size() - 1);
             }
         }
+        // bf16: the branch's four BasicBlocks are also ONE chain launch (conv_bf16_chain.hip; taken in large calls, chain_active()).  The members
+        // keep their own ops -- small calls launch them one by one -- and are pinned to one stream in order, so the events recorded behind the
+        // (then empty) member ops still order every consumer behind the chain launch, which sits at the first member's place.
+        if (dtype == 1)
+            for (int b = 0; b < nb; ++b) {
+                if (!conv_bf16_chain_eligible(kBranchCh[b], xs[b].w) || (int)branch_ops[b].size() > kMaxChain) continue;
+                ChainPlan cp;
+                cp.c = kBranchCh[b]; cp.w = xs[b].w;
+                for (size_t i = 0; i < branch_ops[b].size(); ++i) {
+                    Op& op = ops[branch_ops[b][i]];
+                    convs[op.conv_idx].chain = (int)chains.size();
+                    convs[op.conv_idx].chain_pos = (int)i;
+                    cp.convs.push_back(op.conv_idx);
+                    if (i) op.follow = branch_ops[b][i - 1];
+                }
+                chains.push_back(cp);
+            }
         const std::string tag = p.substr(p.find("stage"));                  // "stage3.1."
         for (int b = 0; b < nb; ++b) name_view(tag + "x" + std::to_string(b), xs[b]);
         // GRNET_FUSE_UP=0: the round-3 fuse layer (one 1x1 launch per up term, an elementwise launch for output 0); the bf16 path keeps it
@@ -416,6 +443,7 @@ struct grnet {
         return outs;
     }
     std::vector<FuseUpPlan> fuse_ups;
+    std::vector<ChainPlan> chains;
 
     // Fuse layer as launched until round 3 (kept for the bf16 path and for A/B runs)
     std::vector<View> hr_fuse_separate(std::vector<View> xs, const std::string& p, const View* out0) {
@@ -872,8 +900,12 @@ struct grnet {
         const bool wino4s = !bf && wino4_env && cin == L.in.c && conv_wino4s_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size()) &&
                             (L.adds.empty() || L.adds[0].shift == 0);          // the small maps: conv_wino4s.hip
         static const int stem_env = getenv("GRNET_STEM") ? atoi(getenv("GRNET_STEM")) : 1;
-        const bool stem_shape = stem_env && cin == L.in.c && L.segs.size() == 1 && conv_stem_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size());
-        const bool stem = !bf && stem_shape, stem_bf = bf && bf16_stem && stem_shape;
+        const bool stem_shape = cin == L.in.c && L.segs.size() == 1 && conv_stem_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size());
+        // GRNET_STEM is the fp32 A/B switch only: a bf16 plan built for conv_bf16_stem (GRNET_BF16_STEM) has no NHWC copy of the frames, so its first
+        // convolution MUST get the stem kernel's weights whatever GRNET_STEM says (round-4 advice: the generic kernel then read fp32 NCHW frames as NHWC bf16)
+        const bool stem = !bf && stem_env && stem_shape, stem_bf = bf && bf16_stem && stem_shape;
+        if (bf && bf16_stem && reinterpret_cast<uintptr_t>(L.in.p) == ~(uintptr_t)0 && !stem_bf)
+            return fail(GRNET_ESTATE, "bf16 plan without a conversion launch, but its first convolution is not eligible for conv_bf16_stem");
         std::vector<double> wfold(wino4 || wino4s || stem || stem_bf ? (size_t)L.cout * cin * 9 : 0);     // BN-folded weights (cout, cin, 3, 3) for the filter transform
         int co0 = 0;
         for (auto& s : L.segs) {
@@ -1312,9 +1344,18 @@ struct grnet {
 
     // Which kernel runs convolution L in a call of n frames: ONE place, used by the launcher, by the executed-FLOP report and by the
     // per-kernel table of bench.py (round-3 review: the report read a hidden "latest n" and ignored the environment masks).
-    enum ConvKernel { K_BF16, K_BF16_STEM, K_WINO4S, K_PW, K_STEM, K_WINO4, K_DIRECT };
+    enum ConvKernel { K_BF16, K_BF16_STEM, K_BF16_CHAIN, K_BF16_CHAIN_MEMBER, K_WINO4S, K_PW, K_STEM, K_WINO4, K_DIRECT };
+    // bf16: does chain `c` run as ONE conv_bf16_chain launch in a call of n frames?  A chain workgroup is one frame on one CU: from about a
+    // quarter of the chip's CUs on it beats eight launches (GRNET_BF16_CHAIN: bit 0 64 ch @28x28, bit 1 128 ch @14x14, bit 2 256 ch @7x7;
+    // GRNET_BF16_CHAIN_MIN: smallest call that takes it).  A forced tile (tests / tuning) switches it off like every special kernel.
+    bool chain_active(const ChainPlan& c, int n) const {
+        static const int chain_min = getenv("GRNET_BF16_CHAIN_MIN") ? atoi(getenv("GRNET_BF16_CHAIN_MIN")) : 64;
+        return dtype == 1 && !conv_tile_hint && n >= chain_min && (chain_mode & (c.w == 28 ? 1 : c.w == 14 ? 2 : 4));
+    }
+    int chain_mode = getenv("GRNET_BF16_CHAIN") ? atoi(getenv("GRNET_BF16_CHAIN")) : 7;      // GRNET_OPT_BF16_CHAIN
     ConvKernel kernel_for(const ConvLayer& L, int n) const {
         static const int w4s_env = getenv("GRNET_WINO4S") ? atoi(getenv("GRNET_WINO4S")) : 7;      // bit 0: 128 @14x14, bit 1: 256 @7x7, bit 2: 256 @14x14
+        if (dtype == 1 && L.chain >= 0 && chain_active(chains[L.chain], n)) return L.chain_pos == 0 ? K_BF16_CHAIN : K_BF16_CHAIN_MEMBER;
         if (dtype == 1) return L.stem_dev ? K_BF16_STEM : K_BF16;      // (a plan built for conv_bf16_stem has no NHWC copy of the frames for the generic kernel)
         if (conv_tile_hint) return K_DIRECT;                   // a forced tile also switches every special kernel off (tests / tuning)
         if (wino4s_runs(L, n) && (w4s_env & (L.in.w == 7 ? 2 : L.in.c == 128 ? 1 : 4))) return K_WINO4S;
@@ -1337,6 +1378,8 @@ struct grnet {
         switch (kernel_for(L, n)) {
             case K_BF16: return "conv_bf16";
             case K_BF16_STEM: return "conv_bf16_stem";
+            case K_BF16_CHAIN: snprintf(b, sizeof b, "conv_bf16_chain<%d,%d>", L.in.c, L.in.w); return b;
+            case K_BF16_CHAIN_MEMBER: snprintf(b, sizeof b, "conv_bf16_chain<%d,%d>+", L.in.c, L.in.w); return b;      // runs inside the chain's launch: no launch, no time of its own
             case K_WINO4S: snprintf(b, sizeof b, "conv_wino4s_f32<%d,%d>", L.in.w, L.in.c); return b;
             case K_PW: snprintf(b, sizeof b, "conv_pw_f32<%d>", L.in.c); return b;
             case K_STEM: return "conv_stem_f32";
@@ -1355,6 +1398,18 @@ struct grnet {
         switch (kernel_for(L, n)) {
             case K_BF16: HIP_TRY(launch_conv_bf16(conv_args(L, frames, n), s, hint_for(L, n))); break;
             case K_BF16_STEM: HIP_TRY(launch_conv_bf16_stem(frames, L.stem_dev, L.b_dev, L.out.p, L.out.ctot, L.out.coff, n, L.relu, s)); break;
+            case K_BF16_CHAIN: {
+                const ChainPlan& cp = chains[L.chain];
+                const ConvLayer& last = convs[cp.convs.back()];
+                ChainArgs ca{};
+                ca.in = L.in.p; ca.in_ctot = L.in.ctot; ca.in_coff = L.in.coff;
+                ca.out = last.out.p; ca.out_ctot = last.out.ctot; ca.out_coff = last.out.coff;
+                ca.N = n; ca.nconv = (int)cp.convs.size();
+                for (int i = 0; i < ca.nconv; ++i) { ca.w[i] = convs[cp.convs[i]].w_dev; ca.bias[i] = convs[cp.convs[i]].b_dev; }
+                HIP_TRY(launch_conv_bf16_chain(ca, cp.c, cp.w, s));
+                break;
+            }
+            case K_BF16_CHAIN_MEMBER: *n_launches = 0; break;       // its work is in the launch of the chain's first member
             case K_WINO4S: {
                 ConvArgs wa = conv_args(L, frames, n);
                 wa.w = L.wino4s_dev;
@@ -1445,7 +1500,11 @@ struct grnet {
             }
             // timing-only ablation (results are garbage): GRNET_ABL_SKIP=<substring of a weight key>[,<substring>...] drops the matching
             // convolution launches and "fuse_up" the grouped fuse launches, events and dependencies stay -- what is a group of launches worth?
+#ifdef GRNET_ABLATION                                                  // diagnostic builds only (make ABLATION=1): a stray variable must not make the product drop launches
             static const char* abl_skip = getenv("GRNET_ABL_SKIP");
+#else
+            static const char* abl_skip = nullptr;
+#endif
             if (abl_skip && (op.kind == Op::CONV || op.kind == Op::FUSEUP)) {
                 const std::string lbl = op_label(op);
                 bool skip = false;
@@ -1632,6 +1691,52 @@ struct grnet {
         if (xadd) hipFree(xadd);
         if (e != hipSuccess) return fail(GRNET_EHIP, std::string("bf16 conv: ") + hipGetErrorString(e));
         if (e2 != hipSuccess) return fail(GRNET_EHIP, std::string("bf16 conv kernel: ") + hipGetErrorString(e2));
+        return 0;
+    }
+
+    // Test / timing hook on a bf16 handle: a chain of nconv 3x3 convolutions c -> c on (n,c,w,w) f32 NCHW in / out (converted to and from NHWC
+    // bf16 around ONE conv_bf16_chain launch).  w_host: nconv x (c,c,3,3), bias_host: nconv x (c).  reps > 0: also times `reps` back-to-back
+    // launches with HIP events (*us_out: us per launch).
+    int op_conv_chain_bf16(const float* in_dev, int n, int c, int wid, int nconv, const float* w_host, const float* bias_host, float* out_dev, int reps,
+                           float* us_out, hipStream_t s) {
+        if (dtype != 1) return fail(GRNET_ESTATE, "grnet_op_conv_chain needs a bf16 handle");
+        if (!conv_bf16_chain_eligible(c, wid) || nconv < 2 || nconv > kMaxChain || (nconv & 1) || n < 1) return fail(GRNET_EINVAL, "shape not eligible for the chain kernel");
+        const size_t wel = (size_t)9 * c * c;
+        std::vector<uint16_t> wp(wel * nconv, 0);
+        for (int i = 0; i < nconv; ++i)
+            for (int co = 0; co < c; ++co)
+                for (int ci = 0; ci < c; ++ci)
+                    for (int t = 0; t < 9; ++t)
+                        wp[i * wel + (((size_t)(ci / 32) * 9 + t) * c + co) * 32 + ci % 32] = f32_to_bf16(w_host[i * wel + ((size_t)co * c + ci) * 9 + t]);
+        void *wd = nullptr, *bd = nullptr, *xin = nullptr, *xout = nullptr;
+        const size_t act_b = (size_t)n * wid * wid * c * 2;
+        auto cleanup = [&]() { if (wd) hipFree(wd); if (bd) hipFree(bd); if (xin) hipFree(xin); if (xout) hipFree(xout); };
+        if (hipMalloc(&wd, wp.size() * 2) != hipSuccess || hipMalloc(&bd, (size_t)nconv * c * 4) != hipSuccess || hipMalloc(&xin, act_b) != hipSuccess ||
+            hipMalloc(&xout, act_b) != hipSuccess) { cleanup(); return fail(GRNET_ENOMEM, "hipMalloc failed"); }
+        hipError_t e = hipMemcpy(wd, wp.data(), wp.size() * 2, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(bd, bias_host, (size_t)nconv * c * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = launch_nchw_f32_to_nhwc_bf16(in_dev, xin, n, c, wid, wid, c, s);
+        ChainArgs ca{};
+        ca.in = xin; ca.in_ctot = c; ca.in_coff = 0; ca.out = xout; ca.out_ctot = c; ca.out_coff = 0; ca.N = n; ca.nconv = nconv;
+        for (int i = 0; i < nconv; ++i) { ca.w[i] = static_cast<const uint16_t*>(wd) + i * wel; ca.bias[i] = static_cast<const float*>(bd) + (size_t)i * c; }
+        if (e == hipSuccess) e = launch_conv_bf16_chain(ca, c, wid, s);
+        if (e == hipSuccess && reps > 0 && us_out) {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            hipEventCreate(&e0); hipEventCreate(&e1);
+            hipEventRecord(e0, s);
+            for (int i = 0; i < reps && e == hipSuccess; ++i) e = launch_conv_bf16_chain(ca, c, wid, s);
+            hipEventRecord(e1, s);
+            hipEventSynchronize(e1);
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            *us_out = ms * 1e3f / reps;
+            hipEventDestroy(e0); hipEventDestroy(e1);
+        }
+        if (e == hipSuccess) e = launch_nhwc_bf16_to_nchw_f32(xout, out_dev, n, c, wid, wid, c, 0, s);
+        hipError_t e2 = hipStreamSynchronize(s);
+        cleanup();
+        if (e != hipSuccess) return fail(GRNET_EHIP, std::string("bf16 chain: ") + hipGetErrorString(e));
+        if (e2 != hipSuccess) return fail(GRNET_EHIP, std::string("bf16 chain kernel: ") + hipGetErrorString(e2));
         return 0;
     }
 
@@ -1836,7 +1941,7 @@ int grnet_create(grnet_t** out_handle, int device_id, int dtype, int max_frames)
     h->build_plan();
     int rc = h->allocate();
     if (rc) { fprintf(stderr, "grnet_create: %s\n", h->err.c_str()); return rc; }
-    if (conv_init() != hipSuccess || conv_bf16_init() != hipSuccess) { fprintf(stderr, "grnet_create: conv_init failed\n"); return GRNET_EHIP; }
+    if (conv_init() != hipSuccess || conv_bf16_init() != hipSuccess || conv_bf16_chain_init() != hipSuccess) { fprintf(stderr, "grnet_create: conv_init failed\n"); return GRNET_EHIP; }
     *out_handle = h.release();
     return 0;
 }
@@ -2013,6 +2118,7 @@ int grnet_set_option(grnet_t* h, int option, int value) {
         return 0;
     }
     if (option == GRNET_OPT_WINOGRAD) { h->wino_mode = value != 0; h->drop_graphs(); return 0; }
+    if (option == GRNET_OPT_BF16_CHAIN) { h->chain_mode = value & 7; h->drop_graphs(); return 0; }
     if (option == GRNET_OPT_MULTI_LANE) {
         h->multi_lane = value != 0;
         h->drop_graphs();
@@ -2306,6 +2412,13 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
     if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("launch_conv: ") + hipGetErrorString(e));
     if (e2 != hipSuccess) return h->fail(GRNET_EHIP, std::string("conv kernel: ") + hipGetErrorString(e2));
     return 0;
+}
+
+int grnet_op_conv_chain(grnet_t* h, const float* in_dev, int n, int c, int wid, int nconv, const float* w_host, const float* bias_host, float* out_dev,
+                        int reps, float* us_out, void* stream) {
+    if (!h || !in_dev || !w_host || !bias_host || !out_dev) return GRNET_EINVAL;
+    DeviceGuard guard(h->device);
+    return h->op_conv_chain_bf16(in_dev, n, c, wid, nconv, w_host, bias_host, out_dev, reps, us_out, static_cast<hipStream_t>(stream));
 }
 
 int grnet_op_bilinear2x(grnet_t* h, const float* in_dev, int n, int c, int hgt, int wid, float* out_dev, void* stream) {

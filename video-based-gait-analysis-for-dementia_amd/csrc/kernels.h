@@ -15,28 +15,36 @@ namespace grk {
 
 // One-time work per device (kernel attributes, device queries) that launchers used to cache in plain function-local statics: two host
 // threads driving two handles raced on those (a thread could see the flag set before the other's hipFuncSetAttribute had finished).
-// call_once per device id; the first result (error code, value) is kept.
+// Only SUCCESS is cached (round-4 advice: one transient failure used to disable a kernel family for the life of the process): a failed
+// attempt is retried by the next launch.  Device ids index a small vector grown under the lock.
 struct PerDeviceOnce {
-    std::once_flag flag[64];
-    hipError_t err[64];
-    int val[64];
+    std::mutex m;
+    std::vector<char> done;
+    std::vector<int> val;
 };
 inline hipError_t current_device(int* dev) {
-    return (hipGetDevice(dev) != hipSuccess || *dev < 0 || *dev >= 64) ? hipErrorInvalidDevice : hipSuccess;
+    return (hipGetDevice(dev) != hipSuccess || *dev < 0) ? hipErrorInvalidDevice : hipSuccess;
 }
 template <typename F>
-hipError_t once_per_device(PerDeviceOnce& c, int dev, F&& f) {      // f(int* value) -> hipError_t
-    std::call_once(c.flag[dev], [&] { c.val[dev] = 0; c.err[dev] = f(&c.val[dev]); });
-    return c.err[dev];
+hipError_t once_per_device(PerDeviceOnce& c, int dev, F&& f, int* value = nullptr) {      // f(int* value) -> hipError_t
+    std::lock_guard<std::mutex> lock(c.m);
+    if ((size_t)dev >= c.done.size()) { c.done.resize(dev + 1, 0); c.val.resize(dev + 1, 0); }
+    if (!c.done[dev]) {
+        int v = 0;
+        const hipError_t e = f(&v);
+        if (e != hipSuccess) return e;
+        c.val[dev] = v;
+        c.done[dev] = 1;
+    }
+    if (value) *value = c.val[dev];
+    return hipSuccess;
 }
 inline hipError_t device_cu_count(int* cus) {                        // CUs of the current device
     static PerDeviceOnce c;
     int dev = 0;
     hipError_t e = current_device(&dev);
     if (e != hipSuccess) return e;
-    e = once_per_device(c, dev, [&](int* v) { return hipDeviceGetAttribute(v, hipDeviceAttributeMultiprocessorCount, dev); });
-    *cus = c.val[dev];
-    return e;
+    return once_per_device(c, dev, [&](int* v) { return hipDeviceGetAttribute(v, hipDeviceAttributeMultiprocessorCount, dev); }, cus);
 }
 
 // Every kernel launch of the library goes through launch_k().  Normally it is a plain launch on the
@@ -256,6 +264,19 @@ struct GruWorkspace {
 // bf16 path (conv_bf16.hip): NHWC bf16 activations, fp32 accumulation on the bf16 matrix cores ----------------------
 hipError_t conv_bf16_init();
 hipError_t launch_conv_bf16(ConvArgs a, hipStream_t s, int tile_hint = 0);     // pointers in `a` address bf16 data (bias fp32)
+// A chain of BasicBlocks of one HR branch in ONE launch, the frame resident in LDS (conv_bf16_chain.hip): convolutions 2k, 2k+1 are conv1 / conv2 of
+// block k (hrnet.py:43-59), every one C -> C, 3x3, stride 1, ReLU; conv2 adds the block's input.  (C, W) in {(64,28), (128,14), (256,7)}.
+constexpr int kMaxChain = 8;
+struct ChainArgs {
+    const void* in; int in_ctot, in_coff;       // NHWC bf16 view (N, W, W, C)
+    void* out; int out_ctot, out_coff;
+    int N, nconv;
+    const void* w[kMaxChain];                   // [C/32][9][C][32] bf16, BatchNorm folded
+    const float* bias[kMaxChain];               // fp32 [C]
+};
+hipError_t conv_bf16_chain_init();
+bool conv_bf16_chain_eligible(int c, int w);
+hipError_t launch_conv_bf16_chain(const ChainArgs& a, int c, int w, hipStream_t s);
 hipError_t launch_nchw_f32_to_nhwc_bf16(const float* in, void* out, int N, int C, int H, int W, int Cp, hipStream_t s);
 // the stem's 3 -> 64 stride-2 convolution straight from the caller's fp32 NCHW frames (N,3,224,224) to NHWC bf16 (N,112,112,out_ctot)
 hipError_t launch_conv_bf16_stem(const float* frames, const void* wpk, const float* bias, void* out, int out_ctot, int out_coff, int N, int relu, hipStream_t s);

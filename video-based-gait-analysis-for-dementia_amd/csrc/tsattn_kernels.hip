@@ -206,9 +206,7 @@ static hipError_t device_lds_per_block(int* bytes) {
     int dev = 0;
     hipError_t e = current_device(&dev);
     if (e != hipSuccess) return e;
-    e = once_per_device(c, dev, [&](int* v) { return hipDeviceGetAttribute(v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev); });
-    *bytes = c.val[dev];
-    return e;
+    return once_per_device(c, dev, [&](int* v) { return hipDeviceGetAttribute(v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev); }, bytes);
 }
 int tsattn_max_frames() {
     int lds = 0;

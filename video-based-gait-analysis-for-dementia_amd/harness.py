@@ -68,37 +68,66 @@ def gather_work_items(items, local_rows, row_floats, world, rank, dist, device, 
     return {vi: torch.cat(parts, 0) for vi, parts in per_video.items()}
 
 
-def share_unique_id(raw, dist, device):
-    """Rank 0's 128-byte communicator id to every rank over the launcher's process group: a device tensor on the nccl backend (RCCL moves
-    device memory only), a host tensor otherwise.  ``raw``: the id on rank 0, any 128 bytes elsewhere.  Returns the id as bytes."""
-    t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone()
-    if dist.get_backend() == "nccl":
-        t = t.to(device)
+def _host_channel_tensor(values, dist, device):
+    """uint8 tensor the launcher's process group can move: device memory on the nccl backend (RCCL moves nothing else), host memory otherwise."""
+    t = torch.tensor(list(values), dtype=torch.uint8)
+    return t.to(device) if dist.get_backend() == "nccl" else t
+
+
+def agree_all_ok(ok, dist, device):
+    """True when EVERY rank passed ok=True (a MIN over the launcher's process group): the ranks take the same branch afterwards."""
+    t = _host_channel_tensor([1 if ok else 0], dist, device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.cpu()[0]))
+
+
+def share_unique_id(raw, dist, device, status=0):
+    """Rank 0's 128-byte communicator id to every rank over the launcher's process group, with a status byte in front: rank 0 ALWAYS enters this
+    broadcast -- with status != 0 and a zeroed id when it could not draw one -- so the other ranks never wait for a sender that has left.
+    ``raw``: the id on rank 0, any 128 bytes elsewhere.  Returns (status, id bytes) as rank 0 sent them."""
+    t = _host_channel_tensor([status & 0xff] + list(bytearray(raw)), dist, device)
     dist.broadcast(t, src=0)
-    return bytes(t.cpu().tolist())
+    got = bytes(t.cpu().tolist())
+    return got[0], got[1:]
 
 
 class RcclComm:
     """The C ABI's own RCCL communicator (grnet_comm_*, include/grnet_hip.h): the exchange then needs PyTorch only for the device buffers.
 
-    Bootstrap: rank 0 draws the 128-byte id (grnet_comm_unique_id) and the launcher's process group -- any backend, it only carries 128 bytes over
-    the host -- broadcasts it; every rank then enters grnet_comm_create (collective: it returns when all ranks have arrived).  ``all_gather`` enqueues
-    ONE ncclAllGather on the caller's stream.  RCCL wants one GPU per rank: two ranks sharing a device (the gloo rehearsals) cannot use this class.
+    Bootstrap, the same steps on every rank (no rank waits in a collective another one skips):
+      1. grnet_comm_probe -- local: can RCCL be bound in this process? -- and a MIN over the ranks; if any rank cannot, EVERY rank raises here;
+      2. rank 0 draws the 128-byte id (grnet_comm_unique_id) and broadcasts status + id over the launcher's process group (any backend: it carries
+         129 bytes over the host); rank 0 enters the broadcast even when drawing failed (status 1, zeroed id) and then every rank raises;
+      3. every rank enters grnet_comm_create (collective inside RCCL: it returns when all ranks have arrived; a rank whose ncclCommInitRank fails
+         after that point is RCCL's to report on the others -- nothing above RCCL can unblock them).
+    ``all_gather`` enqueues ONE ncclAllGather on the caller's stream.  RCCL wants one GPU per rank: two ranks sharing a device (the gloo
+    rehearsals) cannot use this class.
     """
 
     def __init__(self, world, rank, device, dist=None, unique_id=None):
         self._lib = lib = _lib.load()
         self.world, self.rank, self.device = world, rank, torch.device(device)
+        self._h = None
         if unique_id is None:
+            if world > 1 and dist is None:
+                raise ValueError("RcclComm: pass the launcher's torch.distributed (or the 128-byte unique_id of rank 0) when world > 1")
+            probe = lib.grnet_comm_probe()
+            why = "" if probe == 0 else lib.grnet_comm_last_error().decode()
+            if world > 1 and not agree_all_ok(probe == 0, dist, self.device):
+                raise RuntimeError("RcclComm: RCCL cannot be bound on every rank" + (f" (this rank: {why})" if why else " (this rank could)"))
+            if world == 1 and probe != 0:
+                _lib.check_comm(lib, probe, "grnet_comm_probe")
             buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+            status = 0
             if rank == 0:
-                _lib.check_comm(lib, lib.grnet_comm_unique_id(buf, _lib.COMM_ID_BYTES), "grnet_comm_unique_id")
+                status = 0 if lib.grnet_comm_unique_id(buf, _lib.COMM_ID_BYTES) == 0 else 1
+                why = lib.grnet_comm_last_error().decode() if status else ""
             if world > 1:
-                if dist is None:
-                    raise ValueError("RcclComm: pass the launcher's torch.distributed (or the 128-byte unique_id of rank 0) when world > 1")
-                unique_id = share_unique_id(buf.raw, dist, self.device)
+                status, unique_id = share_unique_id(buf.raw if status == 0 else bytes(_lib.COMM_ID_BYTES), dist, self.device, status)
             else:
                 unique_id = buf.raw
+            if status:
+                raise RuntimeError("RcclComm: rank 0 could not draw the communicator id" + (f": {why}" if why else ""))
         if len(unique_id) != _lib.COMM_ID_BYTES:
             raise ValueError(f"RcclComm: the unique id has {len(unique_id)} bytes, not {_lib.COMM_ID_BYTES}")
         h = C.c_void_p()
