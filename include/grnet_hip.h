@@ -112,7 +112,8 @@ int grnet_tsattn_forward(grnet_t* h, const float* x_dev, const float* xs_dev, in
                                    * in round 3 after losing every measurement; their sources are in the history: commit 8d3a931.) */
 #define GRNET_OPT_BF16_CHAIN 8    /* bf16 handles: which HR branches run their four BasicBlocks (8 convolutions, lib/models/hrnet.py:141-187) as ONE launch with
                                    * the frame resident in LDS (csrc/conv_bf16_chain.hip) in calls of >= 64 frames -- bit 0: 64 ch @28x28, bit 1: 128 ch @14x14,
-                                   * bit 2: 256 ch @7x7 (default 7; environment GRNET_BF16_CHAIN); 0: one launch per convolution at every call size */
+                                   * bit 2: 256 ch @7x7, bit 3: 32 ch @56x56 (one launch per BasicBlock there, 19-row bands resident) (default 15; environment
+                                   * GRNET_BF16_CHAIN); 0: one launch per convolution at every call size */
 int grnet_set_option(grnet_t* h, int option, int value);
 
 /* Optional, once per distinct n_frames after grnet_finalize_weights: times every launch configuration of every
@@ -167,7 +168,8 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
 int grnet_op_bilinear2x(grnet_t* h, const float* in_dev, int n, int c, int hgt, int wid, float* out_dev, void* stream);
 /* bf16 handles: a chain of nconv (even, <= 8) 3x3 stride-1 convolutions c -> c on (n,c,wid,wid) maps as ONE launch with the frame resident in LDS
  * (csrc/conv_bf16_chain.hip) -- convolutions 2k, 2k+1 are conv1 / conv2 of BasicBlock k (lib/models/hrnet.py:43-59: conv-BN-ReLU, conv-BN, + block
- * input, ReLU; four of them are one branch of a HighResolutionModule, hrnet.py:141-187).  (c, wid) in {(64,28), (128,14), (256,7)}.
+ * input, ReLU; four of them are one branch of a HighResolutionModule, hrnet.py:141-187).  (c, wid) in {(64,28), (128,14), (256,7)}; (32,56) runs
+ * one launch per BasicBlock with 19-row bands of the frame resident.
  * in_dev / out_dev: f32 NCHW device buffers (rounded to / from NHWC bf16 around the launch); w_host: nconv x (c,c,3,3) folded weights,
  * bias_host: nconv x (c).  reps > 0 and us_out != NULL: `reps` more launches are timed with HIP events (us per launch).  Synchronises. */
 int grnet_op_conv_chain(grnet_t* h, const float* in_dev, int n, int c, int wid, int nconv, const float* w_host, const float* bias_host,

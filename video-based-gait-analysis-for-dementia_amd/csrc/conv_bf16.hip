@@ -35,13 +35,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kCK = 32;        // input channels per K chunk (= one MFMA k-step per tap)
 
-__device__ __forceinline__ u16 f2bf(float f) {           // round to nearest even (finite inputs)
-    unsigned u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (u16)(u >> 16);
-}
 __device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float((unsigned)h << 16); }
-__device__ __forceinline__ unsigned pack2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+// two floats -> two bf16 (round to nearest even) in ONE instruction, v_cvt_pk_bf16_f32 (round 5; the integer form (u + 0x7fff + (u >> 16 & 1)) >> 16 is five vector instructions per value,
+// and the epilogues of the 1x1 and narrow layers are dozens of such values per handful of MFMAs)
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2(float lo, float hi) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2)); }
 // q / d for 0 <= q < 2^20 through one fp32 reciprocal multiply (exact: the +0.5 keeps exact multiples off the rounding edge);
 // an integer division by a run-time value costs ~40 VALU instructions, and a tile of a 32-channel layer has only ~1000 cycles of MFMAs
 __device__ __forceinline__ int fdiv(int q, float inv_d) { return (int)(((float)q + 0.5f) * inv_d); }

@@ -43,12 +43,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ u16 f2bf_c(float f) {           // round to nearest even (finite inputs), as conv_bf16.hip
-    unsigned u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (u16)(u >> 16);
-}
-__device__ __forceinline__ unsigned pack2_c(float lo, float hi) { return (unsigned)f2bf_c(lo) | ((unsigned)f2bf_c(hi) << 16); }
+// two floats -> two bf16 (round to nearest even) in ONE instruction: v_cvt_pk_bf16_f32.  The integer form ((u + 0x7fff + (u >> 16 & 1)) >> 16, five
+// vector instructions per value) made the in-place epilogue -- 4 values x CS x PS tiles per wave and convolution -- cost a third of a k-loop.
+typedef __bf16 bf16x2_c __attribute__((ext_vector_type(2)));
+typedef float f32x2_c __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2_c(float lo, float hi) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_c{lo, hi}, bf16x2_c)); }
+// relu on the bits: negative floats (and -0) are negative integers; one v_max_i32, where fmaxf(x, 0) costs a canonicalising v_max first
+__device__ __forceinline__ float relu_c(float x) { const int i = __float_as_int(x); return __int_as_float(i > 0 ? i : 0); }
 __device__ __forceinline__ float bf_lo(unsigned v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float bf_hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
 
@@ -75,10 +76,54 @@ struct ChainGeom {
     static_assert((PS - 1) * 16 * SB + (2 * P + 2) * SB + (C / 32) * 64 < 65536, "ds_read immediates");
 };
 
+// One convolution's k-loop over the LDS plane, shared by the frame-resident chain and the band-resident block kernel.
+// Per k-step (tap x 32-channel chunk): CS weight fragments requested two steps ahead (ring of three register sets), and per column tile
+// one pixel fragment: tile ps of step s + 1 is requested right behind the MFMAs of tile ps of step s, into the register set they have
+// just read -- a read has PS - 1 MFMA pairs (and the SIMD's other wave) to land.  Left to itself hipcc sinks every read and every
+// weight load to its first use (one register set, lgkmcnt(0) in front of every MFMA pair, vmcnt(0) per step: the loop ran at LDS
+// latency); the sched_barrier behind every group pins the order written here.  The chunk loop stays a loop (9 taps unrolled: the
+// ring positions are static, 9 = 3 x 3), so every address is a per-chunk base + immediates.
+// bread: B operand of tap (0,0), chunk 0, tile 0 of this lane; wc / wn: the weights of this / the next convolution (UNIFORM pointers: with the
+// lane's share kept apart as the 32-bit byte offset wlb every weight load is `global_load v, v_off, s[base]` -- a 64-bit per-lane pointer per
+// k-step cost two registers each, which hipcc hoisted out of the band loop of the frame kernel and spilled); wr[0], wr[1] hold steps 0, 1 on
+// entry and the next convolution's on exit.
+template <int C, int P, int SB, int CS, int PS>
+__device__ __forceinline__ void chain_kloop(f32x4 (&acc)[CS][PS], bf16x8 (&wr)[3][CS], const unsigned char* bread, const u16* wc, const u16* wn, unsigned wlb) {
+    constexpr int NCH = C / 32;
+    bf16x8 bfr[PS];
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps) bfr[ps] = *reinterpret_cast<const bf16x8*>(bread + ps * 16 * SB);
+#pragma unroll 1
+    for (int chunk = 0; chunk < NCH; ++chunk) {
+        const unsigned char* bch = bread + chunk * 64;
+        const u16* wch = wc + (size_t)chunk * 9 * C * 32;
+        const bool lastc = chunk == NCH - 1;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            {                                                             // weights of step s + 2 (taps 9, 10 = taps 0, 1 of the next chunk / of the next convolution)
+                const u16* src = wch + (size_t)(tap + 2) * C * 32;
+                if (tap >= 7) src = lastc ? wn + (size_t)(tap - 7) * C * 32 : src;
+#pragma unroll
+                for (int cs = 0; cs < CS; ++cs) wr[(tap + 2) % 3][cs] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(src + cs * 16 * 32) + wlb);
+            }
+            // the next step's pixel fragments: tap + 1 of this chunk, or tap 0 of the next (the last step of a convolution reads ahead into
+            // the slot padding / the spare slot: nobody uses those values)
+            const int noff = tap < 8 ? (((tap + 1) / 3) * P + ((tap + 1) % 3)) * SB : 64;
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps) {
+#pragma unroll
+                for (int cs = 0; cs < CS; ++cs) acc[cs][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[tap % 3][cs], bfr[ps], acc[cs][ps], 0, 0, 0);
+                bfr[ps] = *reinterpret_cast<const bf16x8*>(bch + ps * 16 * SB + noff);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
 template <int C, int W>
 __global__ __launch_bounds__(512) void conv_bf16_chain(const ChainArgs a) {
     typedef ChainGeom<C, W> G;
-    constexpr int P = G::P, SB = G::SB, CS = G::CS, PS = G::PS, UPP = G::UPP, NU = G::NU, NCH = C / 32;
+    constexpr int P = G::P, SB = G::SB, CS = G::CS, PS = G::PS, UPP = G::UPP, NU = G::NU;
     extern __shared__ __align__(16) unsigned char plane[];
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -119,7 +164,7 @@ __global__ __launch_bounds__(512) void conv_bf16_chain(const ChainArgs a) {
         const int o = o_first + ps * 16;
         if (o % P != 0 && o <= W * P + W) valid |= 1u << ps;
     }
-    const int wl = ((cb * CS * 16 + l15) * 32 + lq * 8);                     // element offset of this lane in a [C][32] weight row block
+    const unsigned wlb = ((cb * CS * 16 + l15) * 32 + lq * 8) * 2;           // byte offset of this lane in a [C][32] weight row block
     const int co = cb * CS * 16 + lq * 4;                                     // first of this lane's 4 output channels (block 0)
 
     f32x4 acc[CS][PS];
@@ -135,53 +180,20 @@ __global__ __launch_bounds__(512) void conv_bf16_chain(const ChainArgs a) {
     // weight fragments of k-step s: element offset (s * C + cs * 16) * 32 from the lane's base
     bf16x8 wr[3][CS];
     {
-        const u16* w0 = reinterpret_cast<const u16*>(a.w[0]) + wl;
+        const unsigned char* w0 = reinterpret_cast<const unsigned char*>(a.w[0]);
 #pragma unroll
         for (int cs = 0; cs < CS; ++cs) {
-            wr[0][cs] = *reinterpret_cast<const bf16x8*>(w0 + (0 * C + cs * 16) * 32);
-            wr[1][cs] = *reinterpret_cast<const bf16x8*>(w0 + (1 * C + cs * 16) * 32);
+            wr[0][cs] = *reinterpret_cast<const bf16x8*>(w0 + (0 * C + cs * 16) * 64 + wlb);
+            wr[1][cs] = *reinterpret_cast<const bf16x8*>(w0 + (1 * C + cs * 16) * 64 + wlb);
         }
     }
     __syncthreads();                                                          // the plane is staged
 
     for (int ci = 0; ci < a.nconv; ++ci) {
-        const u16* wc = reinterpret_cast<const u16*>(a.w[ci]) + wl;
+        const u16* wc = reinterpret_cast<const u16*>(a.w[ci]);
         const int cn = ci + 1 < a.nconv ? ci + 1 : ci;                        // the last convolution re-requests itself (nobody waits for it)
-        const u16* wn = reinterpret_cast<const u16*>(a.w[cn]) + wl;
-        // Per k-step (tap x 32-channel chunk): CS weight fragments requested two steps ahead (ring of three register sets), and per column tile
-        // one pixel fragment: tile ps of step s + 1 is requested right behind the MFMAs of tile ps of step s, into the register set they have
-        // just read -- a read has PS - 1 MFMA pairs (and the SIMD's other wave) to land.  Left to itself hipcc sinks every read and every
-        // weight load to its first use (one register set, lgkmcnt(0) in front of every MFMA pair, vmcnt(0) per step: the loop ran at LDS
-        // latency); the sched_barrier behind every group pins the order written here.  The chunk loop stays a loop (9 taps unrolled: the
-        // ring positions are static, 9 = 3 x 3), so every address is a per-chunk base + immediates.
-        bf16x8 bfr[PS];
-#pragma unroll
-        for (int ps = 0; ps < PS; ++ps) bfr[ps] = *reinterpret_cast<const bf16x8*>(bread + ps * 16 * SB);
-#pragma unroll 1
-        for (int chunk = 0; chunk < NCH; ++chunk) {
-            const unsigned char* bch = bread + chunk * 64;
-            const u16* wch = wc + (size_t)chunk * 9 * C * 32;
-            const bool lastc = chunk == NCH - 1;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                {                                                             // weights of step s + 2 (taps 9, 10 = taps 0, 1 of the next chunk / of the next convolution)
-                    const u16* src = wch + (size_t)(tap + 2) * C * 32;
-                    if (tap >= 7) src = lastc ? wn + (size_t)(tap - 7) * C * 32 : src;
-#pragma unroll
-                    for (int cs = 0; cs < CS; ++cs) wr[(tap + 2) % 3][cs] = *reinterpret_cast<const bf16x8*>(src + cs * 16 * 32);
-                }
-                // the next step's pixel fragments: tap + 1 of this chunk, or tap 0 of the next (the last step of a convolution reads ahead into
-                // the slot padding / the spare slot: nobody uses those values)
-                const int noff = tap < 8 ? (((tap + 1) / 3) * P + ((tap + 1) % 3)) * SB : 64;
-#pragma unroll
-                for (int ps = 0; ps < PS; ++ps) {
-#pragma unroll
-                    for (int cs = 0; cs < CS; ++cs) acc[cs][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[tap % 3][cs], bfr[ps], acc[cs][ps], 0, 0, 0);
-                    bfr[ps] = *reinterpret_cast<const bf16x8*>(bch + ps * 16 * SB + noff);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
+        const u16* wn = reinterpret_cast<const u16*>(a.w[cn]);
+        chain_kloop<C, P, SB, CS, PS>(acc, wr, bread, wc, wn, wlb);
         // ---- in-place epilogue
         const bool first = (ci & 1) == 0;                                     // conv1 of a BasicBlock: the plane still holds the block's input x
         f32x4 bnext[CS];
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(512) void conv_bf16_chain(const ChainArgs a) {
                 u32x2 r = u32x2{0u, 0u};
                 if (first) r = *reinterpret_cast<const u32x2*>(pos);
                 const f32x4 v = acc[cs][ps];
-                const u32x2 pk = u32x2{pack2_c(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)), pack2_c(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f))};
+                const u32x2 pk = u32x2{pack2_c(relu_c(v[0]), relu_c(v[1])), pack2_c(relu_c(v[2]), relu_c(v[3]))};
                 if (valid & (1u << ps)) *reinterpret_cast<u32x2*>(pos) = pk;
                 f32x4 nx = bnext[cs];
                 if (first) { nx[0] += bf_lo(r[0]); nx[1] += bf_hi(r[0]); nx[2] += bf_lo(r[1]); nx[3] += bf_hi(r[1]); }
@@ -217,6 +229,325 @@ __global__ __launch_bounds__(512) void conv_bf16_chain(const ChainArgs a) {
     }
 }
 
+
+// ---- ONE BasicBlock of the 32-channel 56x56 branch with a BAND of the frame resident in LDS (a whole 56x56x32 frame is 200 KB: it does not fit).
+// The launch-per-convolution kernel (conv_bf16_direct) runs these layers at 37.9 us = 0.16 of the matrix peak at 256 frames: they move 2-3
+// tensors of 51 MB each per launch.  Here a workgroup owns R = 19 output rows of one frame (3 bands per frame = 768 workgroups = 3 per CU):
+// input rows y0 - 2 .. y0 + R + 1 (rows outside the image are zero) -> LDS in the flattened, pitch-57 image of the chain kernel; conv1 on
+// rows y0 - 1 .. y0 + R (its rows outside the image are conv2's zero padding: not written, the slots keep their zeros), in place; conv2 on
+// the same R + 2 rows (the two outer ones are dropped: 10 % of the MFMAs buy one tile map and the residual-in-place trick for both
+// convolutions); rows y0 .. y0 + R - 1 -> HBM.  HBM sees 23/19 of the input once and the output once instead of five passes.
+template <int C, int W, int R>
+struct BandGeom {
+    static constexpr int P = W + 1, SB = 2 * C + 32;
+    static constexpr int ROWS = R + 4;                      // plane rows: image rows y0 - 2 .. y0 + R + 1
+    static constexpr int O0 = P + 1;                        // plane row 1, x = 0
+    static constexpr int NOUT = (R + 2) * P - 1;            // plane rows 1 .. R + 2
+    static constexpr int CS = 2, WCB = C / 32, WPG = 8 / WCB;
+    static constexpr int PS = ((NOUT + 15) / 16 + WPG - 1) / WPG, NT = WPG * PS;
+    static constexpr int NSLOT = O0 + NT * 16 + P + 2;
+    static constexpr int LDS = NSLOT * SB;
+    static constexpr int UPP = C / 8;
+    static constexpr int NUI = (ROWS * W * UPP + 511) / 512, NUO = (R * W * UPP + 511) / 512;
+    static constexpr int NB = (W + R - 1) / R;              // bands per frame
+    static_assert(((SB / 32) % 2) == 1 && LDS <= 160 * 1024 && PS <= 32 && NSLOT >= ROWS * P + 1, "band geometry");
+    static_assert((PS - 1) * 16 * SB + (2 * P + 2) * SB + (C / 32) * 64 < 65536, "ds_read immediates");
+};
+
+template <int C, int W, int R, int WPE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void conv_bf16_block_band(const ChainArgs a) {
+    typedef BandGeom<C, W, R> G;
+    constexpr int P = G::P, SB = G::SB, CS = G::CS, PS = G::PS, UPP = G::UPP;
+    extern __shared__ __align__(16) unsigned char plane[];
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb = wave % G::WCB, pg = wave / G::WCB;
+    const int n = blockIdx.x / G::NB, band = blockIdx.x - n * G::NB;
+    if (n >= a.N) return;
+    const int y0 = band * R;
+
+    const u16* inb = reinterpret_cast<const u16*>(a.in) + (size_t)n * W * W * a.in_ctot + a.in_coff;
+    u32x4 stage[G::NUI];
+#pragma unroll
+    for (int i = 0; i < G::NUI; ++i) {
+        const int u = tid + i * 512, px = u / UPP, part = u - px * UPP, r = px / W, x = px - r * W, y = y0 - 2 + r;
+        stage[i] = u32x4{0u, 0u, 0u, 0u};
+        if (u < G::ROWS * W * UPP && y >= 0 && y < W) stage[i] = *reinterpret_cast<const u32x4*>(inb + ((size_t)y * W + x) * a.in_ctot + part * 8);
+    }
+    for (int u = tid; u < G::LDS / 16; u += 512) reinterpret_cast<u32x4*>(plane)[u] = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < G::NUI; ++i) {
+        const int u = tid + i * 512, px = u / UPP, part = u - px * UPP, r = px / W, x = px - r * W;
+        if (u < G::ROWS * W * UPP) *reinterpret_cast<u32x4*>(plane + (r * P + x + 1) * SB + part * 16) = stage[i];
+    }
+
+    const int o_first = G::O0 + pg * PS * 16 + l15;
+    const unsigned char* bread = plane + (o_first - P - 1) * SB + lq * 16;
+    unsigned char* owrite = plane + o_first * SB + (cb * CS * 16 + lq * 4) * 2;
+    unsigned valid1 = 0, valid2 = 0;                          // bit ps: conv1 / conv2 write column tile ps of this lane
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps) {
+        const int o = o_first + ps * 16, r = o / P, y = y0 - 2 + r;
+        const bool px_ok = o - r * P != 0 && r >= 1 && r <= R + 2 && y >= 0 && y < W;
+        if (px_ok) valid1 |= 1u << ps;
+        if (px_ok && r >= 2 && r <= R + 1) valid2 |= 1u << ps;
+    }
+    const unsigned wlb = ((cb * CS * 16 + l15) * 32 + lq * 8) * 2;
+    const int co = cb * CS * 16 + lq * 4;
+
+    f32x4 acc[CS][PS];
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias[0] + co + cs * 16);
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) acc[cs][ps] = bv;
+    }
+    bf16x8 wr[3][CS];
+    const u16* w0 = reinterpret_cast<const u16*>(a.w[0]);
+    const u16* w1 = reinterpret_cast<const u16*>(a.w[1]);
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs) {
+        wr[0][cs] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(w0 + (0 * C + cs * 16) * 32) + wlb);
+        wr[1][cs] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(w0 + (1 * C + cs * 16) * 32) + wlb);
+    }
+    __syncthreads();
+
+    // conv1: t = relu(conv(x) + b1) replaces x (where t exists); conv2's accumulators start from x + b2
+    chain_kloop<C, P, SB, CS, PS>(acc, wr, bread, w0, w1, wlb);
+    f32x4 b2[CS];
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs) b2[cs] = *reinterpret_cast<const f32x4*>(a.bias[1] + co + cs * 16);
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps)
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs) {
+            unsigned char* pos = owrite + ps * 16 * SB + cs * 32;
+            const u32x2 r = *reinterpret_cast<const u32x2*>(pos);
+            const f32x4 v = acc[cs][ps];
+            if (valid1 & (1u << ps)) *reinterpret_cast<u32x2*>(pos) = u32x2{pack2_c(relu_c(v[0]), relu_c(v[1])), pack2_c(relu_c(v[2]), relu_c(v[3]))};
+            f32x4 nx = b2[cs];
+            nx[0] += bf_lo(r[0]); nx[1] += bf_hi(r[0]); nx[2] += bf_lo(r[1]); nx[3] += bf_hi(r[1]);
+            acc[cs][ps] = nx;
+        }
+    __syncthreads();
+    // conv2: y = relu(conv(t) + b2 + x), rows y0 .. y0 + R - 1
+    chain_kloop<C, P, SB, CS, PS>(acc, wr, bread, w1, w1, wlb);
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps)
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs) {
+            const f32x4 v = acc[cs][ps];
+            if (valid2 & (1u << ps))
+                *reinterpret_cast<u32x2*>(owrite + ps * 16 * SB + cs * 32) = u32x2{pack2_c(relu_c(v[0]), relu_c(v[1])), pack2_c(relu_c(v[2]), relu_c(v[3]))};
+        }
+    __syncthreads();
+    u16* outb = reinterpret_cast<u16*>(a.out) + (size_t)n * W * W * a.out_ctot + a.out_coff;
+#pragma unroll
+    for (int i = 0; i < G::NUO; ++i) {
+        const int u = tid + i * 512, px = u / UPP, part = u - px * UPP, r = px / W, x = px - r * W, y = y0 + r;
+        if (u < R * W * UPP && y < W)
+            *reinterpret_cast<u32x4*>(outb + ((size_t)y * W + x) * a.out_ctot + part * 8) = *reinterpret_cast<const u32x4*>(plane + ((r + 2) * P + x + 1) * SB + part * 16);
+    }
+}
+
+// ---- The same block with the WORKGROUP = ONE FRAME walking its NB = 56 / R bands, the next band arriving by LDS-DMA under the current band's MFMAs.
+// The band kernel above spends two thirds of a workgroup's life in its load and store phases (one workgroup per CU: nothing overlaps them; 51 us
+// per BasicBlock at 256 frames against 11.8 us of MFMAs at peak and 22 us of HBM time).  A first persistent version kept the next band in
+// registers (R = 14): 256 VGPRs + 160-284 bytes of scratch, and hipcc parked the prefetched rows in scratch right behind their loads, i.e.
+// waited for them -- no overlap.  So the prefetch takes no registers at all:
+//   * the next band's rows travel HBM -> LDS by LDS-DMA into a dense staging area (lane-linear, as the DMA writes) and are copied LDS -> LDS
+//     into the padded plane when the current band has left;
+//   * vmcnt is in order, and a wave that waits for a weight fragment would wait for every DMA it issued before: the weights of BOTH
+//     convolutions (36 KB for C = 32) live in LDS for the whole launch, so the k-loops issue no vector-memory operation at all and the DMAs
+//     fly through them.  Weight rows are 64 bytes (no room for padding): the 16-byte part p of row r sits at p ^ 2 (r >> 3 & 1), which puts the
+//     16 lanes of every ds_read_b128 group (rows {0-3, 12-15} at part q, rows {4-11} at part q + 1, or the mirror image) on 16 different bank groups;
+//   * barriers are raw s_barrier + lgkmcnt(0): __syncthreads() would drain the DMAs (a pending DMA is a pending LDS write to its fence).
+// LDS: weights 36 KB + plane (R = 8: 12 rows, 72.7 KB) + staging (12 x 56 x 64 B = 43 KB) = 152 KB.  R = 8 tiles the 56 rows exactly (7 bands);
+// 10 of 12 plane rows carry outputs of conv1, 8 of conv2's, 569 of 640 MFMA columns are real: 0.72 of the MFMAs are useful, HBM reads 1.5 x the input.
+#define GRNET_GLOBAL_AS __attribute__((address_space(1)))
+#define GRNET_LDS_AS __attribute__((address_space(3)))
+__device__ __forceinline__ void dma16_c(const u16* src, unsigned char* lds_wave_base) {      // lane l's 16 bytes land at lds_wave_base + 16 l
+    __builtin_amdgcn_global_load_lds((const GRNET_GLOBAL_AS void*)src, (GRNET_LDS_AS void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void lds_barrier() {               // every wave's LDS operations so far are done; vector-memory operations (DMAs, stores) stay in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// k-loop of one 32 -> 32 convolution with the weights in LDS: per tap CS weight fragments (one tap ahead, two register sets) and PS pixel fragments
+// (ring as in chain_kloop); no vector-memory operation.  wl: this lane's fragment of tap 0, block 0 (swizzled part); 2 KB per tap, 1 KB per block.
+template <int P, int SB, int CS, int PS>
+__device__ __forceinline__ void chain_kloop_ldsw(f32x4 (&acc)[CS][PS], const unsigned char* bread, const unsigned char* wl) {
+    bf16x8 bfr[PS], wr[2][CS];
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs) wr[0][cs] = *reinterpret_cast<const bf16x8*>(wl + cs * 1024);
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps) bfr[ps] = *reinterpret_cast<const bf16x8*>(bread + ps * 16 * SB);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        if (tap < 8) {
+#pragma unroll
+            for (int cs = 0; cs < CS; ++cs) wr[(tap + 1) & 1][cs] = *reinterpret_cast<const bf16x8*>(wl + (tap + 1) * 2048 + cs * 1024);
+        }
+        const int noff = (((tap + 1) / 3) * P + ((tap + 1) % 3)) * SB;
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) {
+#pragma unroll
+            for (int cs = 0; cs < CS; ++cs) acc[cs][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[tap & 1][cs], bfr[ps], acc[cs][ps], 0, 0, 0);
+            if (tap < 8) bfr[ps] = *reinterpret_cast<const bf16x8*>(bread + ps * 16 * SB + noff);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int W, int R>
+struct FrameGeom {
+    static constexpr int C = 32;
+    typedef BandGeom<C, W, R> B;
+    static constexpr int WBYTES = 2 * 9 * C * 64;            // both convolutions' weights, 64-byte rows
+    static constexpr int PLANE = B::LDS;
+    static constexpr int UR = W * B::UPP;                     // 16-byte units per row
+    static constexpr int STAGE_UNITS = B::ROWS * UR;
+    static constexpr int LDS = WBYTES + PLANE + STAGE_UNITS * 16;
+    static constexpr int NUS = (STAGE_UNITS + 511) / 512, NUO = (R * UR + 511) / 512;
+    static_assert(W % R == 0 && LDS <= 160 * 1024 && PLANE % 16 == 0, "frame geometry");
+};
+
+template <int W, int R>
+__global__ __launch_bounds__(512) void conv_bf16_block_frame(const ChainArgs a) {
+    constexpr int C = 32;
+    typedef BandGeom<C, W, R> G;
+    typedef FrameGeom<W, R> F;
+    constexpr int P = G::P, SB = G::SB, CS = G::CS, PS = G::PS, UPP = G::UPP, NB = G::NB, UR = F::UR;
+    static_assert(G::WCB == 1, "one channel block of 32");
+    extern __shared__ __align__(16) unsigned char lds[];
+    unsigned char* wlds = lds;                                 // [conv][tap][row 32][4 parts, swizzled] bf16
+    unsigned char* plane = lds + F::WBYTES;
+    unsigned char* stg = plane + F::PLANE;                     // [plane row][x][4 parts]: the NEXT band, as it lies in memory
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = blockIdx.x;
+    if (n >= a.N) return;
+    const u16* inb = reinterpret_cast<const u16*>(a.in) + (size_t)n * W * W * a.in_ctot + a.in_coff;
+    u16* outb = reinterpret_cast<u16*>(a.out) + (size_t)n * W * W * a.out_ctot + a.out_coff;
+
+    auto request = [&](int y0) {                               // rows y0 - 2 .. y0 + R + 1 that exist -> staging, by LDS-DMA (rows outside the image are not requested)
+#pragma unroll
+        for (int i = 0; i < F::NUS; ++i) {
+            const int ub = i * 512 + wave * 64, u = ub + lane, r = u / UR, q = u - r * UR, x = q / UPP, part = q - x * UPP, y = y0 - 2 + r;
+            if (u < F::STAGE_UNITS && y >= 0 && y < W) dma16_c(inb + ((size_t)y * W + x) * a.in_ctot + part * 8, stg + ub * 16);
+        }
+    };
+    auto deposit = [&](int y0) {                               // staging -> interior slots of every plane row; zeros where the band hangs over the image
+#pragma unroll
+        for (int i = 0; i < F::NUS; ++i) {
+            const int u = i * 512 + tid, r = u / UR, q = u - r * UR, x = q / UPP, part = q - x * UPP, y = y0 - 2 + r;
+            if (u < F::STAGE_UNITS) {
+                u32x4 v = u32x4{0u, 0u, 0u, 0u};
+                if (y >= 0 && y < W) v = *reinterpret_cast<const u32x4*>(stg + u * 16);
+                *reinterpret_cast<u32x4*>(plane + (r * P + x + 1) * SB + part * 16) = v;
+            }
+        }
+    };
+    request(0);
+    {   // the weights: global -> registers -> LDS (swizzled); the plane's halo columns and spare slots: zero, once
+        constexpr int WU = 2 * 9 * C * 4, NWU = (WU + 511) / 512;      // 16-byte units of both convolutions
+        u32x4 wv[NWU];
+#pragma unroll
+        for (int i = 0; i < NWU; ++i) {
+            const int v = i * 512 + tid, cv = v / (WU / 2), vv = v - cv * (WU / 2);
+            wv[i] = u32x4{0u, 0u, 0u, 0u};
+            if (v < WU) wv[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(a.w[cv]) + vv * 16);
+        }
+        for (int u = tid; u < F::PLANE / 16; u += 512) reinterpret_cast<u32x4*>(plane)[u] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < NWU; ++i) {
+            const int v = i * 512 + tid, row = (v >> 2) & 31, part = v & 3;
+            if (v < WU) *reinterpret_cast<u32x4*>(wlds + (v >> 2) * 64 + ((part ^ (((row >> 3) & 1) << 1)) * 16)) = wv[i];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's DMAs of band 0 have landed
+    lds_barrier();                                             // ... and everybody's; the plane is zero, the weights are in place
+    deposit(0);
+    lds_barrier();                                             // staging is free, the plane holds band 0
+    const int o_first = G::O0 + wave * PS * 16 + l15;
+    const unsigned char* bread = plane + (o_first - P - 1) * SB + lq * 16;
+    unsigned char* owrite = plane + o_first * SB + lq * 8;
+    const unsigned char* wl0 = wlds + l15 * 64 + ((lq ^ (((l15 >> 3) & 1) << 1)) * 16);
+    const unsigned char* wl1 = wl0 + 9 * C * 64;
+    const int co = lq * 4;
+    f32x4 b1[CS], b2[CS];
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs) {
+        b1[cs] = *reinterpret_cast<const f32x4*>(a.bias[0] + co + cs * 16);
+        b2[cs] = *reinterpret_cast<const f32x4*>(a.bias[1] + co + cs * 16);
+    }
+    if (NB > 1) request(R);                                    // behind the bias loads: waiting for those must not mean waiting for these
+
+#pragma unroll 1
+    for (int band = 0; band < NB; ++band) {
+        const int y0 = band * R;
+        unsigned valid1 = 0, valid2 = 0;
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) {
+            const int o = o_first + ps * 16, r = o / P, y = y0 - 2 + r;
+            const bool px_ok = o - r * P != 0 && r >= 1 && r <= R + 2 && y >= 0 && y < W;
+            if (px_ok) valid1 |= 1u << ps;
+            if (px_ok && r >= 2 && r <= R + 1) valid2 |= 1u << ps;
+        }
+        f32x4 acc[CS][PS];
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs)
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps) acc[cs][ps] = b1[cs];
+        chain_kloop_ldsw<P, SB, CS, PS>(acc, bread, wl0);
+        lds_barrier();
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps)
+#pragma unroll
+            for (int cs = 0; cs < CS; ++cs) {
+                unsigned char* pos = owrite + ps * 16 * SB + cs * 32;
+                const u32x2 r = *reinterpret_cast<const u32x2*>(pos);
+                const f32x4 v = acc[cs][ps];
+                if (valid1 & (1u << ps)) *reinterpret_cast<u32x2*>(pos) = u32x2{pack2_c(relu_c(v[0]), relu_c(v[1])), pack2_c(relu_c(v[2]), relu_c(v[3]))};
+                f32x4 nx = b2[cs];
+                nx[0] += bf_lo(r[0]); nx[1] += bf_hi(r[0]); nx[2] += bf_lo(r[1]); nx[3] += bf_hi(r[1]);
+                acc[cs][ps] = nx;
+            }
+        lds_barrier();
+        chain_kloop_ldsw<P, SB, CS, PS>(acc, bread, wl1);
+        lds_barrier();
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps)
+#pragma unroll
+            for (int cs = 0; cs < CS; ++cs) {
+                const f32x4 v = acc[cs][ps];
+                if (valid2 & (1u << ps))
+                    *reinterpret_cast<u32x2*>(owrite + ps * 16 * SB + cs * 32) = u32x2{pack2_c(relu_c(v[0]), relu_c(v[1])), pack2_c(relu_c(v[2]), relu_c(v[3]))};
+            }
+        // the next band's DMAs (issued a whole band ago) and the previous band's stores are the only vector-memory operations in flight: wait for
+        // them HERE, in front of this band's stores, so that the wait does not include those stores' round trip
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();                                         // the band's rows are in the plane; the next band is in staging
+#pragma unroll
+        for (int i = 0; i < F::NUO; ++i) {
+            const int u = i * 512 + tid, r = u / UR, q = u - r * UR, x = q / UPP, part = q - x * UPP;
+            if (u < R * UR)
+                *reinterpret_cast<u32x4*>(outb + ((size_t)(y0 + r) * W + x) * a.out_ctot + part * 8) = *reinterpret_cast<const u32x4*>(plane + ((r + 2) * P + x + 1) * SB + part * 16);
+        }
+        if (band + 1 < NB) {
+            lds_barrier();                                     // the band's rows have been read out of the plane
+            deposit(y0 + R);
+            lds_barrier();                                     // staging is free, the plane holds the next band
+            if (band + 2 < NB) request(y0 + 2 * R);
+        }
+    }
+}
+
 template <int C, int W>
 hipError_t set_chain_lds() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_chain<C, W>), hipFuncAttributeMaxDynamicSharedMemorySize, ChainGeom<C, W>::LDS);
@@ -228,10 +559,14 @@ hipError_t conv_bf16_chain_init() {
     GRK_TRY((set_chain_lds<64, 28>()));
     GRK_TRY((set_chain_lds<128, 14>()));
     GRK_TRY((set_chain_lds<256, 7>()));
+    GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_block_band<32, 56, 19, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, BandGeom<32, 56, 19>::LDS));
+    GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_block_frame<56, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, FrameGeom<56, 8>::LDS));
+    GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_block_band<32, 56, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, BandGeom<32, 56, 8>::LDS));
     return hipSuccess;
 }
 
-bool conv_bf16_chain_eligible(int c, int w) { return (c == 64 && w == 28) || (c == 128 && w == 14) || (c == 256 && w == 7); }
+bool conv_bf16_chain_eligible(int c, int w) { return (c == 64 && w == 28) || (c == 128 && w == 14) || (c == 256 && w == 7) || (c == 32 && w == 56); }
+int conv_bf16_chain_launches(int c, int w, int nconv) { return c == 32 && w == 56 ? nconv / 2 : 1; }     // the 56x56 branch: one band-resident launch per BasicBlock
 
 // a.in / a.out: NHWC bf16 views of (N, W, W, C) tensors (channel strides in_ctot / out_ctot, first channels in_coff / out_coff, multiples of 8);
 // a.w[i]: [C/32][9][C][32] bf16 (pack_conv's bf16 layout with CoutPad = C), a.bias[i]: fp32 [C]; nconv even, <= kMaxChain:
@@ -239,6 +574,24 @@ bool conv_bf16_chain_eligible(int c, int w) { return (c == 64 && w == 28) || (c 
 hipError_t launch_conv_bf16_chain(const ChainArgs& a, int c, int w, hipStream_t s) {
     if (!conv_bf16_chain_eligible(c, w) || a.nconv < 2 || a.nconv > kMaxChain || (a.nconv & 1) || a.N < 1) return hipErrorInvalidValue;
     if (a.in_ctot % 8 != 0 || a.in_coff % 8 != 0 || a.out_ctot % 8 != 0 || a.out_coff % 8 != 0) return hipErrorInvalidValue;
+    if (c == 32) {                                           // one launch per BasicBlock; block k > 0 reads what block k - 1 wrote: a.mid holds the intermediates
+        ChainArgs b = a;
+        for (int k = 0; k < a.nconv / 2; ++k) {
+            b.nconv = 2;
+            b.w[0] = a.w[2 * k]; b.w[1] = a.w[2 * k + 1]; b.bias[0] = a.bias[2 * k]; b.bias[1] = a.bias[2 * k + 1];
+            if (k > 0) { b.in = a.mid[k - 1]; b.in_ctot = a.mid_ctot[k - 1]; b.in_coff = a.mid_coff[k - 1]; }
+            if (k < a.nconv / 2 - 1) {
+                if (!a.mid[k] || a.mid_ctot[k] % 8 != 0 || a.mid_coff[k] % 8 != 0) return hipErrorInvalidValue;
+                b.out = a.mid[k]; b.out_ctot = a.mid_ctot[k]; b.out_coff = a.mid_coff[k];
+            } else { b.out = a.out; b.out_ctot = a.out_ctot; b.out_coff = a.out_coff; }
+            // 0 (default): workgroup = frame, seven bands of 8 rows, the next band by LDS-DMA under the current band's MFMAs; 19: workgroup = band, one per CU; 8: two per CU
+            static const int band_rows = getenv("GRNET_BF16_BAND") ? atoi(getenv("GRNET_BF16_BAND")) : 0;
+            if (band_rows == 0) GRK_TRY(launch_k(conv_bf16_block_frame<56, 8>, dim3(a.N), dim3(512), FrameGeom<56, 8>::LDS, s, b));
+            else if (band_rows == 19) GRK_TRY(launch_k(conv_bf16_block_band<32, 56, 19, 2>, dim3(a.N * BandGeom<32, 56, 19>::NB), dim3(512), BandGeom<32, 56, 19>::LDS, s, b));
+            else GRK_TRY(launch_k(conv_bf16_block_band<32, 56, 8, 4>, dim3(a.N * BandGeom<32, 56, 8>::NB), dim3(512), BandGeom<32, 56, 8>::LDS, s, b));
+        }
+        return hipSuccess;
+    }
     if (c == 64) return launch_k(conv_bf16_chain<64, 28>, dim3(a.N), dim3(512), ChainGeom<64, 28>::LDS, s, a);
     if (c == 128) return launch_k(conv_bf16_chain<128, 14>, dim3(a.N), dim3(512), ChainGeom<128, 14>::LDS, s, a);
     return launch_k(conv_bf16_chain<256, 7>, dim3(a.N), dim3(512), ChainGeom<256, 7>::LDS, s, a);

@@ -265,7 +265,8 @@ struct GruWorkspace {
 hipError_t conv_bf16_init();
 hipError_t launch_conv_bf16(ConvArgs a, hipStream_t s, int tile_hint = 0);     // pointers in `a` address bf16 data (bias fp32)
 // A chain of BasicBlocks of one HR branch in ONE launch, the frame resident in LDS (conv_bf16_chain.hip): convolutions 2k, 2k+1 are conv1 / conv2 of
-// block k (hrnet.py:43-59), every one C -> C, 3x3, stride 1, ReLU; conv2 adds the block's input.  (C, W) in {(64,28), (128,14), (256,7)}.
+// block k (hrnet.py:43-59), every one C -> C, 3x3, stride 1, ReLU; conv2 adds the block's input.  (C, W) in {(64,28), (128,14), (256,7)}: ONE launch;
+// (32,56): one launch per block, 19-row bands of a frame resident (conv_bf16_block_band).
 constexpr int kMaxChain = 8;
 struct ChainArgs {
     const void* in; int in_ctot, in_coff;       // NHWC bf16 view (N, W, W, C)
@@ -273,7 +274,10 @@ struct ChainArgs {
     int N, nconv;
     const void* w[kMaxChain];                   // [C/32][9][C][32] bf16, BatchNorm folded
     const float* bias[kMaxChain];               // fp32 [C]
+    void* mid[kMaxChain / 2 - 1];               // (32, 56) only -- one band-resident launch per BasicBlock: the output of block k < nconv/2 - 1
+    int mid_ctot[kMaxChain / 2 - 1], mid_coff[kMaxChain / 2 - 1];
 };
+int conv_bf16_chain_launches(int c, int w, int nconv);
 hipError_t conv_bf16_chain_init();
 bool conv_bf16_chain_eligible(int c, int w);
 hipError_t launch_conv_bf16_chain(const ChainArgs& a, int c, int w, hipStream_t s);
