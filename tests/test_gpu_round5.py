@@ -146,3 +146,35 @@ def test_bf16_chain_time_at_256_frames(pkg, shape):
     print(f"\nconv_bf16_chain<{c},{w}> x8 at 256 frames: {us:.1f} us per chain = {us / 8:.2f} us per convolution, {flops / us / 1e6:.0f} TFLOP/s")
     assert torch.isfinite(out).all() and us > 0
     m.close()
+
+
+WIDE = [(128, 128, 56), (256, 256, 56), (480, 256, 56), (64, 64, 56), (256, 256, 28), (128, 128, 28), (160, 128, 56)]
+
+
+@pytest.mark.parametrize("case", WIDE, ids=lambda c: "x".join(map(str, c)))
+def test_bf16_wide_band_kernel(bmodel, oracle, case):
+    """conv_bf16_wide_band (one wide 3x3 stride-1 convolution, a band of the input resident in LDS, 128 / 64 input channels per pass): equal to the
+    fp32 oracle on the same bf16-rounded operands up to the one rounding of its bf16 output -- the bar of every bf16 launch (test_gpu_bf16.py) --
+    with and without ReLU; 480 and 160 input channels take a last pass of 96 / 32 channels; three frames = 24 / 12 / 6 bands."""
+    cin, cout, h = case
+    g = np.random.Generator(np.random.Philox(key=[89, cin * 1000 + cout + h]))
+    n = 3 if h == 28 else 2
+    x = _rb(g.standard_normal((n, cin, h, h)))
+    w = _rb(g.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (cin * 9)))
+    b = (g.standard_normal((cout,)) * 0.1).astype(np.float32)
+    for relu in (True, False):
+        ref = oracle.conv2d(x, w, bias=b)
+        ref = (torch.relu(ref) if relu else ref).numpy()
+        got = bmodel.op_conv2d(torch.from_numpy(x).cuda(), w, b, relu=relu, tile_hint=3003).cpu().numpy()
+        assert got.shape == ref.shape and np.array_equal(got, _rb(got))
+        assert np.all(np.abs(got - ref) <= np.abs(ref) * 2.0 ** -8 + 1e-5), float(np.abs(got - ref).max())
+        for sl in (np.s_[:, :, 0], np.s_[:, :, -1], np.s_[:, :, :, 0], np.s_[:, :, :, -1], np.s_[:, :, 6:8], np.s_[:, :, 13:15]):      # borders, band seams
+            assert np.all(np.abs(got[sl] - ref[sl]) <= np.abs(ref[sl]) * 2.0 ** -8 + 1e-5)
+
+
+def test_bf16_wide_band_refuses_other_shapes(bmodel, pkg):
+    x = torch.zeros(1, 128, 14, 14).cuda()
+    with pytest.raises(pkg._lib.GrnetError, match="not eligible"):
+        bmodel.op_conv2d(x, np.zeros((128, 128, 3, 3), np.float32), None, tile_hint=3003)
+    with pytest.raises(pkg._lib.GrnetError, match="not eligible"):
+        bmodel.op_conv2d(torch.zeros(1, 256, 56, 56).cuda(), np.zeros((32, 256, 3, 3), np.float32), None, tile_hint=3003)

@@ -548,6 +548,153 @@ __global__ __launch_bounds__(512) void conv_bf16_block_frame(const ChainArgs a) 
     }
 }
 
+// ---- ONE wide 3x3 stride-1 convolution (upsample heads hrnet.py:440-453, PARE head pare.py:377-400, layer1's 3x3 hrnet.py:80-100) with a band of
+// the input resident in LDS.  conv_bf16_nhwc runs these layers at 0.25-0.45 of the matrix peak: 224-pixel x 64-channel tiles, 32 input
+// channels per barrier (126 MFMAs per wave between two barriers, each with a vmcnt(0) in front).  Here a workgroup owns R output rows of one
+// frame x CT = CP output channels (CP = 128, or 64 for the 64-channel layers): the R + 2 input rows go HBM -> LDS by LDS-DMA straight into the
+// padded, flattened plane of the chain kernel (the pad units and every zero -- halo column, rows outside the image -- come from a block of
+// zeros: the DMA writes lane-linear, so it cannot skip them), CP input channels per pass; between two barriers a wave issues 9 x CP/32 x 26
+// MFMAs (936 for CP = 128).  Layers with more than CP input channels take several passes (480 = 128 + 128 + 128 + 96) into the same
+// accumulators; their weights are one contiguous stream ([chunk][tap][CoutPad][32]), so the ring of weight fragments runs across passes.
+// The tile leaves through the plane (in place, as in the chain kernel) as whole channel rows.
+template <int CP, int W, int R>
+struct WideGeom {
+    static constexpr int P = W + 1, SB = 2 * CP + 32, UPS = SB / 16;
+    static constexpr int ROWS = R + 2;                      // plane rows: image rows y0 - 1 .. y0 + R
+    static constexpr int O0 = P + 1, NOUT = R * P - 1;
+    static constexpr int CS = 2, WCB = CP / 32, WPG = 8 / WCB;
+    static constexpr int PS = ((NOUT + 15) / 16 + WPG - 1) / WPG, NT = WPG * PS;
+    static constexpr int NSLOT = O0 + NT * 16 + P + 2;
+    static constexpr int LDS = NSLOT * SB;
+    static constexpr int FILL_UNITS = ((ROWS * P + 1) * UPS + 63) / 64 * 64;      // slots 0 .. ROWS * P (the last one: the right halo of the last row), whole wave-instructions
+    static constexpr int NFILL = (FILL_UNITS / 64 + 7) / 8;                        // wave-instructions per wave
+    static constexpr int UPP = CP / 8, NUO = (R * W * UPP + 511) / 512;
+    static constexpr int NB = (W + R - 1) / R;
+    static_assert(((SB / 32) % 2) == 1 && LDS <= 160 * 1024 && PS <= 32 && FILL_UNITS * 16 <= LDS, "wide-band geometry");
+    // (with CP = 128 the farthest pixel fragment lies 89 KB behind the lane's base: past the 16-bit ds_read immediate, hipcc keeps a second base register)
+};
+
+// chain_kloop with a run-time chunk count and weight stride (the output-channel padding of the layer): wc = the pass's first k-step, wtap = elements
+// per k-step (CoutPad x 32); the ring's two leading steps of the NEXT pass are simply the next two k-steps of the stream -- except behind the very
+// last chunk of the layer (last), where the stream ends: the pass's own first steps are re-requested (nobody waits for them).
+template <int P, int SB, int CS, int PS>
+__device__ __forceinline__ void wide_kloop(f32x4 (&acc)[CS][PS], bf16x8 (&wr)[3][CS], const unsigned char* bread, const u16* wc, size_t wtap, int nch, bool last, unsigned wlb) {
+    bf16x8 bfr[PS];
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps) bfr[ps] = *reinterpret_cast<const bf16x8*>(bread + ps * 16 * SB);
+#pragma unroll 1
+    for (int chunk = 0; chunk < nch; ++chunk) {
+        const unsigned char* bch = bread + chunk * 64;
+        const u16* wch = wc + (size_t)chunk * 9 * wtap;
+        const bool lastc = last && chunk == nch - 1;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            {
+                const u16* src = wch + (size_t)(tap + 2) * wtap;
+                if (tap >= 7) src = lastc ? wc + (size_t)(tap - 7) * wtap : src;
+#pragma unroll
+                for (int cs = 0; cs < CS; ++cs) wr[(tap + 2) % 3][cs] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(src + cs * 16 * 32) + wlb);
+            }
+            const int noff = tap < 8 ? (((tap + 1) / 3) * P + ((tap + 1) % 3)) * SB : 64;
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps) {
+#pragma unroll
+                for (int cs = 0; cs < CS; ++cs) acc[cs][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[tap % 3][cs], bfr[ps], acc[cs][ps], 0, 0, 0);
+                bfr[ps] = *reinterpret_cast<const bf16x8*>(bch + ps * 16 * SB + noff);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+template <int CP, int W, int R>
+__global__ __launch_bounds__(512) void conv_bf16_wide_band(const ConvArgs a) {
+    typedef WideGeom<CP, W, R> G;
+    constexpr int P = G::P, SB = G::SB, CS = G::CS, PS = G::PS, UPS = G::UPS, UPP = G::UPP;
+    extern __shared__ __align__(16) unsigned char plane[];
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wcb = wave % G::WCB, pg = wave / G::WCB;
+    const int ncb = a.CoutPad / CP;                            // output-channel tiles of the layer
+    const int cbo = blockIdx.x % ncb, nb = blockIdx.x / ncb, n = nb / G::NB, band = nb - n * G::NB;
+    if (n >= a.N) return;
+    const int y0 = band * R;
+    const u16* inb = reinterpret_cast<const u16*>(a.in) + (size_t)n * W * W * a.in_ctot + a.in_coff;
+    const u16* zeros = reinterpret_cast<const u16*>(a.zeros);
+
+    // DMA unit u = (slot, 16-byte part) of the plane in memory order.  The unit -> pixel map does not depend on the pass, and hipcc would hoist it
+    // out of the pass loop into 2 x NFILL registers held beside the accumulators (164-212 bytes of scratch): the lane index is laundered through an
+    // empty asm per pass, so the map is recomputed (~20 scalar-free instructions per unit, 19 units per pass) instead of kept.
+    auto fill = [&](int c0, int cw) {                          // input channels c0 .. c0 + cw - 1 of the band -> plane, by LDS-DMA
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int i = 0; i < G::NFILL; ++i) {
+            const int ub = (i * 8 + wave) * 64;
+            if (ub >= G::FILL_UNITS) break;                    // wave-uniform
+            const int u = ub + ln, slot = u / UPS, part = u - slot * UPS, r = slot / P, xx = slot - r * P, y = y0 - 1 + r;
+            const bool data = r < G::ROWS && xx != 0 && y >= 0 && y < W && part * 8 < cw;
+            dma16_c(data ? inb + (size_t)(y * W + xx - 1) * a.in_ctot + c0 + part * 8 : zeros, plane + ub * 16);
+        }
+    };
+
+    const int o_first = G::O0 + pg * PS * 16 + l15;
+    const unsigned char* bread = plane + (o_first - P - 1) * SB + lq * 16;
+    unsigned char* owrite = plane + o_first * SB + (wcb * CS * 16 + lq * 4) * 2;
+    unsigned valid = 0;
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps) {
+        const int o = o_first + ps * 16, r = o / P;
+        if (o - r * P != 0 && r >= 1 && r <= R && y0 + r - 1 < W) valid |= 1u << ps;
+    }
+    const int co = cbo * CP + wcb * CS * 16;                   // first output channel of this wave
+    const unsigned wlb = ((co + l15) * 32 + lq * 8) * 2;
+    const size_t wtap = (size_t)a.CoutPad * 32;
+    const u16* wg = reinterpret_cast<const u16*>(a.w);
+    f32x4 acc[CS][PS];
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + co + cs * 16 + lq * 4);
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) acc[cs][ps] = bv;
+    }
+    bf16x8 wr[3][CS];
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs) {
+        wr[0][cs] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(wg + cs * 16 * 32) + wlb);
+        wr[1][cs] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(wg + wtap + cs * 16 * 32) + wlb);
+    }
+    const int npass = (a.CinPad + CP - 1) / CP;
+#pragma unroll 1
+    for (int pass = 0; pass < npass; ++pass) {
+        const int c0 = pass * CP, cw = a.CinPad - c0 < CP ? a.CinPad - c0 : CP;
+        if (pass) __syncthreads();                             // every wave has finished reading the previous pass's plane
+        fill(c0, cw);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        wide_kloop<P, SB, CS, PS>(acc, wr, bread, wg + (size_t)(c0 / 32) * 9 * wtap, wtap, cw / 32, pass == npass - 1, wlb);
+    }
+    // ---- the tile: bias is in the accumulators; ReLU, bf16, in place through the plane, rows y0 .. y0 + R - 1 -> HBM as whole channel rows
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps)
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs) {
+            f32x4 v = acc[cs][ps];
+            if (a.relu) { v[0] = relu_c(v[0]); v[1] = relu_c(v[1]); v[2] = relu_c(v[2]); v[3] = relu_c(v[3]); }
+            if (valid & (1u << ps)) *reinterpret_cast<u32x2*>(owrite + ps * 16 * SB + cs * 32) = u32x2{pack2_c(v[0], v[1]), pack2_c(v[2], v[3])};
+        }
+    __syncthreads();
+    u16* outb = reinterpret_cast<u16*>(a.out) + (size_t)n * W * W * a.out_ctot + a.out_coff + cbo * CP;
+    const int cstore = a.Cout - cbo * CP;                      // real channels of this tile (CoutPad may exceed Cout)
+#pragma unroll
+    for (int i = 0; i < G::NUO; ++i) {
+        const int u = i * 512 + tid, px = u / UPP, part = u - px * UPP, r = px / W, x = px - r * W;
+        if (u < R * W * UPP && y0 + r < W && part * 8 < cstore)
+            *reinterpret_cast<u32x4*>(outb + ((size_t)(y0 + r) * W + x) * a.out_ctot + part * 8) = *reinterpret_cast<const u32x4*>(plane + ((r + 1) * P + x + 1) * SB + part * 16);
+    }
+}
+
 template <int C, int W>
 hipError_t set_chain_lds() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_chain<C, W>), hipFuncAttributeMaxDynamicSharedMemorySize, ChainGeom<C, W>::LDS);
@@ -560,6 +707,9 @@ hipError_t conv_bf16_chain_init() {
     GRK_TRY((set_chain_lds<128, 14>()));
     GRK_TRY((set_chain_lds<256, 7>()));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_block_band<32, 56, 19, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, BandGeom<32, 56, 19>::LDS));
+    GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_band<128, 56, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, WideGeom<128, 56, 7>::LDS));
+    GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_band<128, 28, 14>), hipFuncAttributeMaxDynamicSharedMemorySize, WideGeom<128, 28, 14>::LDS));
+    GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_band<64, 56, 14>), hipFuncAttributeMaxDynamicSharedMemorySize, WideGeom<64, 56, 14>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_block_frame<56, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, FrameGeom<56, 8>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_block_band<32, 56, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, BandGeom<32, 56, 8>::LDS));
     return hipSuccess;
@@ -595,6 +745,22 @@ hipError_t launch_conv_bf16_chain(const ChainArgs& a, int c, int w, hipStream_t 
     if (c == 64) return launch_k(conv_bf16_chain<64, 28>, dim3(a.N), dim3(512), ChainGeom<64, 28>::LDS, s, a);
     if (c == 128) return launch_k(conv_bf16_chain<128, 14>, dim3(a.N), dim3(512), ChainGeom<128, 14>::LDS, s, a);
     return launch_k(conv_bf16_chain<256, 7>, dim3(a.N), dim3(512), ChainGeom<256, 7>::LDS, s, a);
+}
+
+// Wide-band kernel: 3x3, stride 1, no fused addend, 56x56 or 28x28 maps, CinPad a multiple of 32; output channels in tiles of 128 (Cin >= 128) or
+// 64 (Cin = 64 -> 64); every 16-byte group of the output view must lie inside the buffer.
+bool conv_bf16_wide_eligible(const ConvArgs& a) {
+    if (a.ks != 3 || a.stride != 1 || a.n_add != 0 || a.H != a.W || a.Ho != a.H || a.Wo != a.W || a.CinPad % 32 != 0) return false;
+    if (a.in_ctot % 8 != 0 || a.in_coff % 8 != 0 || a.out_ctot % 8 != 0 || a.out_coff % 8 != 0 || a.Cout % 8 != 0) return false;
+    if (a.W == 56 && a.CinPad == 64 && a.CoutPad == 64) return true;
+    return (a.W == 56 || a.W == 28) && a.CinPad >= 128 && a.CoutPad % 128 == 0;
+}
+hipError_t launch_conv_bf16_wide(const ConvArgs& a, hipStream_t s) {
+    if (!conv_bf16_wide_eligible(a) || a.N < 1) return hipErrorInvalidValue;
+    if (a.CinPad == 64) return launch_k(conv_bf16_wide_band<64, 56, 14>, dim3(a.N * WideGeom<64, 56, 14>::NB), dim3(512), WideGeom<64, 56, 14>::LDS, s, a);
+    const int ncb = a.CoutPad / 128;
+    if (a.W == 56) return launch_k(conv_bf16_wide_band<128, 56, 7>, dim3(a.N * WideGeom<128, 56, 7>::NB * ncb), dim3(512), WideGeom<128, 56, 7>::LDS, s, a);
+    return launch_k(conv_bf16_wide_band<128, 28, 14>, dim3(a.N * WideGeom<128, 28, 14>::NB * ncb), dim3(512), WideGeom<128, 28, 14>::LDS, s, a);
 }
 
 }  // namespace grk
