@@ -178,3 +178,20 @@ def test_bf16_wide_band_refuses_other_shapes(bmodel, pkg):
         bmodel.op_conv2d(x, np.zeros((128, 128, 3, 3), np.float32), None, tile_hint=3003)
     with pytest.raises(pkg._lib.GrnetError, match="not eligible"):
         bmodel.op_conv2d(torch.zeros(1, 256, 56, 56).cuda(), np.zeros((32, 256, 3, 3), np.float32), None, tile_hint=3003)
+
+
+@pytest.mark.parametrize("with_add", [True, False])
+def test_bf16_pointwise_256_channel_tile(bmodel, oracle, with_add):
+    """layer1's 64 -> 256 1x1 convolutions (hrnet.py:80-100) at 20 frames: the residual is requested beside the patch DMA (round 5) instead of in
+    the epilogue.  Same bar as every bf16 launch."""
+    g = np.random.Generator(np.random.Philox(key=[90, int(with_add)]))
+    n = 20
+    x = _rb(g.standard_normal((n, 64, 56, 56)))
+    w = _rb(g.standard_normal((256, 64, 1, 1)) * np.sqrt(2.0 / 64))
+    b = (g.standard_normal((256,)) * 0.1).astype(np.float32)
+    add = _rb(g.standard_normal((n, 256, 56, 56))) if with_add else None
+    ref = oracle.conv2d(x, w, bias=b)
+    ref = torch.relu(ref + torch.from_numpy(add) if with_add else ref).numpy()
+    got = bmodel.op_conv2d(torch.from_numpy(x).cuda(), w, b, relu=True, add=torch.from_numpy(add).cuda() if with_add else None).cpu().numpy()
+    assert np.array_equal(got, _rb(got))
+    assert np.all(np.abs(got - ref) <= np.abs(ref) * 2.0 ** -8 + 1e-5), float(np.abs(got - ref).max())

@@ -177,6 +177,29 @@ void conv_bf16_nhwc(const ConvArgs a) {
     const int nchunks = a.CinPad / kCK;
     GRK_TICK(t_tab);
     stage(0, 0);
+    // 1x1 layers (layer1's 64 -> 256 with its residual: 925 MB per launch at 256 frames, 3.6 TB/s): a workgroup's life is a chain of round trips --
+    // patch DMA, a handful of MFMAs, addend loads, LDS transpose, stores.  The first addend does not depend on anything the workgroup computes: it
+    // is requested HERE, beside the patch DMA, and is in registers when the epilogue starts (round 5).
+    constexpr bool EARLY_ADD = KS == 1;
+    const int cstore_e = a.out_ctot - a.out_coff < a.CoutPad ? a.out_ctot - a.out_coff : a.CoutPad;
+    u32x2 radd[EARLY_ADD ? PSW : 1][EARLY_ADD ? CSW : 1];
+    if (EARLY_ADD && a.n_add > 0) {
+        const int sh = a.add_shift[0], hs = a.Ho >> sh, ws = a.Wo >> sh;
+#pragma unroll
+        for (int ps = 0; ps < PSW; ++ps) {
+            const int q = (wp * PSW + ps) * 16 + l15;
+            const int gl = fdiv(q, inv_RW), rem = q - gl * RW;
+            const bool ok = q < a.G * RW && g0 + gl < a.N && y0 * a.Wo + rem < HoWo;
+            const int pix = ok ? y0 * a.Wo + rem : 0, img = ok ? g0 + gl : 0;
+            const int y = fdiv(pix, inv_Wo), x = pix - y * a.Wo;
+            const u16* ap = reinterpret_cast<const u16*>(a.add[0]) + ((size_t)(img * hs + (y >> sh)) * ws + (x >> sh)) * a.add_ctot[0] + a.add_coff[0];
+#pragma unroll
+            for (int cs = 0; cs < CSW; ++cs) {
+                const int co = co0 + (wc * CSW + cs) * 16 + lq * 4;
+                radd[ps][cs] = co < cstore_e ? *reinterpret_cast<const u32x2*>(ap + co) : u32x2{0u, 0u};
+            }
+        }
+    }
 
     int abase[PSW];                                        // bf16 offset of tap (0,0) of this lane's pixel + its k-group, per pixel sub-tile
 #pragma unroll
@@ -264,6 +287,12 @@ void conv_bf16_nhwc(const ConvArgs a) {
         if (k >= a.n_add) break;
         const int sh = a.add_shift[k], hs = a.Ho >> sh, ws = a.Wo >> sh;
         u32x2 r[PSW][CSW];
+        if (EARLY_ADD && k == 0) {
+#pragma unroll
+            for (int ps = 0; ps < PSW; ++ps)
+#pragma unroll
+                for (int cs = 0; cs < CSW; ++cs) r[ps][cs] = radd[ps][cs];
+        } else
 #pragma unroll
         for (int ps = 0; ps < PSW; ++ps) {
             const int pix = pix_[ps] < 0 ? 0 : pix_[ps], img = pix_[ps] < 0 ? 0 : img_[ps];
@@ -755,6 +784,11 @@ hipError_t dispatch_bf16(const ConvArgs& a, int tps, int tc, hipStream_t s) {
     if (reg_env && KS == 3 && tps == 14 && tc == 64 && a.CinPad >= 2 * kCK && aunits <= kRegUnits * 256 &&
         (size_t)a.N * a.H * a.W * a.in_ctot < 0xfffffff0u)                                  // the offsets are 32-bit element counts
         return launch_k(conv_bf16_nhwc<KS, S, 14, 4, 2, 2, true>, grid, dim3(256), lds, s, a);
+    if constexpr (KS == 1) {
+        // 1x1 layers with 256 output channels (layer1's expansions): ONE workgroup writes all 256 channels of its 112 pixels = 56 KB of consecutive
+        // bytes.  With 64-channel tiles four workgroups each write 128 bytes of every 512-byte pixel row, at different times (round 5)
+        if (tps == 7 && tc == 256) return launch_k(conv_bf16_nhwc<1, 1, 7, 16, 1, 4>, grid, dim3(256), lds, s, a);
+    }
     if (tps == 14 && tc == 64) return launch_k(conv_bf16_nhwc<KS, S, 14, 4, 2, 2>, grid, dim3(256), lds, s, a);
     static const int occ_env = getenv("GRNET_BF16_OCC") ? atoi(getenv("GRNET_BF16_OCC")) : 3;      // workgroups per CU from which the four-wave variants run
     if ((long)a.gx * a.gy >= (long)occ_env * 256) {
@@ -790,6 +824,7 @@ inline int blocks_for(long total) { return (int)((total + 255) / 256 < 16384 ? (
 }  // namespace
 
 hipError_t conv_bf16_init() {
+    GRK_TRY(set_lds_bf16(conv_bf16_nhwc<1, 1, 7, 16, 1, 4>));
     GRK_TRY((init_bf16_ks<1, 1>()));
     GRK_TRY((init_bf16_ks<3, 1>()));
     GRK_TRY((init_bf16_ks<3, 2>()));
@@ -814,9 +849,11 @@ hipError_t launch_conv_bf16(ConvArgs a, hipStream_t s, int tile_hint) {
         if (a.Cin == 32) return launch_k(conv_bf16_direct<32, 2>, grid, dim3(256), 0, s, a, R, spf);
         return launch_k(conv_bf16_direct<64, 2>, grid, dim3(256), 0, s, a, R, spf);
     }
-    const int tc = a.CoutPad % 64 == 0 ? 64 : 32;          // measured at 256 frames: 32 everywhere is 1.5x slower
+    int tc = a.CoutPad % 64 == 0 ? 64 : 32;                // measured at 256 frames: 32 everywhere is 1.5x slower
     // 224-pixel tiles for the 56-wide maps, 112 otherwise (measured: 224 everywhere ties at 256 frames and loses 13 % at 16; 112 everywhere loses 28 %)
     int tps = (tile_hint == 7 || tile_hint == 14) ? tile_hint : (a.Wo >= 56 ? 14 : 7);
+    static const int pw256_env = getenv("GRNET_BF16_PW256") ? atoi(getenv("GRNET_BF16_PW256")) : 0;      // measured: 263 vs 237 us for 64 -> 256 with its residual at 256 frames -- off
+    if (pw256_env && tile_hint == 0 && a.ks == 1 && a.CoutPad == 256 && a.Wo == 56 && (long)a.N * a.Ho * a.Wo >= 256L * 112 * 2) { tc = 256; tps = 7; }
     if (!plan_bf16(a, tps, tc)) {
         tps = tps == 14 ? 7 : 14;
         if (!plan_bf16(a, tps, tc)) return hipErrorInvalidValue;
