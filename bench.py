@@ -70,7 +70,7 @@ def parse_args(argv=None):
                     "(RCCL on the nccl backend); capi: the C ABI's own RCCL communicator (grnet_comm_create / grnet_allgather; a second communicator next to the launcher's, "
                     "verified on one rank only so far); auto: capi if every rank can bootstrap it, else torch")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip roofline.dominant_kernel (its per-shape timing launches would sit in a profiler's dispatch list)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the bf16 256-frame leg (BASELINE configs[2]) that the default 1-GPU fp32 run appends as `secondary`")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the legs of BASELINE configs[2] (bf16, 256 frames), [3] (batchgen at 1 GPU) and [4] (tracks) that the default 1-GPU fp32 run appends as the `secondary` list")
     a = ap.parse_args(argv)
     if a.dtype is None:
         a.dtype = "bf16" if a.workload == "tracks" else "f32"
@@ -236,18 +236,19 @@ def roofline_object(fps_per_gpu, dtype, conv_flops_per_frame, conv_ms, conv_ms_s
     return r
 
 
-LAYER_TABLE_FILE = "r04_layer_traffic.json"   # per-kernel counter / algorithmic bytes of this round (tools/layer_table.py), optional
+LAYER_TABLE_FILES = {"f32": "r05_layer_traffic.json", "bf16": "r05_bf16_n256_layer_traffic.json"}   # per-kernel counter / algorithmic bytes of this round (tools/layer_table.py), optional
 
 
 def kernel_objects(table, dtype):
     """`dominant_kernel` (the kernel family whose launches add up to the most time when each runs alone) and the top of the table, from
     GRNet.kernel_table: durations measured live with HIP events (grnet_time_conv), FLOPs from the launch list."""
     peak = PEAK_BF16_MFMA_TFLOPS if dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
-    ratios, why = {}, f"none: profiles/{LAYER_TABLE_FILE} is missing (the per-launch counter passes of this round were not taken)"
+    table_file = LAYER_TABLE_FILES[dtype]
+    ratios, why = {}, f"none: profiles/{table_file} is missing (the per-launch counter passes of this round were not taken)"
     try:
-        with open(os.path.join(ROOT, "profiles", LAYER_TABLE_FILE)) as f:
+        with open(os.path.join(ROOT, "profiles", table_file)) as f:
             ratios = json.load(f).get("counter_over_algorithmic_by_kernel", {})
-        why = f"profiles/{LAYER_TABLE_FILE}"
+        why = f"profiles/{table_file}"
     except (OSError, ValueError):
         pass
 
@@ -263,27 +264,33 @@ def kernel_objects(table, dtype):
     return dom, top
 
 
-TRAFFIC_FILE = "r04_pmc_traffic.json"      # THIS round's counter passes (tools/gpu_profile.sh -> tools/summarize_profiles.py r04)
+ROUND = "r05"
+TRAFFIC_FILES = {("f32", 16): f"{ROUND}_pmc_traffic.json",            # THIS round's counter passes (tools/gpu_profile.sh [f32|bf16] -> tools/summarize_profiles.py)
+                 ("bf16", 256): f"{ROUND}_bf16_n256_pmc_traffic.json"}
 
 
 def stored_traffic(n, dtype, algorithmic_bytes=None):
     """HBM bytes per step of the conv launches from the PMC passes (profiles/): a static, committed measurement of this same
     workload and these same kernels, not collected inside this run (counters need their own rocprofv3 passes).  Only the
-    current round's file is read -- a missing or other-round file gives traffic = null with the reason, never an older number."""
-    out = {"traffic": None, "algorithmic_bytes": algorithmic_bytes}
-    if not (n == FRAMES_PER_GPU and dtype == "f32"):
-        out["traffic_source"] = "none: counter passes exist for the fp32 16-frame workload only"
+    current round's file of this (dtype, frames per call) is read -- a missing or other-round file gives traffic = null with
+    the reason, never an older number."""
+    out = {"traffic": None, "algorithmic_bytes": algorithmic_bytes,
+           "algorithmic_bytes_is": "per LAYER (accounting.step_algorithmic_bytes): input + fused addends + weights read once, output written once, at the "
+                                   "path's storage size; launches that keep intermediates on chip (bf16 BasicBlock chains) move fewer bytes than this"}
+    name = TRAFFIC_FILES.get((dtype, n))
+    if name is None:
+        out["traffic_source"] = f"none: counter passes exist for {sorted(TRAFFIC_FILES)} only"
         return out
-    path = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
+    path = os.path.join(ROOT, "profiles", name)
     try:
         with open(path) as f:
             tj = json.load(f)
     except OSError:
-        out["traffic_source"] = f"none: profiles/{TRAFFIC_FILE} is missing (the counter passes of this round were not taken)"
+        out["traffic_source"] = f"none: profiles/{name} is missing (the counter passes of this round were not taken)"
         return out
     out["traffic"] = tj.get("hbm_bytes_per_step_conv_kernels")
     out["traffic_over_algorithmic"] = round(out["traffic"] / algorithmic_bytes, 3) if out["traffic"] and algorithmic_bytes else None
-    out["traffic_source"] = (f"profiles/{TRAFFIC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this workload with this "
+    out["traffic_source"] = (f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this workload with this "
                              "round's kernels (FETCH x2 gfx950 correction per MI355X_MICROARCH.md, an upper bound for the narrow staging patterns), "
                              "bytes of all conv launches of one step; a stored measurement, not taken inside this run")
     return out
@@ -406,11 +413,7 @@ class GpuWorkload:
             model.set_option(pkg._lib.OPT_MULTI_LANE, 0)      # the same launches one after another on one stream
             conv_ms_serial = min(model.time_convs(n) for _ in range(3))
             model.set_option(pkg._lib.OPT_MULTI_LANE, 1)
-        alg_bytes = None
-        if self.args.dtype == "f32":                          # input + fused addends + weights read once, output written once, fp32
-            alg_bytes = 0
-            for c in model.describe_convs():
-                alg_bytes += 4 * (n * (c["cin"] * c["hin"] * c["win"] + c["cout"] * c["hout"] * c["wout"] + c["add_elems"]) + c["ks"] * c["ks"] * c["cin"] * c["cout"])
+        alg_bytes = pkg.accounting.step_algorithmic_bytes(model.describe_convs(), n, 4 if self.args.dtype == "f32" else 2)
         extra = stored_traffic(n, self.args.dtype, alg_bytes)
         if self.rank == 0 and not getattr(self.args, "light", False) and not getattr(self.args, "no_kernel_table", False):
             extra["dominant_kernel"], extra["kernels_by_time_alone"] = kernel_objects(model.kernel_table(n), self.args.dtype)
@@ -484,7 +487,7 @@ class BatchgenWorkload:
                                executed_flops_per_frame=model.conv_executed_flops_per_frame(n))
 
     def extras(self, line):
-        pass
+        line["phases"] = self.runner.phases()                  # of the latest job on this rank: per-frame path / exchange / replicated temporal branch
 
     def close(self):
         if self.comm is not None:
@@ -592,7 +595,7 @@ def run_rank(args, make_workload=GpuWorkload, out=None):
     wl.close()
     if rank == 0:
         if world == 1 and make_workload is GpuWorkload and args.dtype == "f32" and args.frames == FRAMES_PER_GPU and not args.no_secondary and not batchgen:
-            line["secondary"] = secondary_leg(args)
+            line["secondary"] = secondary_legs(args)
         print(json.dumps(line), file=out or sys.stdout, flush=True)
     if dist is not None:
         dist.barrier()
@@ -600,23 +603,41 @@ def run_rank(args, make_workload=GpuWorkload, out=None):
     return line
 
 
-def secondary_leg(args, frames=256, steps=20, warmup=5):
-    """BASELINE configs[2] under the same clock as the headline: 8 clips x 32 frames = 256 frames per call, bf16 storage / fp32 accumulation on the
-    bf16 matrix cores, timed right after the headline in the same process (a few seconds, no CPU leg: the bf16 path's distance from the
-    fp32 oracle is covered by tests/test_gpu_bf16.py and by `bench.py --dtype bf16`)."""
+def secondary_legs(args):
+    """The other single-GPU-runnable BASELINE configs under the same clock as the headline, in the same process, each with its own
+    config.workload / dtype / roofline (round-4 review: 5 488 and 17 750 frames/s were builder-run numbers only):
+      configs[2]  8 clips x 32 frames = 256 frames per call, bf16 storage / fp32 accumulation                    (20 steps)
+      configs[3]  batch_generation over ONE 10 000-frame video at 1 GPU, fp32, with its phases                   (1 warm + 2 timed jobs, ~6 s)
+      configs[4]  4 person tracks x 64 frames, bf16, crop on a side stream                                       (30 steps)
+    No CPU leg: the bf16 path's distance from the fp32 oracle is covered by tests/test_gpu_bf16.py and `bench.py --dtype bf16`."""
     import copy
-    a = copy.copy(args)
-    a.dtype, a.frames, a.steps, a.warmup, a.inflight, a.light, a.tune_cache = "bf16", frames, steps, warmup, 1, True, None
-    try:
-        wl = GpuWorkload(a, 1, 0, 0, None)
-        elapsed = timed_steps(wl.step, wl.sync, steps, warmup, None, "cuda")
-        fps = frames * steps / elapsed
-        obj = {"config": wl.config(), "metric": f"frames/sec (224x224, 8 clips x seq=32)", "dtype": "bf16", "value": round(fps, 2), "unit": "frames/s",
-               "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4), "roofline": wl.roofline(fps)}
-        wl.close()
-        return obj
-    except Exception as e:                                     # the headline line must not be lost to the second leg
-        return {"error": f"{type(e).__name__}: {e}"}
+
+    def leg(make, a, frames_per_step, metric, extra=None):
+        try:
+            wl = make(a, 1, 0, 0, None)
+            elapsed = timed_steps(wl.step, wl.sync, a.steps, a.warmup, None, "cuda")
+            fps = frames_per_step * a.steps / elapsed
+            obj = {"config": wl.config(), "metric": metric, "dtype": a.dtype, "value": round(fps, 2), "unit": "frames/s", "steps": a.steps, "warmup": a.warmup,
+                   "ms_per_step": round(elapsed / a.steps * 1e3, 4), "roofline": wl.roofline(fps)}
+            if extra:
+                obj.update(extra(wl))
+            wl.close()
+            return obj
+        except Exception as e:                                 # the headline line must not be lost to a secondary leg
+            return {"metric": metric, "error": f"{type(e).__name__}: {e}"}
+
+    base = copy.copy(args)
+    base.inflight, base.light, base.tune_cache, base.no_cpu_baseline = 1, True, None, True
+    a2 = copy.copy(base)
+    a2.dtype, a2.frames, a2.steps, a2.warmup = "bf16", 256, 20, 5
+    a3 = copy.copy(base)
+    a3.workload, a3.dtype, a3.steps, a3.warmup, a3.total_frames, a3.chunk = "batchgen", "f32", 2, 1, 10000, 128
+    a4 = copy.copy(base)
+    a4.workload, a4.dtype, a4.steps, a4.warmup, a4.tracks, a4.track_frames, a4.call_frames, a4.no_overlap = "tracks", "bf16", 30, 5, 4, 64, None, False
+    return [leg(GpuWorkload, a2, 256, "frames/sec (224x224, 8 clips x seq=32)"),
+            leg(BatchgenWorkload, a3, a3.total_frames, f"frames/sec (224x224, {a3.total_frames}-frame video directory, all-gather before the GRU)",
+                lambda wl: {"scaling": "strong", "phases": wl.runner.phases()}),
+            leg(TracksWorkload, a4, a4.tracks * a4.track_frames, f"frames/sec (224x224, {a4.tracks} tracks x seq={a4.track_frames}, crop overlapped with the forward)")]
 
 
 def main(argv=None):

@@ -20,6 +20,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = "video-based-gait-analysis-for-dementia_amd"
+sys.path.insert(0, ROOT)
+accounting = importlib.import_module(PKG + ".accounting")
 N = 16
 
 
@@ -34,6 +36,7 @@ def dump(path, dtype="f32"):
         name = C.create_string_buffer(96)
         m._lib.grnet_conv_kernel_info(m._h, pos, n, name, 96, None)
         c["kernel_family"] = name.value.decode()
+        c["dispatches"] = 0 if c["kernel_family"].endswith("+") else 4 if c["kernel_family"].startswith("conv_bf16_chain<32,") else 1
     json.dump(convs, open(path, "w"))
     m.close()
 
@@ -56,15 +59,24 @@ def conv_dispatches(path, value):
     return out
 
 
-def per_position(rows, n_conv):
-    n_fw = len(rows) // n_conv
-    assert n_fw >= 2 and len(rows) == n_fw * n_conv, (len(rows), n_conv, "dispatches do not tile into forwards")
-    out = []
-    for k in range(n_conv):
-        names = {rows[f * n_conv + k][0] for f in range(n_fw)}
-        assert len(names) == 1, (k, names)
-        vals = [rows[f * n_conv + k][1] for f in range(1, n_fw)]
-        out.append((names.pop(), sum(vals) / len(vals), rows[k][2]))
+def per_position(rows, convs):
+    """Dispatch list (all forwards of the run, in order) -> per convolution of the plan: (kernel, value averaged over the forwards but the first,
+    dispatches).  A plan entry owns c["dispatches"] consecutive dispatches: 1 normally, 0 for a convolution that runs inside a bf16 chain launch
+    (its value is 0: the chain's first member carries the launch), 4 for the 56x56 branch's chain (one launch per BasicBlock)."""
+    per_fw = sum(c.get("dispatches", 1) for c in convs)
+    n_fw = len(rows) // per_fw
+    assert n_fw >= 2 and len(rows) == n_fw * per_fw, (len(rows), per_fw, "dispatches do not tile into forwards")
+    out, base = [], 0
+    for c in convs:
+        nd = c.get("dispatches", 1)
+        if nd == 0:
+            out.append((c.get("kernel_family", "?"), 0.0, 0))
+            continue
+        names = {rows[f * per_fw + base][0] for f in range(n_fw)}
+        assert len(names) == 1, (c["name"], names)
+        vals = [sum(rows[f * per_fw + base + j][1] for j in range(nd)) for f in range(1, n_fw)]
+        out.append((names.pop(), sum(vals) / len(vals), sum(rows[base + j][2] for j in range(nd))))
+        base += nd
     return out
 
 
@@ -93,23 +105,27 @@ def main(rnd, dtype="f32"):
     src = os.path.join(ROOT, "gpurun_out", "bf16") if bf else os.path.join(ROOT, "gpurun_out")
     convs = json.load(open(os.path.join(src, "layers", "convs.json")))
     n_conv = len(convs)
-    dur = per_position(conv_dispatches(os.path.join(src, "prof_serial", "bench_kernel_trace.csv"), lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3), n_conv)
-    fetch = per_position(conv_dispatches(os.path.join(src, "pmc", "FETCH_SIZE_counter_collection.csv"), lambda r: float(r["Counter_Value"]) * 1024.0), n_conv)
-    write = per_position(conv_dispatches(os.path.join(src, "pmc", "WRITE_SIZE_counter_collection.csv"), lambda r: float(r["Counter_Value"]) * 1024.0), n_conv)
+    dur = per_position(conv_dispatches(os.path.join(src, "prof_serial", "bench_kernel_trace.csv"), lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3), convs)
+    fetch = per_position(conv_dispatches(os.path.join(src, "pmc", "FETCH_SIZE_counter_collection.csv"), lambda r: float(r["Counter_Value"]) * 1024.0), convs)
+    write = per_position(conv_dispatches(os.path.join(src, "pmc", "WRITE_SIZE_counter_collection.csv"), lambda r: float(r["Counter_Value"]) * 1024.0), convs)
     rows, by_stage, by_kernel, by_family = [], collections.OrderedDict(), collections.OrderedDict(), collections.OrderedDict()
+    chain_keys = None
     for c, (k, us, nd), (_, fb, _), (_, wb, _) in zip(convs, dur, fetch, write):
         flop = 2.0 * N * c["macs"]
-        if c["cin"]:
-            alg_r = esz * (N * (c["cin"] * c["hin"] * c["win"] + c["add_elems"]) + c["ks"] * c["ks"] * c["cin"] * c["cout"])
-            alg_w = esz * N * c["cout"] * c["hout"] * c["wout"]
-        else:                                            # the grouped fuse launch: add_elems = floats read per frame; it writes outputs 0 .. nb-2
-            nb = c["n_add"]
-            alg_r = 4.0 * N * c["add_elems"]
-            alg_w = 4.0 * N * sum((32 << i) * (56 >> i) ** 2 for i in range(nb - 1))
+        alg_r, alg_w = accounting.conv_algorithmic_bytes(c, N, esz)      # the ONE definition (bench.py uses the same)
         ex = executed_ratio(k, c)
-        rows.append(dict(name=c["name"], kernel=k, dispatches=nd, shape=f'{c["cin"]}->{c["cout"]} k{c["ks"]} s{c["stride"]} @{c["hin"]}', us=us, gflop=flop / 1e9,
+        if nd == 0:                                          # runs inside the chain launch of the row above: its FLOPs and per-layer bytes count there
+            r = rows[-1]
+            r["gflop"] += flop / 1e9; r["alg_mb"] += (alg_r + alg_w) / 1e6; r["fused_layers"] += 1
+            r["tflops"] = r["exec_tflops"] = r["gflop"] / r["us"] * 1e3
+            for key, table in chain_keys:
+                t = table[key]
+                t["gflop"] += flop / 1e9; t["ex"] += flop * ex / 1e9; t["alg"] += (alg_r + alg_w) / 1e6
+            continue
+        rows.append(dict(name=c["name"], kernel=k, dispatches=nd, fused_layers=1, shape=f'{c["cin"]}->{c["cout"]} k{c["ks"]} s{c["stride"]} @{c["hin"]}', us=us, gflop=flop / 1e9,
                          tflops=flop / us / 1e6, exec_tflops=flop * ex / us / 1e6, alg_mb=(alg_r + alg_w) / 1e6, counter_mb=(2 * fb + wb) / 1e6))
-        for key, table in ((stage_of(c["name"]), by_stage), (re.sub(r"<.*", "", k) + " " + rows[-1]["shape"], by_kernel), (c.get("kernel_family", k), by_family)):
+        chain_keys = ((stage_of(c["name"]), by_stage), (re.sub(r"<.*", "", k) + " " + rows[-1]["shape"], by_kernel), (c.get("kernel_family", k), by_family))
+        for key, table in chain_keys:
             t = table.setdefault(key, dict(n=0, us=0.0, gflop=0.0, ex=0.0, alg=0.0, cnt=0.0))
             t["n"] += 1; t["us"] += us; t["gflop"] += flop / 1e9; t["ex"] += flop * ex / 1e9; t["alg"] += (alg_r + alg_w) / 1e6; t["cnt"] += (2 * fb + wb) / 1e6
     dst = os.path.join(ROOT, "profiles")
@@ -118,7 +134,7 @@ def main(rnd, dtype="f32"):
         w.writeheader()
         w.writerows(rows)
     tot = dict(n=len(rows), us=sum(r["us"] for r in rows), gflop=sum(r["gflop"] for r in rows), alg=sum(r["alg_mb"] for r in rows), cnt=sum(r["counter_mb"] for r in rows))
-    lines = [f"# Per-launch table of the {n_conv} convolution-class launches of a {N}-frame {dtype} step ({rnd}), launched one after another (GRNET_MULTI_LANE=0)", "",
+    lines = [f"# Per-launch table of the {len(rows)} convolution-class launches ({n_conv} layers; a bf16 BasicBlock chain is one row) of a {N}-frame {dtype} step ({rnd}), launched one after another (GRNET_MULTI_LANE=0)", "",
              f"Total: {tot['us'] / 1e3:.3f} ms, {tot['gflop']:.1f} algorithmic GFLOP = {tot['gflop'] / tot['us'] * 1e3:.1f} TFLOP/s; counter bytes (FETCH_SIZE x 2 + WRITE_SIZE) "
              f"{tot['cnt'] / 1e3:.2f} GB vs {tot['alg'] / 1e3:.2f} GB algorithmic ({tot['cnt'] / tot['alg']:.2f} x).",
              f"Peak of the {dtype} matrix cores: {peak} TFLOP/s.  `exec` = the multiplies the kernel issues (fp32: F(4x4,3x3) at 1/4 of the direct count, x 1.31 on the padded 14x14 / 7x7 maps; bf16: the direct count).", "",

@@ -57,7 +57,12 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         per_kernel[n][1] += 1
     is_conv = lambda k: "conv_" in k or "hr_fuse_up" in k
     conv_launches_total = sum(v[1] for k, v in per_kernel.items() if is_conv(k))
-    per_fw = int(os.environ.get("CONV_DISPATCHES_PER_FORWARD", "292"))   # 290 conv-class launches, two of them with a half-size last round (2 dispatches)
+    per_fw = int(os.environ.get("CONV_DISPATCHES_PER_FORWARD", "292"))   # fp32: 290 conv-class launches, two of them with a half-size last round (2 dispatches)
+    lj = os.path.join(src, "layers", "convs.json")                       # tools/layer_table.py --dump: the plan with the dispatches each layer owns (bf16 chains: 0 / 1 / 4)
+    if os.path.isfile(lj) and "CONV_DISPATCHES_PER_FORWARD" not in os.environ:
+        plan = json.load(open(lj))
+        if any("dispatches" in c for c in plan) and any(c.get("kernel_family", "").startswith("conv_bf16") for c in plan):
+            per_fw = sum(c.get("dispatches", 1) for c in plan)
     n_forwards = max(1, round(conv_launches_total / per_fw))
     conv_kb = sum(v[0] for k, v in per_kernel.items() if is_conv(k))
     conv_launches = sum(v[1] for k, v in per_kernel.items() if is_conv(k))

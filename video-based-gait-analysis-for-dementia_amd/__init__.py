@@ -1,7 +1,7 @@
 """MI355X-native implementation of MAX-GRNet's per-frame pose/mesh inference path."""
 import importlib as _importlib
 
-from . import netspec, synth  # noqa: F401
+from . import accounting, netspec, synth  # noqa: F401
 
 
 def __getattr__(name):

@@ -296,6 +296,18 @@ class ShardedSequenceRunner:
         self._forward_chunk = forward_chunk or self._grnet_forward
         self._temporal = temporal or (lambda seq: temporal_after_gather(self.model, seq, self.bbox, self.cimg, 1, self.n_total))
         self.result = None
+        # phase marks of the latest step (per-frame path / exchange / temporal branch): four events on the caller's stream, read by phases()
+        self._marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if dev.type == "cuda" else None
+
+    def phases(self):
+        """{per_frame_ms, gather_ms, temporal_ms} of the latest step (device time between events on the step's stream; synchronises).
+        per_frame = this rank's forward calls, gather = the one all-gather + unpacking, temporal = cparams + GRU + corrector / attention
+        block + second head pass on the whole sequence (replicated on every rank: the serial tail of the strong-scaling job)."""
+        if self._marks is None or self.result is None:
+            return None
+        self._marks[3].synchronize()
+        t = [self._marks[i].elapsed_time(self._marks[i + 1]) for i in range(3)]
+        return {"per_frame_ms": round(t[0], 3), "gather_ms": round(t[1], 3), "temporal_ms": round(t[2], 3)}
 
     def _grnet_forward(self, c0, c1, out):
         m = self.model
@@ -304,11 +316,16 @@ class ShardedSequenceRunner:
         _lib.check(m._lib, m._h, rc, "grnet_forward")
 
     def step(self):
+        mark = (lambda i: self._marks[i].record()) if self._marks is not None else (lambda i: None)
+        mark(0)
         for c0, c1, out in self.calls:
             self._forward_chunk(c0, c1, out)
+        mark(1)
         g = gather_pose_records(self.packed, self.n_local, self.world, self.dist, out=self.gathered, comm=self.comm)
         self.seq = unpack_sequence(g, self.n_local, self.n_total, self.record)
+        mark(2)
         self.result = self._temporal(self.seq)
+        mark(3)
         return self.result
 
 
