@@ -167,3 +167,111 @@ def test_multi_track_overlapped_preprocess_stream(pkg, dtype):
             assert np.array_equal(got[t]["pose"][12 * b:12 * b + 12], ref["theta"][0, :, 3:75].cpu().numpy())
             assert np.array_equal(got[t]["verts"][12 * b:12 * b + 12], ref["verts"][0].cpu().numpy())
     m.close()
+
+
+# ---- checkpoint-file round trips (round-4 review: every test built its model from synth in memory; a real MAX-GRNet checkpoint would have been the
+# first thing ever to walk demo.py's --ckpt branch, batch_generation's pretrained_file branch and load_pare_dict) -----------------------------------
+def _reference_format_checkpoint(pkg, path):
+    """A file as the reference writes it: torch.save({'gen_state_dict': model.state_dict()}) with torch tensors, int64 num_batches_tracked, the unused
+    backbone.final_layer.*, head.temperature / init_*, and the SMPL buffers under regressor.smpl.smpl.* including the ones the path never reads
+    (faces_tensor, betas, global_orient, body_pose, vertex_joint_selector.extra_joints_idxs: smplx registers them)."""
+    sd = {}
+    for k, v in pkg.synth.make_state_dict().items():
+        t = torch.as_tensor(np.asarray(v))                        # 0-d stays 0-d (head.temperature, num_batches_tracked), as in a torch state_dict
+        sd[k] = t.to(torch.int64) if k.endswith("num_batches_tracked") else t.to(torch.float32)
+    assert any("final_layer" in k for k in sd) and sd["head.temperature"].ndim == 0 and sd["backbone.bn1.num_batches_tracked"].dtype == torch.int64
+    pre = "regressor.smpl.smpl."
+    for k, v in pkg.synth.make_smpl_tables().items():
+        sd[pre + k] = torch.from_numpy(np.ascontiguousarray(v)).to(torch.int64 if k == "parents" else torch.float32)
+    sd[pre + "faces_tensor"] = torch.zeros(13776, 3, dtype=torch.int64)
+    sd[pre + "betas"] = torch.zeros(1, 10)
+    sd[pre + "global_orient"] = torch.zeros(1, 3)
+    sd[pre + "body_pose"] = torch.zeros(1, 69)
+    sd[pre + "vertex_joint_selector.extra_joints_idxs"] = torch.arange(21)
+    torch.save({"gen_state_dict": sd, "epoch": 7, "performance": 0.0}, path)
+    return sd
+
+
+def test_demo_from_checkpoint_file_equals_synthetic_weights(pkg, tmp_path):
+    """demo.py --ckpt (demo.py:116-122: torch.load(f)['gen_state_dict'] -> load_state_dict(strict=False)) on a reference-format file holding the
+    synthetic weights: the .pkl must be bit-identical to the --synthetic_weights run, and carry the checkpoint's stem as its name (demo.py:254-267)."""
+    sys.path.insert(0, ROOT)
+    demo = importlib.import_module("demo")
+    ck = str(tmp_path / "grnet_epoch7.pth.tar")
+    _reference_format_checkpoint(pkg, ck)
+    frames = pkg.synth.make_frames(26)
+    img_dir = str(tmp_path / "vid")
+    _write_frames(img_dir, frames)
+    tp = str(tmp_path / "tracking.pkl")
+    joblib.dump({3: {"bbox": np.tile(np.array([[112.0, 112.0, 224.0, 224.0]], np.float32), (26, 1)), "frames": np.arange(26)}}, tp)
+    common = ["--img_folder", img_dir, "--tracking_path", tp, "--grnet_batch_size", "16", "--max_frames", "16"]
+    out_ck = demo.main(demo.parser().parse_args(common + ["--output_folder", str(tmp_path / "a"), "--ckpt", ck]))
+    out_sy = demo.main(demo.parser().parse_args(common + ["--output_folder", str(tmp_path / "b"), "--synthetic_weights"]))
+    assert os.path.basename(out_ck).startswith("grnet_epoch7") and out_ck.endswith(".pkl")
+    a, b = joblib.load(out_ck)[3], joblib.load(out_sy)[3]
+    assert set(a) == set(b)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_batch_generation_from_checkpoint_file_strict(pkg, tmp_path):
+    """batch_generation.py:214-218: load_state_dict(torch.load(f)['gen_state_dict'], strict=True) -- the full key set of a reference checkpoint must
+    load strictly (unused and tolerated keys included), and the db must equal the synthetic-weights run bit for bit."""
+    sys.path.insert(0, ROOT)
+    bg = importlib.import_module("batch_generation")
+    ck = str(tmp_path / "model_best.pth.tar")
+    _reference_format_checkpoint(pkg, ck)
+    name = "S001C001P001R001A003"
+    _write_frames(str(tmp_path / "vids" / name), pkg.synth.make_frames(7, start=40))
+    bp = str(tmp_path / "bbox.pkl")
+    joblib.dump({name: np.tile(np.array([[112.0, 112.0, 210.0, 190.0]], np.float32), (7, 1))}, bp)
+    w_ck = bg.prepare_data(fv=bp, vid_folder=str(tmp_path / "vids"), outpath=str(tmp_path / "ck.json"), pretrained_file=ck, max_frames=8)
+    w_sy = bg.prepare_data(fv=bp, vid_folder=str(tmp_path / "vids"), outpath=str(tmp_path / "sy.json"), synthetic_weights=True, max_frames=8)
+    a, b = joblib.load(w_ck[0]), joblib.load(w_sy[0])
+    for k in ("vid_name", "bbox", "joints3D"):
+        assert np.array_equal(a[k], b[k]), k
+    # strict means strict: one key too many, or one missing, is refused like torch refuses it
+    sd = torch.load(ck, map_location="cpu")["gen_state_dict"]
+    sd["backbone.not_a_layer.weight"] = torch.zeros(3)
+    torch.save({"gen_state_dict": sd}, ck)
+    with pytest.raises(RuntimeError, match="unexpected"):
+        bg.prepare_data(fv=bp, vid_folder=str(tmp_path / "vids"), outpath=str(tmp_path / "x.json"), pretrained_file=ck, max_frames=8)
+    del sd["backbone.not_a_layer.weight"], sd["backbone.stage3.2.branches.1.3.bn2.running_var"]
+    torch.save({"gen_state_dict": sd}, ck)
+    with pytest.raises(RuntimeError, match="missing"):
+        bg.prepare_data(fv=bp, vid_folder=str(tmp_path / "vids"), outpath=str(tmp_path / "y.json"), pretrained_file=ck, max_frames=8)
+
+
+def test_load_pare_dict_and_size_mismatch(pkg, tmp_path):
+    """lib/models/grnet.py:93-109: the PARE checkpoint's 'model.head.*' tensors re-keyed to 'head.*'; a file without init_pose / init_shape is refused;
+    a tensor of the wrong size raises like torch's load_state_dict ('size mismatch')."""
+    full = pkg.synth.make_state_dict()
+    pare = {"model.head." + k[len("head."):]: torch.as_tensor(np.asarray(v)) for k, v in full.items() if k.startswith("head.")}
+    pare["model.backbone.conv1.weight"] = torch.zeros(64, 3, 3, 3)          # not a head tensor: ignored
+    pf = str(tmp_path / "pare_w_3dpw_checkpoint.ckpt")
+    torch.save({"state_dict": pare}, pf)
+    frames = torch.from_numpy(pkg.synth.make_frames(3)).cuda()
+    ref_model = pkg.build_synthetic_model(max_frames=4, with_gru=False)
+    ref = ref_model(frames)[-1]
+    m = pkg.GRNet(max_frames=4, pretrained_pare=pf)                           # the constructor argument of the reference (grnet.py:87)
+    rest = {k: v for k, v in full.items() if not k.startswith("head.")}
+    res = m.load_state_dict(rest, strict=False)
+    assert not res.missing_keys, res.missing_keys[:3]                          # head.* came from the PARE file
+    m.load_smpl(pkg.synth.make_smpl_tables())
+    got = m.finalize()(frames)[-1]
+    torch.cuda.synchronize()
+    for k in ("theta", "kp_3d", "verts"):
+        assert torch.equal(got[k], ref[k]), k
+    m.close()
+    ref_model.close()
+    bad = dict(pare)
+    del bad["model.head.init_pose"]
+    torch.save({"state_dict": bad}, pf)
+    with pytest.raises(KeyError, match="VPARE"):
+        pkg.GRNet(max_frames=1, pretrained_pare=pf)
+    m2 = pkg.GRNet(max_frames=1)
+    wrong = dict(full)
+    wrong["backbone.layer1.0.conv1.weight"] = np.zeros((64, 32, 1, 1), np.float32)
+    with pytest.raises(RuntimeError, match="size mismatch for backbone.layer1.0.conv1.weight"):
+        m2.load_state_dict(wrong, strict=False)
+    m2.close()
