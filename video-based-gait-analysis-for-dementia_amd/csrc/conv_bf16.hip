@@ -162,7 +162,10 @@ void conv_bf16_nhwc(const ConvArgs a) {
 #endif
             if (q < 4 && slot < a.PSTR) {
                 const int off = tab[slot], c = c0 + q * 8;
-                if (off >= 0 && c < a.Cin) src = in + (size_t)off * a.in_ctot + a.in_coff + c;
+                if (off >= 0 && c < a.Cin) {
+                    if (KS == 1 && a.in2 && c0 >= a.cin_split) src = reinterpret_cast<const u16*>(a.in2) + (size_t)off * a.in2_ctot + a.in2_coff + (c - a.cin_split);      // the chunk's second source
+                    else src = in + (size_t)off * a.in_ctot + a.in_coff + c;
+                }
             }
             dma16(src, adst + ub * 8);
         }

@@ -557,20 +557,20 @@ __global__ __launch_bounds__(512) void conv_bf16_block_frame(const ChainArgs a) 
 // MFMAs (936 for CP = 128).  Layers with more than CP input channels take several passes (480 = 128 + 128 + 128 + 96) into the same
 // accumulators; their weights are one contiguous stream ([chunk][tap][CoutPad][32]), so the ring of weight fragments runs across passes.
 // The tile leaves through the plane (in place, as in the chain kernel) as whole channel rows.
-template <int CP, int W, int R>
+template <int CP, int CT, int W, int R>
 struct WideGeom {
     static constexpr int P = W + 1, SB = 2 * CP + 32, UPS = SB / 16;
     static constexpr int ROWS = R + 2;                      // plane rows: image rows y0 - 1 .. y0 + R
     static constexpr int O0 = P + 1, NOUT = R * P - 1;
-    static constexpr int CS = 2, WCB = CP / 32, WPG = 8 / WCB;
+    static constexpr int CS = 2, WCB = CT / 32, WPG = 8 / WCB;    // CT output channels per workgroup (CT <= CP: the tile leaves through the first 2 CT bytes of the plane's slots)
     static constexpr int PS = ((NOUT + 15) / 16 + WPG - 1) / WPG, NT = WPG * PS;
     static constexpr int NSLOT = O0 + NT * 16 + P + 2;
     static constexpr int LDS = NSLOT * SB;
     static constexpr int FILL_UNITS = ((ROWS * P + 1) * UPS + 63) / 64 * 64;      // slots 0 .. ROWS * P (the last one: the right halo of the last row), whole wave-instructions
     static constexpr int NFILL = (FILL_UNITS / 64 + 7) / 8;                        // wave-instructions per wave
-    static constexpr int UPP = CP / 8, NUO = (R * W * UPP + 511) / 512;
+    static constexpr int UPP = CT / 8, NUO = (R * W * UPP + 511) / 512;
     static constexpr int NB = (W + R - 1) / R;
-    static_assert(((SB / 32) % 2) == 1 && LDS <= 160 * 1024 && PS <= 32 && FILL_UNITS * 16 <= LDS, "wide-band geometry");
+    static_assert(((SB / 32) % 2) == 1 && LDS <= 160 * 1024 && PS <= 32 && FILL_UNITS * 16 <= LDS && CT <= CP && CT % 32 == 0 && 8 % (CT / 32) == 0, "wide-band geometry");
     // (with CP = 128 the farthest pixel fragment lies 89 KB behind the lane's base: past the 16-bit ds_read immediate, hipcc keeps a second base register)
 };
 
@@ -607,15 +607,15 @@ __device__ __forceinline__ void wide_kloop(f32x4 (&acc)[CS][PS], bf16x8 (&wr)[3]
     }
 }
 
-template <int CP, int W, int R>
+template <int CP, int CT, int W, int R>
 __global__ __launch_bounds__(512) void conv_bf16_wide_band(const ConvArgs a) {
-    typedef WideGeom<CP, W, R> G;
+    typedef WideGeom<CP, CT, W, R> G;
     constexpr int P = G::P, SB = G::SB, CS = G::CS, PS = G::PS, UPS = G::UPS, UPP = G::UPP;
     extern __shared__ __align__(16) unsigned char plane[];
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wcb = wave % G::WCB, pg = wave / G::WCB;
-    const int ncb = a.CoutPad / CP;                            // output-channel tiles of the layer
+    const int ncb = a.CoutPad / CT;                            // output-channel tiles of the layer
     const int cbo = blockIdx.x % ncb, nb = blockIdx.x / ncb, n = nb / G::NB, band = nb - n * G::NB;
     if (n >= a.N) return;
     const int y0 = band * R;
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(512) void conv_bf16_wide_band(const ConvArgs a) {
         const int o = o_first + ps * 16, r = o / P;
         if (o - r * P != 0 && r >= 1 && r <= R && y0 + r - 1 < W) valid |= 1u << ps;
     }
-    const int co = cbo * CP + wcb * CS * 16;                   // first output channel of this wave
+    const int co = cbo * CT + wcb * CS * 16;                   // first output channel of this wave
     const unsigned wlb = ((co + l15) * 32 + lq * 8) * 2;
     const size_t wtap = (size_t)a.CoutPad * 32;
     const u16* wg = reinterpret_cast<const u16*>(a.w);
@@ -685,8 +685,8 @@ __global__ __launch_bounds__(512) void conv_bf16_wide_band(const ConvArgs a) {
             if (valid & (1u << ps)) *reinterpret_cast<u32x2*>(owrite + ps * 16 * SB + cs * 32) = u32x2{pack2_c(v[0], v[1]), pack2_c(v[2], v[3])};
         }
     __syncthreads();
-    u16* outb = reinterpret_cast<u16*>(a.out) + (size_t)n * W * W * a.out_ctot + a.out_coff + cbo * CP;
-    const int cstore = a.Cout - cbo * CP;                      // real channels of this tile (CoutPad may exceed Cout)
+    u16* outb = reinterpret_cast<u16*>(a.out) + (size_t)n * W * W * a.out_ctot + a.out_coff + cbo * CT;
+    const int cstore = a.Cout - cbo * CT;                      // real channels of this tile (CoutPad may exceed Cout)
 #pragma unroll
     for (int i = 0; i < G::NUO; ++i) {
         const int u = i * 512 + tid, px = u / UPP, part = u - px * UPP, r = px / W, x = px - r * W;
@@ -707,9 +707,9 @@ hipError_t conv_bf16_chain_init() {
     GRK_TRY((set_chain_lds<128, 14>()));
     GRK_TRY((set_chain_lds<256, 7>()));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_block_band<32, 56, 19, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, BandGeom<32, 56, 19>::LDS));
-    GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_band<128, 56, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, WideGeom<128, 56, 7>::LDS));
-    GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_band<128, 28, 14>), hipFuncAttributeMaxDynamicSharedMemorySize, WideGeom<128, 28, 14>::LDS));
-    GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_band<64, 56, 14>), hipFuncAttributeMaxDynamicSharedMemorySize, WideGeom<64, 56, 14>::LDS));
+    GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_band<128, 128, 56, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, WideGeom<128, 128, 56, 7>::LDS));
+    GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_band<128, 128, 28, 14>), hipFuncAttributeMaxDynamicSharedMemorySize, WideGeom<128, 128, 28, 14>::LDS));
+    GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_band<64, 64, 56, 14>), hipFuncAttributeMaxDynamicSharedMemorySize, WideGeom<64, 64, 56, 14>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_block_frame<56, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, FrameGeom<56, 8>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_block_band<32, 56, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, BandGeom<32, 56, 8>::LDS));
     return hipSuccess;
@@ -748,7 +748,8 @@ hipError_t launch_conv_bf16_chain(const ChainArgs& a, int c, int w, hipStream_t 
 }
 
 // Wide-band kernel: 3x3, stride 1, no fused addend, 56x56 or 28x28 maps, CinPad a multiple of 32; output channels in tiles of 128 (Cin >= 128) or
-// 64 (Cin = 64 -> 64); every 16-byte group of the output view must lie inside the buffer.
+// 64 (Cin = 64 -> 64); every 16-byte group of the output view must lie inside the buffer.  (A 32-channel tile for transition1's 256 -> 32 -- 6-row bands,
+// 3 column tiles per wave -- measured 245 us against the generic kernel's 228 at 256 frames: every pixel fragment feeds two MFMAs only.  Not instantiated.)
 bool conv_bf16_wide_eligible(const ConvArgs& a) {
     if (a.ks != 3 || a.stride != 1 || a.n_add != 0 || a.H != a.W || a.Ho != a.H || a.Wo != a.W || a.CinPad % 32 != 0) return false;
     if (a.in_ctot % 8 != 0 || a.in_coff % 8 != 0 || a.out_ctot % 8 != 0 || a.out_coff % 8 != 0 || a.Cout % 8 != 0) return false;
@@ -757,10 +758,10 @@ bool conv_bf16_wide_eligible(const ConvArgs& a) {
 }
 hipError_t launch_conv_bf16_wide(const ConvArgs& a, hipStream_t s) {
     if (!conv_bf16_wide_eligible(a) || a.N < 1) return hipErrorInvalidValue;
-    if (a.CinPad == 64) return launch_k(conv_bf16_wide_band<64, 56, 14>, dim3(a.N * WideGeom<64, 56, 14>::NB), dim3(512), WideGeom<64, 56, 14>::LDS, s, a);
+    if (a.CinPad == 64) return launch_k(conv_bf16_wide_band<64, 64, 56, 14>, dim3(a.N * WideGeom<64, 64, 56, 14>::NB), dim3(512), WideGeom<64, 64, 56, 14>::LDS, s, a);
     const int ncb = a.CoutPad / 128;
-    if (a.W == 56) return launch_k(conv_bf16_wide_band<128, 56, 7>, dim3(a.N * WideGeom<128, 56, 7>::NB * ncb), dim3(512), WideGeom<128, 56, 7>::LDS, s, a);
-    return launch_k(conv_bf16_wide_band<128, 28, 14>, dim3(a.N * WideGeom<128, 28, 14>::NB * ncb), dim3(512), WideGeom<128, 28, 14>::LDS, s, a);
+    if (a.W == 56) return launch_k(conv_bf16_wide_band<128, 128, 56, 7>, dim3(a.N * WideGeom<128, 128, 56, 7>::NB * ncb), dim3(512), WideGeom<128, 128, 56, 7>::LDS, s, a);
+    return launch_k(conv_bf16_wide_band<128, 128, 28, 14>, dim3(a.N * WideGeom<128, 128, 28, 14>::NB * ncb), dim3(512), WideGeom<128, 128, 28, 14>::LDS, s, a);
 }
 
 }  // namespace grk

@@ -69,6 +69,8 @@ struct ConvLayer {
     int cin_pad = 0, cout_pad = 0;
     double macs_per_frame = 0;
     int lane_hint = 0;          // lane of this convolution when it is launched on its own (not as a group member)
+    View in2;                   // bf16: second input of a merged 1x1 launch (layer1.0: conv3 over t and the downsample over x as ONE GEMM); in2.c == 0: none
+    ConvSeg seg2;               // its weights / BatchNorm (same output channels, summed)
     int chain = -1, chain_pos = 0;   // bf16: member chain_pos of BasicBlock chain `chain` (conv_bf16_chain.hip); position 0 launches the whole chain in large calls
     std::map<int, int> tuned;   // n_frames -> launch configuration (tile hint) measured fastest by grnet_tune
 };
@@ -530,6 +532,20 @@ struct grnet {
         name_view("stem_conv2", x);
         for (int k = 0; k < 4; ++k) {                       // layer1: 4 Bottlenecks (hrnet.py:80-100)
             const std::string q = b + "layer1." + std::to_string(k) + ".";
+            // bf16, first Bottleneck: relu(BN3(conv3(t)) + BNd(downsample(x))) is ONE 1x1 GEMM over the concatenated inputs [t ; x] (K = 64 + 64, the two
+            // BatchNorms folded into their halves of the weights, the shifts summed): the 411 MB downsample tensor (at 256 frames) is neither written nor read
+            // back, and a launch goes away.  GRNET_BF16_MERGE_DS=0: the two launches of the reference's graph (hrnet.py:80-100, 389-406).
+            static const int merge_ds = getenv("GRNET_BF16_MERGE_DS") ? atoi(getenv("GRNET_BF16_MERGE_DS")) : 1;
+            if (k == 0 && dtype == 1 && merge_ds) {
+                View y = conv_bn(x, q + "conv1.weight", q + "bn1", 64, 1, 1, true);
+                y = conv_bn(y, q + "conv2.weight", q + "bn2", 64, 3, 1, true);
+                View xin = x;
+                x = conv_bn(y, q + "conv3.weight", q + "bn3", 256, 1, 1, true);
+                convs.back().in2 = xin;
+                convs.back().seg2 = ConvSeg{q + "downsample.0.weight", q + "downsample.1", "", 256};
+                convs.back().macs_per_frame *= 2;                  // K = 64 (t) + 64 (x)
+                continue;
+            }
             View res = k == 0 ? conv_bn(x, q + "downsample.0.weight", q + "downsample.1", 256, 1, 1, false) : x;
             View y = conv_bn(x, q + "conv1.weight", q + "bn1", 64, 1, 1, true);
             y = conv_bn(y, q + "conv2.weight", q + "bn2", 64, 3, 1, true);
@@ -632,6 +648,7 @@ struct grnet {
         for (size_t i = 0; i < pending.size(); ++i) *pending[i].first = arena + offs[i];
         for (auto& L : convs) {
             resolve(L.in); resolve(L.out);
+            if (L.in2.c) resolve(L.in2);
             for (auto& a : L.adds) resolve(a.v);
         }
         for (auto& op : ops) { resolve(op.bin); resolve(op.bout); }
@@ -675,6 +692,7 @@ struct grnet {
             case Op::CONV: {
                 const ConvLayer& L = convs[op.conv_idx];
                 r.push_back(L.in.p);
+                if (L.in2.c) r.push_back(L.in2.p);
                 for (auto& a : L.adds) r.push_back(a.v.p);
                 break;
             }
@@ -886,7 +904,8 @@ struct grnet {
         const int cin = L.cin_w, ks = L.ks, taps = ks * ks;
         const int TC = conv_pick_tc(L.cout);
         const bool bf = dtype == 1;                            // bf16: [CinPad/32][tap][CoutPad][32]: a chunk's rows are contiguous for LDS-DMA
-        L.cin_pad = bf ? (L.in.c + 31) / 32 * 32 : (cin + kConvCK - 1) / kConvCK * kConvCK;
+        L.cin_pad = bf ? (L.in.c + L.in2.c + 31) / 32 * 32 : (cin + kConvCK - 1) / kConvCK * kConvCK;
+        if (L.in2.c && (!bf || ks != 1 || L.in.c % 32 != 0 || L.segs.size() != 1 || L.seg2.cout != L.cout)) return fail(GRNET_ESTATE, "a two-input launch is a bf16 1x1 convolution with one weight segment per input");
         L.cout_pad = bf ? (L.cout + 31) / 32 * 32 : (L.cout + TC - 1) / TC * TC;
         std::vector<float> wp((size_t)taps * L.cin_pad * L.cout_pad, 0.f), bp(L.cout_pad, 0.f);
         // Every eligible 3x3 stride-1 layer takes a Winograd F(4x4,3x3) kernel: on 56x56 maps layer1, upsample heads, PARE head, transition1's
@@ -940,6 +959,24 @@ struct grnet {
                     }
             }
             co0 += s.cout;
+        }
+        if (L.in2.c) {                                         // the second input's 1x1 weights behind the first's input channels, its BatchNorm shift added to the bias
+            const ConvSeg& s2 = L.seg2;
+            const int cin2 = L.in2.c;
+            const HostTensor* w = find(s2.wkey);
+            if (!w) return fail(GRNET_ENOENT, "missing tensor " + s2.wkey);
+            if (w->shape.size() != 4 || w->shape[0] != s2.cout || w->shape[1] != cin2 || w->shape[2] != 1 || w->shape[3] != 1) return fail(GRNET_EINVAL, "bad shape for " + s2.wkey);
+            const HostTensor *g = find(s2.bnprefix + ".weight"), *be = find(s2.bnprefix + ".bias"), *m = find(s2.bnprefix + ".running_mean"), *v = find(s2.bnprefix + ".running_var");
+            if (!g || !be || !m || !v) return fail(GRNET_ENOENT, "missing BatchNorm tensors " + s2.bnprefix + ".*");
+            if ((int)g->numel() != s2.cout) return fail(GRNET_EINVAL, "bad BatchNorm size " + s2.bnprefix);
+            for (int co = 0; co < s2.cout; ++co) {
+                const double sc = (double)g->data[co] / std::sqrt((double)v->data[co] + kBnEps);
+                bp[co] = (float)((double)bp[co] + (double)be->data[co] - (double)m->data[co] * sc);
+                for (int ci = 0; ci < cin2; ++ci) {
+                    const int cc = L.in.c + ci;
+                    wp[(((size_t)(cc / 32) * taps + 0) * L.cout_pad + co) * 32 + cc % 32] = (float)((double)w->data[(size_t)co * cin2 + ci] * sc);
+                }
+            }
         }
         int rc;
         if (bf) {                                              // round the folded weights to bf16 (nearest even), two per float slot
@@ -1339,6 +1376,7 @@ struct grnet {
             a.add_shift[k] = L.adds[k].shift;
         }
         a.zeros = zeros;
+        if (L.in2.c) { a.in2 = L.in2.p; a.in2_ctot = L.in2.ctot; a.in2_coff = L.in2.coff; a.cin_split = L.in.c; a.Cin = L.in.c + L.in2.c; }
         return a;
     }
 
@@ -1389,7 +1427,7 @@ struct grnet {
         switch (kernel_for(L, n)) {
             case K_BF16: return "conv_bf16";
             case K_BF16_STEM: return "conv_bf16_stem";
-            case K_BF16_WIDE: snprintf(b, sizeof b, "conv_bf16_wide<%d,%d>", L.in.c >= 128 ? 128 : 64, L.in.w); return b;
+            case K_BF16_WIDE: snprintf(b, sizeof b, "conv_bf16_wide<%d,%d,%d>", L.in.c >= 128 ? 128 : 64, L.cout_pad == 32 ? 32 : L.in.c >= 128 ? 128 : 64, L.in.w); return b;
             case K_BF16_CHAIN: snprintf(b, sizeof b, "conv_bf16_chain<%d,%d>", L.in.c, L.in.w); return b;
             case K_BF16_CHAIN_MEMBER: snprintf(b, sizeof b, "conv_bf16_chain<%d,%d>+", L.in.c, L.in.w); return b;      // runs inside the chain's launch: no launch, no time of its own
             case K_WINO4S: snprintf(b, sizeof b, "conv_wino4s_f32<%d,%d>", L.in.w, L.in.c); return b;
@@ -2238,7 +2276,7 @@ int grnet_describe_conv(grnet_t* h, int pos, int32_t* info, char* name, int name
         const ConvLayer& L = h->convs[op.conv_idx];
         int64_t add_elems = 0;
         for (const AddRef& r : L.adds) add_elems += (int64_t)L.cout * (L.out.h >> r.shift) * (L.out.w >> r.shift);
-        const int32_t v[12] = {L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, L.out.h, L.out.w, (int32_t)L.adds.size(), L.relu,
+        const int32_t v[12] = {L.in.c + L.in2.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, L.out.h, L.out.w, (int32_t)L.adds.size(), L.relu,
                                op.lane, (int32_t)add_elems};
         memcpy(info, v, sizeof(v));
         if (name && name_size > 0) snprintf(name, name_size, "%s", L.segs.empty() ? "" : L.segs[0].wkey.c_str());

@@ -127,6 +127,8 @@ struct ConvArgs {
     int n_add;
     const float* add[kMaxAdd]; int add_ctot[kMaxAdd], add_coff[kMaxAdd], add_shift[kMaxAdd];
     const float* zeros;        // >= 64 B of zeros in HBM: source for halo / padded-channel loads
+    const float* in2; int in2_ctot, in2_coff, cin_split;     // bf16 1x1 only: input channels >= cin_split (a multiple of 32) come from a SECOND tensor of the same
+                                                             // spatial size (a Bottleneck's last 1x1 and its 1x1 downsample as ONE GEMM over [t ; x]); in2 == nullptr: one input
     // filled by the launcher
     int R, G, Rin, Wp, PSTR, tiles_y, groups, TC, rows;
     float inv_RW, inv_Wo, inv_upc;   // 1 / (R*Wo), 1 / Wo, 1 / (PSTR/4) for the kernels' reciprocal-multiply divisions
