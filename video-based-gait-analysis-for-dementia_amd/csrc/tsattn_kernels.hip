@@ -14,6 +14,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace grk {
 
@@ -69,6 +70,117 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restr
         float acc = 0.f;
         for (int j = 0; j < n; ++j) acc = fmaf(p[j], base[(size_t)j * 3 * kE + (2 * kH + h) * kDh + tid], acc);
         xt[((size_t)bi * n + i) * kE + h * kDh + tid] = acc * inv;
+    }
+}
+
+// The same attention for LONG clips, blocked (round 5).  The kernel above reads every key and value of the clip once per QUERY: at 10 000 frames that is
+// 10 000 x 4 x 2 x 10 MB = 800 GB through L2 and 107 ms -- two thirds of the temporal branch that every rank of a BASELINE configs[3] job repeats after the
+// all-gather (profiles/r05_temporal_phases.txt).  Here a workgroup owns 64 queries of one head; keys and values stream through LDS in blocks of 32
+// (read once per 64 queries), S = Q K^T and O += P V run on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products and sums), the softmax
+// is the running-maximum form: per query row m <- max(m, max_j s_j), O <- O exp(m_old - m) + sum_j exp(s_j - m) v_j, l likewise, out = O / l.  Same
+// arithmetic as softmax(QK^T / sqrt(d)) V in fp32 up to the order of the sums; deterministic (no atomics, fixed order).
+// Wave w: queries 16 w .. 16 w + 15.  Row strides: 258 floats for Q / K (258 = 2 mod 32: the 16 rows x 4 columns of an MFMA operand read fall on 64
+// different banks), 272 for V (16 mod 32: 4 rows x 16 columns likewise), 34 for the wave's own P tile (written in the accumulator layout, read back as
+// the A operand of P V).  The 1 / sqrt(d) is folded into Q when it is staged.
+constexpr int kFQ = 64, kFK = 32, kFLd = 258, kFLdV = 272, kFLdP = 34;
+constexpr int kFlashLdsFloats = kFQ * kFLd + kFK * kFLd + kFK * kFLdV + 4 * 16 * kFLdP;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float group16_max(float v) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__global__ __launch_bounds__(256) void temporal_attn_flash_kernel(const float* __restrict__ qkv, float* __restrict__ xt, int n) {
+    extern __shared__ float sm[];
+    float* Qs = sm;
+    float* Ks = Qs + kFQ * kFLd;
+    float* Vs = Ks + kFK * kFLd;
+    float* Ps = Vs + kFK * kFLdV + (threadIdx.x >> 6) * 16 * kFLdP;
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4, wave = tid >> 6;
+    const int q0 = blockIdx.x * kFQ, h = blockIdx.y, bi = blockIdx.z;
+    const float* base = qkv + (size_t)bi * n * 3 * kE;
+    const float scale = 1.0f / sqrtf((float)kDh);
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    // rows are 8-byte aligned (a head starts 1000 bytes into its row): float2 loads; columns 250 .. stride-1 are zero
+    for (int u = tid; u < kFQ * (kFLd / 2); u += 256) {
+        const int r = u / (kFLd / 2), c2 = u - r * (kFLd / 2);
+        f2 v = {0.f, 0.f};
+        if (c2 < kDh / 2 && q0 + r < n) v = *reinterpret_cast<const f2*>(base + (size_t)(q0 + r) * 3 * kE + (0 * kH + h) * kDh + 2 * c2);
+        *reinterpret_cast<f2*>(Qs + r * kFLd + 2 * c2) = f2{v[0] * scale, v[1] * scale};
+    }
+    float m_run[4], l_run[4];
+    f32x4_t O[16];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m_run[r] = -INFINITY; l_run[r] = 0.f; }
+#pragma unroll
+    for (int dt = 0; dt < 16; ++dt) O[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const float* qrow = Qs + (wave * 16 + l15) * kFLd + lq;
+    for (int k0 = 0; k0 < n; k0 += kFK) {
+        __syncthreads();                                       // the previous block's K / V have been read (first pass: Q is being staged)
+        for (int u = tid; u < kFK * (kFLd / 2); u += 256) {
+            const int r = u / (kFLd / 2), c2 = u - r * (kFLd / 2);
+            f2 kv = {0.f, 0.f};
+            if (c2 < kDh / 2 && k0 + r < n) kv = *reinterpret_cast<const f2*>(base + (size_t)(k0 + r) * 3 * kE + (1 * kH + h) * kDh + 2 * c2);
+            *reinterpret_cast<f2*>(Ks + r * kFLd + 2 * c2) = kv;
+        }
+        for (int u = tid; u < kFK * (kFLdV / 2); u += 256) {
+            const int r = u / (kFLdV / 2), c2 = u - r * (kFLdV / 2);
+            f2 vv = {0.f, 0.f};
+            if (c2 < kDh / 2 && k0 + r < n) vv = *reinterpret_cast<const f2*>(base + (size_t)(k0 + r) * 3 * kE + (2 * kH + h) * kDh + 2 * c2);
+            *reinterpret_cast<f2*>(Vs + r * kFLdV + 2 * c2) = vv;
+        }
+        __syncthreads();
+        // S (16 queries x 32 keys) = Q K^T: 63 k-steps of 4 (columns 250, 251 are zeros)
+        f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        const float* k0row = Ks + l15 * kFLd + lq;
+        const float* k1row = Ks + (16 + l15) * kFLd + lq;
+#pragma unroll 9
+        for (int d0 = 0; d0 < 252; d0 += 4) {
+            const float a = qrow[d0];
+            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, k0row[d0], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, k1row[d0], s1, 0, 0, 0);
+        }
+        // lane: rows (queries) 4 lq + r, column (key) l15 of each tile; keys past the clip's end are -inf
+        const bool in0 = k0 + l15 < n, in1 = k0 + 16 + l15 < n;
+        float alpha[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a0 = in0 ? s0[r] : -INFINITY, a1 = in1 ? s1[r] : -INFINITY;
+            const float mx = group16_max(fmaxf(a0, a1));
+            const float m_new = fmaxf(m_run[r], mx);          // finite: key k0 exists
+            alpha[r] = expf(m_run[r] - m_new);
+            const float p0 = expf(a0 - m_new), p1 = expf(a1 - m_new);
+            l_run[r] = l_run[r] * alpha[r] + group16_sum(p0 + p1);
+            m_run[r] = m_new;
+            Ps[(4 * lq + r) * kFLdP + l15] = p0;
+            Ps[(4 * lq + r) * kFLdP + 16 + l15] = p1;
+        }
+#pragma unroll
+        for (int dt = 0; dt < 16; ++dt) { O[dt][0] *= alpha[0]; O[dt][1] *= alpha[1]; O[dt][2] *= alpha[2]; O[dt][3] *= alpha[3]; }
+        // O (16 queries x 256 columns) += P V: 8 k-steps of 4 keys; the P tile is this wave's own (LDS operations of a wave complete in order)
+        const float* prow = Ps + l15 * kFLdP + lq;
+#pragma unroll
+        for (int kk = 0; kk < kFK / 4; ++kk) {
+            const float a = prow[kk * 4];
+            const float* vrow = Vs + (kk * 4 + lq) * kFLdV + l15;
+#pragma unroll
+            for (int dt = 0; dt < 16; ++dt) O[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vrow[dt * 16], O[dt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int q = q0 + wave * 16 + 4 * lq + r;
+        if (q >= n) continue;
+        const float inv = 1.0f / l_run[r];
+        float* orow = xt + ((size_t)bi * n + q) * kE + h * kDh + l15;
+#pragma unroll
+        for (int dt = 0; dt < 16; ++dt)
+            if (dt * 16 + l15 < kDh) orow[dt * 16] = O[dt][r] * inv;
     }
 }
 
@@ -240,7 +352,19 @@ hipError_t launch_tsattn(const float* x, const float* xs, const TsAttnWeights& w
     float* x1 = ys + R * kD;
     GRK_TRY(launch_gemm_nt_bias(x, w.qkv_t_w, w.qkv_t_b, qkv_t, (int)R, 3 * kE, kD, 3 * kE, s));
     GRK_TRY(launch_gemm_nt_bias(xs, w.qkv_s_w, w.qkv_s_b, qkv_s, (int)R, 3 * kE, kD + kF, 3 * kE, s));
-    GRK_TRY(launch_k(temporal_attn_kernel, dim3(n, kH, b), dim3(256), attn_lds, s, qkv_t, xt, n));
+    // clips of >= 1024 frames: the blocked kernel (keys / values read once per 64 queries, fp32 matrix cores); shorter clips: one workgroup per query
+    static const int flash_env = getenv("GRNET_TSATTN_FLASH") ? atoi(getenv("GRNET_TSATTN_FLASH")) : 1024;     // smallest clip that takes it (450 frames: 0.98 ms against 0.87 -- 32 workgroups; 10 000: 29 against 117); 0: never
+    if (flash_env > 0 && n >= flash_env) {
+        static PerDeviceOnce fattr;
+        int dev = 0;
+        GRK_TRY(current_device(&dev));
+        GRK_TRY(once_per_device(fattr, dev, [](int*) {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(temporal_attn_flash_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kFlashLdsFloats * sizeof(float)));
+        }));
+        GRK_TRY(launch_k(temporal_attn_flash_kernel, dim3((n + kFQ - 1) / kFQ, kH, b), dim3(256), kFlashLdsFloats * sizeof(float), s, (const float*)qkv_t, xt, n));
+    } else {
+        GRK_TRY(launch_k(temporal_attn_kernel, dim3(n, kH, b), dim3(256), attn_lds, s, qkv_t, xt, n));
+    }
     GRK_TRY(launch_k(spatial_attn_kernel, dim3((unsigned)R, kH), dim3(256), 0, s, qkv_s, xsp));
     GRK_TRY(launch_k(gate_mean_kernel, dim3((2 * kE + 255) / 256, b), dim3(256), 0, s, xt, xsp, mean, n));
     GRK_TRY(launch_gemm_nt_bias(mean, w.ts_w, w.ts_b, logits, b, 2 * kE, 2 * kE, 2 * kE, s));
