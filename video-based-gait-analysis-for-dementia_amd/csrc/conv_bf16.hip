@@ -667,20 +667,24 @@ __device__ __forceinline__ float wave_sum_b(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+constexpr int kPoolPB = 64;                                // positions per staging buffer (448 = 7 x 64)
 constexpr int kPoolFS = 96 + 8;                            // bf16 per staged position: 96 channels + 16 bytes (the four positions of a k-step land on different banks)
 __global__ __launch_bounds__(384) void attn_pool_bf16_kernel(const u16* __restrict__ heat, int hc, const u16* __restrict__ featA, int CA, int ctA,
                                                                const u16* __restrict__ featB, int CB, int ctB, float* __restrict__ stats,
                                                                float* __restrict__ part, int P) {
     __shared__ __align__(16) float prob[24 * kPoolStrideB];
-    __shared__ __align__(16) u16 fst[2][32 * kPoolFS];    // two buffers of 32 positions x 96 channels, as they lie in memory (NHWC); 57 KB of LDS in all
+    __shared__ __align__(16) u16 fst[2][kPoolPB * kPoolFS];    // two buffers of 64 positions x 96 channels, as they lie in memory (NHWC); 70 KB of LDS in all
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
     const int pbeg = blockIdx.z * kPoolChunkB, cb = blockIdx.y * 96;      // first channel of this workgroup in [featA | featB]
-    // staging: 32 positions x 12 units of 16 bytes = one unit per thread; a unit lies entirely in featA or in featB (128 = 8 x 16)
+    // staging: 64 positions x 12 units of 16 bytes = two units per thread (positions spp and spp + 32); a unit lies entirely in featA or in featB
+    // (128 = 8 x 16).  Round 5: 64 instead of 32 positions per barrier -- the loop is a chain of load -> LDS -> barrier -> 16 MFMAs round trips
     const int spp = tid / 12, sq = tid - spp * 12, sc = cb + sq * 8;
     const u16* ssrc = sc < CA ? featA + ((size_t)n * P + pbeg + spp) * ctA + sc : featB + ((size_t)n * P + pbeg + spp) * ctB + (sc - CA);
     const size_t sstride = sc < CA ? ctA : ctB;
     auto stage = [&](int p0, int buf) {
-        *reinterpret_cast<u32x4*>(&fst[buf][spp * kPoolFS + sq * 8]) = *reinterpret_cast<const u32x4*>(ssrc + (size_t)p0 * sstride);
+        const u32x4 v0 = *reinterpret_cast<const u32x4*>(ssrc + (size_t)p0 * sstride), v1 = *reinterpret_cast<const u32x4*>(ssrc + (size_t)(p0 + 32) * sstride);
+        *reinterpret_cast<u32x4*>(&fst[buf][spp * kPoolFS + sq * 8]) = v0;
+        *reinterpret_cast<u32x4*>(&fst[buf][(spp + 32) * kPoolFS + sq * 8]) = v1;
     };
     stage(0, 0);
     // heat rows of the range -> LDS: thread = (position, 8 joints)
@@ -717,13 +721,13 @@ __global__ __launch_bounds__(384) void attn_pool_bf16_kernel(const u16* __restri
     const float* b1 = prob + (16 + (l15 & 7)) * kPoolStrideB + 4 * lq;  // joints 16..23; lanes 8..15 of the second column tile are zero columns
     const bool j1 = l15 < 8;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    for (int p0 = 0; p0 < kPoolChunkB; p0 += 32) {
-        const int buf = (p0 >> 5) & 1;
+    for (int p0 = 0; p0 < kPoolChunkB; p0 += kPoolPB) {
+        const int buf = (p0 / kPoolPB) & 1;
         __syncthreads();                                                // buffer `buf` is staged (and the probabilities are final); the other one is free
-        if (p0 + 32 < kPoolChunkB) stage(p0 + 32, buf ^ 1);
+        if (p0 + kPoolPB < kPoolChunkB) stage(p0 + kPoolPB, buf ^ 1);
         const u16* fs = &fst[buf][(4 * lq) * kPoolFS + wv * 16 + l15];
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < kPoolPB / 16; ++g) {
             const f32x4 u = *reinterpret_cast<const f32x4*>(b0 + p0 + 16 * g);
             f32x4 v = *reinterpret_cast<const f32x4*>(b1 + p0 + 16 * g);
             if (!j1) v = f32x4{0.f, 0.f, 0.f, 0.f};

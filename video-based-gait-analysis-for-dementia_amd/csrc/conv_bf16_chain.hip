@@ -87,9 +87,13 @@ struct ChainGeom {
 // lane's share kept apart as the 32-bit byte offset wlb every weight load is `global_load v, v_off, s[base]` -- a 64-bit per-lane pointer per
 // k-step cost two registers each, which hipcc hoisted out of the band loop of the frame kernel and spilled); wr[0], wr[1] hold steps 0, 1 on
 // entry and the next convolution's on exit.
-template <int C, int P, int SB, int CS, int PS>
-__device__ __forceinline__ void chain_kloop(f32x4 (&acc)[CS][PS], bf16x8 (&wr)[3][CS], const unsigned char* bread, const u16* wc, const u16* wn, unsigned wlb) {
-    constexpr int NCH = C / 32;
+// RING: register sets of the weight ring = prefetch distance + 1.  3 (two k-steps ahead) where a k-step is >= 14 MFMAs; 9 (eight ahead) for the
+// 256-channel 7x7 chain, whose k-steps are 8 MFMAs = 128 cycles: two steps did not cover an L2 round trip (SQ_WAIT_ANY 0.73 of its wave cycles).
+// RING must divide the 9 taps of a chunk (the ring positions are static in the unrolled tap loop).
+template <int C, int P, int SB, int CS, int PS, int RING = 3>
+__device__ __forceinline__ void chain_kloop(f32x4 (&acc)[CS][PS], bf16x8 (&wr)[RING][CS], const unsigned char* bread, const u16* wc, const u16* wn, unsigned wlb) {
+    constexpr int NCH = C / 32, D = RING - 1;
+    static_assert(9 % RING == 0, "the ring must divide the taps");
     bf16x8 bfr[PS];
 #pragma unroll
     for (int ps = 0; ps < PS; ++ps) bfr[ps] = *reinterpret_cast<const bf16x8*>(bread + ps * 16 * SB);
@@ -100,11 +104,11 @@ __device__ __forceinline__ void chain_kloop(f32x4 (&acc)[CS][PS], bf16x8 (&wr)[3
         const bool lastc = chunk == NCH - 1;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            {                                                             // weights of step s + 2 (taps 9, 10 = taps 0, 1 of the next chunk / of the next convolution)
-                const u16* src = wch + (size_t)(tap + 2) * C * 32;
-                if (tap >= 7) src = lastc ? wn + (size_t)(tap - 7) * C * 32 : src;
+            {                                                             // weights of step s + D (taps 9 .. = the next chunk's / the next convolution's first ones)
+                const u16* src = wch + (size_t)(tap + D) * C * 32;
+                if (tap + D >= 9) src = lastc ? wn + (size_t)(tap + D - 9) * C * 32 : src;
 #pragma unroll
-                for (int cs = 0; cs < CS; ++cs) wr[(tap + 2) % 3][cs] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(src + cs * 16 * 32) + wlb);
+                for (int cs = 0; cs < CS; ++cs) wr[(tap + D) % RING][cs] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(src + cs * 16 * 32) + wlb);
             }
             // the next step's pixel fragments: tap + 1 of this chunk, or tap 0 of the next (the last step of a convolution reads ahead into
             // the slot padding / the spare slot: nobody uses those values)
@@ -112,7 +116,7 @@ __device__ __forceinline__ void chain_kloop(f32x4 (&acc)[CS][PS], bf16x8 (&wr)[3
 #pragma unroll
             for (int ps = 0; ps < PS; ++ps) {
 #pragma unroll
-                for (int cs = 0; cs < CS; ++cs) acc[cs][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[tap % 3][cs], bfr[ps], acc[cs][ps], 0, 0, 0);
+                for (int cs = 0; cs < CS; ++cs) acc[cs][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[tap % RING][cs], bfr[ps], acc[cs][ps], 0, 0, 0);
                 bfr[ps] = *reinterpret_cast<const bf16x8*>(bch + ps * 16 * SB + noff);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -177,15 +181,15 @@ __global__ __launch_bounds__(512) void conv_bf16_chain(const ChainArgs a) {
             for (int ps = 0; ps < PS; ++ps) acc[cs][ps] = bv;
         }
     }
-    // weight fragments of k-step s: element offset (s * C + cs * 16) * 32 from the lane's base
-    bf16x8 wr[3][CS];
+    // weight fragments of k-step s: element offset (s * C + cs * 16) * 32 from the lane's base; the ring starts with steps 0 .. RING - 2
+    constexpr int RING = 3;                                 // (9 for the 256-channel chain, k-steps of 8 MFMAs: 150 us against 145 -- its weight stream is bound by the CU's 64 B/clk vector-memory path, not by latency)
+    bf16x8 wr[RING][CS];
     {
         const unsigned char* w0 = reinterpret_cast<const unsigned char*>(a.w[0]);
 #pragma unroll
-        for (int cs = 0; cs < CS; ++cs) {
-            wr[0][cs] = *reinterpret_cast<const bf16x8*>(w0 + (0 * C + cs * 16) * 64 + wlb);
-            wr[1][cs] = *reinterpret_cast<const bf16x8*>(w0 + (1 * C + cs * 16) * 64 + wlb);
-        }
+        for (int st = 0; st < RING - 1; ++st)
+#pragma unroll
+            for (int cs = 0; cs < CS; ++cs) wr[st][cs] = *reinterpret_cast<const bf16x8*>(w0 + (st * C + cs * 16) * 64 + wlb);
     }
     __syncthreads();                                                          // the plane is staged
 
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(512) void conv_bf16_chain(const ChainArgs a) {
         const u16* wc = reinterpret_cast<const u16*>(a.w[ci]);
         const int cn = ci + 1 < a.nconv ? ci + 1 : ci;                        // the last convolution re-requests itself (nobody waits for it)
         const u16* wn = reinterpret_cast<const u16*>(a.w[cn]);
-        chain_kloop<C, P, SB, CS, PS>(acc, wr, bread, wc, wn, wlb);
+        chain_kloop<C, P, SB, CS, PS, RING>(acc, wr, bread, wc, wn, wlb);
         // ---- in-place epilogue
         const bool first = (ci & 1) == 0;                                     // conv1 of a BasicBlock: the plane still holds the block's input x
         f32x4 bnext[CS];
