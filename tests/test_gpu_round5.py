@@ -112,9 +112,10 @@ def test_bf16_forward_with_chains_equals_forward_without(bmodel, pkg):
         without = bmodel(frames, extras=keys)[-1]
         n_without = bmodel.num_kernel_launches()
     finally:
-        bmodel.set_option(pkg._lib.OPT_BF16_CHAIN, 15)
+        bmodel.set_option(pkg._lib.OPT_BF16_CHAIN, 63)
     torch.cuda.synchronize()
     assert n_without - n_with == 7 * (8 + 7 + 3) + 4 * 8, (n_with, n_without)    # 18 chains of 8 convolutions became 18 launches, 8 chains of the 56x56 branch 4 launches each
+    # (the wide-band and stride-2 band kernels -- bits 4, 5 of the mask -- replace launches one for one: 45 stride-2 layers with up to three shifted addends run here)
     for k in keys + ("theta", "kp_3d", "verts"):
         a, b = with_chain[k].float().cpu().numpy(), without[k].float().cpu().numpy()
         rel = float(np.abs(a - b).max() / np.abs(b).max())
@@ -195,3 +196,29 @@ def test_bf16_pointwise_256_channel_tile(bmodel, oracle, with_add):
     got = bmodel.op_conv2d(torch.from_numpy(x).cuda(), w, b, relu=True, add=torch.from_numpy(add).cuda() if with_add else None).cpu().numpy()
     assert np.array_equal(got, _rb(got))
     assert np.all(np.abs(got - ref) <= np.abs(ref) * 2.0 ** -8 + 1e-5), float(np.abs(got - ref).max())
+
+
+S2 = [(64, 64, 112), (64, 128, 28), (32, 128, 28), (32, 32, 28)]
+
+
+@pytest.mark.parametrize("case", S2, ids=lambda c: "x".join(map(str, c)))
+def test_bf16_stride2_band_kernel(bmodel, oracle, case):
+    """conv_bf16_s2_band (one 3x3 stride-2 convolution; the input band de-interleaved by row and column parity into four LDS sub-planes so that every tap
+    is a constant offset): every shape it is used for, with and without a fused addend and ReLU, against the fp32 oracle on the same bf16-rounded operands
+    up to the one rounding of the bf16 output.  5 frames of 56 / 28 / 14 / 7 output rows: first, middle and last (partial) bands."""
+    cin, cout, h = case
+    g = np.random.Generator(np.random.Philox(key=[91, cin * 1000 + cout + h]))
+    n = 2 if h >= 56 else 5
+    x = _rb(g.standard_normal((n, cin, h, h)))
+    w = _rb(g.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (cin * 9)))
+    b = (g.standard_normal((cout,)) * 0.1).astype(np.float32)
+    add = _rb(g.standard_normal((n, cout, h // 2, h // 2)))
+    lin = oracle.conv2d(x, w, stride=2, bias=b)
+    for relu, with_add in ((True, True), (False, False)):
+        ref = lin + torch.from_numpy(add) if with_add else lin
+        ref = (torch.relu(ref) if relu else ref).numpy()
+        got = bmodel.op_conv2d(torch.from_numpy(x).cuda(), w, b, stride=2, relu=relu, add=torch.from_numpy(add).cuda() if with_add else None, tile_hint=3004).cpu().numpy()
+        assert got.shape == ref.shape and np.array_equal(got, _rb(got))
+        assert np.all(np.abs(got - ref) <= np.abs(ref) * 2.0 ** -8 + 1e-5), float(np.abs(got - ref).max())
+        for sl in (np.s_[:, :, 0], np.s_[:, :, -1], np.s_[:, :, :, 0], np.s_[:, :, :, -1]):
+            assert np.all(np.abs(got[sl] - ref[sl]) <= np.abs(ref[sl]) * 2.0 ** -8 + 1e-5)

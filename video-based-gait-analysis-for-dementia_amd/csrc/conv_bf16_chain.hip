@@ -699,6 +699,196 @@ __global__ __launch_bounds__(512) void conv_bf16_wide_band(const ConvArgs a) {
     }
 }
 
+// ---- ONE 3x3 STRIDE-2 convolution (fuse layers' down paths hrnet.py:213-241, transitions hrnet.py:348-387, the stem's second convolution hrnet.py:470-475) with a
+// band of the input resident in LDS.  conv_bf16_nhwc runs these layers at 0.05-0.16 of the matrix peak and 2-3 x their HBM time: 112-pixel tiles of ~60
+// MFMAs per wave behind a slot table, a DMA wait, an LDS transpose and two barriers, 1 500 ms-scale launches of them per step (1.5 ms of 11).
+// Stride 2 breaks the flattened plane of the stride-1 kernels (tap (dy, dx) of output (Y, X) is input (2Y + dy - 1, 2X + dx - 1): not a constant slot offset)
+// -- unless the input is DE-INTERLEAVED by row and column parity into four sub-planes sub(py, px)[Y'][X'] = in[2Y' + py][2X' + px]: then tap (dy, dx) reads
+// sub(py, px) at (Y + oy, X + ox) with py = (dy != 1), oy = -(dy == 0) and likewise for x, and inside its sub-plane every tap IS a constant offset again.
+// The LDS-DMA does the de-interleaving for free: its source address is per lane.  Each sub-plane is flattened with pitch Wo + 1 (column X' = -1 is the shared
+// zero column, row Y' = y0 - 1 the zero / halo row), R + 1 rows; output column o = (Y - y0)(Wo + 1) + X.  Everything else -- CP input channels per pass,
+// weight ring, MFMA roles, in-place tile through LDS -- is conv_bf16_wide_band's; the epilogue adds the layer's fused addends (nearest-upsampled terms of
+// the fuse sum, hrnet.py:258-265) before the ReLU.
+template <int CP, int CT, int WO, int R>
+struct S2Geom {
+    static constexpr int P = WO + 1, SB = 2 * CP + 32, UPS = SB / 16, OSB = 2 * CT + 32;
+    static constexpr int NOUT = R * P - 1;
+    static constexpr int CS = 2, WCB = CT / 32, WPG = 8 / WCB;
+    static constexpr int PS = ((NOUT + 15) / 16 + WPG - 1) / WPG, NT = WPG * PS;
+    static constexpr int SUBROWS = R + 1;
+    static constexpr int SUB = (SUBROWS * P > NT * 16 + P + 1 ? SUBROWS * P : NT * 16 + P + 1);      // slots per sub-plane: its rows, or what the farthest tap of the last column tile reaches
+    static constexpr int FILL_UNITS = (4 * SUB * UPS + 63) / 64 * 64;
+    static constexpr int NFILL = (FILL_UNITS / 64 + 7) / 8;
+    static constexpr int LDS = (4 * SUB * SB + SB > FILL_UNITS * 16 ? 4 * SUB * SB + SB : FILL_UNITS * 16);
+    static constexpr int UPP = CT / 8, NUO = (R * WO * UPP + 511) / 512;
+    static constexpr int NB = (WO + R - 1) / R;
+    static_assert(((SB / 32) % 2) == 1 && LDS <= 160 * 1024 && PS <= 32 && NT * 16 * OSB <= LDS && CT % 32 == 0 && 8 % (CT / 32) == 0, "stride-2 band geometry");
+    // byte offset of tap (dy, dx) from the lane's base (sub-plane (0,0), row 0, column slot 0)
+    static constexpr int toff(int tap) {
+        const int dy = tap / 3, dx = tap % 3, py = dy != 1, px = dx != 1, oy = dy == 0 ? -1 : 0, ox = dx == 0 ? -1 : 0;
+        return ((py * 2 + px) * SUB + (oy + 1) * P + (ox + 1)) * SB;
+    }
+};
+
+template <typename G, int CS, int PS>
+__device__ __forceinline__ void s2_kloop(f32x4 (&acc)[CS][PS], bf16x8 (&wr)[3][CS], const unsigned char* bread, const u16* wc, size_t wtap, int nch, bool last, unsigned wlb) {
+    constexpr int SB = G::SB;
+    bf16x8 bfr[PS];
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps) bfr[ps] = *reinterpret_cast<const bf16x8*>(bread + ps * 16 * SB + G::toff(0));
+#pragma unroll 1
+    for (int chunk = 0; chunk < nch; ++chunk) {
+        const unsigned char* bch = bread + chunk * 64;
+        const u16* wch = wc + (size_t)chunk * 9 * wtap;
+        const bool lastc = last && chunk == nch - 1;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            {
+                const u16* src = wch + (size_t)(tap + 2) * wtap;
+                if (tap >= 7) src = lastc ? wc + (size_t)(tap - 7) * wtap : src;
+#pragma unroll
+                for (int cs = 0; cs < CS; ++cs) wr[(tap + 2) % 3][cs] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(src + cs * 16 * 32) + wlb);
+            }
+            const int noff = tap < 8 ? G::toff(tap + 1) : G::toff(0) + 64;      // the next chunk's first tap; behind the last chunk it reads ahead into padding / the spare slot
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps) {
+#pragma unroll
+                for (int cs = 0; cs < CS; ++cs) acc[cs][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[tap % 3][cs], bfr[ps], acc[cs][ps], 0, 0, 0);
+                bfr[ps] = *reinterpret_cast<const bf16x8*>(bch + ps * 16 * SB + noff);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+template <int CP, int CT, int WO, int R>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(S2Geom<CP, CT, WO, R>::LDS <= 80 * 1024 ? 4 : 2))) void conv_bf16_s2_band(const ConvArgs a) {
+    typedef S2Geom<CP, CT, WO, R> G;
+    constexpr int P = G::P, SB = G::SB, CS = G::CS, PS = G::PS, UPS = G::UPS, UPP = G::UPP, OSB = G::OSB, WI = 2 * WO;
+    extern __shared__ __align__(16) unsigned char plane[];
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wcb = wave % G::WCB, pg = wave / G::WCB;
+    const int ncb = a.CoutPad / CT;
+    const int cbo = blockIdx.x % ncb, nb = blockIdx.x / ncb, n = nb / G::NB, band = nb - n * G::NB;
+    if (n >= a.N) return;
+    const int y0 = band * R;
+    const u16* inb = reinterpret_cast<const u16*>(a.in) + (size_t)n * WI * WI * a.in_ctot + a.in_coff;
+    const u16* zeros = reinterpret_cast<const u16*>(a.zeros);
+
+    auto fill = [&](int c0, int cw) {                          // input channels c0 .. c0 + cw - 1 of the band, de-interleaved -> the four sub-planes, by LDS-DMA
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                           // (keeps hipcc from hoisting the unit -> pixel map out of the pass loop into registers, as in the wide kernel)
+#pragma unroll
+        for (int i = 0; i < G::NFILL; ++i) {
+            const int ub = (i * 8 + wave) * 64;
+            if (ub >= G::FILL_UNITS) break;                    // wave-uniform
+            const int u = ub + ln, slot = u / UPS, part = u - slot * UPS, sub = slot / G::SUB, ss = slot - sub * G::SUB, rr = ss / P, xx = ss - rr * P;
+            const int py = sub >> 1, px = sub & 1, row = 2 * (y0 - 1 + rr) + py, col = 2 * (xx - 1) + px;
+            const bool data = sub < 4 && rr < G::SUBROWS && !(py == 0 && rr == 0) && row >= 0 && row < WI && col >= 0 && col < WI && part * 8 < cw;
+            dma16_c(data ? inb + (size_t)(row * WI + col) * a.in_ctot + c0 + part * 8 : zeros, plane + ub * 16);
+        }
+    };
+
+    const int o_first = pg * PS * 16 + l15;
+    const unsigned char* bread = plane + o_first * SB + lq * 16;
+    const int co = cbo * CT + wcb * CS * 16;
+    const unsigned wlb = ((co + l15) * 32 + lq * 8) * 2;
+    const size_t wtap = (size_t)a.CoutPad * 32;
+    const u16* wg = reinterpret_cast<const u16*>(a.w);
+    f32x4 acc[CS][PS];
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + co + cs * 16 + lq * 4);
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) acc[cs][ps] = bv;
+    }
+    bf16x8 wr[3][CS];
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs) {
+        wr[0][cs] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(wg + cs * 16 * 32) + wlb);
+        wr[1][cs] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(wg + wtap + cs * 16 * 32) + wlb);
+    }
+    const int npass = (a.CinPad + CP - 1) / CP;
+#pragma unroll 1
+    for (int pass = 0; pass < npass; ++pass) {
+        const int c0 = pass * CP, cw = a.CinPad - c0 < CP ? a.CinPad - c0 : CP;
+        if (pass) __syncthreads();
+        fill(c0, cw);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        s2_kloop<G, CS, PS>(acc, wr, bread, wg + (size_t)(c0 / 32) * 9 * wtap, wtap, cw / 32, pass == npass - 1, wlb);
+    }
+    // ---- epilogue: + fused addends (nearest-upsampled by 2^shift), ReLU, bf16; through LDS as whole channel rows
+    const int Ho = WO;
+    unsigned valid = 0;
+    int pix[PS];                                               // (Y << 8) | X of this lane's column of tile ps
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps) {
+        const int o = o_first + ps * 16, yy = o / P, X = o - yy * P;
+        pix[ps] = ((y0 + yy) << 8) | X;
+        if (X < WO && yy < R && y0 + yy < Ho) valid |= 1u << ps;
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxAdd; ++k) {
+        if (k >= a.n_add) break;
+        const int sh = a.add_shift[k], hs = Ho >> sh, ws = WO >> sh;
+        const u16* ab = reinterpret_cast<const u16*>(a.add[k]) + (size_t)n * hs * ws * a.add_ctot[k] + a.add_coff[k] + co + lq * 4;
+        u32x2 r[PS][CS];
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) {
+            const bool ok = (valid >> ps) & 1u;
+            const int Y = ok ? pix[ps] >> 8 : 0, X = ok ? pix[ps] & 255 : 0;
+            const u16* ap = ab + ((size_t)(Y >> sh) * ws + (X >> sh)) * a.add_ctot[k];
+#pragma unroll
+            for (int cs = 0; cs < CS; ++cs) r[ps][cs] = ok ? *reinterpret_cast<const u32x2*>(ap + cs * 16) : u32x2{0u, 0u};
+        }
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps)
+#pragma unroll
+            for (int cs = 0; cs < CS; ++cs) {
+                acc[cs][ps][0] += bf_lo(r[ps][cs][0]); acc[cs][ps][1] += bf_hi(r[ps][cs][0]);
+                acc[cs][ps][2] += bf_lo(r[ps][cs][1]); acc[cs][ps][3] += bf_hi(r[ps][cs][1]);
+            }
+    }
+    __syncthreads();                                           // every wave has finished reading the sub-planes
+    unsigned char* owrite = plane + o_first * OSB + (wcb * CS * 16 + lq * 4) * 2;
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps)
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs) {
+            f32x4 v = acc[cs][ps];
+            if (a.relu) { v[0] = relu_c(v[0]); v[1] = relu_c(v[1]); v[2] = relu_c(v[2]); v[3] = relu_c(v[3]); }
+            if (valid & (1u << ps)) *reinterpret_cast<u32x2*>(owrite + ps * 16 * OSB + cs * 32) = u32x2{pack2_c(v[0], v[1]), pack2_c(v[2], v[3])};
+        }
+    __syncthreads();
+    u16* outb = reinterpret_cast<u16*>(a.out) + (size_t)n * Ho * WO * a.out_ctot + a.out_coff + cbo * CT;
+    const int cstore = a.Cout - cbo * CT;
+#pragma unroll
+    for (int i = 0; i < G::NUO; ++i) {
+        const int u = i * 512 + tid, px = u / UPP, part = u - px * UPP, yy = px / WO, X = px - yy * WO;
+        if (u < R * WO * UPP && y0 + yy < Ho && part * 8 < cstore)
+            *reinterpret_cast<u32x4*>(outb + ((size_t)(y0 + yy) * WO + X) * a.out_ctot + part * 8) = *reinterpret_cast<const u32x4*>(plane + (yy * P + X) * OSB + part * 16);
+    }
+}
+
+template <int CP, int CT, int WO, int R>
+hipError_t set_s2_lds() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_s2_band<CP, CT, WO, R>), hipFuncAttributeMaxDynamicSharedMemorySize, S2Geom<CP, CT, WO, R>::LDS);
+}
+template <int CP, int CT, int WO, int R>
+hipError_t launch_s2(const ConvArgs& a, hipStream_t s) {
+    typedef S2Geom<CP, CT, WO, R> G;
+    return launch_k(conv_bf16_s2_band<CP, CT, WO, R>, dim3(a.N * G::NB * (a.CoutPad / CT)), dim3(512), G::LDS, s, a);
+}
+// (CP, CT, Wo, R) per layer shape: the band is as tall as the four sub-planes' LDS allows
+// Measured at 256 frames against conv_bf16_nhwc (profiles/r05_s2_band_vs_generic.txt): the band kernel wins where a workgroup's MFMA share is large enough to
+// carry its fill -> barrier -> store round trip -- 64 -> 128 @28->14 (20.6 / 23.1 us against 30.2 / 35.1), 32 -> 128 @28->14 (10.5 / 17.3), 32 -> 32 @28->14
+// (7.8 / 9.8), the stem's 64 -> 64 @112->56 (216 / 237) -- ties on the 14->7 layers and loses on 256 -> 64 (four passes, each with an exposed fill:
+// 174 / 144), 32 -> 32 and 32 -> 64 @56->28 (7-row bands 26.7 / 40.7 against 27.6 / 34.4; 3-row bands with two workgroups per CU 35.0 / 47.5),
+// 64 -> 64 @28->14 (17.7 / 12.9), 128 -> 256 @14->7 (30.1 / 24.0): those stay on the generic kernel and are not instantiated.
+#define GRK_S2_SHAPES(X) X(64, 64, 56, 3) X(64, 128, 14, 14) X(32, 128, 14, 14) X(32, 32, 14, 14)
+
 template <int C, int W>
 hipError_t set_chain_lds() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_chain<C, W>), hipFuncAttributeMaxDynamicSharedMemorySize, ChainGeom<C, W>::LDS);
@@ -711,6 +901,9 @@ hipError_t conv_bf16_chain_init() {
     GRK_TRY((set_chain_lds<128, 14>()));
     GRK_TRY((set_chain_lds<256, 7>()));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_block_band<32, 56, 19, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, BandGeom<32, 56, 19>::LDS));
+#define GRK_S2_SET(cp, ct, wo, r) GRK_TRY((set_s2_lds<cp, ct, wo, r>()));
+    GRK_S2_SHAPES(GRK_S2_SET)
+#undef GRK_S2_SET
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_band<128, 128, 56, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, WideGeom<128, 128, 56, 7>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_band<128, 128, 28, 14>), hipFuncAttributeMaxDynamicSharedMemorySize, WideGeom<128, 128, 28, 14>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_band<64, 64, 56, 14>), hipFuncAttributeMaxDynamicSharedMemorySize, WideGeom<64, 64, 56, 14>::LDS));
@@ -766,6 +959,30 @@ hipError_t launch_conv_bf16_wide(const ConvArgs& a, hipStream_t s) {
     const int ncb = a.CoutPad / 128;
     if (a.W == 56) return launch_k(conv_bf16_wide_band<128, 128, 56, 7>, dim3(a.N * WideGeom<128, 128, 56, 7>::NB * ncb), dim3(512), WideGeom<128, 128, 56, 7>::LDS, s, a);
     return launch_k(conv_bf16_wide_band<128, 128, 28, 14>, dim3(a.N * WideGeom<128, 128, 28, 14>::NB * ncb), dim3(512), WideGeom<128, 128, 28, 14>::LDS, s, a);
+}
+
+// Stride-2 band kernel: 3x3, stride 2, even input size, <= 3 fused addends; (input channels per pass, output-channel tile) by the layer's channel counts.
+static int s2_cp(const ConvArgs& a) { return a.CinPad >= 64 ? 64 : 32; }
+static int s2_ct(const ConvArgs& a) { return a.CoutPad >= 128 ? 128 : a.CoutPad; }
+bool conv_bf16_s2_eligible(const ConvArgs& a) {
+    if (a.ks != 3 || a.stride != 2 || a.H != a.W || a.Ho != a.Wo || a.H != 2 * a.Ho || a.CinPad % 32 != 0 || a.n_add > kMaxAdd || a.relu_from != 0) return false;
+    if (a.in_ctot % 8 != 0 || a.in_coff % 8 != 0 || a.out_ctot % 8 != 0 || a.out_coff % 8 != 0 || a.Cout % 32 != 0 || a.CoutPad != a.Cout) return false;
+    for (int k = 0; k < a.n_add; ++k)
+        if (a.add_ctot[k] % 4 != 0 || a.add_coff[k] % 4 != 0) return false;
+    const int cp = s2_cp(a), ct = s2_ct(a);
+    if (a.CinPad != cp) return false;                          // one pass (layers with more input channels lose to the generic kernel: see GRK_S2_SHAPES)
+#define GRK_S2_HAS(cp_, ct_, wo_, r_) if (cp == cp_ && ct == ct_ && a.Wo == wo_) return true;
+    GRK_S2_SHAPES(GRK_S2_HAS)
+#undef GRK_S2_HAS
+    return false;
+}
+hipError_t launch_conv_bf16_s2(const ConvArgs& a, hipStream_t s) {
+    if (!conv_bf16_s2_eligible(a) || a.N < 1) return hipErrorInvalidValue;
+    const int cp = s2_cp(a), ct = s2_ct(a);
+#define GRK_S2_GO(cp_, ct_, wo_, r_) if (cp == cp_ && ct == ct_ && a.Wo == wo_) return launch_s2<cp_, ct_, wo_, r_>(a, s);
+    GRK_S2_SHAPES(GRK_S2_GO)
+#undef GRK_S2_GO
+    return hipErrorInvalidValue;
 }
 
 }  // namespace grk

@@ -1382,7 +1382,7 @@ struct grnet {
 
     // Which kernel runs convolution L in a call of n frames: ONE place, used by the launcher, by the executed-FLOP report and by the
     // per-kernel table of bench.py (round-3 review: the report read a hidden "latest n" and ignored the environment masks).
-    enum ConvKernel { K_BF16, K_BF16_STEM, K_BF16_CHAIN, K_BF16_CHAIN_MEMBER, K_BF16_WIDE, K_WINO4S, K_PW, K_STEM, K_WINO4, K_DIRECT };
+    enum ConvKernel { K_BF16, K_BF16_STEM, K_BF16_CHAIN, K_BF16_CHAIN_MEMBER, K_BF16_WIDE, K_BF16_S2, K_WINO4S, K_PW, K_STEM, K_WINO4, K_DIRECT };
     // bf16: does chain `c` run as ONE conv_bf16_chain launch in a call of n frames?  A chain workgroup is one frame on one CU: from about a
     // quarter of the chip's CUs on it beats eight launches (GRNET_BF16_CHAIN: bit 0 64 ch @28x28, bit 1 128 ch @14x14, bit 2 256 ch @7x7, bit 3 32 ch @56x56 --
     // there a launch per BasicBlock with 19-row bands resident;
@@ -1392,19 +1392,26 @@ struct grnet {
         return dtype == 1 && !conv_tile_hint && n >= chain_min && (chain_mode & (c.w == 28 ? 1 : c.w == 14 ? 2 : c.w == 7 ? 4 : 8));
     }
     // bf16: the wide 3x3 stride-1 layers (upsample heads, PARE head, layer1's 3x3) on conv_bf16_wide_band.  A workgroup is a band of 7 / 14 rows of one
-    // frame x 128 (64) output channels: from 32 frames per call on a launch has at least one workgroup per CU (GRNET_BF16_WIDE=0: the generic kernel;
+    // frame x 128 (64) output channels: from 32 frames per call on a launch has at least one workgroup per CU (bit 4 of the GRNET_OPT_BF16_CHAIN mask;
     // GRNET_BF16_WIDE_MIN: smallest call).  A forced tile switches it off like every special kernel.
     bool wide_runs(const ConvLayer& L, int n) const {
-        static const int wide_env = getenv("GRNET_BF16_WIDE") ? atoi(getenv("GRNET_BF16_WIDE")) : 1;
         static const int wide_min = getenv("GRNET_BF16_WIDE_MIN") ? atoi(getenv("GRNET_BF16_WIDE_MIN")) : 32;
-        if (dtype != 1 || !wide_env || conv_tile_hint || n < wide_min || L.stem_dev || !L.w_dev) return false;
+        if (dtype != 1 || !(chain_mode & 16) || conv_tile_hint || n < wide_min || L.stem_dev || !L.w_dev) return false;
         return conv_bf16_wide_eligible(conv_args(L, nullptr, n));
     }
-    int chain_mode = getenv("GRNET_BF16_CHAIN") ? atoi(getenv("GRNET_BF16_CHAIN")) : 15;      // GRNET_OPT_BF16_CHAIN
+    // bf16: the 3x3 stride-2 layers (fuse-layer down paths, transitions, the stem's second convolution) on conv_bf16_s2_band, from 64 frames per call on
+    // (a workgroup is a band of one frame; GRNET_BF16_S2_MIN).  Bit 5 of the GRNET_OPT_BF16_CHAIN mask.
+    bool s2_runs(const ConvLayer& L, int n) const {
+        static const int s2_min = getenv("GRNET_BF16_S2_MIN") ? atoi(getenv("GRNET_BF16_S2_MIN")) : 64;
+        if (dtype != 1 || !(chain_mode & 32) || conv_tile_hint || n < s2_min || L.stem_dev || !L.w_dev || L.in2.c) return false;
+        return conv_bf16_s2_eligible(conv_args(L, nullptr, n));
+    }
+    int chain_mode = getenv("GRNET_BF16_CHAIN") ? atoi(getenv("GRNET_BF16_CHAIN")) : 63;      // bits 0-3: BasicBlock chains by branch, bit 4: wide-band kernel, bit 5: stride-2 band kernel      // GRNET_OPT_BF16_CHAIN
     ConvKernel kernel_for(const ConvLayer& L, int n) const {
         static const int w4s_env = getenv("GRNET_WINO4S") ? atoi(getenv("GRNET_WINO4S")) : 7;      // bit 0: 128 @14x14, bit 1: 256 @7x7, bit 2: 256 @14x14
         if (dtype == 1 && L.chain >= 0 && chain_active(chains[L.chain], n)) return L.chain_pos == 0 ? K_BF16_CHAIN : K_BF16_CHAIN_MEMBER;
         if (dtype == 1 && wide_runs(L, n)) return K_BF16_WIDE;
+        if (dtype == 1 && s2_runs(L, n)) return K_BF16_S2;
         if (dtype == 1) return L.stem_dev ? K_BF16_STEM : K_BF16;      // (a plan built for conv_bf16_stem has no NHWC copy of the frames for the generic kernel)
         if (conv_tile_hint) return K_DIRECT;                   // a forced tile also switches every special kernel off (tests / tuning)
         if (wino4s_runs(L, n) && (w4s_env & (L.in.w == 7 ? 2 : L.in.c == 128 ? 1 : 4))) return K_WINO4S;
@@ -1427,7 +1434,8 @@ struct grnet {
         switch (kernel_for(L, n)) {
             case K_BF16: return "conv_bf16";
             case K_BF16_STEM: return "conv_bf16_stem";
-            case K_BF16_WIDE: snprintf(b, sizeof b, "conv_bf16_wide<%d,%d,%d>", L.in.c >= 128 ? 128 : 64, L.cout_pad == 32 ? 32 : L.in.c >= 128 ? 128 : 64, L.in.w); return b;
+            case K_BF16_WIDE: snprintf(b, sizeof b, "conv_bf16_wide<%d,%d>", L.in.c >= 128 ? 128 : 64, L.in.w); return b;
+            case K_BF16_S2: snprintf(b, sizeof b, "conv_bf16_s2<%d>", L.out.w); return b;
             case K_BF16_CHAIN: snprintf(b, sizeof b, "conv_bf16_chain<%d,%d>", L.in.c, L.in.w); return b;
             case K_BF16_CHAIN_MEMBER: snprintf(b, sizeof b, "conv_bf16_chain<%d,%d>+", L.in.c, L.in.w); return b;      // runs inside the chain's launch: no launch, no time of its own
             case K_WINO4S: snprintf(b, sizeof b, "conv_wino4s_f32<%d,%d>", L.in.w, L.in.c); return b;
@@ -1466,6 +1474,7 @@ struct grnet {
             }
             case K_BF16_CHAIN_MEMBER: *n_launches = 0; break;       // its work is in the launch of the chain's first member
             case K_BF16_WIDE: HIP_TRY(launch_conv_bf16_wide(conv_args(L, frames, n), s)); break;
+            case K_BF16_S2: HIP_TRY(launch_conv_bf16_s2(conv_args(L, frames, n), s)); break;
             case K_WINO4S: {
                 ConvArgs wa = conv_args(L, frames, n);
                 wa.w = L.wino4s_dev;
@@ -1725,19 +1734,20 @@ struct grnet {
         if (add_dev) { a.n_add = 1; a.add[0] = static_cast<const float*>(xadd); a.add_ctot[0] = cout8; a.add_coff[0] = 0; a.add_shift[0] = 0; }
         a.zeros = zeros;
         if (const char* d = getenv("GRNET_CONV_DBG")) a.dbg = atoi(d);
-        const bool wide = tile_hint == 3003;                    // conv_bf16_wide_band on this one convolution
-        if (wide && !conv_bf16_wide_eligible(a)) {
+        const bool wide = tile_hint == 3003, s2 = tile_hint == 3004;      // conv_bf16_wide_band / conv_bf16_s2_band on this one convolution
+        if ((wide && !conv_bf16_wide_eligible(a)) || (s2 && !conv_bf16_s2_eligible(a))) {
             hipFree(wd); hipFree(bd); hipFree(xin); hipFree(xout);
             if (xadd) hipFree(xadd);
-            return fail(GRNET_EINVAL, "shape not eligible for the wide-band kernel");
+            return fail(GRNET_EINVAL, "shape not eligible for the band kernel");
         }
-        if (e == hipSuccess) e = wide ? launch_conv_bf16_wide(a, s) : launch_conv_bf16(a, s, tile_hint);
+        auto launch_one = [&]() { return wide ? launch_conv_bf16_wide(a, s) : s2 ? launch_conv_bf16_s2(a, s) : launch_conv_bf16(a, s, tile_hint); };
+        if (e == hipSuccess) e = launch_one();
         if (const char* r = getenv("GRNET_CONV_REPS")) {       // timing loop for tools/bf16_micro.py
             const int reps = atoi(r);
             hipEvent_t e0, e1;
             hipEventCreate(&e0); hipEventCreate(&e1);
             hipEventRecord(e0, s);
-            for (int i = 0; i < reps && e == hipSuccess; ++i) e = wide ? launch_conv_bf16_wide(a, s) : launch_conv_bf16(a, s, tile_hint);
+            for (int i = 0; i < reps && e == hipSuccess; ++i) e = launch_one();
             hipEventRecord(e1, s);
             hipEventSynchronize(e1);
             float ms = 0;
@@ -2187,7 +2197,7 @@ int grnet_set_option(grnet_t* h, int option, int value) {
         return 0;
     }
     if (option == GRNET_OPT_WINOGRAD) { h->wino_mode = value != 0; h->drop_graphs(); return 0; }
-    if (option == GRNET_OPT_BF16_CHAIN) { h->chain_mode = value & 15; h->drop_graphs(); return 0; }
+    if (option == GRNET_OPT_BF16_CHAIN) { h->chain_mode = value & 63; h->drop_graphs(); return 0; }
     if (option == GRNET_OPT_MULTI_LANE) {
         h->multi_lane = value != 0;
         h->drop_graphs();

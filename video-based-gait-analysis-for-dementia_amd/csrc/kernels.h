@@ -286,6 +286,9 @@ hipError_t launch_conv_bf16_chain(const ChainArgs& a, int c, int w, hipStream_t 
 // one wide 3x3 stride-1 convolution with a band of the input resident in LDS (conv_bf16_chain.hip: conv_bf16_wide_band); pointers as launch_conv_bf16
 bool conv_bf16_wide_eligible(const ConvArgs& a);
 hipError_t launch_conv_bf16_wide(const ConvArgs& a, hipStream_t s);
+// one 3x3 stride-2 convolution with a band of the input resident in LDS, de-interleaved by row / column parity (conv_bf16_chain.hip: conv_bf16_s2_band)
+bool conv_bf16_s2_eligible(const ConvArgs& a);
+hipError_t launch_conv_bf16_s2(const ConvArgs& a, hipStream_t s);
 hipError_t launch_nchw_f32_to_nhwc_bf16(const float* in, void* out, int N, int C, int H, int W, int Cp, hipStream_t s);
 // the stem's 3 -> 64 stride-2 convolution straight from the caller's fp32 NCHW frames (N,3,224,224) to NHWC bf16 (N,112,112,out_ctot)
 hipError_t launch_conv_bf16_stem(const float* frames, const void* wpk, const float* bias, void* out, int out_ctot, int out_coff, int N, int relu, hipStream_t s);
