@@ -110,13 +110,14 @@ int grnet_tsattn_forward(grnet_t* h, const float* x_dev, const float* xs_dev, in
                                    * convolution is the direct implicit GEMM.  grnet_op_conv2d tile hints 2001 / 2020 (+ K split) run the two kernels on
                                    * one convolution.  (Options 4, 5, 6 -- grouped launches, the persistent dataflow launch and its fence -- were removed
                                    * in round 3 after losing every measurement; their sources are in the history: commit 8d3a931.) */
-#define GRNET_OPT_BF16_CHAIN 8    /* bf16 handles, a mask of the band- / frame-resident kernels of csrc/conv_bf16_chain.hip (default 63; environment GRNET_BF16_CHAIN; 0: one
+#define GRNET_OPT_BF16_CHAIN 8    /* bf16 handles, a mask of the band- / frame-resident kernels of csrc/conv_bf16_chain.hip (default 127; environment GRNET_BF16_CHAIN; 0: one
                                    * launch of the generic kernel per convolution at every call size).  Bits 0-3: the four BasicBlocks (8 convolutions,
                                    * lib/models/hrnet.py:141-187) of an HR branch as ONE launch with the frame resident in LDS, in calls of >= 64 frames -- bit 0:
                                    * 64 ch @28x28, bit 1: 128 ch @14x14, bit 2: 256 ch @7x7, bit 3: 32 ch @56x56 (one launch per BasicBlock there, 8-row bands
                                    * streamed through LDS).  Bit 4: the wide 3x3 stride-1 layers (upsample heads, PARE head, layer1's 3x3) with a band of the
                                    * input resident, >= 32 frames.  Bit 5: the 3x3 stride-2 layers (fuse layers' down paths, transitions, the stem's second
-                                   * convolution) with the band de-interleaved by row / column parity, >= 64 frames. */
+                                   * convolution) with the band de-interleaved by row / column parity, >= 64 frames.  Bit 6: layer1's 64 -> 256 expansions
+                                   * (hrnet.py:80-100) also run the NEXT Bottleneck's 256 -> 64 reduction from the tile they hold in LDS, >= 19 frames. */
 int grnet_set_option(grnet_t* h, int option, int value);
 
 /* Optional, once per distinct n_frames after grnet_finalize_weights: times every launch configuration of every

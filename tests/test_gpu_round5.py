@@ -112,9 +112,9 @@ def test_bf16_forward_with_chains_equals_forward_without(bmodel, pkg):
         without = bmodel(frames, extras=keys)[-1]
         n_without = bmodel.num_kernel_launches()
     finally:
-        bmodel.set_option(pkg._lib.OPT_BF16_CHAIN, 63)
+        bmodel.set_option(pkg._lib.OPT_BF16_CHAIN, 127)
     torch.cuda.synchronize()
-    assert n_without - n_with == 7 * (8 + 7 + 3) + 4 * 8, (n_with, n_without)    # 18 chains of 8 convolutions became 18 launches, 8 chains of the 56x56 branch 4 launches each
+    assert n_without - n_with == 7 * (8 + 7 + 3) + 4 * 8 + 3, (n_with, n_without)    # + 3 layer1 reductions run inside their expansions' launches; 18 chains of 8 convolutions became 18 launches, 8 chains of the 56x56 branch 4 launches each
     # (the wide-band and stride-2 band kernels -- bits 4, 5 of the mask -- replace launches one for one: 45 stride-2 layers with up to three shifted addends run here)
     for k in keys + ("theta", "kp_3d", "verts"):
         a, b = with_chain[k].float().cpu().numpy(), without[k].float().cpu().numpy()
@@ -222,3 +222,22 @@ def test_bf16_stride2_band_kernel(bmodel, oracle, case):
         assert np.all(np.abs(got - ref) <= np.abs(ref) * 2.0 ** -8 + 1e-5), float(np.abs(got - ref).max())
         for sl in (np.s_[:, :, 0], np.s_[:, :, -1], np.s_[:, :, :, 0], np.s_[:, :, :, -1]):
             assert np.all(np.abs(got[sl] - ref[sl]) <= np.abs(ref[sl]) * 2.0 ** -8 + 1e-5)
+
+
+def test_bf16_layer1_pairs_are_bit_identical(bmodel, pkg):
+    """layer1's 64 -> 256 expansion + the next Bottleneck's 256 -> 64 reduction as one launch (bit 6 of the mask): the reduction reads the very bf16 tile
+    the stand-alone launch would read from HBM, in the same k order -- the whole forward must not change by a bit (compared with the 256-channel tile
+    of the expansion forced either way, so that the only difference is where the reduction runs)."""
+    frames = torch.from_numpy(np.tile(pkg.synth.make_frames(8), (8, 1, 1, 1))).cuda()
+    a = bmodel(frames, extras=("features",))[-1]
+    n_a = bmodel.num_kernel_launches()
+    bmodel.set_option(pkg._lib.OPT_BF16_CHAIN, 127 - 64)
+    try:
+        b = bmodel(frames, extras=("features",))[-1]
+        n_b = bmodel.num_kernel_launches()
+    finally:
+        bmodel.set_option(pkg._lib.OPT_BF16_CHAIN, 127)
+    torch.cuda.synchronize()
+    assert n_b - n_a == 3
+    for k in ("features", "theta", "verts"):
+        assert torch.equal(a[k], b[k]), k

@@ -349,6 +349,40 @@ void conv_bf16_nhwc(const ConvArgs a) {
 #endif
         *reinterpret_cast<u32x4*>(out + ((size_t)img * HoWo + pix) * a.out_ctot + a.out_coff + co0 + part * 8) = v;
     }
+    // ---- second stage of a 1x1 PAIR (round 5; layer1, hrnet.py:80-100): the workgroup holds all 256 output channels of its 112 pixels in LDS, bf16, exactly
+    // as the next Bottleneck's 256 -> 64 reduction would read them from HBM -- so it runs that reduction now: 16 output channels per wave, K = 256 in 8
+    // k-steps, B = the tile (one ds_read_b128 per pixel tile and step), A = the reduction's weights from L2.  The 411 MB tensor (256 frames) is still
+    // written (it is the next block's residual) but is not read back for the reduction.  Same k order and operands as the stand-alone launch: bit-identical.
+    if constexpr (KS == 1 && TCS == 16 && WP == 1 && WC == 4) {
+        if (a.w2) {
+            const u16* w2 = reinterpret_cast<const u16*>(a.w2);
+            f32x4 acc2[PSW];
+            const f32x4 b2 = *reinterpret_cast<const f32x4*>(a.bias2 + wave * 16 + lq * 4);
+#pragma unroll
+            for (int ps = 0; ps < PSW; ++ps) acc2[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bf16x8 af2[TC / 32];
+#pragma unroll
+            for (int ch = 0; ch < TC / 32; ++ch) af2[ch] = *reinterpret_cast<const bf16x8*>(w2 + ((size_t)ch * 64 + wave * 16 + l15) * 32 + lq * 8);
+#pragma unroll
+            for (int ch = 0; ch < TC / 32; ++ch)
+#pragma unroll
+                for (int ps = 0; ps < PSW; ++ps) {
+                    const bf16x8 bt = *reinterpret_cast<const bf16x8*>(o_lds + (ps * 16 + l15) * TCP + ch * 32 + lq * 8);
+                    acc2[ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af2[ch], bt, acc2[ps], 0, 0, 0);
+                }
+            u16* out2 = reinterpret_cast<u16*>(a.out2);
+#pragma unroll
+            for (int ps = 0; ps < PSW; ++ps) {
+                if (pix_[ps] < 0) continue;
+                f32x4 v = acc2[ps] + b2;
+                if (a.relu2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                *reinterpret_cast<u32x2*>(out2 + ((size_t)img_[ps] * HoWo + pix_[ps]) * a.out2_ctot + a.out2_coff + wave * 16 + lq * 4) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+            }
+        }
+    }
 #ifdef GRNET_ABLATION
     if (a.dbg & 8) {                                       // phase accounting on request only: 5 atomics per workgroup on one line distort the timing
         GRK_TICK(t_end);
@@ -870,7 +904,8 @@ hipError_t launch_conv_bf16(ConvArgs a, hipStream_t s, int tile_hint) {
     // 224-pixel tiles for the 56-wide maps, 112 otherwise (measured: 224 everywhere ties at 256 frames and loses 13 % at 16; 112 everywhere loses 28 %)
     int tps = (tile_hint == 7 || tile_hint == 14) ? tile_hint : (a.Wo >= 56 ? 14 : 7);
     static const int pw256_env = getenv("GRNET_BF16_PW256") ? atoi(getenv("GRNET_BF16_PW256")) : 0;      // measured: 263 vs 237 us for 64 -> 256 with its residual at 256 frames -- off
-    if (pw256_env && tile_hint == 0 && a.ks == 1 && a.CoutPad == 256 && a.Wo == 56 && (long)a.N * a.Ho * a.Wo >= 256L * 112 * 2) { tc = 256; tps = 7; }
+    if ((pw256_env || a.w2) && tile_hint == 0 && a.ks == 1 && a.CoutPad == 256 && a.Wo == 56 && (long)a.N * a.Ho * a.Wo >= 256L * 112 * 2) { tc = 256; tps = 7; }
+    if (a.w2 && tc != 256) return hipErrorInvalidValue;    // a pair needs the 256-channel tile
     if (!plan_bf16(a, tps, tc)) {
         tps = tps == 14 ? 7 : 14;
         if (!plan_bf16(a, tps, tc)) return hipErrorInvalidValue;

@@ -127,6 +127,9 @@ struct ConvArgs {
     int n_add;
     const float* add[kMaxAdd]; int add_ctot[kMaxAdd], add_coff[kMaxAdd], add_shift[kMaxAdd];
     const float* zeros;        // >= 64 B of zeros in HBM: source for halo / padded-channel loads
+    const float* w2; const float* bias2; float* out2; int out2_ctot, out2_coff, relu2;      // bf16 1x1 pair (layer1: Bottleneck k's 64 -> 256 expansion, then Bottleneck k+1's
+                                                             // 256 -> 64 reduction from the tile the workgroup still holds in LDS): w2 packed [8][1][64][32], bias2 [64];
+                                                             // out2: the reduction's NHWC bf16 view.  w2 == nullptr: none
     const float* in2; int in2_ctot, in2_coff, cin_split;     // bf16 1x1 only: input channels >= cin_split (a multiple of 32) come from a SECOND tensor of the same
                                                              // spatial size (a Bottleneck's last 1x1 and its 1x1 downsample as ONE GEMM over [t ; x]); in2 == nullptr: one input
     // filled by the launcher
