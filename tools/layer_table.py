@@ -109,22 +109,24 @@ def main(rnd, dtype="f32"):
     fetch = per_position(conv_dispatches(os.path.join(src, "pmc", "FETCH_SIZE_counter_collection.csv"), lambda r: float(r["Counter_Value"]) * 1024.0), convs)
     write = per_position(conv_dispatches(os.path.join(src, "pmc", "WRITE_SIZE_counter_collection.csv"), lambda r: float(r["Counter_Value"]) * 1024.0), convs)
     rows, by_stage, by_kernel, by_family = [], collections.OrderedDict(), collections.OrderedDict(), collections.OrderedDict()
-    chain_keys = None
+    open_launch = {}                                         # kernel family -> (row index, table keys) of its latest launch that carries fused layers
     for c, (k, us, nd), (_, fb, _), (_, wb, _) in zip(convs, dur, fetch, write):
         flop = 2.0 * N * c["macs"]
         alg_r, alg_w = accounting.conv_algorithmic_bytes(c, N, esz)      # the ONE definition (bench.py uses the same)
         ex = executed_ratio(k, c)
-        if nd == 0:                                          # runs inside the chain launch of the row above: its FLOPs and per-layer bytes count there
-            r = rows[-1]
+        if nd == 0:                                          # runs inside a chain / pair launch (family name + "+"): its FLOPs and per-layer bytes count THERE.  The
+            ri, keys = open_launch[c["kernel_family"].rstrip("+")]          # plan interleaves the branches of a module, so the launch is found by family, not by position
+            r = rows[ri]
             r["gflop"] += flop / 1e9; r["alg_mb"] += (alg_r + alg_w) / 1e6; r["fused_layers"] += 1
             r["tflops"] = r["exec_tflops"] = r["gflop"] / r["us"] * 1e3
-            for key, table in chain_keys:
+            for key, table in keys:
                 t = table[key]
                 t["gflop"] += flop / 1e9; t["ex"] += flop * ex / 1e9; t["alg"] += (alg_r + alg_w) / 1e6
             continue
         rows.append(dict(name=c["name"], kernel=k, dispatches=nd, fused_layers=1, shape=f'{c["cin"]}->{c["cout"]} k{c["ks"]} s{c["stride"]} @{c["hin"]}', us=us, gflop=flop / 1e9,
                          tflops=flop / us / 1e6, exec_tflops=flop * ex / us / 1e6, alg_mb=(alg_r + alg_w) / 1e6, counter_mb=(2 * fb + wb) / 1e6))
         chain_keys = ((stage_of(c["name"]), by_stage), (re.sub(r"<.*", "", k) + " " + rows[-1]["shape"], by_kernel), (c.get("kernel_family", k), by_family))
+        open_launch[c.get("kernel_family", k)] = (len(rows) - 1, chain_keys)
         for key, table in chain_keys:
             t = table.setdefault(key, dict(n=0, us=0.0, gflop=0.0, ex=0.0, alg=0.0, cnt=0.0))
             t["n"] += 1; t["us"] += us; t["gflop"] += flop / 1e9; t["ex"] += flop * ex / 1e9; t["alg"] += (alg_r + alg_w) / 1e6; t["cnt"] += (2 * fb + wb) / 1e6
