@@ -241,3 +241,58 @@ def test_bf16_layer1_pairs_are_bit_identical(bmodel, pkg):
     assert n_b - n_a == 3
     for k in ("features", "theta", "verts"):
         assert torch.equal(a[k], b[k]), k
+
+
+# ----------------------------------------------------------------------------- the grouped fuse launch on the bf16 path (csrc/hr_fuse.hip: hr_fuse_up_bf16)
+FUSE_MODULES = [("stage2", 0, 2)] + [("stage3", m, 3) for m in range(4)] + [("stage4", m, 4) for m in range(3)]
+
+
+@pytest.fixture(scope="module", params=[2, 1], ids=["output0", "grouped"])
+def fmodel(request, pkg):
+    """GRNET_BF16_FUSE_UP is read when a handle builds its plan: 0 (default) = the round-3 layout (one 1x1 launch per up term); 2 = output 0 of every fuse layer by hr_fuse_up_bf16, the others by their
+    finishing stride-2 convolution; 1 = the fp32 path's layout (outputs 0 .. nb-2 by ONE grouped launch, chains D_ij stored)."""
+    import os
+    old = os.environ.get("GRNET_BF16_FUSE_UP")
+    os.environ["GRNET_BF16_FUSE_UP"] = str(request.param)
+    try:
+        m = pkg.build_synthetic_model(max_frames=16, with_gru=False, dtype="bf16")
+    finally:
+        if old is None:
+            os.environ.pop("GRNET_BF16_FUSE_UP")
+        else:
+            os.environ["GRNET_BF16_FUSE_UP"] = old
+    m.fuse_mode = request.param
+    yield m
+    m.close()
+
+
+@pytest.mark.parametrize("n", [1, 3, 16])
+def test_bf16_fuse_layer_of_every_hr_module_matches_oracle(fmodel, pkg, oracle, synth_weights, n):
+    """As tests/test_gpu_round4.py does for fp32: the module's branch outputs x_b and outputs y_i are read back from the bf16 forward, the fp32 oracle's
+    fuse layer (hrnet.py:189-244, 258-265) runs on those x_b, and every y_i must agree to bf16 accuracy: weights and the stored 1x1 terms / chain
+    links are rounded to bf16 (2^-9 relative each), so max |diff| <= 1.5e-2 of the tensor's scale and the mean error <= 2e-3 of its rms; outputs >= 0."""
+    frames = pkg.synth.make_frames(n)
+    fmodel(torch.from_numpy(frames).cuda().unsqueeze(0))
+    torch.cuda.synchronize()
+    for stage, m, nb in FUSE_MODULES:
+        tag = f"{stage}.{m}."
+        xs = [fmodel.debug_tensor(tag + f"x{b}", n).cpu() for b in range(nb)]
+        ref = oracle.hr_fuse(xs, synth_weights, f"backbone.{tag}")
+        for i in range(nb):
+            got = fmodel.debug_tensor(tag + f"y{i}", n).cpu().numpy()
+            r = ref[i].numpy()
+            assert got.shape == r.shape and got.min() >= 0.0
+            err = np.abs(got - r)
+            assert err.max() <= 1.5e-2 * np.abs(r).max(), (tag, i, float(err.max() / np.abs(r).max()))
+            assert err.mean() <= 2e-3 * np.sqrt(np.mean(r * r)), (tag, i, float(err.mean() / np.sqrt(np.mean(r * r))))
+
+
+def test_bf16_fuse_layer_launch_count_and_macs(fmodel):
+    """8 fuse-up launches; in the grouped layout they replace all 31 1x1 launches, in the output-0 one the 18 that feed output 0 (and the 8 elementwise
+    sums either way); the MACs still add up to SURVEY 8(d)'s 15 441 563 648 per frame."""
+    convs = fmodel.describe_convs()
+    assert len([c for c in convs if c["cin"] == 0]) == 8
+    assert sum(c["macs"] for c in convs) == 15441563648
+    left = [c for c in convs if c["ks"] == 1 and "fuse_layers" in c["name"] and c["cin"]]
+    assert len(left) == (0 if fmodel.fuse_mode == 1 else 13)
+    assert not any("fuse_layers.0." in c["name"] for c in left)

@@ -620,7 +620,11 @@ __global__ __launch_bounds__(512) void conv_bf16_wide_band(const ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wcb = wave % G::WCB, pg = wave / G::WCB;
     const int ncb = a.CoutPad / CT;                            // output-channel tiles of the layer
-    const int cbo = blockIdx.x % ncb, nb = blockIdx.x / ncb, n = nb / G::NB, band = nb - n * G::NB;
+    // workgroups go to the 8 XCDs round-robin by blockIdx: with a.xcd the ids are re-dealt so that CONSECUTIVE tiles -- the ncb output-channel tiles of a band,
+    // then the frame's next band (which shares two halo rows) -- run on ONE XCD at about the same time and meet in its L2
+    int bid = blockIdx.x;
+    if (a.xcd && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int cbo = bid % ncb, nb = bid / ncb, n = nb / G::NB, band = nb - n * G::NB;
     if (n >= a.N) return;
     const int y0 = band * R;
     const u16* inb = reinterpret_cast<const u16*>(a.in) + (size_t)n * W * W * a.in_ctot + a.in_coff;
@@ -673,9 +677,15 @@ __global__ __launch_bounds__(512) void conv_bf16_wide_band(const ConvArgs a) {
     for (int pass = 0; pass < npass; ++pass) {
         const int c0 = pass * CP, cw = a.CinPad - c0 < CP ? a.CinPad - c0 : CP;
         if (pass) __syncthreads();                             // every wave has finished reading the previous pass's plane
+#ifdef GRNET_ABLATION                                                  // timing-only builds (make ABLATION=1; GRNET_WIDE_DBG bit 0: no fill, bit 1: no k-loop)
+        if (!(a.dbg & 1) || pass == 0)
+#endif
         fill(c0, cw);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#ifdef GRNET_ABLATION
+        if (!(a.dbg & 2))
+#endif
         wide_kloop<P, SB, CS, PS>(acc, wr, bread, wg + (size_t)(c0 / 32) * 9 * wtap, wtap, cw / 32, pass == npass - 1, wlb);
     }
     // ---- the tile: bias is in the accumulators; ReLU, bf16, in place through the plane, rows y0 .. y0 + R - 1 -> HBM as whole channel rows
@@ -696,6 +706,212 @@ __global__ __launch_bounds__(512) void conv_bf16_wide_band(const ConvArgs a) {
         const int u = i * 512 + tid, px = u / UPP, part = u - px * UPP, r = px / W, x = px - r * W;
         if (u < R * W * UPP && y0 + r < W && part * 8 < cstore)
             *reinterpret_cast<u32x4*>(outb + ((size_t)(y0 + r) * W + x) * a.out_ctot + part * 8) = *reinterpret_cast<const u32x4*>(plane + ((r + 1) * P + x + 1) * SB + part * 16);
+    }
+}
+
+// ---- The wide 3x3 convolution again, with BOTH operands streamed through LDS by DMA under the MFMAs (round 5).  conv_bf16_wide_band holds CP = 128
+// channels of the band in one plane and refills it between passes: fill -> vmcnt(0) -> barrier -> 936 MFMAs per wave -> barrier, nothing overlapped (one
+// workgroup per CU owns the whole LDS).  Ablated at 256 frames (make ABLATION=1, GRNET_WIDE_DBG): 480 -> 256 @56 takes 1 277 us, 1 054 without the three
+// refills, 177 without any k-loop (first fill + store): the k-loop alone runs at 2.0 PFLOP/s -- the MFMA issue rate at the clock the chip holds under this
+// load -- and 0.4 of 1.28 ms is exposed fill and store.
+// Here a plane holds ONE 32-channel chunk of the band (slot stride 64 + 32 bytes: 32 * odd, conflict-free b128 reads as before) and two planes alternate:
+// chunk c is computed from plane c % 2 while the pieces of chunk c + 1 land in the other one.  ONE barrier per chunk, behind tap 7: every wave's reads of
+// chunk c are done by then (tap 8's fragments are in registers) and its pieces of chunk c + 1 have landed, so tap 8 reads ahead into chunk c + 1 and the
+// first piece of chunk c + 2 goes out; 234 MFMAs per wave between barriers.
+// vmcnt retires in order, and hipcc drains it to ZERO in front of every use of a loaded register while an LDS-DMA it knows of is in flight (seen in the ISA of
+// a first version with the weights by global_load: one vmcnt(0) per tap).  So NO register-returning vector load is left in the loop: the weights go through
+// LDS too -- every wave DMAs the 2 KiB (32 output channels x 32 k) of its own fragments per k-step into a private ring of three slots, two steps ahead, XOR-
+// swizzled like the frame kernel's -- every DMA is inline asm the compiler does not count, and the waits are explicit: per tap the wave issues W(t+2) (two
+// pieces) and at most one plane piece, and waits in the middle of the tap with vmcnt(2 + I(t-1) + I(t)) -- everything up to W(t+1) has landed, the plane
+// pieces of this and the previous tap may still fly -- then reads W(t+1)'s fragments for the next tap.  I(t) = 1 on the taps that carry a plane piece
+// (tap 8 and taps 0 .. NFILL-2: every wave issues the same count -- a wave without an own last piece re-requests the plane's last one, and behind the
+// last chunk the pieces fetch zeros into the plane nobody reads any more).
+template <int CT, int W, int R>
+struct RingGeom {
+    static constexpr int P = W + 1, SB = 96, UPS = SB / 16;
+    static constexpr int ROWS = R + 2;
+    static constexpr int O0 = P + 1, NOUT = R * P - 1;
+    static constexpr int CS = 2, WCB = CT / 32, WPG = 8 / WCB;
+    static constexpr int PS = ((NOUT + 15) / 16 + WPG - 1) / WPG, NT = WPG * PS;
+    static constexpr int NPIECE = ((ROWS * P + 1) * UPS + 63) / 64;                 // one-KiB DMA pieces of a plane: slots 0 .. ROWS * P
+    static constexpr int PB = NPIECE * 1024;                                        // plane stride, bytes
+    static constexpr int NFILL = (NPIECE + 7) / 8;                                  // pieces per wave and chunk
+    static constexpr int WRING = 2 * PB;                                            // the waves' weight rings: 8 x 3 slots x 2 KiB (a plane's dead columns read into them: garbage, never stored)
+    static constexpr int OSB = 2 * CT + 32;                                         // slot stride of the output tile (staged over everything)
+    static constexpr int LDS = WRING + 8 * 3 * 2048;
+    static constexpr int UPP = CT / 8, NUO = (R * W * UPP + 511) / 512;
+    static constexpr int NB = (W + R - 1) / R;
+    static constexpr bool piece_at(int tap) { return tap == 8 || tap < NFILL - 1; }
+    static_assert(LDS <= 160 * 1024 && NFILL >= 2 && NFILL <= 7 && PS <= 32 && (O0 + NT * 16) * OSB <= LDS && CT % 32 == 0 && 8 % (CT / 32) == 0, "ring geometry");
+    static_assert((PS - 1) * 16 * SB + (2 * P + 2) * SB + 64 < 65536 && (O0 + NT * 16 + P + 2) * SB + 64 <= LDS - PB, "ds_read immediates / the farthest dead read stays inside the allocation");
+};
+
+// LDS-DMA pieces the compiler does not know of: lane l's 16 bytes land at lds + 16 l (M0 = LDS byte address of the piece).
+// uniform base + 32-bit lane offset, only the lanes of `mask` (all lanes are on around it: the callers are in uniform control flow)
+__device__ __forceinline__ void dma16_masked(unsigned off, const void* base, unsigned lds, unsigned long long mask) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, %3\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(off), "s"(base), "s"(lds), "s"(mask) : "memory");
+}
+// all lanes (the weights).  One wait state between the M0 write and the DMA that reads it.
+__device__ __forceinline__ void dma16_hidden_s(unsigned off, const void* base, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds) : "memory");
+}
+
+template <int CT, int W, int R>
+__global__ __launch_bounds__(512) void conv_bf16_wide_ring(const ConvArgs a) {
+    typedef RingGeom<CT, W, R> G;
+    constexpr int P = G::P, SB = G::SB, CS = G::CS, PS = G::PS, UPS = G::UPS, UPP = G::UPP, PB = G::PB, NFILL = G::NFILL, OSB = G::OSB;
+    extern __shared__ __align__(16) unsigned char plane[];
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wcb = wave % G::WCB, pg = wave / G::WCB;
+    const int ncb = a.CoutPad / CT;
+    const int cbo = blockIdx.x % ncb, nb = blockIdx.x / ncb, n = nb / G::NB, band = nb - n * G::NB;
+    if (n >= a.N) return;
+    const int y0 = band * R;
+    const unsigned char* inb = reinterpret_cast<const unsigned char*>(reinterpret_cast<const u16*>(a.in) + (size_t)n * W * W * a.in_ctot + a.in_coff);
+    const int nch = a.CinPad / 32, nstep = nch * 9;
+    const unsigned lds0 = (unsigned)(size_t)plane;                                  // LDS byte address of the allocation (M0 takes byte addresses)
+
+    // this lane's share of plane piece i: byte offset of its 16 bytes of chunk 0 in the frame (chunk c: + 64 c).  Units that must read zero -- halo column, rows
+    // outside the image -- are the same for every chunk: they are zeroed ONCE below and their lanes are switched off in every piece (EXEC), so a piece needs
+    // no second source and is `global_load_lds v_off, s[base]`; the pad units (never read) stay on and fetch the frame's first bytes, so that no piece is empty
+    // (an instruction without lanes would not count in vmcnt, and the waits below count instructions)
+    unsigned poff[NFILL];
+    int pdst[NFILL];
+    unsigned long long pmask[NFILL];
+#pragma unroll
+    for (int i = 0; i < NFILL; ++i) {
+        int pc = i * 8 + wave;
+        pc = pc < G::NPIECE ? pc : G::NPIECE - 1;                                   // no own last piece: the plane's last one again
+        const int u = pc * 64 + lane, slot = u / UPS, part = u - slot * UPS, r = slot / P, xx = slot - r * P, y = y0 - 1 + r;
+        const bool data = part < 4 && r < G::ROWS && xx != 0 && y >= 0 && y < W;
+        poff[i] = data ? (unsigned)(((y * W + xx - 1) * a.in_ctot + part * 8) * 2) : 0u;
+        pdst[i] = pc * 1024;
+        pmask[i] = __ballot(data || part >= 4);
+        if (!data && part < 4) {                                                    // both planes: never written again
+            *reinterpret_cast<u32x4*>(plane + pdst[i] + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4*>(plane + PB + pdst[i] + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    auto piece = [&](int i, int c, int pl) {                                        // behind the last chunk: chunk 0 again, into the plane nobody reads any more
+        int ce = c < nch ? c : 0;
+#ifdef GRNET_ABLATION
+        if (a.dbg & 8) ce = 0;                                                      // bit 3: every piece fetches chunk 0 (cache hits): issue cost without the memory latency
+#endif
+        dma16_masked(poff[i], inb + ce * 64, lds0 + pl + pdst[i], pmask[i]);
+    };
+    // weights of k-step s for this wave: rows co .. co + 31 of [step][CoutPad][32]; piece cs = 16 rows x 64 B, lane (row = l >> 2, unit = l & 3) fetches the unit
+    // (l & 3) ^ 2 (row >> 3 & 1) of its row: the fragment read below finds k-group lq of row l15 at unit lq ^ 2 (l15 >> 3) -- conflict-free b128 reads of 64-byte rows
+    const int co = cbo * CT + wcb * CS * 16;
+    const unsigned wlane = (unsigned)(((co + (lane >> 2)) * 32 + (((lane & 3) ^ (2 * ((lane >> 5) & 1))) * 8)) * 2);
+    const size_t wstep = (size_t)a.CoutPad * 64;                                    // bytes per k-step
+    const unsigned char* wg = reinterpret_cast<const unsigned char*>(a.w);
+    const unsigned wring = lds0 + G::WRING + wave * (3 * 2048);
+    auto wdma = [&](int s, int slot) {                                              // behind the layer's last step the stream ends: its first steps again (nobody reads them)
+        const unsigned char* base = wg + (size_t)(s < nstep ? s : s - nstep) * wstep;
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs) dma16_hidden_s(wlane + cs * 1024, base, wring + slot * 2048 + cs * 1024);
+    };
+    const unsigned char* aread = plane + G::WRING + wave * (3 * 2048) + l15 * 64 + ((lq ^ (2 * (l15 >> 3))) * 16);
+
+    const int o_first = G::O0 + pg * PS * 16 + l15;
+    const unsigned char* bread = plane + (o_first - P - 1) * SB + lq * 16;
+    unsigned valid = 0;
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps) {
+        const int o = o_first + ps * 16, r = o / P;
+        if (o - r * P != 0 && r >= 1 && r <= R && y0 + r - 1 < W) valid |= 1u << ps;
+    }
+    f32x4 acc[CS][PS];
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + co + cs * 16 + lq * 4);
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) acc[cs][ps] = bv;
+    }
+    // ---- prologue: chunk 0 -> plane 0, k-steps 0 and 1, the last piece of chunk 1 (the piece "tap 8 of chunk -1" would have issued)
+#pragma unroll
+    for (int i = 0; i < NFILL; ++i) piece(i, 0, 0);
+    wdma(0, 0);
+    wdma(1, 1);
+    piece(NFILL - 1, 1, PB);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CS + 1) : "memory");                   // in order: chunk 0 and step 0 have landed; step 1 and the piece of chunk 1 may fly
+    __syncthreads();                                                                // (and the zeroed halo units are everybody's)
+    bf16x8 bfr[PS], afr[3][CS];                                                     // fragment sets in ring order too: step s0 + tap uses set tap % 3 (9 = 3 x 3)
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs) afr[0][cs] = *reinterpret_cast<const bf16x8*>(aread + cs * 1024);
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps) bfr[ps] = *reinterpret_cast<const bf16x8*>(bread + ps * 16 * SB);
+    int cur = 0, nxt = PB;
+#pragma unroll 1
+    for (int c = 0; c < nch; ++c) {
+        const unsigned char* bc = bread + cur;
+        const unsigned char* bn = bread + nxt;
+        const int s0 = c * 9;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // k-step s0 + tap + 2 -> ring slot (tap + 2) % 3 (9 = 3 x 3: the slot is static), then this tap's plane piece: chunk c + 1 on taps 0 .. NFILL-2
+            // (pieces 0 .. NFILL-2; into the other plane), chunk c + 2 on tap 8 (piece NFILL-1; into THIS plane, which the barrier behind tap 7 has freed)
+#ifdef GRNET_ABLATION                                                  // timing-only builds (make ABLATION=1; GRNET_WIDE_DBG bit 0: no plane pieces, bit 1: no weight pieces, bit 2: no waits)
+            if (!(a.dbg & 2))
+#endif
+            wdma(s0 + tap + 2, (tap + 2) % 3);
+#ifdef GRNET_ABLATION
+            if (!(a.dbg & 1)) {
+#endif
+            if (tap == 8) piece(NFILL - 1, c + 2, cur);
+            else if (tap < NFILL - 1) piece(tap, c + 1, nxt);
+#ifdef GRNET_ABLATION
+            }
+#endif
+            const unsigned char* nb_ = tap < 8 ? bc + (((tap + 1) / 3) * P + ((tap + 1) % 3)) * SB : bn;
+            constexpr int HALF = PS / 2;
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps) {
+                if (ps == HALF) {
+                    // everything up to k-step s0 + tap + 1 has landed (issued one tap ago); behind it: that tap's plane piece, this tap's two weight pieces and plane piece
+#ifdef GRNET_ABLATION
+                    if (!(a.dbg & 4))
+#endif
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CS + (G::piece_at((tap + 8) % 9) ? 1 : 0) + (G::piece_at(tap) ? 1 : 0)) : "memory");
+#pragma unroll
+                    for (int cs = 0; cs < CS; ++cs) afr[(tap + 1) % 3][cs] = *reinterpret_cast<const bf16x8*>(aread + ((tap + 1) % 3) * 2048 + cs * 1024);
+                }
+#pragma unroll
+                for (int cs = 0; cs < CS; ++cs) acc[cs][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[tap % 3][cs], bfr[ps], acc[cs][ps], 0, 0, 0);
+                bfr[ps] = *reinterpret_cast<const bf16x8*>(nb_ + ps * 16 * SB);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (tap == 7) {
+                // every read of chunk c has returned (tap 8's fragments included); this wave's pieces of chunk c + 1 landed with the wait in the middle of this tap
+                // (the last one went out on tap NFILL-2 <= 5)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+        }
+        const int t = cur; cur = nxt; nxt = t;
+    }
+    // ---- the tile: ReLU, bf16, staged over planes and rings (every piece has landed, every wave is done reading), rows y0 .. y0 + R - 1 -> HBM as whole channel rows
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned char* owrite = plane + o_first * OSB + (wcb * CS * 16 + lq * 4) * 2;
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps)
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs) {
+            f32x4 v = acc[cs][ps];
+            if (a.relu) { v[0] = relu_c(v[0]); v[1] = relu_c(v[1]); v[2] = relu_c(v[2]); v[3] = relu_c(v[3]); }
+            if (valid & (1u << ps)) *reinterpret_cast<u32x2*>(owrite + ps * 16 * OSB + cs * 32) = u32x2{pack2_c(v[0], v[1]), pack2_c(v[2], v[3])};
+        }
+    __syncthreads();
+    u16* outb = reinterpret_cast<u16*>(a.out) + (size_t)n * W * W * a.out_ctot + a.out_coff + cbo * CT;
+    const int cstore = a.Cout - cbo * CT;
+#pragma unroll
+    for (int i = 0; i < G::NUO; ++i) {
+        const int u = i * 512 + tid, px = u / UPP, part = u - px * UPP, r = px / W, x = px - r * W;
+        if (u < R * W * UPP && y0 + r < W && part * 8 < cstore)
+            *reinterpret_cast<u32x4*>(outb + ((size_t)(y0 + r) * W + x) * a.out_ctot + part * 8) = *reinterpret_cast<const u32x4*>(plane + ((r + 1) * P + x + 1) * OSB + part * 16);
     }
 }
 
@@ -908,6 +1124,8 @@ hipError_t conv_bf16_chain_init() {
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_band<128, 128, 28, 14>), hipFuncAttributeMaxDynamicSharedMemorySize, WideGeom<128, 128, 28, 14>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_band<64, 64, 56, 14>), hipFuncAttributeMaxDynamicSharedMemorySize, WideGeom<64, 64, 56, 14>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_block_frame<56, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, FrameGeom<56, 8>::LDS));
+    GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_ring<128, 56, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<128, 56, 7>::LDS));
+    GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_ring<128, 28, 14>), hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<128, 28, 14>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_block_band<32, 56, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, BandGeom<32, 56, 8>::LDS));
     return hipSuccess;
 }
@@ -953,10 +1171,22 @@ bool conv_bf16_wide_eligible(const ConvArgs& a) {
     if (a.W == 56 && a.CinPad == 64 && a.CoutPad == 64) return true;
     return (a.W == 56 || a.W == 28) && a.CinPad >= 128 && a.CoutPad % 128 == 0;
 }
-hipError_t launch_conv_bf16_wide(const ConvArgs& a, hipStream_t s) {
-    if (!conv_bf16_wide_eligible(a) || a.N < 1) return hipErrorInvalidValue;
+hipError_t launch_conv_bf16_wide(const ConvArgs& a0, hipStream_t s) {
+    if (!conv_bf16_wide_eligible(a0) || a0.N < 1) return hipErrorInvalidValue;
+    static const int xcd_env = getenv("GRNET_BF16_XCD") ? atoi(getenv("GRNET_BF16_XCD")) : 1;
+    ConvArgs a = a0;
+    a.xcd = xcd_env;
+#ifdef GRNET_ABLATION
+    a.dbg = getenv("GRNET_WIDE_DBG") ? atoi(getenv("GRNET_WIDE_DBG")) : 0;
+#endif
     if (a.CinPad == 64) return launch_k(conv_bf16_wide_band<64, 64, 56, 14>, dim3(a.N * WideGeom<64, 64, 56, 14>::NB), dim3(512), WideGeom<64, 64, 56, 14>::LDS, s, a);
     const int ncb = a.CoutPad / 128;
+    // 1 (default): the ring of one-chunk planes; 0: the 128-channel plane refilled between passes (A/B)
+    static const int ring_env = getenv("GRNET_BF16_WIDE_RING") ? atoi(getenv("GRNET_BF16_WIDE_RING")) : 1;
+    if (ring_env && a.CinPad >= 64) {
+        if (a.W == 56) return launch_k(conv_bf16_wide_ring<128, 56, 7>, dim3(a.N * RingGeom<128, 56, 7>::NB * ncb), dim3(512), RingGeom<128, 56, 7>::LDS, s, a);
+        return launch_k(conv_bf16_wide_ring<128, 28, 14>, dim3(a.N * RingGeom<128, 28, 14>::NB * ncb), dim3(512), RingGeom<128, 28, 14>::LDS, s, a);
+    }
     if (a.W == 56) return launch_k(conv_bf16_wide_band<128, 128, 56, 7>, dim3(a.N * WideGeom<128, 128, 56, 7>::NB * ncb), dim3(512), WideGeom<128, 128, 56, 7>::LDS, s, a);
     return launch_k(conv_bf16_wide_band<128, 128, 28, 14>, dim3(a.N * WideGeom<128, 128, 28, 14>::NB * ncb), dim3(512), WideGeom<128, 128, 28, 14>::LDS, s, a);
 }

@@ -87,6 +87,7 @@ struct FuseUpPlan {
     float* w_dev[3][3] = {};             // [output i][source j - i - 1], pack_fuse_up_weights
     float* b_dev[3] = {};                // [output i]: sum over j of the folded BatchNorm shifts
     double macs_per_frame = 0;
+    int only = -1;                       // >= 0: this plan finishes output `only` alone (bf16: one launch per output, each on its branch's lane)
 };
 
 // The 8 convolutions (4 BasicBlocks) of one branch of one HR module, runnable as ONE launch on the bf16 path (conv_bf16_chain.hip).
@@ -342,9 +343,12 @@ struct grnet {
             }
         const std::string tag = p.substr(p.find("stage"));                  // "stage3.1."
         for (int b = 0; b < nb; ++b) name_view(tag + "x" + std::to_string(b), xs[b]);
-        // GRNET_FUSE_UP=0: the round-3 fuse layer (one 1x1 launch per up term, an elementwise launch for output 0); the bf16 path keeps it
+        // GRNET_FUSE_UP=0: the round-3 fuse layer (one 1x1 launch per up term, an elementwise launch for output 0)
+        // (GRNET_BF16_FUSE_UP=0 does the same for the bf16 path, which has the grouped launch since round 5)
         static const int fuse_up_env = getenv("GRNET_FUSE_UP") ? atoi(getenv("GRNET_FUSE_UP")) : 1;
-        std::vector<View> outs = (dtype == 0 && fuse_up_env) ? hr_fuse_grouped(xs, p, out0, branch_tail) : hr_fuse_separate(xs, p, out0);
+        const int fuse_up_bf_env = getenv("GRNET_BF16_FUSE_UP") ? atoi(getenv("GRNET_BF16_FUSE_UP")) : 0;    // read per handle: the tests build all three.  0 is the default: at 256 frames the lane-overlapped step is 10.68 / 10.91 / 10.67 ms for 0 / 1 / 2 (one lane: 11.69 / 11.39) -- the small launches hide behind the other lanes, the stored D_ij of layout 1 do not
+        std::vector<View> outs = (dtype == 0 ? fuse_up_env : fuse_up_bf_env == 1) ? hr_fuse_grouped(xs, p, out0, branch_tail)
+                                                                                  : hr_fuse_separate(xs, p, out0, dtype == 1 && fuse_up_bf_env == 2, branch_tail);
         for (int i = 0; i < nb; ++i) name_view(tag + "y" + std::to_string(i), outs[i]);
         cur_lane = 0;
         return outs;
@@ -380,7 +384,9 @@ struct grnet {
                 for (int i = j + 1; i < nb; ++i)
                     if (level < i - j && !(i == nb - 1 && j == nb - 2)) members.push_back(i);
                 // GRNET_FUSE_MERGE (A/B switch): 2 = all first convolutions of a branch in one launch, 1 = only the ReLU'd ones, 0 = none
-                static const int merge_env = getenv("GRNET_FUSE_MERGE") ? atoi(getenv("GRNET_FUSE_MERGE")) : 2;
+                // (the bf16 kernels have no per-segment ReLU: every first convolution is its own launch there)
+                static const int merge_env_f32 = getenv("GRNET_FUSE_MERGE") ? atoi(getenv("GRNET_FUSE_MERGE")) : 2;
+                const int merge_env = dtype == 1 ? 0 : merge_env_f32;
                 std::vector<int> solo;
                 if (level == 0 && merge_env < 2) {
                     std::vector<int> keep;
@@ -425,8 +431,9 @@ struct grnet {
             fp.outs.push_back(outs[i]);
             fp.extra.push_back({});
             for (int j = 0; j < i; ++j) fp.extra.back().push_back(d[i][j]);
-            for (int j = i + 1; j < nb; ++j) fp.macs_per_frame += (double)xs[j].h * xs[j].w * kBranchCh[j] * kBranchCh[i];
         }
+        for (int i = 0; i < nb - 1; ++i)
+            for (int j = i + 1; j < nb; ++j) fp.macs_per_frame += (double)xs[j].h * xs[j].w * kBranchCh[j] * kBranchCh[i];
         fuse_ups.push_back(fp);
         Op op;
         op.kind = Op::FUSEUP;
@@ -450,20 +457,37 @@ struct grnet {
     std::vector<ChainPlan> chains;
 
     // Fuse layer as launched until round 3 (kept for the bf16 path and for A/B runs)
-    std::vector<View> hr_fuse_separate(std::vector<View> xs, const std::string& p, const View* out0) {
+    // up0 (bf16, round 5): output 0 -- the full-resolution one, 4 of the layer's launches -- is finished by ONE hr_fuse_up_bf16 launch instead (only = 0);
+    // the other outputs keep their finishing stride-2 convolution, which adds everything in its epilogue and writes no D_ij to memory
+    std::vector<View> hr_fuse_separate(std::vector<View> xs, const std::string& p, const View* out0, bool up0 = false, const std::vector<int>& branch_tail = {}) {
         const int nb = (int)xs.size();
         // up terms t[i][j], j > i: conv1x1 + BN at the resolution of branch j (nearest upsample is
         // applied where the term is consumed: it commutes with the per-pixel conv/BN)
         std::vector<std::vector<View>> t(nb, std::vector<View>(nb));
         for (int i = 0; i < nb; ++i)
             for (int j = i + 1; j < nb; ++j) {
+                if (up0 && i == 0) continue;
                 const std::string q = p + "fuse_layers." + std::to_string(i) + "." + std::to_string(j) + ".";
                 cur_lane = j;
                 t[i][j] = conv_bn(xs[j], q + "0.weight", q + "1", kBranchCh[i], 1, 1, false);
             }
         cur_lane = 0;
         std::vector<View> outs(nb);
-        {   // output 0: elementwise sum of the identity and the upsampled terms
+        if (up0) {
+            FuseUpPlan fp;
+            fp.nb = nb; fp.prefix = p; fp.xs = xs; fp.only = 0;
+            outs[0] = out0 ? *out0 : new_buffer(kBranchCh[0], xs[0].h, xs[0].w);
+            fp.outs.push_back(outs[0]);
+            fp.extra.push_back({});
+            for (int j = 1; j < nb; ++j) fp.macs_per_frame += (double)xs[j].h * xs[j].w * kBranchCh[j] * kBranchCh[0];
+            fuse_ups.push_back(fp);
+            Op op;
+            op.kind = Op::FUSEUP;
+            op.conv_idx = (int)fuse_ups.size() - 1;
+            op.lane = 0;
+            op.follow = branch_tail[0];
+            ops.push_back(op);
+        } else {   // output 0: elementwise sum of the identity and the upsampled terms
             View o = out0 ? *out0 : new_buffer(kBranchCh[0], xs[0].h, xs[0].w);
             Op op;
             op.kind = Op::SUM;
@@ -716,8 +740,12 @@ struct grnet {
                 break;
             case Op::BILINEAR: r.push_back(op.bin.p); break;
             case Op::FUSEUP:
-                for (auto& v : fuse_ups[op.conv_idx].xs) r.push_back(v.p);
-                for (auto& e : fuse_ups[op.conv_idx].extra) for (auto& v : e) r.push_back(v.p);
+            {
+                const FuseUpPlan& fp = fuse_ups[op.conv_idx];
+                for (size_t j = fp.only < 0 ? 0 : fp.only; j < fp.xs.size(); ++j) r.push_back(fp.xs[j].p);
+                for (size_t i = 0; i < fp.extra.size(); ++i)
+                    if (fp.only < 0 || fp.only == (int)i) for (auto& v : fp.extra[i]) r.push_back(v.p);
+            }
                 break;
             case Op::POOL: r.push_back(v_heat.p); r.push_back(v_smpl_feats.p); r.push_back(v_csmap.p); break;
             default: break;                                     // TAIL / SMPL follow POOL on lane 0
@@ -729,7 +757,10 @@ struct grnet {
         else if (op.kind == Op::SUM) w.push_back(sum_views[op.conv_idx].first.p);
         else if (op.kind == Op::BILINEAR) w.push_back(op.bout.p);
         else if (op.kind == Op::CONVERT) w.push_back(v_in8.p);
-        else if (op.kind == Op::FUSEUP) for (auto& v : fuse_ups[op.conv_idx].outs) w.push_back(v.p);
+        else if (op.kind == Op::FUSEUP) {
+            const FuseUpPlan& fp = fuse_ups[op.conv_idx];
+            for (size_t i = 0; i < fp.outs.size(); ++i) if (fp.only < 0 || fp.only == (int)i) w.push_back(fp.outs[i].p);
+        }
     }
 
     // Static list scheduling of the op list onto the kLanes streams.  The plan writes "branch b on lane b",
@@ -1142,6 +1173,7 @@ struct grnet {
     // BatchNorm folded in fp64, weights in the MFMA B-fragment order of hr_fuse.hip, the shifts of an output's terms summed into one bias.
     int pack_fuse_up(FuseUpPlan& fp) {
         for (int i = 0; i < fp.nb - 1; ++i) {
+            if (fp.only >= 0 && fp.only != i) continue;
             const int co = kBranchCh[i];
             std::vector<double> bias(co, 0.0);
             for (int j = i + 1; j < fp.nb; ++j) {
@@ -1159,8 +1191,9 @@ struct grnet {
                     bias[c] += (double)be->data[c] - (double)m->data[c] * sc;
                     for (int k = 0; k < ci; ++k) wf[(size_t)c * ci + k] = (double)w->data[(size_t)c * ci + k] * sc;
                 }
-                std::vector<float> packed((size_t)co * ci);
-                pack_fuse_up_weights(wf.data(), co, ci, packed.data());
+                std::vector<float> packed((size_t)co * ci / (dtype == 1 ? 2 : 1));
+                if (dtype == 1) pack_fuse_up_weights_bf16(wf.data(), co, ci, reinterpret_cast<unsigned short*>(packed.data()));
+                else pack_fuse_up_weights(wf.data(), co, ci, packed.data());
                 if (int rc = upload(packed, &fp.w_dev[i][j - i - 1])) return rc;
             }
             std::vector<float> bf(bias.begin(), bias.end());
@@ -1534,8 +1567,9 @@ struct grnet {
     }
     int launch_fuse_up_op(const FuseUpPlan& fp, int n, hipStream_t s) {
         FuseUpArgs a{};
-        a.N = n; a.nb = fp.nb;
+        a.N = n; a.nb = fp.nb; a.only = fp.only;
         for (int i = 0; i < fp.nb - 1; ++i) {
+            if (fp.only >= 0 && fp.only != i) continue;
             FuseUpOut& fo = a.o[i];
             fo.out = fp.outs[i].p; fo.out_ctot = fp.outs[i].ctot; fo.out_coff = fp.outs[i].coff;
             fo.base = fp.xs[i].p; fo.base_ctot = fp.xs[i].ctot; fo.base_coff = fp.xs[i].coff;
@@ -1545,7 +1579,7 @@ struct grnet {
             for (int k = 0; k < fo.n_extra; ++k) { fo.extra[k] = fp.extra[i][k].p; fo.extra_ctot[k] = fp.extra[i][k].ctot; fo.extra_coff[k] = fp.extra[i][k].coff; }
             for (int j = i + 1; j < fp.nb; ++j) fo.src[j - i - 1] = FuseUpSrc{fp.xs[j].p, fp.xs[j].ctot, fp.xs[j].coff, fp.w_dev[i][j - i - 1]};
         }
-        HIP_TRY(launch_hr_fuse_up(a, s));
+        HIP_TRY(dtype == 1 ? launch_hr_fuse_up_bf16(a, s) : launch_hr_fuse_up(a, s));
         return 0;
     }
 
@@ -1588,8 +1622,8 @@ struct grnet {
                 rec->n_chain = lane_last[lane] ? 1 : 0;
                 if (lane_last[lane]) rec->deps.push_back(lane_last[lane]);
                 if (multi_lane)
-                    for (int w : op.waits)
-                        if (op_node[w]) rec->deps.push_back(op_node[w]);
+                    for (int w : op.waits)                          // several waited ops can be ONE node (the members of a chain launch): an edge is added once
+                        if (op_node[w] && std::find(rec->deps.begin(), rec->deps.end(), op_node[w]) == rec->deps.end()) rec->deps.push_back(op_node[w]);
             }
             // timing-only ablation (results are garbage): GRNET_ABL_SKIP=<substring of a weight key>[,<substring>...] drops the matching
             // convolution launches and "fuse_up" the grouped fuse launches, events and dependencies stay -- what is a group of launches worth?
@@ -2348,7 +2382,7 @@ int grnet_conv_kernel_info(grnet_t* h, int pos, int n_frames, char* name, int na
     const Op* op = nth_conv_op(h, pos);
     if (!op) return GRNET_EINVAL;
     if (op->kind == Op::FUSEUP) {
-        if (name && name_size > 0) snprintf(name, name_size, "hr_fuse_up_f32<%d>", h->fuse_ups[op->conv_idx].nb);
+        if (name && name_size > 0) snprintf(name, name_size, h->dtype == 1 ? "hr_fuse_up_bf16<%d>" : "hr_fuse_up_f32<%d>", h->fuse_ups[op->conv_idx].nb);
         if (executed_macs_per_frame) *executed_macs_per_frame = h->fuse_ups[op->conv_idx].macs_per_frame;
         return 0;
     }

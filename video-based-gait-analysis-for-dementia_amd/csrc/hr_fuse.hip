@@ -221,4 +221,181 @@ hipError_t launch_hr_fuse_up(const FuseUpArgs& a, hipStream_t s) {
     return launch_k(hr_fuse_up_f32<4>, grid, dim3(256), 0, s, a);
 }
 
+
+// ================================================================================================================================================
+// The same launch on the bf16 path (round 5): NHWC bf16 activations, bf16 matrix cores, fp32 sums.  Until now the bf16 path kept round 3's fuse layer
+// (hr_fuse_separate: 31 1x1 launches of 8-10 us + 8 elementwise launches per forward at 256 frames, ~0.5 ms of 10.7).  Channels-last makes this kernel
+// simpler than the fp32 one: a source pixel's 32 k-values of a chunk are 64 contiguous bytes, so the B operand of v_mfma_f32_16x16x32_bf16 (lane: pixel
+// l & 15, k-group l >> 4) is ONE 16-byte global load, the A operand (W_ij packed [C_j / 32][C_i][32], BatchNorm folded) likewise, and phase 2 reads and
+// writes whole 16-byte channel groups.  Workgroup = (output i, frame, band of 8 >> i rows), 4 waves:
+//   phase 1: every (source j, 16-pixel tile of the band at resolution j, 16-channel block of C_i) is one MFMA column tile; the tiles are dealt to the
+//            waves round-robin, a tile's K = C_j / 32 steps are loaded at once; T_j = bf16(W_ij x_j) -> LDS [pixel][C_i] (rounded where the separate
+//            launches stored it);
+//   phase 2: out = relu(x_i + sum_k D_ik + sum_j T_j[y >> (j-i)][x >> (j-i)] + bias_i), fp32, 16-byte loads / stores; x_i and the D's are requested
+//            before the barrier.
+namespace {
+
+typedef __bf16 bf16x8_f __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4_f __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_f __attribute__((ext_vector_type(2)));
+typedef unsigned short u16_f;
+typedef __bf16 bf16x2_f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2_f(float lo, float hi) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2_f)); }
+__device__ __forceinline__ void add8_f(float (&acc)[8], u32x4_f v) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { acc[2 * k] += __uint_as_float(v[k] << 16); acc[2 * k + 1] += __uint_as_float(v[k] & 0xffff0000u); }
+}
+
+template <int NB, int I>
+struct OutGeomB {
+    static constexpr int CI = 32 << I, WI = 56 >> I, BR = 8 >> I, NSRC = NB - 1 - I, NCB = CI / 16, UPP = CI / 8;
+    static constexpr int NU = BR * WI * UPP, NIT = (NU + 255) / 256;
+};
+template <int NB, int I, int S>
+struct SrcGeomB {
+    typedef OutGeomB<NB, I> G;
+    static constexpr int J = I + 1 + S, CJ = 32 << J, SH = S + 1, WJ = G::WI >> SH, ROWS = G::BR >> SH, PJ = ROWS * WJ, NPT = (PJ + 15) / 16, NK = CJ / 32;
+    static constexpr int TILES = NPT * G::NCB;
+    static_assert(ROWS >= 1, "band geometry");
+};
+template <int NB, int I, int S> struct TOffB { static constexpr int v = TOffB<NB, I, S - 1>::v + SrcGeomB<NB, I, S - 1>::PJ * OutGeomB<NB, I>::CI; };      // bf16 elements
+template <int NB, int I> struct TOffB<NB, I, 0> { static constexpr int v = 0; };
+
+// tiles t0, t0 + 4, ... of source S for this wave (t0 = the wave's first tile of this source, continuing the round-robin over all sources)
+template <int NB, int I, int S>
+__device__ __forceinline__ void src_tiles_bf16(const FuseUpSrc& src, int n, int band, int lane, int first, u16_f* T) {
+    typedef SrcGeomB<NB, I, S> Q;
+    typedef OutGeomB<NB, I> G;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const u16_f* xb = reinterpret_cast<const u16_f*>(src.x) + (size_t)n * Q::WJ * Q::WJ * src.ctot + src.coff + (size_t)band * Q::PJ * src.ctot;
+    const u16_f* wb = reinterpret_cast<const u16_f*>(src.w);
+    u16_f* Ts = T + TOffB<NB, I, S>::v;
+#pragma unroll
+    for (int t = 0; t < (Q::TILES + 3) / 4; ++t) {
+        const int tile = first + 4 * t;
+        if (tile >= Q::TILES) break;                           // wave-uniform
+        const int pt = tile / G::NCB, cb = tile - pt * G::NCB, px = pt * 16 + l15;
+        const u16_f* xp = xb + (size_t)(px < Q::PJ ? px : 0) * src.ctot + lq * 8;      // columns past the band re-read pixel 0 and are never stored
+        const u16_f* wp = wb + ((size_t)cb * 16 + l15) * 32 + lq * 8;
+        bf16x8_f bq[Q::NK], aq[Q::NK];
+#pragma unroll
+        for (int k = 0; k < Q::NK; ++k) {
+            bq[k] = *reinterpret_cast<const bf16x8_f*>(xp + k * 32);
+            aq[k] = *reinterpret_cast<const bf16x8_f*>(wp + (size_t)k * G::CI * 32);
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < Q::NK; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[k], bq[k], acc, 0, 0, 0);
+        if (px < Q::PJ) *reinterpret_cast<u32x2_f*>(Ts + px * G::CI + cb * 16 + lq * 4) = u32x2_f{pack2_f(acc[0], acc[1]), pack2_f(acc[2], acc[3])};
+    }
+}
+
+template <int NB, int I>
+__device__ __forceinline__ void fuse_up_body_bf16(const FuseUpOut& o, int n, int band, u16_f* T) {
+    typedef OutGeomB<NB, I> G;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the waves take the tiles of all sources round-robin: tile g of the concatenated list goes to wave g % 4
+    {
+        typedef SrcGeomB<NB, I, 0> Q0;
+        src_tiles_bf16<NB, I, 0>(o.src[0], n, band, lane, wave, T);
+        if constexpr (G::NSRC >= 2) {
+            typedef SrcGeomB<NB, I, 1> Q1;
+            constexpr int base1 = Q0::TILES;
+            src_tiles_bf16<NB, I, 1>(o.src[1], n, band, lane, (wave + 4 - base1 % 4) % 4, T);
+            if constexpr (G::NSRC >= 3) {
+                constexpr int base2 = base1 + Q1::TILES;
+                src_tiles_bf16<NB, I, 2>(o.src[2], n, band, lane, (wave + 4 - base2 % 4) % 4, T);
+            }
+        }
+    }
+    // phase 2 operands that do not depend on phase 1: requested before the barrier
+    const u16_f* xb = reinterpret_cast<const u16_f*>(o.base) + (size_t)n * G::WI * G::WI * o.base_ctot + o.base_coff;
+    u32x4_f bv[G::NIT], e0[G::NIT], e1[G::NIT];
+#pragma unroll
+    for (int it = 0; it < G::NIT; ++it) {
+        const int u = it * 256 + tid, px = u / G::UPP, part = u - px * G::UPP, yl = px / G::WI, x = px - yl * G::WI;
+        const size_t pix = (size_t)(band * G::BR + yl) * G::WI + x;
+        bv[it] = e0[it] = e1[it] = u32x4_f{0u, 0u, 0u, 0u};
+        if (u < G::NU) {
+            bv[it] = *reinterpret_cast<const u32x4_f*>(xb + pix * o.base_ctot + part * 8);
+            if constexpr (I >= 1) {
+                if (o.n_extra >= 1) e0[it] = *reinterpret_cast<const u32x4_f*>(reinterpret_cast<const u16_f*>(o.extra[0]) + ((size_t)n * G::WI * G::WI + pix) * o.extra_ctot[0] + o.extra_coff[0] + part * 8);
+                if constexpr (I >= 2) { if (o.n_extra >= 2) e1[it] = *reinterpret_cast<const u32x4_f*>(reinterpret_cast<const u16_f*>(o.extra[1]) + ((size_t)n * G::WI * G::WI + pix) * o.extra_ctot[1] + o.extra_coff[1] + part * 8); }
+            }
+        }
+    }
+    __syncthreads();
+    u16_f* ob = reinterpret_cast<u16_f*>(o.out) + (size_t)n * G::WI * G::WI * o.out_ctot + o.out_coff;
+#pragma unroll
+    for (int it = 0; it < G::NIT; ++it) {
+        const int u = it * 256 + tid, px = u / G::UPP, part = u - px * G::UPP, yl = px / G::WI, x = px - yl * G::WI;
+        if (u >= G::NU) continue;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        add8_f(acc, bv[it]);
+        if constexpr (I >= 1) { add8_f(acc, e0[it]); if constexpr (I >= 2) add8_f(acc, e1[it]); }
+        {
+            typedef SrcGeomB<NB, I, 0> Q;
+            add8_f(acc, *reinterpret_cast<const u32x4_f*>(T + TOffB<NB, I, 0>::v + ((yl >> Q::SH) * Q::WJ + (x >> Q::SH)) * G::CI + part * 8));
+        }
+        if constexpr (G::NSRC >= 2) {
+            typedef SrcGeomB<NB, I, 1> Q;
+            add8_f(acc, *reinterpret_cast<const u32x4_f*>(T + TOffB<NB, I, 1>::v + ((yl >> Q::SH) * Q::WJ + (x >> Q::SH)) * G::CI + part * 8));
+        }
+        if constexpr (G::NSRC >= 3) {
+            typedef SrcGeomB<NB, I, 2> Q;
+            add8_f(acc, *reinterpret_cast<const u32x4_f*>(T + TOffB<NB, I, 2>::v + ((yl >> Q::SH) * Q::WJ + (x >> Q::SH)) * G::CI + part * 8));
+        }
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(o.bias + part * 8), b1 = *reinterpret_cast<const f32x4*>(o.bias + part * 8 + 4);
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = acc[k] + b0[k]; v[4 + k] = acc[4 + k] + b1[k]; }
+        if (o.relu) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        *reinterpret_cast<u32x4_f*>(ob + ((size_t)(band * G::BR + yl) * G::WI + x) * o.out_ctot + part * 8) =
+            u32x4_f{pack2_f(v[0], v[1]), pack2_f(v[2], v[3]), pack2_f(v[4], v[5]), pack2_f(v[6], v[7])};
+    }
+}
+
+template <int NB, int I> constexpr int lds_elems_b() { return TOffB<NB, I, OutGeomB<NB, I>::NSRC>::v; }
+template <int NB> constexpr int lds_elems_b_max() {
+    int m = lds_elems_b<NB, 0>();
+    if constexpr (NB >= 3) m = lds_elems_b<NB, 1>() > m ? lds_elems_b<NB, 1>() : m;
+    if constexpr (NB >= 4) m = lds_elems_b<NB, 2>() > m ? lds_elems_b<NB, 2>() : m;
+    return (m + 7) & ~7;
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void hr_fuse_up_bf16(const FuseUpArgs a) {
+    __shared__ __align__(16) u16_f T[lds_elems_b_max<NB>()];
+    const int per = a.N * 7, i = a.only >= 0 ? a.only : blockIdx.x / per, rem = a.only >= 0 ? blockIdx.x : blockIdx.x - i * per, n = rem / 7, band = rem - n * 7;
+    if (i == 0) fuse_up_body_bf16<NB, 0>(a.o[0], n, band, T);
+    if constexpr (NB >= 3) { if (i == 1) fuse_up_body_bf16<NB, 1>(a.o[1], n, band, T); }
+    if constexpr (NB >= 4) { if (i == 2) fuse_up_body_bf16<NB, 2>(a.o[2], n, band, T); }
+}
+
+}  // namespace
+
+// folded 1x1 weights (cout, cin) fp64 -> [cin / 32][cout][32] bf16 (round to nearest even): the layout of every bf16 convolution (grnet.cpp: pack_conv)
+void pack_fuse_up_weights_bf16(const double* w, int cout, int cin, unsigned short* out) {
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            float f = (float)w[(size_t)co * cin + ci];
+            unsigned u;
+            __builtin_memcpy(&u, &f, 4);
+            u += 0x7fffu + ((u >> 16) & 1u);
+            out[((size_t)(ci / 32) * cout + co) * 32 + ci % 32] = (unsigned short)(u >> 16);
+        }
+}
+
+hipError_t launch_hr_fuse_up_bf16(const FuseUpArgs& a, hipStream_t s) {
+    if (a.N < 1 || a.nb < 2 || a.nb > 4) return hipErrorInvalidValue;
+    if (a.only >= a.nb - 1) return hipErrorInvalidValue;
+    const dim3 grid(a.N * 7 * (a.only >= 0 ? 1 : a.nb - 1));
+    if (a.nb == 2) return launch_k(hr_fuse_up_bf16<2>, grid, dim3(256), 0, s, a);
+    if (a.nb == 3) return launch_k(hr_fuse_up_bf16<3>, grid, dim3(256), 0, s, a);
+    return launch_k(hr_fuse_up_bf16<4>, grid, dim3(256), 0, s, a);
+}
+
 }  // namespace grk

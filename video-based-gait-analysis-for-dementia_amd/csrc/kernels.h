@@ -189,9 +189,12 @@ struct FuseUpOut {
     const float* extra[2]; int extra_ctot[2], extra_coff[2];
     FuseUpSrc src[3];                                // j = i+1 .. nb-1
 };
-struct FuseUpArgs { int N, nb; FuseUpOut o[3]; };
+struct FuseUpArgs { int N, nb; FuseUpOut o[3]; int only = -1; };      // only >= 0 (bf16 launch): this output alone, grid N * 7
 hipError_t launch_hr_fuse_up(const FuseUpArgs& a, hipStream_t s);
 void pack_fuse_up_weights(const double* w_folded /* (cout, cin) */, int cout, int cin, float* out /* cout * cin */);
+// the same launch on NHWC bf16 tensors (pointers address bf16 data, bias fp32); weights [cin / 32][cout][32] bf16
+hipError_t launch_hr_fuse_up_bf16(const FuseUpArgs& a, hipStream_t s);
+void pack_fuse_up_weights_bf16(const double* w_folded /* (cout, cin) */, int cout, int cin, unsigned short* out /* cout * cin */);
 
 // nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (hrnet.py:443)
 hipError_t launch_bilinear2x(const float* in, float* out, int N, int C, int H, int W, hipStream_t s);
