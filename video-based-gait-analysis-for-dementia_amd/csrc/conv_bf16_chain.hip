@@ -765,7 +765,9 @@ __global__ __launch_bounds__(512) void conv_bf16_wide_ring(const ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wcb = wave % G::WCB, pg = wave / G::WCB;
     const int ncb = a.CoutPad / CT;
-    const int cbo = blockIdx.x % ncb, nb = blockIdx.x / ncb, n = nb / G::NB, band = nb - n * G::NB;
+    int bid = blockIdx.x;                                                           // a.xcd: consecutive tiles on ONE XCD (see conv_bf16_wide_band)
+    if (a.xcd && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int cbo = bid % ncb, nb = bid / ncb, n = nb / G::NB, band = nb - n * G::NB;
     if (n >= a.N) return;
     const int y0 = band * R;
     const unsigned char* inb = reinterpret_cast<const unsigned char*>(reinterpret_cast<const u16*>(a.in) + (size_t)n * W * W * a.in_ctot + a.in_coff);
@@ -1124,7 +1126,7 @@ hipError_t conv_bf16_chain_init() {
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_band<128, 128, 28, 14>), hipFuncAttributeMaxDynamicSharedMemorySize, WideGeom<128, 128, 28, 14>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_band<64, 64, 56, 14>), hipFuncAttributeMaxDynamicSharedMemorySize, WideGeom<64, 64, 56, 14>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_block_frame<56, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, FrameGeom<56, 8>::LDS));
-    GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_ring<128, 56, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<128, 56, 7>::LDS));
+    GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_ring<128, 56, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<128, 56, 8>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_ring<128, 28, 14>), hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<128, 28, 14>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_block_band<32, 56, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, BandGeom<32, 56, 8>::LDS));
     return hipSuccess;
@@ -1184,7 +1186,9 @@ hipError_t launch_conv_bf16_wide(const ConvArgs& a0, hipStream_t s) {
     // 1 (default): the ring of one-chunk planes; 0: the 128-channel plane refilled between passes (A/B)
     static const int ring_env = getenv("GRNET_BF16_WIDE_RING") ? atoi(getenv("GRNET_BF16_WIDE_RING")) : 1;
     if (ring_env && a.CinPad >= 64) {
-        if (a.W == 56) return launch_k(conv_bf16_wide_ring<128, 56, 7>, dim3(a.N * RingGeom<128, 56, 7>::NB * ncb), dim3(512), RingGeom<128, 56, 7>::LDS, s, a);
+        // 56x56: 8-row bands (7 per frame, 15 column tiles per wave, 244 registers) measured against 7-row ones (8 per frame): 480 -> 256 1 240 / 1 240 us,
+        // 256 -> 256 648 / 666, 128 -> 128 210 / 216 at 256 frames
+        if (a.W == 56) return launch_k(conv_bf16_wide_ring<128, 56, 8>, dim3(a.N * RingGeom<128, 56, 8>::NB * ncb), dim3(512), RingGeom<128, 56, 8>::LDS, s, a);
         return launch_k(conv_bf16_wide_ring<128, 28, 14>, dim3(a.N * RingGeom<128, 28, 14>::NB * ncb), dim3(512), RingGeom<128, 28, 14>::LDS, s, a);
     }
     if (a.W == 56) return launch_k(conv_bf16_wide_band<128, 128, 56, 7>, dim3(a.N * WideGeom<128, 128, 56, 7>::NB * ncb), dim3(512), WideGeom<128, 128, 56, 7>::LDS, s, a);
