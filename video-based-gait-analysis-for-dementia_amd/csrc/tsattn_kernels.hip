@@ -75,15 +75,19 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restr
 
 // The same attention for LONG clips, blocked (round 5).  The kernel above reads every key and value of the clip once per QUERY: at 10 000 frames that is
 // 10 000 x 4 x 2 x 10 MB = 800 GB through L2 and 107 ms -- two thirds of the temporal branch that every rank of a BASELINE configs[3] job repeats after the
-// all-gather (profiles/r05_temporal_phases.txt).  Here a workgroup owns 64 queries of one head; keys and values stream through LDS in blocks of 32
-// (read once per 64 queries), S = Q K^T and O += P V run on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products and sums), the softmax
+// all-gather (profiles/r05_temporal_phases.txt).  Here a workgroup owns 128 queries of one head (8 waves x 16); keys and values stream through LDS in blocks
+// of 32 (read once per 128 queries), S = Q K^T and O += P V run on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products and sums), the softmax
 // is the running-maximum form: per query row m <- max(m, max_j s_j), O <- O exp(m_old - m) + sum_j exp(s_j - m) v_j, l likewise, out = O / l.  Same
 // arithmetic as softmax(QK^T / sqrt(d)) V in fp32 up to the order of the sums; deterministic (no atomics, fixed order).
-// Wave w: queries 16 w .. 16 w + 15.  Row strides: 258 floats for Q / K (258 = 2 mod 32: the 16 rows x 4 columns of an MFMA operand read fall on 64
-// different banks), 272 for V (16 mod 32: 4 rows x 16 columns likewise), 34 for the wave's own P tile (written in the accumulator layout, read back as
-// the A operand of P V).  The 1 / sqrt(d) is folded into Q when it is staged.
-constexpr int kFQ = 64, kFK = 32, kFLd = 258, kFLdV = 272, kFLdP = 34;
-constexpr int kFlashLdsFloats = kFQ * kFLd + kFK * kFLd + kFK * kFLdV + 4 * 16 * kFLdP;
+// A first version (4 waves, Q in LDS, K / V block loaded between two barriers: 19.4 ms at 10 000 frames) ran the matrix cores a fifth of the time -- one wave
+// per SIMD, and nothing under the block load.  Now: the wave's Q fragment (its A operand of every S tile: 63 values per lane, 1 / sqrt(d) folded in) lives in
+// REGISTERS, which frees 66 KB of LDS for eight waves per workgroup (two per SIMD: one wave's softmax and staging under the other's MFMAs); the NEXT block of
+// K and V is requested into registers before the current block is computed and stored to LDS behind it.
+// Row strides: 258 floats for K (258 = 2 mod 32: the 16 rows x 4 columns of an MFMA operand read fall on 64 different banks), 272 for V (16 mod 32: 4 rows x
+// 16 columns likewise), 34 for the wave's own P tile (written in the accumulator layout, read back as the A operand of P V).
+constexpr int kFW = 8, kFQ = 16 * kFW, kFK = 32, kFLd = 258, kFLdV = 272, kFLdP = 34;
+constexpr int kFlashLdsFloats = kFK * kFLd + kFK * kFLdV + kFW * 16 * kFLdP;
+constexpr int kFU = kFK * (kDh / 2), kFLoads = (kFU + 64 * kFW - 1) / (64 * kFW);       // float2 units of a K (or V) block; per thread
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float group16_max(float v) {
 #pragma unroll
@@ -95,10 +99,9 @@ __device__ __forceinline__ float group16_sum(float v) {
     for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-__global__ __launch_bounds__(256) void temporal_attn_flash_kernel(const float* __restrict__ qkv, float* __restrict__ xt, int n) {
+__global__ __launch_bounds__(64 * kFW) void temporal_attn_flash_kernel(const float* __restrict__ qkv, float* __restrict__ xt, int n) {
     extern __shared__ float sm[];
-    float* Qs = sm;
-    float* Ks = Qs + kFQ * kFLd;
+    float* Ks = sm;
     float* Vs = Ks + kFK * kFLd;
     float* Ps = Vs + kFK * kFLdV + (threadIdx.x >> 6) * 16 * kFLdP;
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4, wave = tid >> 6;
@@ -106,44 +109,58 @@ __global__ __launch_bounds__(256) void temporal_attn_flash_kernel(const float* _
     const float* base = qkv + (size_t)bi * n * 3 * kE;
     const float scale = 1.0f / sqrtf((float)kDh);
     typedef float f2 __attribute__((ext_vector_type(2)));
-    // rows are 8-byte aligned (a head starts 1000 bytes into its row): float2 loads; columns 250 .. stride-1 are zero
-    for (int u = tid; u < kFQ * (kFLd / 2); u += 256) {
-        const int r = u / (kFLd / 2), c2 = u - r * (kFLd / 2);
-        f2 v = {0.f, 0.f};
-        if (c2 < kDh / 2 && q0 + r < n) v = *reinterpret_cast<const f2*>(base + (size_t)(q0 + r) * 3 * kE + (0 * kH + h) * kDh + 2 * c2);
-        *reinterpret_cast<f2*>(Qs + r * kFLd + 2 * c2) = f2{v[0] * scale, v[1] * scale};
+    // this lane's part of the wave's Q fragment: query 16 wave + l15, columns 4 j + lq (columns 250, 251: zero; queries past the clip: zero rows, never stored)
+    float qf[63];
+    {
+        const int q = q0 + wave * 16 + l15;
+        const float* qrow = base + (size_t)(q < n ? q : 0) * 3 * kE + (0 * kH + h) * kDh + lq;
+#pragma unroll
+        for (int j = 0; j < 63; ++j) qf[j] = (q < n && 4 * j + lq < kDh) ? qrow[4 * j] * scale : 0.f;
     }
+    // staging map of a K / V block: unit u = (row, float2 column); rows are 8-byte aligned (a head starts 1000 bytes into its row)
+    for (int u = tid; u < kFK * (kFLd - kDh); u += 64 * kFW) Ks[(u / (kFLd - kDh)) * kFLd + kDh + u % (kFLd - kDh)] = 0.f;      // K columns 250 .. 257: zero for good
+    for (int u = tid; u < kFK * (kFLdV - kDh); u += 64 * kFW) Vs[(u / (kFLdV - kDh)) * kFLdV + kDh + u % (kFLdV - kDh)] = 0.f;
+    f2 kreg[kFLoads], vreg[kFLoads];
+    auto request = [&](int k0) {                               // keys past the clip's end: zero rows (their scores are masked below)
+        const float* kb = base + (size_t)k0 * 3 * kE + (1 * kH + h) * kDh;
+        const float* vb = base + (size_t)k0 * 3 * kE + (2 * kH + h) * kDh;
+#pragma unroll
+        for (int i = 0; i < kFLoads; ++i) {
+            const int u = i * 64 * kFW + tid, r = u / (kDh / 2), c2 = u - r * (kDh / 2);      // (recomputed per block: eight registers matter here)
+            const bool ok = u < kFU && k0 + r < n;
+            kreg[i] = ok ? *reinterpret_cast<const f2*>(kb + r * 3 * kE + 2 * c2) : f2{0.f, 0.f};
+            vreg[i] = ok ? *reinterpret_cast<const f2*>(vb + r * 3 * kE + 2 * c2) : f2{0.f, 0.f};
+        }
+    };
+    auto deposit = [&]() {
+#pragma unroll
+        for (int i = 0; i < kFLoads; ++i)
+            if (i * 64 * kFW + tid < kFU) {
+                const int u = i * 64 * kFW + tid, r = u / (kDh / 2), c2 = u - r * (kDh / 2);
+                *reinterpret_cast<f2*>(Ks + r * kFLd + 2 * c2) = kreg[i];
+                *reinterpret_cast<f2*>(Vs + r * kFLdV + 2 * c2) = vreg[i];
+            }
+    };
     float m_run[4], l_run[4];
     f32x4_t O[16];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { m_run[r] = -INFINITY; l_run[r] = 0.f; }
 #pragma unroll
     for (int dt = 0; dt < 16; ++dt) O[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const float* qrow = Qs + (wave * 16 + l15) * kFLd + lq;
+    request(0);
+    deposit();
     for (int k0 = 0; k0 < n; k0 += kFK) {
-        __syncthreads();                                       // the previous block's K / V have been read (first pass: Q is being staged)
-        for (int u = tid; u < kFK * (kFLd / 2); u += 256) {
-            const int r = u / (kFLd / 2), c2 = u - r * (kFLd / 2);
-            f2 kv = {0.f, 0.f};
-            if (c2 < kDh / 2 && k0 + r < n) kv = *reinterpret_cast<const f2*>(base + (size_t)(k0 + r) * 3 * kE + (1 * kH + h) * kDh + 2 * c2);
-            *reinterpret_cast<f2*>(Ks + r * kFLd + 2 * c2) = kv;
-        }
-        for (int u = tid; u < kFK * (kFLdV / 2); u += 256) {
-            const int r = u / (kFLdV / 2), c2 = u - r * (kFLdV / 2);
-            f2 vv = {0.f, 0.f};
-            if (c2 < kDh / 2 && k0 + r < n) vv = *reinterpret_cast<const f2*>(base + (size_t)(k0 + r) * 3 * kE + (2 * kH + h) * kDh + 2 * c2);
-            *reinterpret_cast<f2*>(Vs + r * kFLdV + 2 * c2) = vv;
-        }
-        __syncthreads();
+        __syncthreads();                                       // block k0 is in LDS
+        if (k0 + kFK < n) request(k0 + kFK);                   // the next block: in flight under this block's MFMAs
         // S (16 queries x 32 keys) = Q K^T: 63 k-steps of 4 (columns 250, 251 are zeros)
         f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
         const float* k0row = Ks + l15 * kFLd + lq;
         const float* k1row = Ks + (16 + l15) * kFLd + lq;
-#pragma unroll 9
-        for (int d0 = 0; d0 < 252; d0 += 4) {
-            const float a = qrow[d0];
-            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, k0row[d0], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, k1row[d0], s1, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 63; ++j) {
+            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j], k0row[4 * j], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j], k1row[4 * j], s1, 0, 0, 0);
+            if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);   // operand reads are hoisted at most 4 steps (8 registers) ahead, not 63
         }
         // lane: rows (queries) 4 lq + r, column (key) l15 of each tile; keys past the clip's end are -inf
         const bool in0 = k0 + l15 < n, in1 = k0 + 16 + l15 < n;
@@ -170,7 +187,10 @@ __global__ __launch_bounds__(256) void temporal_attn_flash_kernel(const float* _
             const float* vrow = Vs + (kk * 4 + lq) * kFLdV + l15;
 #pragma unroll
             for (int dt = 0; dt < 16; ++dt) O[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vrow[dt * 16], O[dt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);                 // (one k-step's 16 V reads in flight, not all eight)
         }
+        __syncthreads();                                       // every wave has read block k0
+        if (k0 + kFK < n) deposit();
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -220,12 +240,27 @@ __global__ __launch_bounds__(256) void spatial_attn_kernel(const float* __restri
 }
 
 // mean over the n frames of a clip of [x_t | x_s]  -> (b, 2000).  attention_utils.py:183-184.
-__global__ __launch_bounds__(256) void gate_mean_kernel(const float* __restrict__ xt, const float* __restrict__ xs, float* __restrict__ mean, int n) {
-    const int e = blockIdx.x * 256 + threadIdx.x, bi = blockIdx.y;
+// Two launches: partial sums over blocks of kMeanRows frames (grid z), then the partials in a fixed order -- one workgroup column per clip walked all
+// 10 000 frames of a configs[3] job by itself (8 workgroups, 3.7 ms for 80 MB; now ~0.1 ms).  Deterministic: no atomics.
+constexpr int kMeanRows = 128;
+__global__ __launch_bounds__(256) void gate_mean_partial_kernel(const float* __restrict__ xt, const float* __restrict__ xs, float* __restrict__ part, int n, int nblk) {
+    const int e = blockIdx.x * 256 + threadIdx.x, bi = blockIdx.y, blk = blockIdx.z;
     if (e >= 2 * kE) return;
     const float* src = (e < kE ? xt : xs) + (size_t)bi * n * kE + (e < kE ? e : e - kE);
+    const int i0 = blk * kMeanRows, i1 = min(n, i0 + kMeanRows);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = i0;
+    for (; i + 4 <= i1; i += 4) {
+        s0 += src[(size_t)i * kE]; s1 += src[(size_t)(i + 1) * kE]; s2 += src[(size_t)(i + 2) * kE]; s3 += src[(size_t)(i + 3) * kE];
+    }
+    for (; i < i1; ++i) s0 += src[(size_t)i * kE];
+    part[((size_t)bi * nblk + blk) * 2 * kE + e] = (s0 + s1) + (s2 + s3);
+}
+__global__ __launch_bounds__(256) void gate_mean_final_kernel(const float* __restrict__ part, float* __restrict__ mean, int n, int nblk) {
+    const int e = blockIdx.x * 256 + threadIdx.x, bi = blockIdx.y;
+    if (e >= 2 * kE) return;
     float s = 0.f;
-    for (int i = 0; i < n; ++i) s += src[(size_t)i * kE];
+    for (int k = 0; k < nblk; ++k) s += part[((size_t)bi * nblk + k) * 2 * kE + e];
     mean[(size_t)bi * 2 * kE + e] = s / (float)n;
 }
 
@@ -361,12 +396,16 @@ hipError_t launch_tsattn(const float* x, const float* xs, const TsAttnWeights& w
         GRK_TRY(once_per_device(fattr, dev, [](int*) {
             return hipFuncSetAttribute(reinterpret_cast<const void*>(temporal_attn_flash_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kFlashLdsFloats * sizeof(float)));
         }));
-        GRK_TRY(launch_k(temporal_attn_flash_kernel, dim3((n + kFQ - 1) / kFQ, kH, b), dim3(256), kFlashLdsFloats * sizeof(float), s, (const float*)qkv_t, xt, n));
+        GRK_TRY(launch_k(temporal_attn_flash_kernel, dim3((n + kFQ - 1) / kFQ, kH, b), dim3(64 * kFW), kFlashLdsFloats * sizeof(float), s, (const float*)qkv_t, xt, n));
     } else {
         GRK_TRY(launch_k(temporal_attn_kernel, dim3(n, kH, b), dim3(256), attn_lds, s, qkv_t, xt, n));
     }
     GRK_TRY(launch_k(spatial_attn_kernel, dim3((unsigned)R, kH), dim3(256), 0, s, qkv_s, xsp));
-    GRK_TRY(launch_k(gate_mean_kernel, dim3((2 * kE + 255) / 256, b), dim3(256), 0, s, xt, xsp, mean, n));
+    {   // partial sums in yt (free until the fc_t GEMM writes it: nblk x 2000 <= n x 3072 floats per clip)
+        const int nblk = (n + kMeanRows - 1) / kMeanRows;
+        GRK_TRY(launch_k(gate_mean_partial_kernel, dim3((2 * kE + 255) / 256, b, nblk), dim3(256), 0, s, (const float*)xt, (const float*)xsp, yt, n, nblk));
+        GRK_TRY(launch_k(gate_mean_final_kernel, dim3((2 * kE + 255) / 256, b), dim3(256), 0, s, (const float*)yt, mean, n, nblk));
+    }
     GRK_TRY(launch_gemm_nt_bias(mean, w.ts_w, w.ts_b, logits, b, 2 * kE, 2 * kE, 2 * kE, s));
     const long total = (long)R * kE;
     GRK_TRY(launch_k(gate_apply_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, s, logits, xt, xsp, n, total));
