@@ -61,7 +61,7 @@ def parse_args(argv=None):
                     "batchgen: BASELINE configs[3] -- ONE job of --total-frames frames sharded over the GPUs in calls of <= --chunk frames, one all-gather of the "
                     "per-frame records, then the temporal branch (GRU + attention + second head pass) on the whole sequence; a step is the whole job (strong scaling)")
     ap.add_argument("--total-frames", type=int, default=10000, help="batchgen: frames of the whole job")
-    ap.add_argument("--chunk", type=int, default=128, help="batchgen: frames per grnet_forward call")
+    ap.add_argument("--chunk", type=int, default=400, help="batchgen: frames per grnet_forward call (400 = the reference's MAX_seqlen, batch_generation.py:34,303: it feeds a video in calls of >= 400 frames)")
     ap.add_argument("--tracks", type=int, default=4, help="tracks: person tracks per GPU")
     ap.add_argument("--track-frames", type=int, default=64, help="tracks: frames per track")
     ap.add_argument("--call-frames", type=int, default=None, help="tracks: frames per forward call (default: all tracks of a step in ONE call; --track-frames = one call per track)")
@@ -631,7 +631,7 @@ def secondary_legs(args):
     a2 = copy.copy(base)
     a2.dtype, a2.frames, a2.steps, a2.warmup = "bf16", 256, 20, 5
     a3 = copy.copy(base)
-    a3.workload, a3.dtype, a3.steps, a3.warmup, a3.total_frames, a3.chunk = "batchgen", "f32", 2, 1, 10000, 128
+    a3.workload, a3.dtype, a3.steps, a3.warmup, a3.total_frames, a3.chunk = "batchgen", "f32", 2, 1, 10000, 400
     a4 = copy.copy(base)
     a4.workload, a4.dtype, a4.steps, a4.warmup, a4.tracks, a4.track_frames, a4.call_frames, a4.no_overlap = "tracks", "bf16", 30, 5, 4, 64, None, False
     return [leg(GpuWorkload, a2, 256, "frames/sec (224x224, 8 clips x seq=32)"),

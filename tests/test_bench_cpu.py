@@ -118,7 +118,7 @@ def test_workload_defaults():
     a = bench.parse_args([])
     assert (a.workload, a.dtype, a.steps, a.warmup, a.frames) == ("clip", "f32", 300, 20, 16)
     a = bench.parse_args(["--workload", "batchgen"])
-    assert (a.dtype, a.steps, a.warmup, a.total_frames, a.chunk) == ("f32", 3, 1, 10000, 128)
+    assert (a.dtype, a.steps, a.warmup, a.total_frames, a.chunk) == ("f32", 3, 1, 10000, 400)      # 400 = the reference's MAX_seqlen (batch_generation.py:34)
     a = bench.parse_args(["--workload", "tracks"])
     assert (a.dtype, a.steps, a.warmup, a.tracks, a.track_frames, a.call_frames) == ("bf16", 30, 5, 4, 64, None)
     assert bench.parse_args(["--workload", "tracks", "--dtype", "f32"]).dtype == "f32"

@@ -11,3 +11,4 @@ timeout 600 python bench.py --workload tracks > $D/bench_tracks_n1.json 2> $D/be
 GRNET_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 30 --warmup 5 > $D/bench_gpus2_gloo.json 2> $D/bench_gpus2_gloo.err
 GRNET_BENCH_BACKEND=gloo timeout 600 python bench.py --workload batchgen --gpus 2 --total-frames 2000 > $D/bench_batchgen_gpus2_gloo.json 2> $D/bench_batchgen_gpus2_gloo.err
 tail -4 $D/pytest_gpu.log; tail -7 $D/smoke.log; for f in bench bench_batchgen_n1 bench_tracks_n1 bench_gpus2_gloo bench_batchgen_gpus2_gloo; do tail -1 $D/$f.json | cut -c1-260; done
+python tools/temporal_phases.py 10000 > $D/temporal_phases.txt 2>&1; python tools/temporal_phases.py 450 >> $D/temporal_phases.txt 2>&1; cat $D/temporal_phases.txt
