@@ -1181,6 +1181,7 @@ hipError_t launch_conv_bf16_wide(const ConvArgs& a0, hipStream_t s) {
 #ifdef GRNET_ABLATION
     a.dbg = getenv("GRNET_WIDE_DBG") ? atoi(getenv("GRNET_WIDE_DBG")) : 0;
 #endif
+    // (64 -> 64 on the ring kernel -- 7-row bands, two chunks: the second streams under the first -- measured 93 us against the band kernel's 79: stays here)
     if (a.CinPad == 64) return launch_k(conv_bf16_wide_band<64, 64, 56, 14>, dim3(a.N * WideGeom<64, 64, 56, 14>::NB), dim3(512), WideGeom<64, 64, 56, 14>::LDS, s, a);
     const int ncb = a.CoutPad / 128;
     // 1 (default): the ring of one-chunk planes; 0: the 128-channel plane refilled between passes (A/B)
