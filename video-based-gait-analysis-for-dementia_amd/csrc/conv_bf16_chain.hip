@@ -491,6 +491,7 @@ __global__ __launch_bounds__(512) void conv_bf16_block_frame(const ChainArgs a) 
         b2[cs] = *reinterpret_cast<const f32x4*>(a.bias[1] + co + cs * 16);
     }
     if (NB > 1) request(R);                                    // behind the bias loads: waiting for those must not mean waiting for these
+    const bool direct_store = !(a.flags & 1);
 
 #pragma unroll 1
     for (int band = 0; band < NB; ++band) {
@@ -524,6 +525,25 @@ __global__ __launch_bounds__(512) void conv_bf16_block_frame(const ChainArgs a) 
             }
         lds_barrier();
         chain_kloop_ldsw<P, SB, CS, PS>(acc, bread, wl1);
+        // the block's output rows leave straight from the accumulators (round 5: was in place through the plane, a barrier, then 16-byte stores): 8 bytes per lane, the
+        // four k-groups of a pixel make 32 contiguous bytes, the two channel blocks its 64-byte row; nothing of this band's output is needed in LDS again
+        if (direct_store) {
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps) {
+                int of = o_first;
+                asm volatile("" : "+v"(of));                   // (tile-independent pixel offsets: not to be hoisted out of the band loop into 2 x PS registers)
+                const int o = of + ps * 16, r = o / P, x = o - r * P - 1;
+                u16* op = outb + ((size_t)(y0 + r - 2) * W + x) * a.out_ctot + lq * 4;
+#pragma unroll
+                for (int cs = 0; cs < CS; ++cs) {
+                    const f32x4 v = acc[cs][ps];
+                    if (valid2 & (1u << ps)) *reinterpret_cast<u32x2*>(op + cs * 16) = u32x2{pack2_c(relu_c(v[0]), relu_c(v[1])), pack2_c(relu_c(v[2]), relu_c(v[3]))};
+                }
+            }
+            // in order: everything older than this band's CS x PS stores -- the next band's DMAs, issued a whole band ago -- has landed (stores in the queue can only make
+            // the count stricter)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CS * PS) : "memory");
+        } else {
         lds_barrier();
 #pragma unroll
         for (int ps = 0; ps < PS; ++ps)
@@ -542,6 +562,7 @@ __global__ __launch_bounds__(512) void conv_bf16_block_frame(const ChainArgs a) 
             const int u = i * 512 + tid, r = u / UR, q = u - r * UR, x = q / UPP, part = q - x * UPP;
             if (u < R * UR)
                 *reinterpret_cast<u32x4*>(outb + ((size_t)(y0 + r) * W + x) * a.out_ctot + part * 8) = *reinterpret_cast<const u32x4*>(plane + ((r + 2) * P + x + 1) * SB + part * 16);
+        }
         }
         if (band + 1 < NB) {
             lds_barrier();                                     // the band's rows have been read out of the plane
@@ -1152,6 +1173,8 @@ hipError_t launch_conv_bf16_chain(const ChainArgs& a, int c, int w, hipStream_t 
                 b.out = a.mid[k]; b.out_ctot = a.mid_ctot[k]; b.out_coff = a.mid_coff[k];
             } else { b.out = a.out; b.out_ctot = a.out_ctot; b.out_coff = a.out_coff; }
             // 0 (default): workgroup = frame, seven bands of 8 rows, the next band by LDS-DMA under the current band's MFMAs; 19: workgroup = band, one per CU; 8: two per CU
+            static const int frame_direct = getenv("GRNET_BF16_FRAME_DIRECT") ? atoi(getenv("GRNET_BF16_FRAME_DIRECT")) : 1;
+            b.flags = frame_direct ? 0 : 1;
             static const int band_rows = getenv("GRNET_BF16_BAND") ? atoi(getenv("GRNET_BF16_BAND")) : 0;
             if (band_rows == 0) GRK_TRY(launch_k(conv_bf16_block_frame<56, 8>, dim3(a.N), dim3(512), FrameGeom<56, 8>::LDS, s, b));
             else if (band_rows == 19) GRK_TRY(launch_k(conv_bf16_block_band<32, 56, 19, 2>, dim3(a.N * BandGeom<32, 56, 19>::NB), dim3(512), BandGeom<32, 56, 19>::LDS, s, b));

@@ -284,6 +284,7 @@ struct ChainArgs {
     const float* bias[kMaxChain];               // fp32 [C]
     void* mid[kMaxChain / 2 - 1];               // (32, 56) only -- one band-resident launch per BasicBlock: the output of block k < nconv/2 - 1
     int mid_ctot[kMaxChain / 2 - 1], mid_coff[kMaxChain / 2 - 1];
+    int flags = 0;                                   // bit 0 (conv_bf16_block_frame): the block's output through the plane + 16-byte stores instead of straight from the accumulators (A/B)
 };
 int conv_bf16_chain_launches(int c, int w, int nconv);
 hipError_t conv_bf16_chain_init();
