@@ -484,6 +484,11 @@ __global__ __launch_bounds__(512) void conv_bf16_block_frame(const ChainArgs a) 
     const unsigned char* wl0 = wlds + l15 * 64 + ((lq ^ (((l15 >> 3) & 1) << 1)) * 16);
     const unsigned char* wl1 = wl0 + 9 * C * 64;
     const int co = lq * 4;
+    // conv2 needs rows 2 .. R + 1 of the plane only (conv1: rows 1 .. R + 2): its own, shorter tile run -- PS2 = 4 column tiles per wave from slot 2 P + 1 on
+    // instead of conv1's PS = 5 from P + 1 on (a fifth of conv2's MFMAs and fragment reads computed rows nobody stores)
+    constexpr int NOUT2 = R * P - 1, PS2 = ((NOUT2 + 15) / 16 + 7) / 8;
+    const int o2_first = 2 * P + 1 + wave * PS2 * 16 + l15;
+    const unsigned char* bread2 = plane + (o2_first - P - 1) * SB + lq * 16;
     f32x4 b1[CS], b2[CS];
 #pragma unroll
     for (int cs = 0; cs < CS; ++cs) {
@@ -510,6 +515,50 @@ __global__ __launch_bounds__(512) void conv_bf16_block_frame(const ChainArgs a) 
 #pragma unroll
             for (int ps = 0; ps < PS; ++ps) acc[cs][ps] = b1[cs];
         chain_kloop_ldsw<P, SB, CS, PS>(acc, bread, wl0);
+        if (direct_store) {
+            // conv2's accumulators start from x + bias2, read at conv2's OWN columns while the plane still holds x (nobody has written yet)
+            f32x4 acc2[CS][PS2];
+            unsigned v2 = 0;
+#pragma unroll
+            for (int ps = 0; ps < PS2; ++ps) {
+                const int o = o2_first + ps * 16, r = o / P, y = y0 - 2 + r;
+                if (o - r * P != 0 && r >= 2 && r <= R + 1 && y >= 0 && y < W) v2 |= 1u << ps;
+#pragma unroll
+                for (int cs = 0; cs < CS; ++cs) {
+                    const u32x2 rr = *reinterpret_cast<const u32x2*>(plane + (o2_first + ps * 16) * SB + lq * 8 + cs * 32);
+                    f32x4 nx = b2[cs];
+                    nx[0] += bf_lo(rr[0]); nx[1] += bf_hi(rr[0]); nx[2] += bf_lo(rr[1]); nx[3] += bf_hi(rr[1]);
+                    acc2[cs][ps] = nx;
+                }
+            }
+            lds_barrier();                                     // every wave has read what it needs of x
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps)
+#pragma unroll
+                for (int cs = 0; cs < CS; ++cs) {
+                    const f32x4 v = acc[cs][ps];
+                    if (valid1 & (1u << ps)) *reinterpret_cast<u32x2*>(owrite + ps * 16 * SB + cs * 32) = u32x2{pack2_c(relu_c(v[0]), relu_c(v[1])), pack2_c(relu_c(v[2]), relu_c(v[3]))};
+                }
+            lds_barrier();
+            chain_kloop_ldsw<P, SB, CS, PS2>(acc2, bread2, wl1);
+            // the block's output rows leave straight from the accumulators (round 5: was in place through the plane, a barrier, then 16-byte stores): 8 bytes per lane, the
+            // four k-groups of a pixel make 32 contiguous bytes, the two channel blocks its 64-byte row; nothing of this band's output is needed in LDS again
+#pragma unroll
+            for (int ps = 0; ps < PS2; ++ps) {
+                int of = o2_first;
+                asm volatile("" : "+v"(of));                   // (tile-independent pixel offsets: not to be hoisted out of the band loop into 2 x PS registers)
+                const int o = of + ps * 16, r = o / P, x = o - r * P - 1;
+                u16* op = outb + ((size_t)(y0 + r - 2) * W + x) * a.out_ctot + lq * 4;
+#pragma unroll
+                for (int cs = 0; cs < CS; ++cs) {
+                    const f32x4 v = acc2[cs][ps];
+                    if (v2 & (1u << ps)) *reinterpret_cast<u32x2*>(op + cs * 16) = u32x2{pack2_c(relu_c(v[0]), relu_c(v[1])), pack2_c(relu_c(v[2]), relu_c(v[3]))};
+                }
+            }
+            // in order: everything older than this band's CS x PS2 stores -- the next band's DMAs, issued a whole band ago -- has landed (stores in the queue can only make
+            // the count stricter)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CS * PS2) : "memory");
+        } else {
         lds_barrier();
 #pragma unroll
         for (int ps = 0; ps < PS; ++ps)
@@ -525,25 +574,6 @@ __global__ __launch_bounds__(512) void conv_bf16_block_frame(const ChainArgs a) 
             }
         lds_barrier();
         chain_kloop_ldsw<P, SB, CS, PS>(acc, bread, wl1);
-        // the block's output rows leave straight from the accumulators (round 5: was in place through the plane, a barrier, then 16-byte stores): 8 bytes per lane, the
-        // four k-groups of a pixel make 32 contiguous bytes, the two channel blocks its 64-byte row; nothing of this band's output is needed in LDS again
-        if (direct_store) {
-#pragma unroll
-            for (int ps = 0; ps < PS; ++ps) {
-                int of = o_first;
-                asm volatile("" : "+v"(of));                   // (tile-independent pixel offsets: not to be hoisted out of the band loop into 2 x PS registers)
-                const int o = of + ps * 16, r = o / P, x = o - r * P - 1;
-                u16* op = outb + ((size_t)(y0 + r - 2) * W + x) * a.out_ctot + lq * 4;
-#pragma unroll
-                for (int cs = 0; cs < CS; ++cs) {
-                    const f32x4 v = acc[cs][ps];
-                    if (valid2 & (1u << ps)) *reinterpret_cast<u32x2*>(op + cs * 16) = u32x2{pack2_c(relu_c(v[0]), relu_c(v[1])), pack2_c(relu_c(v[2]), relu_c(v[3]))};
-                }
-            }
-            // in order: everything older than this band's CS x PS stores -- the next band's DMAs, issued a whole band ago -- has landed (stores in the queue can only make
-            // the count stricter)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CS * PS) : "memory");
-        } else {
         lds_barrier();
 #pragma unroll
         for (int ps = 0; ps < PS; ++ps)
