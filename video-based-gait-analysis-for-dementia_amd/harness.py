@@ -262,7 +262,8 @@ class ClipRunner:
 class ShardedSequenceRunner:
     """BASELINE configs[3] as one job: a sequence of ``n_total`` frames (a 10 000-frame video directory) sharded over the ranks
     (shard_range: ceil(n/world) frames each), every rank running the per-frame path on its shard in calls of <= ``chunk`` frames
-    (batch_generation.py:289-329; 128 is where the kernels are efficient and what --max_frames sizes the activation arena for),
+    (batch_generation.py:289-329; the reference feeds a video in calls of >= 400 frames -- MAX_seqlen, batch_generation.py:34,303 -- and bench.py / batch_generation.py
+    here default to 400: 5 800 / 5 880 / 5 930 frames/s at 128 / 256 / 400 frames per call; --max_frames sizes the activation arena for it),
     ONE all-gather of the per-frame records (theta, kp_3d, kp_2d, point_local_feat, cam_shape_feats: 19.4 KB per frame, written by
     the kernels straight into the send block -- every call's output pointers aim at its frames' slots, no packing kernel), then
     the temporal branch (grnet.py:154-173: cparams, GRU gait encoder, corrector + attention block, second head pass) on the whole
