@@ -296,3 +296,20 @@ def test_bf16_fuse_layer_launch_count_and_macs(fmodel):
     left = [c for c in convs if c["ks"] == 1 and "fuse_layers" in c["name"] and c["cin"]]
     assert len(left) == (0 if fmodel.fuse_mode == 1 else 13)
     assert not any("fuse_layers.0." in c["name"] for c in left)
+
+
+def test_blocked_temporal_attention_two_clips_ragged_blocks(pkg, oracle):
+    """temporal_attn_flash_kernel (clips >= 1 024 frames: 128 queries per workgroup, keys / values in blocks of 32, Q fragment in registers, next block in
+    flight) on TWO clips of 1 100 frames -- a last query block of 76 rows (4.75 waves) and a last key block of 12 -- and the two-stage frame mean of the gate
+    (9 partial blocks of 128 frames): the whole attention block against the oracle, each clip also alone (clips must not see each other)."""
+    from .conftest import rel_err
+    m = pkg.build_synthetic_model(max_frames=2, with_gru=True, with_tsattn=True, use_gait_feat=False)
+    tsd = pkg.synth.make_tsattn_state_dict()
+    x, xs = pkg.synth.make_tsattn_inputs(2, 1100)
+    xd, xsd = torch.from_numpy(x).cuda(), torch.from_numpy(xs).cuda()
+    y = m.tsattn_forward(xd, xsd).cpu().numpy()
+    ref = oracle.ts_attn_block(x, xs, tsd)
+    assert y.shape == ref.shape and rel_err(y, ref) < 5e-5, rel_err(y, ref)
+    y1 = m.tsattn_forward(xd[1:2], xsd[1:2]).cpu().numpy()
+    assert np.array_equal(y1[0], y[1])
+    m.close()
