@@ -693,6 +693,9 @@ __global__ __launch_bounds__(256) void fuse_sum_bf16_kernel(const SumArgs a) {
     }
 }
 
+// (attn_pool_bf16x_kernel below is the form that runs since round 5: the same workgroup, but the GEMM on the bf16 matrix cores -- the probabilities as hi + lo bf16 pairs,
+// the features transposed out of their NHWC rows by ds_read_b64_tr_b16 -- and the range's features requested at once: 254 -> 171 us at 256 frames, results equal to 1e-6.
+// This fp32-MFMA form stays as the A/B reference, GRNET_BF16_POOL_X16=0.)
 // Attention pooling on NHWC bf16 maps (keypoint_attention.py:42-48): per frame the GEMM out[c][j] = sum_p feat[p][c] * prob[p][j] on the
 // fp32 matrix cores, the structure of the fp32 path's attn_pool_kernel (head_kernels.hip): workgroup = (frame, 96 channels, one of
 // kPoolSplit position ranges) = 6 waves; the range's exp(h - range max) is built once per workgroup in LDS (fp32) and the softmax over
@@ -781,6 +784,113 @@ __global__ __launch_bounds__(384) void attn_pool_bf16_kernel(const u16* __restri
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(f, u[k], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f, v[k], acc1, 0, 0, 0);
             }
+        }
+    }
+    const int ct = blockIdx.y * 6 + wv;
+    float* o = part + (((size_t)n * kPoolSplit + blockIdx.z) * (CA + CB) + ct * 16 + 4 * lq) * 24;      // [n][split][192][24]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        o[r * 24 + l15] = acc0[r];
+        if (l15 < 8) o[r * 24 + 16 + l15] = acc1[r];
+    }
+}
+
+__global__ __launch_bounds__(384) void attn_pool_bf16x_kernel(const u16* __restrict__ heat, int hc, const u16* __restrict__ featA, int CA, int ctA,
+                                                               const u16* __restrict__ featB, int CB, int ctB, float* __restrict__ stats,
+                                                               float* __restrict__ part, int P) {
+    __shared__ __align__(16) float prob[24 * kPoolStrideB];
+    __shared__ __align__(16) u16 fst[2][kPoolPB * kPoolFS];    // two buffers of 64 positions x 96 channels, as they lie in memory (NHWC); 70 KB of LDS in all
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int pbeg = blockIdx.z * kPoolChunkB, cb = blockIdx.y * 96;      // first channel of this workgroup in [featA | featB]
+    // staging: 64 positions x 12 units of 16 bytes = two units per thread (positions spp and spp + 32); a unit lies entirely in featA or in featB
+    // (128 = 8 x 16).  Round 5: 64 instead of 32 positions per barrier -- the loop is a chain of load -> LDS -> barrier -> 16 MFMAs round trips
+    const int spp = tid / 12, sq = tid - spp * 12, sc = cb + sq * 8;
+    const u16* ssrc = sc < CA ? featA + ((size_t)n * P + pbeg + spp) * ctA + sc : featB + ((size_t)n * P + pbeg + spp) * ctB + (sc - CA);
+    const size_t sstride = sc < CA ? ctA : ctB;
+    // the range's 448 positions x 96 channels (86 KB) are requested AT ONCE, 14 16-byte units per thread, and wait in registers under the softmax below; the loop
+    // only moves them to LDS one 64-position block ahead (with the bf16 matrix cores a block is 8 MFMAs per wave: a block-ahead request would wait for HBM every time)
+    constexpr int NBLK = kPoolChunkB / kPoolPB;
+    u32x4 fv[2 * NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+        fv[2 * b] = *reinterpret_cast<const u32x4*>(ssrc + (size_t)(b * kPoolPB) * sstride);
+        fv[2 * b + 1] = *reinterpret_cast<const u32x4*>(ssrc + (size_t)(b * kPoolPB + 32) * sstride);
+    }
+    auto deposit = [&](int b, int buf) {
+        *reinterpret_cast<u32x4*>(&fst[buf][spp * kPoolFS + sq * 8]) = fv[2 * b];
+        *reinterpret_cast<u32x4*>(&fst[buf][(spp + 32) * kPoolFS + sq * 8]) = fv[2 * b + 1];
+    };
+    // heat rows of the range -> LDS: thread = (position, 8 joints)
+    for (int u = tid; u < kPoolChunkB * 3; u += 384) {
+        const int p = u / 3, jg = u - p * 3;
+        const u32x4 h8 = *reinterpret_cast<const u32x4*>(heat + ((size_t)n * P + pbeg + p) * hc + jg * 8);      // channels 8 jg .. 8 jg + 7 (channel 0 = background)
+        const u16 nx = heat[((size_t)n * P + pbeg + p) * hc + jg * 8 + 8];                                          // channel 8 jg + 8 = joint 8 jg + 7
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int ch = k + 1;                                                                                   // joint 8 jg + k is channel 8 jg + k + 1
+            const u16 v = ch < 8 ? (u16)(h8[ch >> 1] >> (16 * (ch & 1))) : nx;
+            prob[(jg * 8 + k) * kPoolStrideB + p] = bf2f(v);
+        }
+    }
+    __syncthreads();
+    for (int j = (tid >> 6) * 4; j < (tid >> 6) * 4 + 4; ++j) {
+        float* row = prob + j * kPoolStrideB;
+        float hv[kPoolChunkB / 64], m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < kPoolChunkB / 64; ++i) { hv[i] = row[lane + 64 * i]; m = fmaxf(m, hv[i]); }
+        m = wave_max_b(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < kPoolChunkB / 64; ++i) { hv[i] = expf(hv[i] - m); sum += hv[i]; }
+        sum = wave_sum_b(sum);
+        // the row in place as TWO bf16 rows: e = hi + lo (hi = bf16(e), lo = bf16(e - hi): 16 bits of mantissa, 2^-17 relative) -- [hi 448][lo 448] in the 452 floats
+        // of the fp32 row; every lane holds its 7 values, and the wave (one row at a time) has read the whole row before it writes
+        {
+            u16* hrow = reinterpret_cast<u16*>(row);
+#pragma unroll
+            for (int i = 0; i < kPoolChunkB / 64; ++i) {
+                const unsigned hb = __float_as_uint(hv[i]) + 0x7fffu + ((__float_as_uint(hv[i]) >> 16) & 1u);
+                const float hf = __uint_as_float(hb & 0xffff0000u), lf = hv[i] - hf;
+                const unsigned lb = __float_as_uint(lf) + 0x7fffu + ((__float_as_uint(lf) >> 16) & 1u);
+                hrow[lane + 64 * i] = (u16)(hb >> 16);
+                hrow[kPoolChunkB + lane + 64 * i] = (u16)(lb >> 16);
+            }
+        }
+        if (lane == 0 && blockIdx.y == 0) {
+            float* st = stats + (((size_t)n * kPoolSplit + blockIdx.z) * 24 + j) * 2;      // [n][range][joint][max, sum]
+            st[0] = m;
+            st[1] = sum;
+        }
+    }
+    const int wv = tid >> 6;                                            // row tile of this wave: channels cb + 16 wv .. + 15
+    // bf16 matrix cores: out[c][j] += sum over 32 positions of feat[p][c] * (hi + lo)[j][p] -- products of bf16 pairs are exact in fp32, the sums fp32 as before.
+    // A (channels x positions) comes TRANSPOSED out of the staged NHWC rows: ds_read_b64_tr_b16 hands lane i of a 16-lane group channel i of four positions
+    // (lane 4q + p supplies row q, channels 4p .. 4p + 3), two of them make the lane's 8 positions of the k-step; B (joints x positions) is 16 contiguous bytes
+    // of the joint's hi / lo row.  4 MFMAs (16 cycles) per 32 positions instead of 16 fp32 ones (32 cycles).
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __bf16 bf16x8p __attribute__((ext_vector_type(8)));
+    const unsigned char* pb0 = reinterpret_cast<const unsigned char*>(prob) + (size_t)l15 * kPoolStrideB * 4 + lq * 16;                // joints 0 .. 15
+    const unsigned char* pb1 = reinterpret_cast<const unsigned char*>(prob) + (size_t)(16 + (l15 & 7)) * kPoolStrideB * 4 + lq * 16;    // joints 16 .. 23 (lanes 8 .. 15: copies, columns never stored)
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    deposit(0, 0);
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+        const int buf = b & 1, p0 = b * kPoolPB;
+        __syncthreads();                                                // buffer `buf` is staged (and the probabilities are final); the other one is free
+        if (b + 1 < NBLK) deposit(b + 1, buf ^ 1);
+        const u16* fs = &fst[buf][(8 * lq + (l15 >> 2)) * kPoolFS + wv * 16 + 4 * (l15 & 3)];
+#pragma unroll
+        for (int g = 0; g < kPoolPB / 32; ++g) {
+            const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(fs + (32 * g) * kPoolFS));
+            const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(fs + (32 * g + 4) * kPoolFS));
+            const bf16x8p af = __builtin_bit_cast(bf16x8p, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+            const int pe = (p0 + 32 * g) * 2;
+            const bf16x8p h0 = *reinterpret_cast<const bf16x8p*>(pb0 + pe), l0 = *reinterpret_cast<const bf16x8p*>(pb0 + kPoolChunkB * 2 + pe);
+            const bf16x8p h1 = *reinterpret_cast<const bf16x8p*>(pb1 + pe), l1 = *reinterpret_cast<const bf16x8p*>(pb1 + kPoolChunkB * 2 + pe);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, h0, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, l0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, h1, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, l1, acc1, 0, 0, 0);
         }
     }
     const int ct = blockIdx.y * 6 + wv;
@@ -971,6 +1081,10 @@ hipError_t launch_softmax_pool_bf16(const void* heat, int hc, const void* featA,
                                     int P, hipStream_t s) {
     if (CA != 128 || CB != 64 || P != kPoolChunkB * kPoolSplit || hc < 32 || hc % 8 != 0 || ctA % 8 != 0 || ctB % 8 != 0) return hipErrorInvalidValue;
     float* part = pool_ws + (size_t)N * kPoolStatsFloats;
+    const int x16 = getenv("GRNET_BF16_POOL_X16") ? atoi(getenv("GRNET_BF16_POOL_X16")) : 1;     // 0: the fp32-MFMA form (A/B; read per launch)
+    if (x16)
+        return launch_k(attn_pool_bf16x_kernel, dim3(N, (CA + CB) / 96, kPoolSplit), dim3(384), 0, s, reinterpret_cast<const u16*>(heat), hc, reinterpret_cast<const u16*>(featA),
+                        CA, ctA, reinterpret_cast<const u16*>(featB), CB, ctB, pool_ws, part, P);
     return launch_k(attn_pool_bf16_kernel, dim3(N, (CA + CB) / 96, kPoolSplit), dim3(384), 0, s, reinterpret_cast<const u16*>(heat), hc, reinterpret_cast<const u16*>(featA),
                     CA, ctA, reinterpret_cast<const u16*>(featB), CB, ctB, pool_ws, part, P);
 }
