@@ -124,8 +124,11 @@ __device__ __forceinline__ void chain_kloop(f32x4 (&acc)[CS][PS], bf16x8 (&wr)[R
     }
 }
 
+// Registers: the 256-channel 7x7 chain (L2-bound on its weight stream, MFMA-busy 0.41) is held to 96 (five waves per SIMD; 32 bytes of scratch): two of its workgroups fit
+// a CU -- 158 -> 147 us per chain alone at 256 frames -- and one fits BESIDE a workgroup of the 128-channel 14x14 chain (2 x 96 + 2 x 160 registers, 45 + 74 KB of LDS), which
+// is launched on another lane at the same time.  The step did not show the latter (10.59-10.68 ms either way, three pairs on one box).
 template <int C, int W>
-__global__ __launch_bounds__(512) void conv_bf16_chain(const ChainArgs a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 256 ? 5 : 2))) void conv_bf16_chain(const ChainArgs a) {
     typedef ChainGeom<C, W> G;
     constexpr int P = G::P, SB = G::SB, CS = G::CS, PS = G::PS, UPP = G::UPP, NU = G::NU;
     extern __shared__ __align__(16) unsigned char plane[];
