@@ -780,7 +780,7 @@ __global__ __launch_bounds__(512) void conv_bf16_wide_band(const ConvArgs a) {
 // pieces of this and the previous tap may still fly -- then reads W(t+1)'s fragments for the next tap.  I(t) = 1 on the taps that carry a plane piece
 // (tap 8 and taps 0 .. NFILL-2: every wave issues the same count -- a wave without an own last piece re-requests the plane's last one, and behind the
 // last chunk the pieces fetch zeros into the plane nobody reads any more).
-template <int CT, int W, int R>
+template <int CT, int W, int R, bool DIRECT = false>
 struct RingGeom {
     static constexpr int P = W + 1, SB = 96, UPS = SB / 16;
     static constexpr int ROWS = R + 2;
@@ -796,7 +796,7 @@ struct RingGeom {
     static constexpr int UPP = CT / 8, NUO = (R * W * UPP + 511) / 512;
     static constexpr int NB = (W + R - 1) / R;
     static constexpr bool piece_at(int tap) { return tap == 8 || tap < NFILL - 1; }
-    static_assert(LDS <= 160 * 1024 && NFILL >= 2 && NFILL <= 7 && PS <= 32 && (O0 + NT * 16) * OSB <= LDS && CT % 32 == 0 && 8 % (CT / 32) == 0, "ring geometry");
+    static_assert(LDS <= 160 * 1024 && NFILL >= 2 && NFILL <= 7 && PS <= 32 && (DIRECT || (O0 + NT * 16) * OSB <= LDS) && CT % 32 == 0 && 8 % (CT / 32) == 0, "ring geometry");
     static_assert((PS - 1) * 16 * SB + (2 * P + 2) * SB + 64 < 65536 && (O0 + NT * 16 + P + 2) * SB + 64 <= LDS - PB, "ds_read immediates / the farthest dead read stays inside the allocation");
 };
 
@@ -810,9 +810,9 @@ __device__ __forceinline__ void dma16_hidden_s(unsigned off, const void* base, u
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds) : "memory");
 }
 
-template <int CT, int W, int R>
+template <int CT, int W, int R, bool DIRECT = false>
 __global__ __launch_bounds__(512) void conv_bf16_wide_ring(const ConvArgs a) {
-    typedef RingGeom<CT, W, R> G;
+    typedef RingGeom<CT, W, R, DIRECT> G;
     constexpr int P = G::P, SB = G::SB, CS = G::CS, PS = G::PS, UPS = G::UPS, UPP = G::UPP, PB = G::PB, NFILL = G::NFILL, OSB = G::OSB;
     extern __shared__ __align__(16) unsigned char plane[];
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
@@ -947,6 +947,25 @@ __global__ __launch_bounds__(512) void conv_bf16_wide_ring(const ConvArgs a) {
             }
         }
         const int t = cur; cur = nxt; nxt = t;
+    }
+    if constexpr (DIRECT) {
+        // 256 output channels per workgroup: the tile (R x W pixels x 512 bytes) does not fit the LDS beside nothing -- it leaves straight from the accumulators, 8 bytes per
+        // lane and block (a pixel's 64 bytes of this wave are two stores back to back; the eight channel waves complete its 512-byte row in L2)
+        const int cstore = a.Cout - cbo * CT;
+        u16* outw = reinterpret_cast<u16*>(a.out) + (size_t)n * W * W * a.out_ctot + a.out_coff + cbo * CT + wcb * CS * 16 + lq * 4;
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) {
+            const int o = o_first + ps * 16, r = o / P, x = o - r * P - 1;
+            u16* op = outw + ((size_t)(y0 + r - 1) * W + x) * a.out_ctot;
+#pragma unroll
+            for (int cs = 0; cs < CS; ++cs) {
+                f32x4 v = acc[cs][ps];
+                if (a.relu) { v[0] = relu_c(v[0]); v[1] = relu_c(v[1]); v[2] = relu_c(v[2]); v[3] = relu_c(v[3]); }
+                if ((valid & (1u << ps)) && wcb * CS * 16 + cs * 16 + lq * 4 < cstore) *reinterpret_cast<u32x2*>(op + cs * 16) = u32x2{pack2_c(v[0], v[1]), pack2_c(v[2], v[3])};
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           // no piece may land in an LDS that already belongs to somebody else
+        return;
     }
     // ---- the tile: ReLU, bf16, staged over planes and rings (every piece has landed, every wave is done reading), rows y0 .. y0 + R - 1 -> HBM as whole channel rows
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1181,6 +1200,7 @@ hipError_t conv_bf16_chain_init() {
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_band<64, 64, 56, 14>), hipFuncAttributeMaxDynamicSharedMemorySize, WideGeom<64, 64, 56, 14>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_block_frame<56, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, FrameGeom<56, 8>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_ring<128, 56, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<128, 56, 8>::LDS));
+    GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_ring<256, 56, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<256, 56, 4, true>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_ring<128, 28, 14>), hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<128, 28, 14>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_block_band<32, 56, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, BandGeom<32, 56, 8>::LDS));
     return hipSuccess;
@@ -1243,6 +1263,13 @@ hipError_t launch_conv_bf16_wide(const ConvArgs& a0, hipStream_t s) {
     // 1 (default): the ring of one-chunk planes; 0: the 128-channel plane refilled between passes (A/B)
     static const int ring_env = getenv("GRNET_BF16_WIDE_RING") ? atoi(getenv("GRNET_BF16_WIDE_RING")) : 1;
     if (ring_env && a.CinPad >= 64) {
+        // 256 output channels at 56x56: ONE workgroup for all channels of a 4-row band (eight channel waves, 15 column tiles each) -- the band is fetched once, not once per
+        // 128-channel tile: 6 input rows per 4 output rows instead of 2 x 10 per 8, 5 plane pieces per chunk and wave instead of 7; the tile leaves from the accumulators.
+        // Alone it ties the 128-channel tiles (1 222 / 1 221 us for 480 -> 256, 644 / 647 for 256 -> 256 at 256 frames); in the step 10.49 against 10.51-10.53 ms (two pairs).
+        // GRNET_BF16_WIDE_CT256=0: 128-channel tiles
+        static const int ct256_env = getenv("GRNET_BF16_WIDE_CT256") ? atoi(getenv("GRNET_BF16_WIDE_CT256")) : 1;
+        if (ct256_env && a.W == 56 && a.CoutPad == 256)
+            return launch_k(conv_bf16_wide_ring<256, 56, 4, true>, dim3(a.N * RingGeom<256, 56, 4, true>::NB), dim3(512), RingGeom<256, 56, 4, true>::LDS, s, a);
         // 56x56: 8-row bands (7 per frame, 15 column tiles per wave, 244 registers) measured against 7-row ones (8 per frame): 480 -> 256 1 240 / 1 240 us,
         // 256 -> 256 648 / 666, 128 -> 128 210 / 216 at 256 frames
         if (a.W == 56) return launch_k(conv_bf16_wide_ring<128, 56, 8>, dim3(a.N * RingGeom<128, 56, 8>::NB * ncb), dim3(512), RingGeom<128, 56, 8>::LDS, s, a);
