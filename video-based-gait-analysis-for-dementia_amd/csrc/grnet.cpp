@@ -509,9 +509,30 @@ struct grnet {
         for (int i = 2; i < nb; ++i)
             for (int j = 0; j < i - 1; ++j) d[i][j] = xs[j];
         for (int level = 0; level < nb; ++level) {
+            // the ReLU'd first links of the chains that start at ONE branch share their input: one launch with their output channels side by side (round 5, bf16 as well:
+            // stage 4's chains (2,0) and (3,0) read the 56x56 branch once instead of twice).  GRNET_FUSE_MERGE_FIRST=0: one launch per chain
+            static const int merge_first_env = getenv("GRNET_FUSE_MERGE_FIRST") ? atoi(getenv("GRNET_FUSE_MERGE_FIRST")) : 1;
+            std::vector<std::vector<char>> merged(nb, std::vector<char>(nb, 0));
+            if (level == 0 && merge_first_env)
+                for (int j = 0; j < nb - 2; ++j) {
+                    std::vector<int> members;
+                    for (int i = j + 2; i < nb; ++i)
+                        if (i - j - 1 > 0) members.push_back(i);                   // chain (i, j) has more than one link: its first link is ReLU'd, kBranchCh[j] channels
+                    if (members.size() < 2) continue;
+                    std::vector<ConvSeg> segs;
+                    for (int i : members) {
+                        const std::string q = p + "fuse_layers." + std::to_string(i) + "." + std::to_string(j) + ".0.";
+                        segs.push_back(ConvSeg{q + "0.weight", q + "1", "", kBranchCh[j]});
+                    }
+                    cur_lane = j;
+                    View m = add_conv(xs[j], segs, 3, 2, true);
+                    int off = 0;
+                    for (int i : members) { d[i][j] = slice(m, off, kBranchCh[j]); off += kBranchCh[j]; merged[i][j] = 1; }
+                }
             for (int i = 2; i < nb; ++i)
                 for (int j = 0; j < i - 1; ++j) {
                     if (level >= i - j) continue;
+                    if (merged[i][j]) continue;
                     const bool last = level == i - j - 1;
                     cur_lane = j;
                     const std::string q = p + "fuse_layers." + std::to_string(i) + "." + std::to_string(j) + "." + std::to_string(level) + ".";
