@@ -464,9 +464,29 @@ struct grnet {
         // up terms t[i][j], j > i: conv1x1 + BN at the resolution of branch j (nearest upsample is
         // applied where the term is consumed: it commutes with the per-pixel conv/BN)
         std::vector<std::vector<View>> t(nb, std::vector<View>(nb));
+        // the up terms W_ij x_j of ONE source branch j (linear 1x1 convolutions at the source's resolution) share their input: one launch, output channels side by side
+        // (round 5; 31 -> 18 launches of the 1x1 terms per forward, 10.28 against 10.34 ms at 256 frames bf16; GRNET_FUSE_MERGE_UP=0: one launch per term)
+        static const int merge_up_env = getenv("GRNET_FUSE_MERGE_UP") ? atoi(getenv("GRNET_FUSE_MERGE_UP")) : 1;
+        std::vector<std::vector<char>> tdone(nb, std::vector<char>(nb, 0));
+        if (merge_up_env)
+            for (int j = 1; j < nb; ++j) {
+                std::vector<int> members;
+                for (int i = (up0 ? 1 : 0); i < j; ++i) members.push_back(i);
+                if (members.size() < 2) continue;
+                std::vector<ConvSeg> segs;
+                for (int i : members) {
+                    const std::string q = p + "fuse_layers." + std::to_string(i) + "." + std::to_string(j) + ".";
+                    segs.push_back(ConvSeg{q + "0.weight", q + "1", "", kBranchCh[i]});
+                }
+                cur_lane = j;
+                View m = add_conv(xs[j], segs, 1, 1, false);
+                int off = 0;
+                for (int i : members) { t[i][j] = slice(m, off, kBranchCh[i]); off += kBranchCh[i]; tdone[i][j] = 1; }
+            }
         for (int i = 0; i < nb; ++i)
             for (int j = i + 1; j < nb; ++j) {
                 if (up0 && i == 0) continue;
+                if (tdone[i][j]) continue;
                 const std::string q = p + "fuse_layers." + std::to_string(i) + "." + std::to_string(j) + ".";
                 cur_lane = j;
                 t[i][j] = conv_bn(xs[j], q + "0.weight", q + "1", kBranchCh[i], 1, 1, false);
