@@ -8,11 +8,12 @@ import torch
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=16)
+ap.add_argument("--dtype", default="f32")
 ap.add_argument("--dump", type=float, nargs=2, default=None)
 ap.add_argument("--out", default=None)
 args = ap.parse_args()
 pkg = importlib.import_module("video-based-gait-analysis-for-dementia_amd")
-m = pkg.build_synthetic_model(max_frames=args.frames, with_gru=False)
+m = pkg.build_synthetic_model(max_frames=args.frames, with_gru=False, dtype=args.dtype)
 x = torch.from_numpy(pkg.synth.make_frames(args.frames)).cuda()
 m(x.unsqueeze(0)); torch.cuda.synchronize()
 m.tune(args.frames)
