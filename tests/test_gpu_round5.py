@@ -5,6 +5,8 @@ Bar (bf16 has no reference mode; stated as in test_gpu_bf16.py): every intermedi
 convolution path stores it, so the chain must equal (i) the fp32 oracle evaluated block by block on bf16-rounded operands with the
 intermediates rounded to bf16, and (ii) the launch-per-convolution kernels, both up to fp32 summation order: a different order flips an
 output rounding on ties, i.e. single elements differ by ONE bf16 ulp (2^-8 .. 2^-7 relative)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -314,3 +316,51 @@ def test_blocked_temporal_attention_two_clips_ragged_blocks(pkg, oracle):
     y1 = m.tsattn_forward(xd[1:2], xsd[1:2]).cpu().numpy()
     assert np.array_equal(y1[0], y[1])
     m.close()
+
+
+# ---- GRU recurrence, round 5: rows-per-wave kernel, hand-off inside the XCD's L2 (gru_kernels.hip) --------------------------------------
+_GRU_VARIANT_SCRIPT = r"""
+import importlib, json, sys
+import numpy as np, torch
+sys.path.insert(0, {root!r})
+pkg = importlib.import_module({name!r})
+oracle = importlib.import_module("oracle.grnet_oracle")
+m = pkg.build_synthetic_model(max_frames=4, with_gru=True)
+sd = pkg.synth.make_gru_state_dict()
+res = {{}}
+for (b, t) in {cases!r}:
+    x, cp = pkg.synth.make_gru_inputs(b, t)
+    y, ph, _ = m.gru_forward(torch.from_numpy(x).cuda(), torch.from_numpy(cp).cuda())
+    torch.cuda.synchronize()
+    ry, rph, _ = oracle.gru_forward(x, cp, sd)
+    e = lambda a, r: float(np.abs(a.cpu().numpy().astype(np.float64) - r).max() / np.abs(r).max())
+    res["%d_%d" % (b, t)] = [e(y, ry), e(ph, rph), bool(torch.isfinite(y).all() and torch.isfinite(ph).all())]
+print("RESULT " + json.dumps(res))
+"""
+
+
+def _gru_variant(env, cases):
+    import json
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    PKG_NAME = "video-based-gait-analysis-for-dementia_amd"
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", _GRU_VARIANT_SCRIPT.format(root=ROOT, name=PKG_NAME, cases=cases)], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    return json.loads(line[len("RESULT "):])
+
+
+@pytest.mark.parametrize("env", [{}, {"GRNET_GRU_AGENT": "1"}, {"GRNET_GRU_SPLIT": "2"}, {"GRNET_GRU_SPLIT": "1"}, {"GRNET_GRU_SPLIT": "0"}],
+                         ids=["default", "agent_scope_stores", "libm_gates", "column_slices", "unsplit"])
+def test_gru_recurrence_variants_long_sequences(env):
+    """Every form of the recurrence against the oracle (gait_feat_encoder.py:79-104) on sequences long enough for an error of the gate
+    functions or a missed hand-off to show: 1 x 2000 steps (each direction 2 layers x 2000 dependent steps), 3 x 257 (six groups of eight
+    workgroups), 16 x 9 (the largest batch the split form takes).  The default takes the v_exp / v_rcp gate functions and, where the eight
+    slices of a group share an XCD, workgroup-scope granule stores; GRNET_GRU_AGENT=1 is the path of a group that spans XCDs."""
+    res = _gru_variant(env, [(1, 2000), (3, 257), (16, 9)])
+    for k, (ey, eph, finite) in res.items():
+        assert finite, (k, env)
+        assert ey < 1e-4 and eph < 1e-4, (k, env, ey, eph)

@@ -1943,7 +1943,7 @@ struct grnet {
     int gait_correct(const float* plf, const float* csf, const float* cam, int cam_ld, const float* bbox, const float* cimg, int b, int T,
                      const grnet_outputs_t& o, const grnet_gait_outputs_t& g, hipStream_t s) {
         const size_t M = (size_t)b * T;
-        const size_t gru_need = M * 3072 * 2 + 2 * M * 900 + 2 * M * 600 + (size_t)b * 1200 + (size_t)b * 2400 + 1024;
+        const size_t gru_need = M * 3072 * 2 + 2 * M * 900 + 2 * M * 600 + (size_t)b * 1200 + (size_t)b * 2 * kGruXbufU64PerSeq + 1024;
         auto al = [](size_t f) { return (f + 63) & ~(size_t)63; };         // every sub-buffer starts 256-byte aligned (16-byte vector loads, 8-byte granules)
         const size_t own = al(M * 3) + al((size_t)b * 3) + al(M * 4) + al(M * 3072);
         float* ws = nullptr;
@@ -2256,7 +2256,7 @@ int grnet_gru_forward(grnet_t* h, const float* x, const float* cp, int b, int T,
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t rows = (size_t)b * T;
     float* ws = nullptr;                                   // handle-owned scratch: no allocation once a size has been seen
-    const size_t need = rows * 3072 * 2 + 2 * rows * 900 + 2 * rows * 600 + (size_t)b * 1200 + (size_t)b * 2400 + 1024;
+    const size_t need = rows * 3072 * 2 + 2 * rows * 900 + 2 * rows * 600 + (size_t)b * 1200 + (size_t)b * 2 * kGruXbufU64PerSeq + 1024;
     if (int rc = h->temporal_scratch(kGemmWsFloats + need, &ws)) return rc;
     GemmWorkspaceLease lease(ws, kGemmWsFloats);
     ws += kGemmWsFloats;

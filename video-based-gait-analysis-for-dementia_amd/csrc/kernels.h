@@ -267,8 +267,10 @@ struct GruWorkspace {
     float* l0;       // (b*T, 600)
     float* l1;       // (b*T, 600)
     float* hfin;     // (b, 1200)
-    unsigned long long* xbuf = nullptr;   // (b, 2 dirs, 2 parities, 300) 8-byte {h value, step tag} granules of the split recurrence (may be null)
+    unsigned long long* xbuf = nullptr;   // b * kGruXbufU64PerSeq 8-byte words: (b, 2 dirs, 2 parities, 300) {h value, step tag} granules of the split recurrence, then
+                                          // (b, 2 dirs, 8 slices) {XCC id, 1} placement words (may be null: the unsplit kernel runs)
 };
+constexpr int kGruXbufU64PerSeq = 2 * 2 * 300 + 2 * 8;
 // bf16 path (conv_bf16.hip): NHWC bf16 activations, fp32 accumulation on the bf16 matrix cores ----------------------
 hipError_t conv_bf16_init();
 hipError_t launch_conv_bf16(ConvArgs a, hipStream_t s, int tile_hint = 0);     // pointers in `a` address bf16 data (bias fp32)
