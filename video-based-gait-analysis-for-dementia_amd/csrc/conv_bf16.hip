@@ -982,6 +982,169 @@ hipError_t init_bf16_ks() {
 
 inline int blocks_for(long total) { return (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384); }
 
+// ---- layer1's 64 -> 256 1x1 convolutions as a STREAM (round 5).  These launches are HBM traffic and nothing else (256 frames: read 103 + 411 MB, write
+// 411 MB; 32 KFLOP per 1.2 KB), and conv_bf16_nhwc moves it at 3.6-3.9 TB/s: a workgroup's life there is request -> wait -> MFMA -> epilogue -> store, and with
+// two workgroups per CU the memory system idles while both compute.  The same bytes as a plain copy-shaped kernel run at 5.7-6.0 TB/s
+// (tools/micro/stream_mix.hip: 153-162 us against 239-254).  Here the loads never stop:
+//   * persistent workgroups (4 waves) walk 32-pixel tiles; tile t + 1's input and residual are requested into REGISTERS (16 bytes per lane, whole rows:
+//     5 loads per lane) before tile t is touched, and are written to LDS a whole tile of work later -- ordinary loads, no LDS-DMA, so hipcc's counted
+//     vmcnt waits apply and the stores of tile t do not wait for them;
+//   * barriers are s_waitcnt lgkmcnt(0) + s_barrier (a __syncthreads() would drain the prefetch);
+//   * wave w holds the weights of output channels 64 w .. 64 w + 63 (and, for a pair, 16 w .. + 15 of the reduction) in registers for the whole launch;
+//   * the residual goes global -> registers -> LDS tile ([pixel][256] bf16, 544-byte slots) and is added in the accumulators' layout exactly where and as
+//     conv_bf16_nhwc adds it ((acc + residual) + bias, ReLU, round to bf16: bit-identical); the result replaces it IN PLACE, leaves as whole 512-byte
+//     rows (16 bytes per lane), and is the B operand of the pair's 256 -> 64 reduction (second stage of the generic kernel: same operands, same order).
+// KC: 32-channel chunks of the input (2: one tensor; 4: [t ; x], the Bottleneck's last 1x1 and its downsample as one GEMM); RES: one same-size addend.
+template <int KC, bool RES, bool PAIR>
+__global__ __launch_bounds__(256) void conv_bf16_pw_stream(const ConvArgs a, int ntiles) {
+    constexpr int TP = 32, ISB = KC * 64 + 32, OSB = 512 + 32, IU = KC * 4, NIN = TP * IU / 256;      // pixels per tile; LDS slot strides (32 x odd bytes); 16-byte input units per pixel / per thread
+    __shared__ __align__(16) unsigned char inl[TP * ISB];
+    __shared__ __align__(16) unsigned char tile[TP * OSB];
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u16* w = reinterpret_cast<const u16*>(a.w);
+    bf16x8 af[KC][4];
+    f32x4 bv[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) af[kc][cb] = *reinterpret_cast<const bf16x8*>(w + ((size_t)kc * 256 + wave * 64 + cb * 16 + l15) * 32 + lq * 8);
+        bv[cb] = *reinterpret_cast<const f32x4*>(a.bias + wave * 64 + cb * 16 + lq * 4);
+    }
+    bf16x8 af2[8];
+    f32x4 b2 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (PAIR) {
+        const u16* w2 = reinterpret_cast<const u16*>(a.w2);
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) af2[ch] = *reinterpret_cast<const bf16x8*>(w2 + ((size_t)ch * 64 + wave * 16 + l15) * 32 + lq * 8);
+        b2 = *reinterpret_cast<const f32x4*>(a.bias2 + wave * 16 + lq * 4);
+    }
+    const u16* in = reinterpret_cast<const u16*>(a.in) + a.in_coff;
+    const u16* in2 = KC == 4 ? reinterpret_cast<const u16*>(a.in2) + a.in2_coff : nullptr;
+    const u16* res = RES ? reinterpret_cast<const u16*>(a.add[0]) + a.add_coff[0] : nullptr;
+    u16* out = reinterpret_cast<u16*>(a.out) + a.out_coff;
+    u16* out2 = PAIR ? reinterpret_cast<u16*>(a.out2) + a.out2_coff : nullptr;
+    const float lo1 = a.relu ? 0.f : -__builtin_inff(), lo2 = a.relu2 ? 0.f : -__builtin_inff();      // max(v, -inf) = v: no branch per value
+    u32x4 nin[NIN], nres[4];
+    auto request = [&](int t) {                               // tile t's rows -> registers (clamped: the last iteration re-requests its own tile instead of branching)
+        const size_t p0 = (size_t)(t < ntiles ? t : ntiles - 1) * TP;
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) {
+            const int u = i * 256 + tid, px = u / IU, part = u - px * IU;
+            if (KC == 4 && part >= 8) nin[i] = *reinterpret_cast<const u32x4*>(in2 + (p0 + px) * a.in2_ctot + (part - 8) * 8);
+            else nin[i] = *reinterpret_cast<const u32x4*>(in + (p0 + px) * a.in_ctot + part * 8);
+        }
+        if (RES) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int u = i * 256 + tid, px = u >> 5, part = u & 31;
+                nres[i] = *reinterpret_cast<const u32x4*>(res + (p0 + px) * a.add_ctot[0] + part * 8);
+            }
+        }
+    };
+    auto lds_sync = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    request(blockIdx.x);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const size_t p0 = (size_t)t * TP;
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) {
+            const int u = i * 256 + tid, px = u / IU, part = u - px * IU;
+            *reinterpret_cast<u32x4*>(inl + px * ISB + part * 16) = nin[i];
+        }
+        if (RES) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int u = i * 256 + tid, px = u >> 5, part = u & 31;
+                *reinterpret_cast<u32x4*>(tile + px * OSB + part * 16) = nres[i];
+            }
+        }
+        request(t + gridDim.x);                               // in flight under everything below
+        lds_sync();
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) acc[cb][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const bf16x8 bt = *reinterpret_cast<const bf16x8*>(inl + (pt * 16 + l15) * ISB + kc * 64 + lq * 16);
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) acc[cb][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kc][cb], bt, acc[cb][pt], 0, 0, 0);
+            }
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                unsigned char* pos = tile + (pt * 16 + l15) * OSB + (wave * 64 + cb * 16) * 2 + lq * 8;
+                f32x4 v = acc[cb][pt];
+                if (RES) {
+                    const u32x2 r = *reinterpret_cast<const u32x2*>(pos);
+                    v[0] += bf2f((u16)(r[0] & 0xffffu)); v[1] += bf2f((u16)(r[0] >> 16));
+                    v[2] += bf2f((u16)(r[1] & 0xffffu)); v[3] += bf2f((u16)(r[1] >> 16));
+                }
+                v = v + bv[cb];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], lo1);
+                *reinterpret_cast<u32x2*>(pos) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+            }
+        lds_sync();                                           // the tile is complete (and nobody reads inl any more)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int u = i * 256 + tid, px = u >> 5, part = u & 31;
+            *reinterpret_cast<u32x4*>(out + (p0 + px) * a.out_ctot + part * 8) = *reinterpret_cast<const u32x4*>(tile + px * OSB + part * 16);
+        }
+        if (PAIR) {
+            f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch)
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) {
+                    const bf16x8 bt = *reinterpret_cast<const bf16x8*>(tile + (pt * 16 + l15) * OSB + ch * 64 + lq * 16);
+                    acc2[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af2[ch], bt, acc2[pt], 0, 0, 0);
+                }
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                f32x4 v = acc2[pt] + b2;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], lo2);
+                *reinterpret_cast<u32x2*>(inl + (pt * 16 + l15) * ISB + wave * 32 + lq * 8) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};      // inl: staging for whole 128-byte rows
+            }
+            lds_sync();
+            const int px = tid >> 3, part = tid & 7;
+            *reinterpret_cast<u32x4*>(out2 + (p0 + px) * a.out2_ctot + part * 8) = *reinterpret_cast<const u32x4*>(inl + px * ISB + part * 16);
+        }
+        lds_sync();                                           // everybody is done with inl and the tile: the next iteration writes both
+    }
+}
+
+bool pw_stream_eligible(const ConvArgs& a) {
+    if (!(a.ks == 1 && a.stride == 1 && a.Cout == 256 && a.CoutPad == 256 && a.relu_from == 0 && a.H == a.Ho && a.W == a.Wo)) return false;
+    if (a.in2 ? !(a.Cin == 128 && a.CinPad == 128 && a.cin_split == 64 && a.n_add == 0 && a.in2_ctot % 8 == 0 && a.in2_coff % 8 == 0) : !(a.Cin == 64 && a.CinPad == 64 && a.n_add <= 1)) return false;
+    if (a.n_add == 1 && (a.add_shift[0] != 0 || a.add_ctot[0] % 8 != 0 || a.add_coff[0] % 8 != 0)) return false;
+    if (a.out_ctot - a.out_coff < 256) return false;
+    if (a.w2 && (a.out2_ctot % 8 != 0 || a.out2_coff % 8 != 0)) return false;
+    if (a.in2 && !a.w2) return false;                         // instantiated: <2, res, pair>, <2, res, none>, <2, none, *>, <4, none, pair>
+    const long px = (long)a.N * a.H * a.W;
+    static const int stream_env = getenv("GRNET_BF16_PW_STREAM") ? atoi(getenv("GRNET_BF16_PW_STREAM")) : 1;     // 2: whatever the call size (tests)
+    return px % 32 == 0 && (stream_env == 2 || px / 32 >= 512L * 8);      // persistent workgroups: at least eight tiles each, or their fixed cost (the weights) does not pay
+}
+hipError_t launch_pw_stream(const ConvArgs& a, hipStream_t s) {
+    const int ntiles = (int)((long)a.N * a.H * a.W / 32);
+    static const int wgs_env = getenv("GRNET_BF16_PW_STREAM_WGS") ? atoi(getenv("GRNET_BF16_PW_STREAM_WGS")) : 2;      // workgroups per CU
+    int cus = 0;
+    GRK_TRY(device_cu_count(&cus));
+    const dim3 grid(std::min(ntiles, cus * wgs_env));
+    if (a.in2) return launch_k(conv_bf16_pw_stream<4, false, true>, grid, dim3(256), 0, s, a, ntiles);
+    if (a.n_add == 1) return a.w2 ? launch_k(conv_bf16_pw_stream<2, true, true>, grid, dim3(256), 0, s, a, ntiles) : launch_k(conv_bf16_pw_stream<2, true, false>, grid, dim3(256), 0, s, a, ntiles);
+    return a.w2 ? launch_k(conv_bf16_pw_stream<2, false, true>, grid, dim3(256), 0, s, a, ntiles) : launch_k(conv_bf16_pw_stream<2, false, false>, grid, dim3(256), 0, s, a, ntiles);
+}
+
 }  // namespace
 
 hipError_t conv_bf16_init() {
@@ -999,6 +1162,8 @@ hipError_t launch_conv_bf16(ConvArgs a, hipStream_t s, int tile_hint) {
     if (!((a.ks == 1 && a.stride == 1) || (a.ks == 3 && (a.stride == 1 || a.stride == 2)))) return hipErrorInvalidValue;
     if (a.CinPad % kCK != 0 || a.CoutPad % 32 != 0 || a.in_ctot % 8 != 0 || a.in_coff % 8 != 0 || a.out_ctot % 8 != 0 || a.out_coff % 8 != 0)
         return hipErrorInvalidValue;
+    static const int stream_env = getenv("GRNET_BF16_PW_STREAM") ? atoi(getenv("GRNET_BF16_PW_STREAM")) : 1;     // 0: layer1's 64 -> 256 1x1 layers on conv_bf16_nhwc
+    if (stream_env && tile_hint == 0 && pw_stream_eligible(a)) return launch_pw_stream(a, s);
     static const int direct_env = getenv("GRNET_BF16_DIRECT") ? atoi(getenv("GRNET_BF16_DIRECT")) : 1;
     if (direct_env && tile_hint == 0 && bf16_direct_eligible(a)) {
         // rows per strip: enough strips to give every SIMD about two waves, at most 8 rows (weights and the first rows are a strip's fixed cost)
