@@ -628,9 +628,15 @@ __global__ __launch_bounds__(256) void nhwc_bf16_to_nchw_f32_kernel(const u16* _
 
 // nn.Upsample(scale_factor=2, bilinear, align_corners=True) on NHWC bf16 (hrnet.py:443); one workgroup = one output row of one frame,
 // one thread = 8 channels of one output pixel (32-bit index arithmetic: the flat 64-bit index cost four 64-bit divisions per thread).
+// (fp contract off: hipcc's default fuses fy - y0 = yo * sy - y0 into ONE fma on the unrounded product -- a last-bit difference in the tap weight that the
+// reference's separate multiply, truncate and subtract (UpSampleBilinear2d: h1r = rheight * h2; h1lambda = h1r - h1) does not have)
 __global__ __launch_bounds__(256) void bilinear2x_bf16_kernel(const u16* __restrict__ in, u16* __restrict__ out, int N, int C, int H, int W) {
+#pragma clang fp contract(off)
     const int Ho = 2 * H, Wo = 2 * W, C8 = C / 8;
-    const int n = blockIdx.x / Ho, yo = blockIdx.x - n * Ho;
+    // workgroups are dealt to the 8 XCDs round-robin: with consecutive output rows on consecutive ids every input row (shared by ~4 output rows) was fetched into four
+    // L2s.  Re-dealt so that an XCD walks a contiguous range of rows (round 5)
+    const int bid = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int n = bid / Ho, yo = bid - n * Ho;
     const float sy = (float)(H - 1) / (float)(Ho - 1), sx = (float)(W - 1) / (float)(Wo - 1);
     const float fy = __fmul_rn((float)yo, sy);
     const int y0 = (int)fy, y1 = y0 + 1 < H ? y0 + 1 : H - 1;
@@ -663,11 +669,59 @@ __global__ __launch_bounds__(256) void bilinear2x_bf16_kernel(const u16* __restr
     }
 }
 
+// The same with the two input rows of a workgroup staged in LDS (round 5): the kernel above pulls 64 bytes through the CU's vector L1 for every 16 it writes (four taps
+// per output unit: 3.1 TB/s of algorithmic bytes at 256 frames).  Here a workgroup = one input row pair (y0, y0 + 1) of one frame: both rows come in once, as whole
+// rows of 16-byte units, and the output rows whose upper tap row is y0 (about two) are interpolated from LDS.  Same arithmetic per element (bit-identical).
+__global__ __launch_bounds__(256) void bilinear2x_bf16_rows_kernel(const u16* __restrict__ in, u16* __restrict__ out, int N, int C, int H, int W) {
+#pragma clang fp contract(off)
+    extern __shared__ __align__(16) u32x4 brow[];              // [2][W * C / 8]
+    const int Ho = 2 * H, Wo = 2 * W, C8 = C / 8, units = W * C8;
+    const int bid = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;     // an XCD walks a contiguous range of rows
+    const int n = bid / H, y0 = bid - n * H, y1 = y0 + 1 < H ? y0 + 1 : H - 1;
+    const u32x4* r0 = reinterpret_cast<const u32x4*>(in + ((size_t)n * H + y0) * W * C);
+    const u32x4* r1 = reinterpret_cast<const u32x4*>(in + ((size_t)n * H + y1) * W * C);
+    for (int u = threadIdx.x; u < units; u += 256) {
+        brow[u] = r0[u];
+        brow[units + u] = r1[u];
+    }
+    __syncthreads();
+    const float sy = (float)(H - 1) / (float)(Ho - 1), sx = (float)(W - 1) / (float)(Wo - 1);
+    const float inv_c8 = 1.0f / (float)C8;
+    for (int yo = 2 * y0 - 1 < 0 ? 0 : 2 * y0 - 1; yo <= 2 * y0 + 3 && yo < Ho; ++yo) {      // (+ 3: the last row's fy = (Ho - 1) * sy may round to just below H - 1)
+        const float fy = __fmul_rn((float)yo, sy);
+        if ((int)fy != y0) continue;                           // (uniform) this row's upper tap row belongs to another workgroup
+        const float wy = fy - (float)y0;
+        u16* orow = out + ((size_t)n * Ho + yo) * Wo * C;
+        for (int i = threadIdx.x; i < Wo * C8; i += 256) {
+            const int xo = fdiv(i, inv_c8), c8 = i - xo * C8;
+            const float fx = __fmul_rn((float)xo, sx);
+            const int x0 = (int)fx, x1 = x0 + 1 < W ? x0 + 1 : W - 1;
+            const float wx = fx - (float)x0;
+            const u32x4 v00 = brow[x0 * C8 + c8], v01 = brow[x1 * C8 + c8], v10 = brow[units + x0 * C8 + c8], v11 = brow[units + x1 * C8 + c8];
+            u32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float r[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float a00 = bf2f((u16)(v00[k] >> (16 * h))), a01 = bf2f((u16)(v01[k] >> (16 * h)));
+                    const float a10 = bf2f((u16)(v10[k] >> (16 * h))), a11 = bf2f((u16)(v11[k] >> (16 * h)));
+                    const float top = __fmaf_rn(wx, a01 - a00, a00), bot = __fmaf_rn(wx, a11 - a10, a10);
+                    r[h] = __fmaf_rn(wy, bot - top, top);
+                }
+                o[k] = pack2(r[0], r[1]);
+            }
+            *reinterpret_cast<u32x4*>(orow + (size_t)i * 8) = o;
+        }
+    }
+}
+
 // out = relu?( sum_k nearest_up(add_k) ) on NHWC bf16 (hrnet.py:258-265, output 0 of a fuse layer); one workgroup = one row of one
 // frame, one thread = 8 channels of a pixel (32-bit index arithmetic).
 __global__ __launch_bounds__(256) void fuse_sum_bf16_kernel(const SumArgs a) {
     const int C8 = a.C / 8, rpb = a.H % 4 == 0 ? 4 : 1;        // rows per workgroup (a 32-channel row of 56 pixels is only 224 units)
-    const int n = (blockIdx.x * rpb) / a.H, yb = blockIdx.x * rpb - n * a.H;
+    const int bid = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;     // an XCD walks a contiguous range of rows: the low-resolution addends' rows are shared by 2-8 output rows
+    const int n = (bid * rpb) / a.H, yb = bid * rpb - n * a.H;
     u16* out = reinterpret_cast<u16*>(a.out);
     const float inv_c8 = 1.0f / (float)C8, inv_wc = 1.0f / (float)(a.W * C8);
     for (int i0 = threadIdx.x; i0 < rpb * a.W * C8; i0 += 256) {
@@ -1234,6 +1288,10 @@ hipError_t launch_nhwc_bf16_to_nchw_f32(const void* in, float* out, int N, int C
 }
 hipError_t launch_bilinear2x_bf16(const void* in, void* out, int N, int C, int H, int W, hipStream_t s) {
     if (C % 8 != 0) return hipErrorInvalidValue;
+    static const int rows_env = getenv("GRNET_BF16_BILINEAR_ROWS") ? atoi(getenv("GRNET_BF16_BILINEAR_ROWS")) : 1;     // 0: four taps per output unit through the vector L1
+    const size_t lds = (size_t)2 * W * C * 2;
+    if (rows_env && lds <= 48 * 1024)
+        return launch_k(bilinear2x_bf16_rows_kernel, dim3(N * H), dim3(256), lds, s, reinterpret_cast<const u16*>(in), reinterpret_cast<u16*>(out), N, C, H, W);
     return launch_k(bilinear2x_bf16_kernel, dim3(N * 2 * H), dim3(256), 0, s, reinterpret_cast<const u16*>(in), reinterpret_cast<u16*>(out), N, C, H, W);
 }
 hipError_t launch_fuse_sum_bf16(const SumArgs& a, hipStream_t s) {
