@@ -151,14 +151,14 @@ def test_bf16_chain_time_at_256_frames(pkg, shape):
     m.close()
 
 
-WIDE = [(128, 128, 56), (256, 256, 56), (480, 256, 56), (64, 64, 56), (256, 256, 28), (128, 128, 28), (160, 128, 56)]
+WIDE = [(128, 128, 56), (256, 256, 56), (480, 256, 56), (64, 64, 56), (256, 256, 28), (128, 128, 28), (160, 128, 56), (256, 32, 56)]
 
 
 @pytest.mark.parametrize("case", WIDE, ids=lambda c: "x".join(map(str, c)))
 def test_bf16_wide_band_kernel(bmodel, oracle, case):
     """conv_bf16_wide_band (one wide 3x3 stride-1 convolution, a band of the input resident in LDS, 128 / 64 input channels per pass): equal to the
     fp32 oracle on the same bf16-rounded operands up to the one rounding of its bf16 output -- the bar of every bf16 launch (test_gpu_bf16.py) --
-    with and without ReLU; 480 and 160 input channels take a last pass of 96 / 32 channels; three frames = 24 / 12 / 6 bands."""
+    with and without ReLU; 480 and 160 input channels take a last pass of 96 / 32 channels; three frames = 24 / 12 / 6 bands; 256 -> 32: transition1's layer on the ring kernel with one 32-channel block."""
     cin, cout, h = case
     g = np.random.Generator(np.random.Philox(key=[89, cin * 1000 + cout + h]))
     n = 3 if h == 28 else 2
@@ -180,7 +180,7 @@ def test_bf16_wide_band_refuses_other_shapes(bmodel, pkg):
     with pytest.raises(pkg._lib.GrnetError, match="not eligible"):
         bmodel.op_conv2d(x, np.zeros((128, 128, 3, 3), np.float32), None, tile_hint=3003)
     with pytest.raises(pkg._lib.GrnetError, match="not eligible"):
-        bmodel.op_conv2d(torch.zeros(1, 256, 56, 56).cuda(), np.zeros((32, 256, 3, 3), np.float32), None, tile_hint=3003)
+        bmodel.op_conv2d(torch.zeros(1, 256, 56, 56).cuda(), np.zeros((96, 256, 3, 3), np.float32), None, tile_hint=3003)
 
 
 @pytest.mark.parametrize("with_add", [True, False])

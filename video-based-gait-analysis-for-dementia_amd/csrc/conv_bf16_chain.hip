@@ -1201,6 +1201,7 @@ hipError_t conv_bf16_chain_init() {
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_block_frame<56, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, FrameGeom<56, 8>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_ring<128, 56, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<128, 56, 8>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_ring<256, 56, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<256, 56, 4, true>::LDS));
+    GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_ring<32, 56, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<32, 56, 8>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_ring<128, 28, 14>), hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<128, 28, 14>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_block_band<32, 56, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, BandGeom<32, 56, 8>::LDS));
     return hipSuccess;
@@ -1247,6 +1248,9 @@ bool conv_bf16_wide_eligible(const ConvArgs& a) {
     if (a.ks != 3 || a.stride != 1 || a.n_add != 0 || a.H != a.W || a.Ho != a.H || a.Wo != a.W || a.CinPad % 32 != 0) return false;
     if (a.in_ctot % 8 != 0 || a.in_coff % 8 != 0 || a.out_ctot % 8 != 0 || a.out_coff % 8 != 0 || a.Cout % 8 != 0) return false;
     if (a.W == 56 && a.CinPad == 64 && a.CoutPad == 64) return true;
+    // transition1's 256 -> 32 (hrnet.py:348-387): the ring kernel with ONE 32-channel block, every wave a column group (conv_bf16_nhwc ran it at 0.18 of the peak, 2.0 TB/s)
+    static const int ct32_env = getenv("GRNET_BF16_WIDE_CT32") ? atoi(getenv("GRNET_BF16_WIDE_CT32")) : 1;
+    if (ct32_env && a.W == 56 && a.CinPad >= 128 && a.CoutPad == 32) return true;
     return (a.W == 56 || a.W == 28) && a.CinPad >= 128 && a.CoutPad % 128 == 0;
 }
 hipError_t launch_conv_bf16_wide(const ConvArgs& a0, hipStream_t s) {
@@ -1259,6 +1263,7 @@ hipError_t launch_conv_bf16_wide(const ConvArgs& a0, hipStream_t s) {
 #endif
     // (64 -> 64 on the ring kernel -- 7-row bands, two chunks: the second streams under the first -- measured 93 us against the band kernel's 79: stays here)
     if (a.CinPad == 64) return launch_k(conv_bf16_wide_band<64, 64, 56, 14>, dim3(a.N * WideGeom<64, 64, 56, 14>::NB), dim3(512), WideGeom<64, 64, 56, 14>::LDS, s, a);
+    if (a.CoutPad == 32) return launch_k(conv_bf16_wide_ring<32, 56, 8>, dim3(a.N * RingGeom<32, 56, 8>::NB), dim3(512), RingGeom<32, 56, 8>::LDS, s, a);
     const int ncb = a.CoutPad / 128;
     // 1 (default): the ring of one-chunk planes; 0: the 128-channel plane refilled between passes (A/B)
     static const int ring_env = getenv("GRNET_BF16_WIDE_RING") ? atoi(getenv("GRNET_BF16_WIDE_RING")) : 1;
