@@ -169,6 +169,7 @@ int grnet_time_convs(grnet_t* h, int n_frames, void* stream, float* ms_out);
 int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, int wid, const float* w_host,
                     const float* bias_host, int cout, int ks, int stride, int relu, const float* add_dev,
                     float* out_dev, int tile_hint, void* stream);
+/* (a bf16 handle runs the bf16 path's NHWC kernel between two layout conversions: c a multiple of 8) */
 int grnet_op_bilinear2x(grnet_t* h, const float* in_dev, int n, int c, int hgt, int wid, float* out_dev, void* stream);
 /* bf16 handles: a chain of nconv (even, <= 8) 3x3 stride-1 convolutions c -> c on (n,c,wid,wid) maps as ONE launch with the frame resident in LDS
  * (csrc/conv_bf16_chain.hip) -- convolutions 2k, 2k+1 are conv1 / conv2 of BasicBlock k (lib/models/hrnet.py:43-59: conv-BN-ReLU, conv-BN, + block

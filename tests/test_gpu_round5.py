@@ -402,3 +402,17 @@ def test_bf16_layer1_stream_kernel_is_bit_identical_to_the_generic_one(n):
     assert ref[1:] == got[1:]
     unpaired = _pw_stream_run({"GRNET_BF16_PW_STREAM": "2", "GRNET_BF16_CHAIN": str(127 - 64)}, n)
     assert unpaired[1:] == ref[1:]
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 28, 28), (3, 128, 14, 14), (2, 256, 7, 7), (1, 128, 28, 28), (2, 256, 28, 28), (16, 256, 14, 14)])
+def test_bf16_bilinear2x_rows_kernel(bmodel, oracle, shape):
+    """bilinear2x_bf16_rows_kernel (an input row pair per workgroup, staged in LDS; fp contraction off) through the op entry of a bf16 handle: the fp32 two-tap
+    formula of nn.Upsample(scale_factor=2, bilinear, align_corners=True) (hrnet.py:443) on the bf16-rounded input, rounded once to bf16 -- every element within
+    one bf16 rounding of torch's CPU kernel, every output row written (the last one's source coordinate rounds to just below H - 1), results bf16 values."""
+    g = np.random.Generator(np.random.Philox(key=[97, shape[1] * 100 + shape[2]]))
+    x = _rb(g.standard_normal(shape))
+    ref = oracle.upsample_bilinear2x(x).numpy()
+    got = bmodel.op_bilinear2x(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert got.shape == ref.shape and np.array_equal(got, _rb(got))
+    assert np.all(np.abs(got - ref) <= np.abs(ref) * 2.0 ** -8 + 1e-5), float(np.abs(got - ref).max())
+    assert np.all(np.abs(got[:, :, -1] - ref[:, :, -1]) <= np.abs(ref[:, :, -1]) * 2.0 ** -8 + 1e-5) and np.all(np.abs(got[:, :, 0] - ref[:, :, 0]) <= np.abs(ref[:, :, 0]) * 2.0 ** -8 + 1e-5)

@@ -1181,7 +1181,10 @@ bool pw_stream_eligible(const ConvArgs& a) {
     if (!(a.ks == 1 && a.stride == 1 && a.Cout == 256 && a.CoutPad == 256 && a.relu_from == 0 && a.H == a.Ho && a.W == a.Wo)) return false;
     if (a.in2 ? !(a.Cin == 128 && a.CinPad == 128 && a.cin_split == 64 && a.n_add == 0 && a.in2_ctot % 8 == 0 && a.in2_coff % 8 == 0) : !(a.Cin == 64 && a.CinPad == 64 && a.n_add <= 1)) return false;
     if (a.n_add == 1 && (a.add_shift[0] != 0 || a.add_ctot[0] % 8 != 0 || a.add_coff[0] % 8 != 0)) return false;
-    if (a.out_ctot - a.out_coff < 256) return false;
+    if (a.out_ctot - a.out_coff < 256 || a.in_ctot - a.in_coff < 64) return false;               // whole 512- / 128-byte rows are read and written
+    if (a.n_add == 1 && a.add_ctot[0] - a.add_coff[0] < 256) return false;
+    if (a.in2 && a.in2_ctot - a.in2_coff < 64) return false;
+    if (a.w2 && a.out2_ctot - a.out2_coff < 64) return false;
     if (a.w2 && (a.out2_ctot % 8 != 0 || a.out2_coff % 8 != 0)) return false;
     if (a.in2 && !a.w2) return false;                         // instantiated: <2, res, pair>, <2, res, none>, <2, none, *>, <4, none, pair>
     const long px = (long)a.N * a.H * a.W;

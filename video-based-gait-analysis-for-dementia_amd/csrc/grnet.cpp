@@ -2606,7 +2606,22 @@ int grnet_op_conv_chain(grnet_t* h, const float* in_dev, int n, int c, int wid, 
 int grnet_op_bilinear2x(grnet_t* h, const float* in_dev, int n, int c, int hgt, int wid, float* out_dev, void* stream) {
     if (!h || !in_dev || !out_dev) return GRNET_EINVAL;
     DeviceGuard guard(h->device);
-    hipError_t e = launch_bilinear2x(in_dev, out_dev, n, c, hgt, wid, static_cast<hipStream_t>(stream));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (h->dtype == 1) {                                       // bf16 handle: the bf16 NHWC kernel of the bf16 path (fp32 NCHW -> bf16 NHWC -> x2 -> fp32 NCHW)
+        if (n < 1 || c < 8 || c % 8 != 0 || hgt < 1 || wid < 1) return h->fail(GRNET_EINVAL, "bilinear2x (bf16): channels must be a multiple of 8");
+        const size_t nin = (size_t)n * hgt * wid * c;
+        void* tmp = nullptr;
+        hipError_t eb = hipMallocAsync(&tmp, nin * 2 * 5, s);
+        if (eb != hipSuccess) return h->fail(GRNET_EHIP, std::string("bilinear2x (bf16) scratch: ") + hipGetErrorString(eb));
+        void* up = static_cast<unsigned short*>(tmp) + nin;
+        eb = launch_nchw_f32_to_nhwc_bf16(in_dev, tmp, n, c, hgt, wid, c, s);
+        if (eb == hipSuccess) eb = launch_bilinear2x_bf16(tmp, up, n, c, hgt, wid, s);
+        if (eb == hipSuccess) eb = launch_nhwc_bf16_to_nchw_f32(up, out_dev, n, c, 2 * hgt, 2 * wid, c, 0, s);
+        (void)hipFreeAsync(tmp, s);
+        if (eb != hipSuccess) return h->fail(GRNET_EHIP, std::string("bilinear2x (bf16): ") + hipGetErrorString(eb));
+        return 0;
+    }
+    hipError_t e = launch_bilinear2x(in_dev, out_dev, n, c, hgt, wid, s);
     if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("bilinear2x: ") + hipGetErrorString(e));
     return 0;
 }
