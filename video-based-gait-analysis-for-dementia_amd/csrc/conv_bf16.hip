@@ -1049,21 +1049,26 @@ inline int blocks_for(long total) { return (int)((total + 255) / 256 < 16384 ? (
 //     conv_bf16_nhwc adds it ((acc + residual) + bias, ReLU, round to bf16: bit-identical); the result replaces it IN PLACE, leaves as whole 512-byte
 //     rows (16 bytes per lane), and is the B operand of the pair's 256 -> 64 reduction (second stage of the generic kernel: same operands, same order).
 // KC: 32-channel chunks of the input (2: one tensor; 4: [t ; x], the Bottleneck's last 1x1 and its downsample as one GEMM); RES: one same-size addend.
-template <int KC, bool RES, bool PAIR>
+// CT: output channels (= CoutPad) -- 256: 64 per wave (layer1's expansions); 64 / 32: one 16-channel block per wave (waves beyond CT / 16 only move rows): layer1's first
+// 64 -> 64 and the PARE head's 128 -> 64 / 128 -> 25 (round 5).  TWO: input chunks 2, 3 come from a.in2.
+template <int KC, int CT, bool TWO, bool RES, bool PAIR>
 __global__ __launch_bounds__(256) void conv_bf16_pw_stream(const ConvArgs a, int ntiles) {
-    constexpr int TP = 32, ISB = KC * 64 + 32, OSB = 512 + 32, IU = KC * 4, NIN = TP * IU / 256;      // pixels per tile; LDS slot strides (32 x odd bytes); 16-byte input units per pixel / per thread
+    constexpr int TP = 32, ISB = KC * 64 + 32, OSB = CT * 2 + 32, IU = KC * 4, NIN = TP * IU / 256, NBW = CT >= 64 ? CT / 64 : 1, OU = CT / 8, NOUT = (TP * OU + 255) / 256;      // pixels per tile; LDS slot strides (32 x odd bytes); 16-byte input units per pixel / per thread
     __shared__ __align__(16) unsigned char inl[TP * ISB];
     __shared__ __align__(16) unsigned char tile[TP * OSB];
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u16* w = reinterpret_cast<const u16*>(a.w);
-    bf16x8 af[KC][4];
-    f32x4 bv[4];
+    static_assert(!PAIR || CT == 256, "the pair's reduction reads 256 channels");
+    const int co = (wave * 16 * NBW) % CT;                     // first output channel of this wave (a wave without a block of its own recomputes another's and stores nothing)
+    const bool own = wave * 16 * NBW < CT;
+    bf16x8 af[KC][NBW];
+    f32x4 bv[NBW];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
+    for (int cb = 0; cb < NBW; ++cb) {
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) af[kc][cb] = *reinterpret_cast<const bf16x8*>(w + ((size_t)kc * 256 + wave * 64 + cb * 16 + l15) * 32 + lq * 8);
-        bv[cb] = *reinterpret_cast<const f32x4*>(a.bias + wave * 64 + cb * 16 + lq * 4);
+        for (int kc = 0; kc < KC; ++kc) af[kc][cb] = *reinterpret_cast<const bf16x8*>(w + ((size_t)kc * CT + co + cb * 16 + l15) * 32 + lq * 8);
+        bv[cb] = *reinterpret_cast<const f32x4*>(a.bias + co + cb * 16 + lq * 4);
     }
     bf16x8 af2[8];
     f32x4 b2 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1074,25 +1079,25 @@ __global__ __launch_bounds__(256) void conv_bf16_pw_stream(const ConvArgs a, int
         b2 = *reinterpret_cast<const f32x4*>(a.bias2 + wave * 16 + lq * 4);
     }
     const u16* in = reinterpret_cast<const u16*>(a.in) + a.in_coff;
-    const u16* in2 = KC == 4 ? reinterpret_cast<const u16*>(a.in2) + a.in2_coff : nullptr;
+    const u16* in2 = TWO ? reinterpret_cast<const u16*>(a.in2) + a.in2_coff : nullptr;
     const u16* res = RES ? reinterpret_cast<const u16*>(a.add[0]) + a.add_coff[0] : nullptr;
     u16* out = reinterpret_cast<u16*>(a.out) + a.out_coff;
     u16* out2 = PAIR ? reinterpret_cast<u16*>(a.out2) + a.out2_coff : nullptr;
     const float lo1 = a.relu ? 0.f : -__builtin_inff(), lo2 = a.relu2 ? 0.f : -__builtin_inff();      // max(v, -inf) = v: no branch per value
-    u32x4 nin[NIN], nres[4];
+    u32x4 nin[NIN], nres[NOUT];
     auto request = [&](int t) {                               // tile t's rows -> registers (clamped: the last iteration re-requests its own tile instead of branching)
         const size_t p0 = (size_t)(t < ntiles ? t : ntiles - 1) * TP;
 #pragma unroll
         for (int i = 0; i < NIN; ++i) {
             const int u = i * 256 + tid, px = u / IU, part = u - px * IU;
-            if (KC == 4 && part >= 8) nin[i] = *reinterpret_cast<const u32x4*>(in2 + (p0 + px) * a.in2_ctot + (part - 8) * 8);
+            if (TWO && part >= 8) nin[i] = *reinterpret_cast<const u32x4*>(in2 + (p0 + px) * a.in2_ctot + (part - 8) * 8);
             else nin[i] = *reinterpret_cast<const u32x4*>(in + (p0 + px) * a.in_ctot + part * 8);
         }
         if (RES) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int u = i * 256 + tid, px = u >> 5, part = u & 31;
-                nres[i] = *reinterpret_cast<const u32x4*>(res + (p0 + px) * a.add_ctot[0] + part * 8);
+            for (int i = 0; i < NOUT; ++i) {
+                const int u = i * 256 + tid, px = u / OU, part = u - px * OU;
+                if (u < TP * OU) nres[i] = *reinterpret_cast<const u32x4*>(res + (p0 + px) * a.add_ctot[0] + part * 8);
             }
         }
     };
@@ -1111,16 +1116,16 @@ __global__ __launch_bounds__(256) void conv_bf16_pw_stream(const ConvArgs a, int
         }
         if (RES) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int u = i * 256 + tid, px = u >> 5, part = u & 31;
-                *reinterpret_cast<u32x4*>(tile + px * OSB + part * 16) = nres[i];
+            for (int i = 0; i < NOUT; ++i) {
+                const int u = i * 256 + tid, px = u / OU, part = u - px * OU;
+                if (u < TP * OU) *reinterpret_cast<u32x4*>(tile + px * OSB + part * 16) = nres[i];
             }
         }
         request(t + gridDim.x);                               // in flight under everything below
         lds_sync();
-        f32x4 acc[4][2];
+        f32x4 acc[NBW][2];
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
+        for (int cb = 0; cb < NBW; ++cb)
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) acc[cb][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1129,13 +1134,13 @@ __global__ __launch_bounds__(256) void conv_bf16_pw_stream(const ConvArgs a, int
             for (int pt = 0; pt < 2; ++pt) {
                 const bf16x8 bt = *reinterpret_cast<const bf16x8*>(inl + (pt * 16 + l15) * ISB + kc * 64 + lq * 16);
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) acc[cb][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kc][cb], bt, acc[cb][pt], 0, 0, 0);
+                for (int cb = 0; cb < NBW; ++cb) acc[cb][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kc][cb], bt, acc[cb][pt], 0, 0, 0);
             }
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-                unsigned char* pos = tile + (pt * 16 + l15) * OSB + (wave * 64 + cb * 16) * 2 + lq * 8;
+            for (int cb = 0; cb < NBW; ++cb) {
+                unsigned char* pos = tile + (pt * 16 + l15) * OSB + (co + cb * 16) * 2 + lq * 8;
                 f32x4 v = acc[cb][pt];
                 if (RES) {
                     const u32x2 r = *reinterpret_cast<const u32x2*>(pos);
@@ -1145,13 +1150,13 @@ __global__ __launch_bounds__(256) void conv_bf16_pw_stream(const ConvArgs a, int
                 v = v + bv[cb];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], lo1);
-                *reinterpret_cast<u32x2*>(pos) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+                if (own) *reinterpret_cast<u32x2*>(pos) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
             }
         lds_sync();                                           // the tile is complete (and nobody reads inl any more)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int u = i * 256 + tid, px = u >> 5, part = u & 31;
-            *reinterpret_cast<u32x4*>(out + (p0 + px) * a.out_ctot + part * 8) = *reinterpret_cast<const u32x4*>(tile + px * OSB + part * 16);
+        for (int i = 0; i < NOUT; ++i) {
+            const int u = i * 256 + tid, px = u / OU, part = u - px * OU;
+            if (u < TP * OU) *reinterpret_cast<u32x4*>(out + (p0 + px) * a.out_ctot + part * 8) = *reinterpret_cast<const u32x4*>(tile + px * OSB + part * 16);
         }
         if (PAIR) {
             f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -1178,15 +1183,16 @@ __global__ __launch_bounds__(256) void conv_bf16_pw_stream(const ConvArgs a, int
 }
 
 bool pw_stream_eligible(const ConvArgs& a) {
-    if (!(a.ks == 1 && a.stride == 1 && a.Cout == 256 && a.CoutPad == 256 && a.relu_from == 0 && a.H == a.Ho && a.W == a.Wo)) return false;
-    if (a.in2 ? !(a.Cin == 128 && a.CinPad == 128 && a.cin_split == 64 && a.n_add == 0 && a.in2_ctot % 8 == 0 && a.in2_coff % 8 == 0) : !(a.Cin == 64 && a.CinPad == 64 && a.n_add <= 1)) return false;
-    if (a.n_add == 1 && (a.add_shift[0] != 0 || a.add_ctot[0] % 8 != 0 || a.add_coff[0] % 8 != 0)) return false;
-    if (a.out_ctot - a.out_coff < 256 || a.in_ctot - a.in_coff < 64) return false;               // whole 512- / 128-byte rows are read and written
-    if (a.n_add == 1 && a.add_ctot[0] - a.add_coff[0] < 256) return false;
-    if (a.in2 && a.in2_ctot - a.in2_coff < 64) return false;
-    if (a.w2 && a.out2_ctot - a.out2_coff < 64) return false;
-    if (a.w2 && (a.out2_ctot % 8 != 0 || a.out2_coff % 8 != 0)) return false;
-    if (a.in2 && !a.w2) return false;                         // instantiated: <2, res, pair>, <2, res, none>, <2, none, *>, <4, none, pair>
+    if (!(a.ks == 1 && a.stride == 1 && a.Cout <= a.CoutPad && a.relu_from == 0 && a.H == a.Ho && a.W == a.Wo)) return false;
+    static const int small_env = getenv("GRNET_BF16_PW_STREAM_SMALL") ? atoi(getenv("GRNET_BF16_PW_STREAM_SMALL")) : 3;     // bit 0: 64 / 32 output channels on 56x56 maps, bit 1: on smaller maps
+    if (!(a.CoutPad == 256 || ((a.CoutPad == 64 || a.CoutPad == 32) && (small_env & (a.W >= 56 ? 1 : 2))))) return false;
+    if (a.in2 ? !(a.Cin == 128 && a.CinPad == 128 && a.cin_split == 64 && a.in2_ctot % 8 == 0 && a.in2_coff % 8 == 0 && a.in2_ctot - a.in2_coff >= 64 && a.in_ctot - a.in_coff >= 64)
+              : !((a.Cin == 64 && a.CinPad == 64) || (a.Cin == 128 && a.CinPad == 128)) || a.in_ctot - a.in_coff < a.CinPad) return false;
+    if (a.n_add > 1 || (a.n_add == 1 && (a.add_shift[0] != 0 || a.add_ctot[0] % 8 != 0 || a.add_coff[0] % 8 != 0 || a.add_ctot[0] - a.add_coff[0] < a.CoutPad))) return false;
+    if (a.out_ctot - a.out_coff < a.CoutPad) return false;                                      // whole rows of CoutPad channels are written (padding channels: zeros, as the generic kernel's)
+    if (a.w2 && (a.CoutPad != 256 || a.out2_ctot % 8 != 0 || a.out2_coff % 8 != 0 || a.out2_ctot - a.out2_coff < 64)) return false;
+    // instantiated: 64 -> 256 {residual, none} x {pair, none}; [t ; x] -> 256 + pair; 64 / 128 -> 64 / 32 without addend
+    if (a.CoutPad == 256 ? (a.in2 ? !(a.w2 && a.n_add == 0) : a.Cin != 64) : (a.in2 || a.n_add != 0 || a.w2)) return false;
     const long px = (long)a.N * a.H * a.W;
     static const int stream_env = getenv("GRNET_BF16_PW_STREAM") ? atoi(getenv("GRNET_BF16_PW_STREAM")) : 1;     // 2: whatever the call size (tests)
     return px % 32 == 0 && (stream_env == 2 || px / 32 >= 512L * 8);      // persistent workgroups: at least eight tiles each, or their fixed cost (the weights) does not pay
@@ -1197,9 +1203,15 @@ hipError_t launch_pw_stream(const ConvArgs& a, hipStream_t s) {
     int cus = 0;
     GRK_TRY(device_cu_count(&cus));
     const dim3 grid(std::min(ntiles, cus * wgs_env));
-    if (a.in2) return launch_k(conv_bf16_pw_stream<4, false, true>, grid, dim3(256), 0, s, a, ntiles);
-    if (a.n_add == 1) return a.w2 ? launch_k(conv_bf16_pw_stream<2, true, true>, grid, dim3(256), 0, s, a, ntiles) : launch_k(conv_bf16_pw_stream<2, true, false>, grid, dim3(256), 0, s, a, ntiles);
-    return a.w2 ? launch_k(conv_bf16_pw_stream<2, false, true>, grid, dim3(256), 0, s, a, ntiles) : launch_k(conv_bf16_pw_stream<2, false, false>, grid, dim3(256), 0, s, a, ntiles);
+#define GRK_PWS(KC, CT, TWO, RES, PAIR) launch_k(conv_bf16_pw_stream<KC, CT, TWO, RES, PAIR>, grid, dim3(256), 0, s, a, ntiles)
+    if (a.CoutPad == 256) {
+        if (a.in2) return GRK_PWS(4, 256, true, false, true);
+        if (a.n_add == 1) return a.w2 ? GRK_PWS(2, 256, false, true, true) : GRK_PWS(2, 256, false, true, false);
+        return a.w2 ? GRK_PWS(2, 256, false, false, true) : GRK_PWS(2, 256, false, false, false);
+    }
+    if (a.CoutPad == 64) return a.Cin == 64 ? GRK_PWS(2, 64, false, false, false) : GRK_PWS(4, 64, false, false, false);
+    return a.Cin == 64 ? GRK_PWS(2, 32, false, false, false) : GRK_PWS(4, 32, false, false, false);
+#undef GRK_PWS
 }
 
 }  // namespace
