@@ -864,6 +864,19 @@ __global__ __launch_bounds__(384) void attn_pool_bf16x_kernel(const u16* __restr
     // the range's 448 positions x 96 channels (86 KB) are requested AT ONCE, 14 16-byte units per thread, and wait in registers under the softmax below; the loop
     // only moves them to LDS one 64-position block ahead (with the bf16 matrix cores a block is 8 MFMAs per wave: a block-ahead request would wait for HBM every time)
     constexpr int NBLK = kPoolChunkB / kPoolPB;
+    // the heat rows are requested FIRST (round 5): vector-memory loads return in order, so behind the 14 feature units the softmax below could not start before the
+    // whole 86 KB had arrived -- now it runs under that transfer
+    constexpr int NH = (kPoolChunkB * 3 + 383) / 384;
+    u32x4 hq[NH];
+    u16 hx[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        const int u = i * 384 + tid, p = u / 3, jg = u - p * 3;
+        if (u < kPoolChunkB * 3) {
+            hq[i] = *reinterpret_cast<const u32x4*>(heat + ((size_t)n * P + pbeg + p) * hc + jg * 8);      // channels 8 jg .. 8 jg + 7 (channel 0 = background)
+            hx[i] = heat[((size_t)n * P + pbeg + p) * hc + jg * 8 + 8];                                      // channel 8 jg + 8 = joint 8 jg + 7
+        }
+    }
     u32x4 fv[2 * NBLK];
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) {
@@ -875,10 +888,12 @@ __global__ __launch_bounds__(384) void attn_pool_bf16x_kernel(const u16* __restr
         *reinterpret_cast<u32x4*>(&fst[buf][(spp + 32) * kPoolFS + sq * 8]) = fv[2 * b + 1];
     };
     // heat rows of the range -> LDS: thread = (position, 8 joints)
-    for (int u = tid; u < kPoolChunkB * 3; u += 384) {
-        const int p = u / 3, jg = u - p * 3;
-        const u32x4 h8 = *reinterpret_cast<const u32x4*>(heat + ((size_t)n * P + pbeg + p) * hc + jg * 8);      // channels 8 jg .. 8 jg + 7 (channel 0 = background)
-        const u16 nx = heat[((size_t)n * P + pbeg + p) * hc + jg * 8 + 8];                                          // channel 8 jg + 8 = joint 8 jg + 7
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        const int u = i * 384 + tid, p = u / 3, jg = u - p * 3;
+        if (u >= kPoolChunkB * 3) break;
+        const u32x4 h8 = hq[i];
+        const u16 nx = hx[i];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int ch = k + 1;                                                                                   // joint 8 jg + k is channel 8 jg + k + 1
