@@ -849,6 +849,13 @@ __global__ __launch_bounds__(384) void attn_pool_bf16_kernel(const u16* __restri
     }
 }
 
+// workgroup barrier for LDS data only: s_waitcnt lgkmcnt(0) + s_barrier.  (__syncthreads() also waits for vmcnt(0): with the range's features requested up front it held
+// every barrier of attn_pool_bf16x_kernel until all 86 KB had arrived)
+__device__ __forceinline__ void pool_lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 __global__ __launch_bounds__(384) void attn_pool_bf16x_kernel(const u16* __restrict__ heat, int hc, const u16* __restrict__ featA, int CA, int ctA,
                                                                const u16* __restrict__ featB, int CB, int ctB, float* __restrict__ stats,
                                                                float* __restrict__ part, int P) {
@@ -901,7 +908,7 @@ __global__ __launch_bounds__(384) void attn_pool_bf16x_kernel(const u16* __restr
             prob[(jg * 8 + k) * kPoolStrideB + p] = bf2f(v);
         }
     }
-    __syncthreads();
+    pool_lds_sync();
     for (int j = (tid >> 6) * 4; j < (tid >> 6) * 4 + 4; ++j) {
         float* row = prob + j * kPoolStrideB;
         float hv[kPoolChunkB / 64], m = -INFINITY;
@@ -910,7 +917,7 @@ __global__ __launch_bounds__(384) void attn_pool_bf16x_kernel(const u16* __restr
         m = wave_max_b(m);
         float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < kPoolChunkB / 64; ++i) { hv[i] = expf(hv[i] - m); sum += hv[i]; }
+        for (int i = 0; i < kPoolChunkB / 64; ++i) { hv[i] = __builtin_amdgcn_exp2f((hv[i] - m) * 1.442695040888963f); sum += hv[i]; }      // v_exp_f32 (1 ulp; arguments <= 0): libm's expf was a third of this workgroup's instructions
         sum = wave_sum_b(sum);
         // the row in place as TWO bf16 rows: e = hi + lo (hi = bf16(e), lo = bf16(e - hi): 16 bits of mantissa, 2^-17 relative) -- [hi 448][lo 448] in the 452 floats
         // of the fp32 row; every lane holds its 7 values, and the wave (one row at a time) has read the whole row before it writes
@@ -918,11 +925,10 @@ __global__ __launch_bounds__(384) void attn_pool_bf16x_kernel(const u16* __restr
             u16* hrow = reinterpret_cast<u16*>(row);
 #pragma unroll
             for (int i = 0; i < kPoolChunkB / 64; ++i) {
-                const unsigned hb = __float_as_uint(hv[i]) + 0x7fffu + ((__float_as_uint(hv[i]) >> 16) & 1u);
-                const float hf = __uint_as_float(hb & 0xffff0000u), lf = hv[i] - hf;
-                const unsigned lb = __float_as_uint(lf) + 0x7fffu + ((__float_as_uint(lf) >> 16) & 1u);
-                hrow[lane + 64 * i] = (u16)(hb >> 16);
-                hrow[kPoolChunkB + lane + 64 * i] = (u16)(lb >> 16);
+                const unsigned hb = pack2(hv[i], 0.f);                                        // v_cvt_pk_bf16_f32: the same round-to-nearest-even as the integer form, one instruction
+                const float lf = hv[i] - __uint_as_float(hb << 16);
+                hrow[lane + 64 * i] = (u16)hb;
+                hrow[kPoolChunkB + lane + 64 * i] = (u16)pack2(lf, 0.f);
             }
         }
         if (lane == 0 && blockIdx.y == 0) {
@@ -945,7 +951,7 @@ __global__ __launch_bounds__(384) void attn_pool_bf16x_kernel(const u16* __restr
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) {
         const int buf = b & 1, p0 = b * kPoolPB;
-        __syncthreads();                                                // buffer `buf` is staged (and the probabilities are final); the other one is free
+        pool_lds_sync();                                                // buffer `buf` is staged (and the probabilities are final); the other one is free
         if (b + 1 < NBLK) deposit(b + 1, buf ^ 1);
         const u16* fs = &fst[buf][(8 * lq + (l15 >> 2)) * kPoolFS + wv * 16 + 4 * (l15 & 3)];
 #pragma unroll
