@@ -856,16 +856,21 @@ __device__ __forceinline__ void pool_lds_sync() {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
-__global__ __launch_bounds__(384) void attn_pool_bf16x_kernel(const u16* __restrict__ heat, int hc, const u16* __restrict__ featA, int CA, int ctA,
+// NW: waves = 16-channel tiles of the workgroup.  6: two workgroups per (frame, range), 96 channels each, both building the range's softmax; 12 (round 5): ONE workgroup
+// for all 192 channels -- the softmax (heat staging, exp, hi / lo split: most of the kernel's vector instructions) is built once, by twice the waves.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_pool_bf16x_kernel(const u16* __restrict__ heat, int hc, const u16* __restrict__ featA, int CA, int ctA,
                                                                const u16* __restrict__ featB, int CB, int ctB, float* __restrict__ stats,
                                                                float* __restrict__ part, int P) {
-    __shared__ __align__(16) float prob[24 * kPoolStrideB];
-    __shared__ __align__(16) u16 fst[2][kPoolPB * kPoolFS];    // two buffers of 64 positions x 96 channels, as they lie in memory (NHWC); 70 KB of LDS in all
+    constexpr int NT = NW * 64, NU = NW * 2, FS = NW * 16 + 8;        // threads; 16-byte units per staged position; bf16 per staged position (+ 16 bytes: the four positions of a k-step on different banks)
+    extern __shared__ __align__(16) unsigned char pool_lds[];
+    float* prob = reinterpret_cast<float*>(pool_lds);                  // [24][kPoolStrideB]
+    u16 (*fst)[kPoolPB * FS] = reinterpret_cast<u16 (*)[kPoolPB * FS]>(pool_lds + 24 * kPoolStrideB * 4);      // two buffers of 64 positions x NW * 16 channels, as they lie in memory (NHWC)
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
-    const int pbeg = blockIdx.z * kPoolChunkB, cb = blockIdx.y * 96;      // first channel of this workgroup in [featA | featB]
+    const int pbeg = blockIdx.z * kPoolChunkB, cb = blockIdx.y * NW * 16;      // first channel of this workgroup in [featA | featB]
     // staging: 64 positions x 12 units of 16 bytes = two units per thread (positions spp and spp + 32); a unit lies entirely in featA or in featB
     // (128 = 8 x 16).  Round 5: 64 instead of 32 positions per barrier -- the loop is a chain of load -> LDS -> barrier -> 16 MFMAs round trips
-    const int spp = tid / 12, sq = tid - spp * 12, sc = cb + sq * 8;
+    const int spp = tid / NU, sq = tid - spp * NU, sc = cb + sq * 8;
     const u16* ssrc = sc < CA ? featA + ((size_t)n * P + pbeg + spp) * ctA + sc : featB + ((size_t)n * P + pbeg + spp) * ctB + (sc - CA);
     const size_t sstride = sc < CA ? ctA : ctB;
     // the range's 448 positions x 96 channels (86 KB) are requested AT ONCE, 14 16-byte units per thread, and wait in registers under the softmax below; the loop
@@ -873,12 +878,12 @@ __global__ __launch_bounds__(384) void attn_pool_bf16x_kernel(const u16* __restr
     constexpr int NBLK = kPoolChunkB / kPoolPB;
     // the heat rows are requested FIRST (round 5): vector-memory loads return in order, so behind the 14 feature units the softmax below could not start before the
     // whole 86 KB had arrived -- now it runs under that transfer
-    constexpr int NH = (kPoolChunkB * 3 + 383) / 384;
+    constexpr int NH = (kPoolChunkB * 3 + NT - 1) / NT;
     u32x4 hq[NH];
     u16 hx[NH];
 #pragma unroll
     for (int i = 0; i < NH; ++i) {
-        const int u = i * 384 + tid, p = u / 3, jg = u - p * 3;
+        const int u = i * NT + tid, p = u / 3, jg = u - p * 3;
         if (u < kPoolChunkB * 3) {
             hq[i] = *reinterpret_cast<const u32x4*>(heat + ((size_t)n * P + pbeg + p) * hc + jg * 8);      // channels 8 jg .. 8 jg + 7 (channel 0 = background)
             hx[i] = heat[((size_t)n * P + pbeg + p) * hc + jg * 8 + 8];                                      // channel 8 jg + 8 = joint 8 jg + 7
@@ -891,13 +896,13 @@ __global__ __launch_bounds__(384) void attn_pool_bf16x_kernel(const u16* __restr
         fv[2 * b + 1] = *reinterpret_cast<const u32x4*>(ssrc + (size_t)(b * kPoolPB + 32) * sstride);
     }
     auto deposit = [&](int b, int buf) {
-        *reinterpret_cast<u32x4*>(&fst[buf][spp * kPoolFS + sq * 8]) = fv[2 * b];
-        *reinterpret_cast<u32x4*>(&fst[buf][(spp + 32) * kPoolFS + sq * 8]) = fv[2 * b + 1];
+        *reinterpret_cast<u32x4*>(&fst[buf][spp * FS + sq * 8]) = fv[2 * b];
+        *reinterpret_cast<u32x4*>(&fst[buf][(spp + 32) * FS + sq * 8]) = fv[2 * b + 1];
     };
     // heat rows of the range -> LDS: thread = (position, 8 joints)
 #pragma unroll
     for (int i = 0; i < NH; ++i) {
-        const int u = i * 384 + tid, p = u / 3, jg = u - p * 3;
+        const int u = i * NT + tid, p = u / 3, jg = u - p * 3;
         if (u >= kPoolChunkB * 3) break;
         const u32x4 h8 = hq[i];
         const u16 nx = hx[i];
@@ -909,7 +914,7 @@ __global__ __launch_bounds__(384) void attn_pool_bf16x_kernel(const u16* __restr
         }
     }
     pool_lds_sync();
-    for (int j = (tid >> 6) * 4; j < (tid >> 6) * 4 + 4; ++j) {
+    for (int j = (tid >> 6) * (24 / NW); j < (tid >> 6) * (24 / NW) + 24 / NW; ++j) {
         float* row = prob + j * kPoolStrideB;
         float hv[kPoolChunkB / 64], m = -INFINITY;
 #pragma unroll
@@ -953,11 +958,11 @@ __global__ __launch_bounds__(384) void attn_pool_bf16x_kernel(const u16* __restr
         const int buf = b & 1, p0 = b * kPoolPB;
         pool_lds_sync();                                                // buffer `buf` is staged (and the probabilities are final); the other one is free
         if (b + 1 < NBLK) deposit(b + 1, buf ^ 1);
-        const u16* fs = &fst[buf][(8 * lq + (l15 >> 2)) * kPoolFS + wv * 16 + 4 * (l15 & 3)];
+        const u16* fs = &fst[buf][(8 * lq + (l15 >> 2)) * FS + wv * 16 + 4 * (l15 & 3)];
 #pragma unroll
         for (int g = 0; g < kPoolPB / 32; ++g) {
-            const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(fs + (32 * g) * kPoolFS));
-            const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(fs + (32 * g + 4) * kPoolFS));
+            const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(fs + (32 * g) * FS));
+            const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(fs + (32 * g + 4) * FS));
             const bf16x8p af = __builtin_bit_cast(bf16x8p, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
             const int pe = (p0 + 32 * g) * 2;
             const bf16x8p h0 = *reinterpret_cast<const bf16x8p*>(pb0 + pe), l0 = *reinterpret_cast<const bf16x8p*>(pb0 + kPoolChunkB * 2 + pe);
@@ -968,7 +973,7 @@ __global__ __launch_bounds__(384) void attn_pool_bf16x_kernel(const u16* __restr
             acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, l1, acc1, 0, 0, 0);
         }
     }
-    const int ct = blockIdx.y * 6 + wv;
+    const int ct = blockIdx.y * NW + wv;
     float* o = part + (((size_t)n * kPoolSplit + blockIdx.z) * (CA + CB) + ct * 16 + 4 * lq) * 24;      // [n][split][192][24]
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1239,6 +1244,8 @@ hipError_t launch_pw_stream(const ConvArgs& a, hipStream_t s) {
 
 hipError_t conv_bf16_init() {
     GRK_TRY(set_lds_bf16(conv_bf16_nhwc<1, 1, 7, 16, 1, 4>));
+    GRK_TRY(set_lds_bf16(attn_pool_bf16x_kernel<6>));
+    GRK_TRY(set_lds_bf16(attn_pool_bf16x_kernel<12>));
     GRK_TRY((init_bf16_ks<1, 1>()));
     GRK_TRY((init_bf16_ks<3, 1>()));
     GRK_TRY((init_bf16_ks<3, 2>()));
@@ -1342,8 +1349,13 @@ hipError_t launch_softmax_pool_bf16(const void* heat, int hc, const void* featA,
     float* part = pool_ws + (size_t)N * kPoolStatsFloats;
     const int x16 = getenv("GRNET_BF16_POOL_X16") ? atoi(getenv("GRNET_BF16_POOL_X16")) : 1;     // 0: the fp32-MFMA form (A/B; read per launch)
     if (x16)
-        return launch_k(attn_pool_bf16x_kernel, dim3(N, (CA + CB) / 96, kPoolSplit), dim3(384), 0, s, reinterpret_cast<const u16*>(heat), hc, reinterpret_cast<const u16*>(featA),
+        {
+            static const int nw_env = getenv("GRNET_BF16_POOL_WAVES") ? atoi(getenv("GRNET_BF16_POOL_WAVES")) : 12;      // 12 (default): one workgroup for all 192 channels; 6: two of 96
+            if (nw_env == 12) return launch_k(attn_pool_bf16x_kernel<12>, dim3(N, 1, kPoolSplit), dim3(768), (size_t)24 * kPoolStrideB * 4 + 2 * kPoolPB * (12 * 16 + 8) * 2, s, reinterpret_cast<const u16*>(heat), hc, reinterpret_cast<const u16*>(featA),
                         CA, ctA, reinterpret_cast<const u16*>(featB), CB, ctB, pool_ws, part, P);
+            return launch_k(attn_pool_bf16x_kernel<6>, dim3(N, (CA + CB) / 96, kPoolSplit), dim3(384), (size_t)24 * kPoolStrideB * 4 + 2 * kPoolPB * (6 * 16 + 8) * 2, s, reinterpret_cast<const u16*>(heat), hc, reinterpret_cast<const u16*>(featA),
+                        CA, ctA, reinterpret_cast<const u16*>(featB), CB, ctB, pool_ws, part, P);
+        }
     return launch_k(attn_pool_bf16_kernel, dim3(N, (CA + CB) / 96, kPoolSplit), dim3(384), 0, s, reinterpret_cast<const u16*>(heat), hc, reinterpret_cast<const u16*>(featA),
                     CA, ctA, reinterpret_cast<const u16*>(featB), CB, ctB, pool_ws, part, P);
 }
