@@ -416,3 +416,11 @@ def test_bf16_bilinear2x_rows_kernel(bmodel, oracle, shape):
     assert got.shape == ref.shape and np.array_equal(got, _rb(got))
     assert np.all(np.abs(got - ref) <= np.abs(ref) * 2.0 ** -8 + 1e-5), float(np.abs(got - ref).max())
     assert np.all(np.abs(got[:, :, -1] - ref[:, :, -1]) <= np.abs(ref[:, :, -1]) * 2.0 ** -8 + 1e-5) and np.all(np.abs(got[:, :, 0] - ref[:, :, 0]) <= np.abs(ref[:, :, 0]) * 2.0 ** -8 + 1e-5)
+
+
+def test_bf16_pooling_workgroup_forms_are_bit_identical():
+    """attn_pool_bf16x_kernel<12> (one workgroup builds a (frame, range)'s softmax for all 192 channels) against <6> (two workgroups of 96 channels, each building
+    it): the same values in the same order -- the whole forward may not change by a bit."""
+    a = _pw_stream_run({}, 8)
+    b = _pw_stream_run({"GRNET_BF16_POOL_WAVES": "6"}, 8)
+    assert a == b
