@@ -442,17 +442,31 @@ __global__ __launch_bounds__(512) void conv_bf16_block_frame(const ChainArgs a) 
     const u16* inb = reinterpret_cast<const u16*>(a.in) + (size_t)n * W * W * a.in_ctot + a.in_coff;
     u16* outb = reinterpret_cast<u16*>(a.out) + (size_t)n * W * W * a.out_ctot + a.out_coff;
 
+    // (round 5) unit i of this thread = (plane row r, column x, 16-byte part) is the same in every band: kept packed (r : 4 | x : 6 | part : 2 bits, two units per
+    // register) instead of two divisions per unit and band in request() and again in deposit()
+    unsigned upk[(F::NUS + 1) / 2];
+#pragma unroll
+    for (int i = 0; i < (F::NUS + 1) / 2; ++i) upk[i] = 0u;
+#pragma unroll
+    for (int i = 0; i < F::NUS; ++i) {
+        const int u = i * 512 + tid, r = u / UR, q = u - r * UR, x = q / UPP, part = q - x * UPP;
+        upk[i >> 1] |= (unsigned)((r << 8) | (x << 2) | part) << (16 * (i & 1));
+    }
     auto request = [&](int y0) {                               // rows y0 - 2 .. y0 + R + 1 that exist -> staging, by LDS-DMA (rows outside the image are not requested)
 #pragma unroll
         for (int i = 0; i < F::NUS; ++i) {
-            const int ub = i * 512 + wave * 64, u = ub + lane, r = u / UR, q = u - r * UR, x = q / UPP, part = q - x * UPP, y = y0 - 2 + r;
+            const int ub = i * 512 + wave * 64, u = ub + lane;
+            const unsigned pk = upk[i >> 1] >> (16 * (i & 1));
+            const int r = (pk >> 8) & 15, x = (pk >> 2) & 63, part = pk & 3, y = y0 - 2 + r;
             if (u < F::STAGE_UNITS && y >= 0 && y < W) dma16_c(inb + ((size_t)y * W + x) * a.in_ctot + part * 8, stg + ub * 16);
         }
     };
     auto deposit = [&](int y0) {                               // staging -> interior slots of every plane row; zeros where the band hangs over the image
 #pragma unroll
         for (int i = 0; i < F::NUS; ++i) {
-            const int u = i * 512 + tid, r = u / UR, q = u - r * UR, x = q / UPP, part = q - x * UPP, y = y0 - 2 + r;
+            const int u = i * 512 + tid;
+            const unsigned pk = upk[i >> 1] >> (16 * (i & 1));
+            const int r = (pk >> 8) & 15, x = (pk >> 2) & 63, part = pk & 3, y = y0 - 2 + r;
             if (u < F::STAGE_UNITS) {
                 u32x4 v = u32x4{0u, 0u, 0u, 0u};
                 if (y >= 0 && y < W) v = *reinterpret_cast<const u32x4*>(stg + u * 16);
