@@ -5,7 +5,7 @@ demo.py (argparse :391-456, loop :126-231, pickle :254-267), with the model runn
 Out of scope here (rows 12, 17, 19): ffmpeg video decoding, the YOLOv3+SORT tracker and the
 matplotlib / pyrender output video.  So this entry point takes what the reference takes once those
 steps are done: --img_folder (extracted frames) and --tracking_path (joblib {id: {'bbox','frames'}}).
-The reference's --cpu_only has no counterpart: there is deliberately no CPU fallback.
+The reference's --cpu_only (demo.py:46-49,403) is accepted and refused with one line: there is deliberately no CPU fallback.
 """
 import argparse
 import importlib
@@ -20,6 +20,8 @@ ROOT = osp.dirname(osp.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "video-based-gait-analysis-for-dementia_amd"
 MIN_NUM_FRAMES = 25          # demo.py:41
+CPU_ONLY_MESSAGE = ("--cpu_only: this build has no CPU path (a CPU fallback would have to run the test oracle as the product); "
+                    "BASELINE configs[0] is covered by tests/test_gpu_harness.py::test_demo_entry_point on the GPU")
 
 
 def load_cfg(path):
@@ -140,6 +142,7 @@ def parser():
     p.add_argument("--img_folder", type=str, default=None)
     p.add_argument("--joint_type", type=str, default="spin")
     p.add_argument("--save_vid", action="store_false")
+    p.add_argument("--cpu_only", action="store_true", help="the reference's CPU switch (demo.py:403): parsed, and refused -- this build has no CPU path")
     # additions of this implementation
     p.add_argument("--synthetic_weights", action="store_true", help="seed-defined weights (no checkpoint exists offline)")
     p.add_argument("--smpl_dir", type=str, default="data/smpl_data")
@@ -150,6 +153,8 @@ def parser():
 
 if __name__ == "__main__":
     a = parser().parse_args()
+    if a.cpu_only:
+        sys.exit(CPU_ONLY_MESSAGE)
     for flag in ("mesh_render", "display", "save_obj"):
         if getattr(a, flag):
             sys.exit(f"--{flag} belongs to steps outside the per-frame path (SURVEY 8f) and is not implemented")

@@ -13,6 +13,16 @@
  * be captured into a hipGraph by the caller (or by the library: GRNET_OPT_USE_GRAPH).
  * All tensors are fp32, dense, row-major ("C order"); device pointers are plain HIP device
  * pointers (e.g. torch.Tensor.data_ptr()), owned by the caller and never freed by the library.
+ *
+ * Environment.  The library reads exactly these variables (tests/test_host_cpu.py greps csrc/ for any other getenv):
+ *   GRNET_TRACE=1        one line per plan / schedule / tuning decision on stderr; no effect on results
+ *   GRNET_MULTI_LANE=0   process-wide default of GRNET_OPT_MULTI_LANE (profiling: the launches one after another on one stream)
+ *   GRNET_WINO=0         process-wide default of GRNET_OPT_WINOGRAD
+ *   GRNET_BF16_CHAIN=<mask>  process-wide default of GRNET_OPT_BF16_CHAIN
+ *   GRNET_RCCL_LIB=<name>    the ONE library the exchange binds instead of librccl.so.1 (csrc/exchange.cpp)
+ * The Python host adds GRNET_LIB_PATH (load another build of this library, tools/ only) and bench.py GRNET_BENCH_BACKEND (gloo rehearsals).
+ * Every other GRNET_* name that earlier rounds' notes mention is an A/B switch of DIAGNOSTIC builds (make ABLATION=1; csrc/kernels.h
+ * GRNET_AB): in this library it is a compile-time constant and setting the variable does nothing.
  */
 #ifndef GRNET_HIP_H
 #define GRNET_HIP_H
@@ -110,14 +120,27 @@ int grnet_tsattn_forward(grnet_t* h, const float* x_dev, const float* xs_dev, in
                                    * convolution is the direct implicit GEMM.  grnet_op_conv2d tile hints 2001 / 2020 (+ K split) run the two kernels on
                                    * one convolution.  (Options 4, 5, 6 -- grouped launches, the persistent dataflow launch and its fence -- were removed
                                    * in round 3 after losing every measurement; their sources are in the history: commit 8d3a931.) */
-#define GRNET_OPT_BF16_CHAIN 8    /* bf16 handles, a mask of the band- / frame-resident kernels of csrc/conv_bf16_chain.hip (default 127; environment GRNET_BF16_CHAIN; 0: one
-                                   * launch of the generic kernel per convolution at every call size).  Bits 0-3: the four BasicBlocks (8 convolutions,
-                                   * lib/models/hrnet.py:141-187) of an HR branch as ONE launch with the frame resident in LDS, in calls of >= 64 frames -- bit 0:
-                                   * 64 ch @28x28, bit 1: 128 ch @14x14, bit 2: 256 ch @7x7, bit 3: 32 ch @56x56 (one launch per BasicBlock there, 8-row bands
-                                   * streamed through LDS).  Bit 4: the wide 3x3 stride-1 layers (upsample heads, PARE head, layer1's 3x3) with a band of the
-                                   * input resident, >= 32 frames.  Bit 5: the 3x3 stride-2 layers (fuse layers' down paths, transitions, the stem's second
-                                   * convolution) with the band de-interleaved by row / column parity, >= 64 frames.  Bit 6: layer1's 64 -> 256 expansions
-                                   * (hrnet.py:80-100) also run the NEXT Bottleneck's 256 -> 64 reduction from the tile they hold in LDS, >= 19 frames. */
+#define GRNET_OPT_BF16_CHAIN 8    /* bf16 handles, a mask of the band- / frame-resident kernel groups of csrc/conv_bf16_chain.hip and csrc/conv_bf16.hip (default: all bits = -1;
+                                   * process-wide default from the environment variable GRNET_BF16_CHAIN; 0: one launch of the generic kernel per convolution at every
+                                   * call size).  Bits 0-3: the four BasicBlocks (8 convolutions, lib/models/hrnet.py:141-187) of an HR branch as ONE launch with the
+                                   * frame resident in LDS, in calls of >= 64 frames -- bit 0: 64 ch @28x28, bit 1: 128 ch @14x14, bit 2: 256 ch @7x7, bit 3: 32 ch
+                                   * @56x56 (one launch per BasicBlock there, 8-row bands streamed through LDS).  Bit 4: the wide 3x3 stride-1 layers (upsample
+                                   * heads, PARE head, layer1's 3x3) with a band of the input resident, >= 32 frames.  Bit 5: the 3x3 stride-2 layers (fuse layers'
+                                   * down paths, transitions, the stem's second convolution) with the band de-interleaved by row / column parity, >= 64 frames.
+                                   * Bit 6: layer1's 64 -> 256 expansions (hrnet.py:80-100) also run the NEXT Bottleneck's 256 -> 64 reduction from the tile they
+                                   * hold in LDS, >= 19 frames.  Bit 7: the 1x1 layers of layer1 and of the PARE head on the persistent stream kernel
+                                   * (conv_bf16_pw_stream, bit-identical to the generic kernel), >= 42 frames. */
+#define GRNET_OPT_GRU_MODE 9      /* form of the bi-GRU recurrence (csrc/gru_kernels.hip; gait_feat_encoder.py:79-104).  3 (default): W_hh resident in registers, split over 8
+                                   * workgroups per (sequence, direction), rows per wave, v_exp / v_rcp gate functions, h_t handed over inside the XCD's L2
+                                   * (workgroup-scope granule stores + L1-bypassing polls) where the 8 workgroups verifiably share an XCD; 2: the same with
+                                   * expf / tanhf; 1: column slices, agent-scope hand-off; 0: one workgroup per (sequence, direction) (also taken for b > 16 or
+                                   * T < 8).  + 16: agent-scope granule stores whatever the placement.  The L2 hand-off relies on write-through of workgroup-scope
+                                   * stores into the XCD's shared L2: if a poll ever runs into its bound the kernel sets a host-visible word, the
+                                   * NEXT grnet_gru_forward / grnet_gait_correct on the handle returns GRNET_ESTATE once (the earlier call's outputs are
+                                   * NaN-poisoned) and the handle moves itself to + 16, then to 0. */
+#define GRNET_OPT_BF16_MIN_FRAMES 10 /* bf16 handles: smallest call (frames) from which EVERY kernel group of GRNET_OPT_BF16_CHAIN runs; 0 (default): each group's own
+                                   * measured threshold (64 / 32 / 64 / 19 / 42 frames).  1 lets tests and small-batch deployments take the LDS-resident kernels
+                                   * at any call size. */
 int grnet_set_option(grnet_t* h, int option, int value);
 
 /* Optional, once per distinct n_frames after grnet_finalize_weights: times every launch configuration of every

@@ -27,6 +27,14 @@ class FakeWorkload:
     def sync(self):
         pass
 
+    def exchange_state(self):
+        """As the real workloads: this rank's send block, the gathered (world, block) buffer, its frame range (16 frames per rank)."""
+        torch = self.torch
+        local = torch.arange(self.n, dtype=torch.float32) + 1000.0 * self.rank
+        gathered = torch.empty(self.world * self.n, dtype=torch.float32)
+        self.dist.all_gather_into_tensor(gathered, local)
+        return {"local": local, "gathered": gathered.view(self.world, -1), "frames": (self.rank * self.n, (self.rank + 1) * self.n)}
+
     def config(self):
         return {"workload": "fake", "frames_per_gpu": self.n, "steps_done_rank0": self.steps}
 

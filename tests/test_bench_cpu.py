@@ -57,7 +57,9 @@ def test_two_ranks_end_to_end_through_the_launcher():
     assert len(lines) == 1, p.stdout                       # rank 0 only
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 20 and j["warmup"] == 2 and j["scaling"] == "weak" and j["higher_is_better"] is True
-    assert j["config"]["steps_done_rank0"] == 22
+    assert j["config"]["steps_done_rank0"] == 22 + 1                      # + the step in front of the exchange proof
+    # what the collective itself delivered (round-5 review): both ranks' records arrived, slot r == rank r's block, 2 x 16 frames
+    assert j["config"]["exchange_ranks"] == 2 and j["config"]["frames_total"] == 32 and "slot r" in j["config"]["exchange_check"]
     # rank 1 sleeps 4 ms per step, rank 0 only 2 ms: the reported time is the slower rank's (and the all-gather couples them)
     assert j["ms_per_step"] >= 4.0
     assert abs(j["value"] - 16 * 2 * 20 / (j["ms_per_step"] * 20 / 1e3)) / j["value"] < 1e-3

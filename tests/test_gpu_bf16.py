@@ -73,6 +73,47 @@ def test_bf16_forward_error_is_storage_rounding_noise(bmodel, pkg, oracle, synth
     assert (R @ R.transpose(1, 2) - torch.eye(3, device=R.device)).abs().max() < 1e-4   # the fp32 tail still returns rotations
 
 
+@pytest.mark.parametrize("n", [64, 256])
+def test_bf16_production_call_sizes_vs_oracle(pkg, oracle, synth_weights, synth_smpl, n):
+    """The same bound as above at the call sizes the bf16 configs actually run (BASELINE configs[2] / [4]: 64-256 frames per call), where
+    EVERY kernel group of GRNET_OPT_BF16_CHAIN is on (they start at 19-64 frames per call, include/grnet_hip.h): BasicBlock chains, wide
+    bands, stride-2 bands, layer1's 1x1 pairs / Bottleneck launches, the fused stem -- and with them the plan logic that wires the launches
+    together (fuse-layer merges, shifted addends, chain members).  8 distinct frames are tiled, so the oracle (grnet.py:129-175 outputs +
+    the intermediates) and its bf16-storage emulation run on 8 frames only; every copy of a frame must give the same bits."""
+    base = pkg.synth.make_frames(8)
+    m = pkg.build_synthetic_model(max_frames=n, with_gru=False, dtype="bf16")
+    try:
+        frames = torch.from_numpy(np.tile(base, (n // 8, 1, 1, 1))).cuda()
+        keys = ("features", "part_attn", "smpl_feats", "point_local_feat")
+        out = m(frames, extras=keys)[-1]
+        n_on = m.num_kernel_launches()
+        m.set_option(pkg._lib.OPT_BF16_CHAIN, 0)
+        m(frames[:n])
+        n_off = m.num_kernel_launches()
+        m.set_option(pkg._lib.OPT_BF16_CHAIN, -1)
+        torch.cuda.synchronize()
+        # the LDS-resident groups really ran: 18 chains of 8 convolutions are 18 launches, the 56x56 branch's 8 chains 4 launches each, layer1 and the stem fewer still
+        assert n_off - n_on >= 7 * (8 + 7 + 3) + 4 * 8 + 3, (n_on, n_off)
+        ref = oracle.grnet_forward(base, synth_weights, synth_smpl, return_intermediates=True)
+        with oracle.bf16_storage():
+            emu = oracle.grnet_forward(base, synth_weights, synth_smpl, return_intermediates=True)
+        report = {}
+        for k in keys + ("theta", "rotmat", "kp_3d", "kp_2d", "verts"):
+            full = out[k].reshape(n // 8, 8, *out[k].shape[1:]) if out[k].shape[0] == n else out[k].reshape(n // 8, 8, *out[k].shape[2:])
+            assert torch.equal(full[0], full[n // 8 - 1]) and torch.equal(full[0], full[(n // 8) // 2]), k      # a frame's result does not depend on its place in the call
+            a = full[0].cpu().numpy()
+            a = a[:, 1:] if k == "part_attn" else a
+            r, e = np.asarray(ref[k]).reshape(a.shape), np.asarray(emu[k]).reshape(a.shape)
+            report[k] = (rel_err(a, r), rel_err(e, r))
+            assert report[k][0] < 2.0 * report[k][1] + 1e-3, (n, k, report[k])
+        print(n, report)
+        assert report["features"][0] < 4e-2 and report["point_local_feat"][0] < 1.5e-2
+        d = out["kp_3d"].reshape(-1, 29, 3)[:8].cpu().numpy() - np.asarray(ref["kp_3d"]).reshape(-1, 29, 3)
+        assert np.linalg.norm(d, axis=-1).mean() < 0.015
+    finally:
+        m.close()
+
+
 def test_bf16_frames_are_independent_and_graph_equals_eager(bmodel, pkg):
     frames = torch.from_numpy(pkg.synth.make_frames(16)).cuda()
     full = bmodel(frames)[-1]

@@ -114,7 +114,7 @@ def test_bf16_forward_with_chains_equals_forward_without(bmodel, pkg):
         without = bmodel(frames, extras=keys)[-1]
         n_without = bmodel.num_kernel_launches()
     finally:
-        bmodel.set_option(pkg._lib.OPT_BF16_CHAIN, 127)
+        bmodel.set_option(pkg._lib.OPT_BF16_CHAIN, -1)
     torch.cuda.synchronize()
     assert n_without - n_with == 7 * (8 + 7 + 3) + 4 * 8 + 3, (n_with, n_without)    # + 3 layer1 reductions run inside their expansions' launches; 18 chains of 8 convolutions became 18 launches, 8 chains of the 56x56 branch 4 launches each
     # (the wide-band and stride-2 band kernels -- bits 4, 5 of the mask -- replace launches one for one: 45 stride-2 layers with up to three shifted addends run here)
@@ -233,12 +233,12 @@ def test_bf16_layer1_pairs_are_bit_identical(bmodel, pkg):
     frames = torch.from_numpy(np.tile(pkg.synth.make_frames(8), (8, 1, 1, 1))).cuda()
     a = bmodel(frames, extras=("features",))[-1]
     n_a = bmodel.num_kernel_launches()
-    bmodel.set_option(pkg._lib.OPT_BF16_CHAIN, 127 - 64)
+    bmodel.set_option(pkg._lib.OPT_BF16_CHAIN, 255 - 64)
     try:
         b = bmodel(frames, extras=("features",))[-1]
         n_b = bmodel.num_kernel_launches()
     finally:
-        bmodel.set_option(pkg._lib.OPT_BF16_CHAIN, 127)
+        bmodel.set_option(pkg._lib.OPT_BF16_CHAIN, -1)
     torch.cuda.synchronize()
     assert n_b - n_a == 3
     for k in ("features", "theta", "verts"):
@@ -249,21 +249,12 @@ def test_bf16_layer1_pairs_are_bit_identical(bmodel, pkg):
 FUSE_MODULES = [("stage2", 0, 2)] + [("stage3", m, 3) for m in range(4)] + [("stage4", m, 4) for m in range(3)]
 
 
-@pytest.fixture(scope="module", params=[2, 1], ids=["output0", "grouped"])
-def fmodel(request, pkg):
-    """GRNET_BF16_FUSE_UP is read when a handle builds its plan: 0 (default) = the round-3 layout (one 1x1 launch per up term); 2 = output 0 of every fuse layer by hr_fuse_up_bf16, the others by their
-    finishing stride-2 convolution; 1 = the fp32 path's layout (outputs 0 .. nb-2 by ONE grouped launch, chains D_ij stored)."""
-    import os
-    old = os.environ.get("GRNET_BF16_FUSE_UP")
-    os.environ["GRNET_BF16_FUSE_UP"] = str(request.param)
-    try:
-        m = pkg.build_synthetic_model(max_frames=16, with_gru=False, dtype="bf16")
-    finally:
-        if old is None:
-            os.environ.pop("GRNET_BF16_FUSE_UP")
-        else:
-            os.environ["GRNET_BF16_FUSE_UP"] = old
-    m.fuse_mode = request.param
+@pytest.fixture(scope="module")
+def fmodel(pkg):
+    """The bf16 plan's fuse layer (hr_fuse_separate: one merged 1x1 launch per source branch, every output finished by its stride-2 convolution's epilogue, output 0
+    by an elementwise sum).  Round 5 also measured two layouts around the grouped launch hr_fuse_up_bf16 (output 0 only / the fp32 path's layout); both lost and are
+    A/B variants of diagnostic builds only (GRNET_AB(BF16_FUSE_UP) in csrc/grnet.cpp) -- this fixture used to build them through an environment variable."""
+    m = pkg.build_synthetic_model(max_frames=16, with_gru=False, dtype="bf16")
     yield m
     m.close()
 
@@ -290,15 +281,13 @@ def test_bf16_fuse_layer_of_every_hr_module_matches_oracle(fmodel, pkg, oracle, 
 
 
 def test_bf16_fuse_layer_launch_count_and_macs(fmodel):
-    """8 fuse-up launches; in the grouped layout they replace all 31 1x1 launches, in the output-0 one the 18 that feed output 0 (and the 8 elementwise
-    sums either way); the MACs still add up to SURVEY 8(d)'s 15 441 563 648 per frame."""
+    """The default bf16 layout has no grouped launch; the 31 1x1 up terms are 18 launches (the terms of ONE source branch merged, output channels side by side);
+    the MACs still add up to SURVEY 8(d)'s 15 441 563 648 per frame."""
     convs = fmodel.describe_convs()
-    assert len([c for c in convs if c["cin"] == 0]) == 8
+    assert len([c for c in convs if c["cin"] == 0]) == 0
     assert sum(c["macs"] for c in convs) == 15441563648
     left = [c for c in convs if c["ks"] == 1 and "fuse_layers" in c["name"] and c["cin"]]
-    # output-0 layout: the terms of outputs >= 1 stay 1x1 launches, those of ONE source branch merged (stage 4: W_13 and W_23 are one launch): 3 x 2 + 4 x 1
-    assert len(left) == (0 if fmodel.fuse_mode == 1 else 10)
-    assert not any("fuse_layers.0." in c["name"] for c in left)
+    assert len(left) == 18, len(left)
 
 
 def test_blocked_temporal_attention_two_clips_ragged_blocks(pkg, oracle):
@@ -319,89 +308,60 @@ def test_blocked_temporal_attention_two_clips_ragged_blocks(pkg, oracle):
 
 
 # ---- GRU recurrence, round 5: rows-per-wave kernel, hand-off inside the XCD's L2 (gru_kernels.hip) --------------------------------------
-_GRU_VARIANT_SCRIPT = r"""
-import importlib, json, sys
-import numpy as np, torch
-sys.path.insert(0, {root!r})
-pkg = importlib.import_module({name!r})
-oracle = importlib.import_module("oracle.grnet_oracle")
-m = pkg.build_synthetic_model(max_frames=4, with_gru=True)
-sd = pkg.synth.make_gru_state_dict()
-res = {{}}
-for (b, t) in {cases!r}:
-    x, cp = pkg.synth.make_gru_inputs(b, t)
-    y, ph, _ = m.gru_forward(torch.from_numpy(x).cuda(), torch.from_numpy(cp).cuda())
-    torch.cuda.synchronize()
-    ry, rph, _ = oracle.gru_forward(x, cp, sd)
-    e = lambda a, r: float(np.abs(a.cpu().numpy().astype(np.float64) - r).max() / np.abs(r).max())
-    res["%d_%d" % (b, t)] = [e(y, ry), e(ph, rph), bool(torch.isfinite(y).all() and torch.isfinite(ph).all())]
-print("RESULT " + json.dumps(res))
-"""
-
-
-def _gru_variant(env, cases):
-    import json
-    import subprocess
-    import sys
-    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    PKG_NAME = "video-based-gait-analysis-for-dementia_amd"
-    e = dict(os.environ)
-    e.update(env)
-    r = subprocess.run([sys.executable, "-c", _GRU_VARIANT_SCRIPT.format(root=ROOT, name=PKG_NAME, cases=cases)], env=e, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
-    return json.loads(line[len("RESULT "):])
-
-
-@pytest.mark.parametrize("env", [{}, {"GRNET_GRU_AGENT": "1"}, {"GRNET_GRU_SPLIT": "2"}, {"GRNET_GRU_SPLIT": "1"}, {"GRNET_GRU_SPLIT": "0"}],
-                         ids=["default", "agent_scope_stores", "libm_gates", "column_slices", "unsplit"])
-def test_gru_recurrence_variants_long_sequences(env):
-    """Every form of the recurrence against the oracle (gait_feat_encoder.py:79-104) on sequences long enough for an error of the gate
+@pytest.mark.parametrize("mode", [3, 3 + 16, 2, 1, 0], ids=["default", "agent_scope_stores", "libm_gates", "column_slices", "unsplit"])
+def test_gru_recurrence_variants_long_sequences(pkg, oracle, mode):
+    """Every form of the recurrence (GRNET_OPT_GRU_MODE) against the oracle (gait_feat_encoder.py:79-104) on sequences long enough for an error of the gate
     functions or a missed hand-off to show: 1 x 2000 steps (each direction 2 layers x 2000 dependent steps), 3 x 257 (six groups of eight
     workgroups), 16 x 9 (the largest batch the split form takes).  The default takes the v_exp / v_rcp gate functions and, where the eight
-    slices of a group share an XCD, workgroup-scope granule stores; GRNET_GRU_AGENT=1 is the path of a group that spans XCDs."""
-    res = _gru_variant(env, [(1, 2000), (3, 257), (16, 9)])
-    for k, (ey, eph, finite) in res.items():
-        assert finite, (k, env)
-        assert ey < 1e-4 and eph < 1e-4, (k, env, ey, eph)
+    slices of a group share an XCD, workgroup-scope granule stores; + 16 is the path of a group that spans XCDs (and the handle's own fall-back
+    after a hand-off timeout)."""
+    m = pkg.build_synthetic_model(max_frames=4, with_gru=True)
+    try:
+        m.set_option(pkg._lib.OPT_GRU_MODE, mode)
+        sd = pkg.synth.make_gru_state_dict()
+        for (b, t) in [(1, 2000), (3, 257), (16, 9)]:
+            x, cp = pkg.synth.make_gru_inputs(b, t)
+            y, ph, _ = m.gru_forward(torch.from_numpy(x).cuda(), torch.from_numpy(cp).cuda())
+            torch.cuda.synchronize()
+            ry, rph, _ = oracle.gru_forward(x, cp, sd)
+            e = lambda a, r: float(np.abs(a.cpu().numpy().astype(np.float64) - r).max() / np.abs(r).max())
+            assert bool(torch.isfinite(y).all() and torch.isfinite(ph).all()), (b, t, mode)
+            assert e(y, ry) < 1e-4 and e(ph, rph) < 1e-4, (b, t, mode, e(y, ry), e(ph, rph))
+        with pytest.raises(pkg._lib.GrnetError):
+            m.set_option(pkg._lib.OPT_GRU_MODE, 7)
+    finally:
+        m.close()
 
 
 # ---- layer1's 64 -> 256 1x1 layers as a stream (csrc/conv_bf16.hip: conv_bf16_pw_stream) -------------------------------------------------
-_PW_STREAM_SCRIPT = r"""
-import importlib, sys, hashlib
-import numpy as np, torch
-sys.path.insert(0, {root!r})
-pkg = importlib.import_module({name!r})
-m = pkg.build_synthetic_model(max_frames={n}, with_gru=False, dtype="bf16")
-frames = torch.from_numpy(np.tile(pkg.synth.make_frames(8), ({n} // 8, 1, 1, 1))).cuda()
-out = m(frames, extras=("features",))[-1]
-torch.cuda.synchronize()
-print("RESULT", m.num_kernel_launches(), *[hashlib.sha256(out[k].cpu().numpy().tobytes()).hexdigest() for k in ("features", "theta", "verts")])
-"""
-
-
-def _pw_stream_run(env, n):
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    e = dict(os.environ)
-    e.update(env)
-    r = subprocess.run([sys.executable, "-c", _PW_STREAM_SCRIPT.format(root=root, name="video-based-gait-analysis-for-dementia_amd", n=n)], env=e, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    return [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1].split()[1:]
+def _forward_digest(m, frames):
+    import hashlib
+    out = m(frames, extras=("features",))[-1]
+    torch.cuda.synchronize()
+    return [m.num_kernel_launches()] + [hashlib.sha256(out[k].cpu().numpy().tobytes()).hexdigest() for k in ("features", "theta", "verts")]
 
 
 @pytest.mark.parametrize("n", [8, 64])
-def test_bf16_layer1_stream_kernel_is_bit_identical_to_the_generic_one(n):
+def test_bf16_layer1_stream_kernel_is_bit_identical_to_the_generic_one(pkg, bmodel, n):
     """conv_bf16_pw_stream (persistent workgroups, register prefetch; all three forms: [t ; x] two-input + pair, residual + pair, residual alone) against
     conv_bf16_nhwc on the same layers: same operands, same k order, same (acc + residual) + bias -> ReLU -> bf16 -- the whole forward may not change by a
-    bit.  8 frames: forced on (fewer tiles than workgroups, the clamped re-request of the last tile); 64 frames: the size it is picked at."""
-    ref = _pw_stream_run({"GRNET_BF16_PW_STREAM": "0"}, n)
-    got = _pw_stream_run({"GRNET_BF16_PW_STREAM": "2"}, n)
-    assert ref[0] == got[0]                                   # same number of launches
-    assert ref[1:] == got[1:]
-    unpaired = _pw_stream_run({"GRNET_BF16_PW_STREAM": "2", "GRNET_BF16_CHAIN": str(127 - 64)}, n)
-    assert unpaired[1:] == ref[1:]
+    bit.  GRNET_OPT_BF16_CHAIN bit 7 switches the stream kernel, bit 8 the Bottleneck launches that replace both in large calls (off here).  8 frames: forced
+    on with GRNET_OPT_BF16_MIN_FRAMES = 1 (fewer tiles than workgroups, the clamped re-request of the last tile); 64 frames: the size it is picked at."""
+    lib = pkg._lib
+    frames = torch.from_numpy(np.tile(pkg.synth.make_frames(8), (n // 8, 1, 1, 1))).cuda()
+    try:
+        bmodel.set_option(lib.OPT_BF16_MIN_FRAMES, 1)
+        bmodel.set_option(lib.OPT_BF16_CHAIN, 255 - 128)
+        ref = _forward_digest(bmodel, frames)
+        bmodel.set_option(lib.OPT_BF16_CHAIN, 255)
+        got = _forward_digest(bmodel, frames)
+        assert ref == got                                         # same number of launches, same bits
+        bmodel.set_option(lib.OPT_BF16_CHAIN, 255 - 64)
+        unpaired = _forward_digest(bmodel, frames)
+        assert unpaired[1:] == ref[1:]
+    finally:
+        bmodel.set_option(lib.OPT_BF16_CHAIN, -1)
+        bmodel.set_option(lib.OPT_BF16_MIN_FRAMES, 0)
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 28, 28), (3, 128, 14, 14), (2, 256, 7, 7), (1, 128, 28, 28), (2, 256, 28, 28), (16, 256, 14, 14)])
@@ -416,11 +376,3 @@ def test_bf16_bilinear2x_rows_kernel(bmodel, oracle, shape):
     assert got.shape == ref.shape and np.array_equal(got, _rb(got))
     assert np.all(np.abs(got - ref) <= np.abs(ref) * 2.0 ** -8 + 1e-5), float(np.abs(got - ref).max())
     assert np.all(np.abs(got[:, :, -1] - ref[:, :, -1]) <= np.abs(ref[:, :, -1]) * 2.0 ** -8 + 1e-5) and np.all(np.abs(got[:, :, 0] - ref[:, :, 0]) <= np.abs(ref[:, :, 0]) * 2.0 ** -8 + 1e-5)
-
-
-def test_bf16_pooling_workgroup_forms_are_bit_identical():
-    """attn_pool_bf16x_kernel<12> (one workgroup builds a (frame, range)'s softmax for all 192 channels) against <6> (two workgroups of 96 channels, each building
-    it): the same values in the same order -- the whole forward may not change by a bit."""
-    a = _pw_stream_run({}, 8)
-    b = _pw_stream_run({"GRNET_BF16_POOL_WAVES": "6"}, 8)
-    assert a == b

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("GRNET_LIB_PATH") or os.path.join(_HERE, "libgrnet_hip
 
 OK, EINVAL, ENOENT, ENOMEM, EHIP, ESTATE = 0, -22, -2, -12, -5, -1
 DTYPE_F32, DTYPE_I64 = 0, 1
-OPT_USE_GRAPH, OPT_CONV_TILE, OPT_MULTI_LANE, OPT_WINOGRAD, OPT_BF16_CHAIN = 1, 2, 3, 7, 8
+OPT_USE_GRAPH, OPT_CONV_TILE, OPT_MULTI_LANE, OPT_WINOGRAD, OPT_BF16_CHAIN, OPT_GRU_MODE, OPT_BF16_MIN_FRAMES = 1, 2, 3, 7, 8, 9, 10
 
 
 class Outputs(C.Structure):

@@ -1020,7 +1020,7 @@ hipError_t dispatch_bf16(const ConvArgs& a, int tps, int tc, hipStream_t s) {
     // where the per-chunk staging code stood in front of the MFMAs (256 -> 256 @56x56 at 256 frames: 1 127 -> 1 045 us, 480 -> 256:
     // 1 924 -> 1 770).  The 16-channel-per-wave variants lose more to the registers (152 instead of 116: three waves per SIMD instead
     // of four) than they gain: 32 -> 32 @56x56 40.7 -> 48.5 us, 64 -> 64 @28x28 32.3 -> 36.6, 64 -> 256 1x1 272 -> 300.
-    static const int reg_env = getenv("GRNET_BF16_REG") ? atoi(getenv("GRNET_BF16_REG")) : 1;
+    static const int reg_env = GRNET_AB(BF16_REG, 1);
     const int aunits = (a.PSTR * kSlotU + 63) & ~63;
     if (reg_env && KS == 3 && tps == 14 && tc == 64 && a.CinPad >= 2 * kCK && aunits <= kRegUnits * 256 &&
         (size_t)a.N * a.H * a.W * a.in_ctot < 0xfffffff0u)                                  // the offsets are 32-bit element counts
@@ -1031,7 +1031,7 @@ hipError_t dispatch_bf16(const ConvArgs& a, int tps, int tc, hipStream_t s) {
         if (tps == 7 && tc == 256) return launch_k(conv_bf16_nhwc<1, 1, 7, 16, 1, 4>, grid, dim3(256), lds, s, a);
     }
     if (tps == 14 && tc == 64) return launch_k(conv_bf16_nhwc<KS, S, 14, 4, 2, 2>, grid, dim3(256), lds, s, a);
-    static const int occ_env = getenv("GRNET_BF16_OCC") ? atoi(getenv("GRNET_BF16_OCC")) : 3;      // workgroups per CU from which the four-wave variants run
+    static const int occ_env = GRNET_AB(BF16_OCC, 3);      // workgroups per CU from which the four-wave variants run
     if ((long)a.gx * a.gy >= (long)occ_env * 256) {
         if (tps == 14 && tc == 32) return launch_k(conv_bf16_nhwc<KS, S, 14, 2, 2, 2, false, true>, grid, dim3(256), lds, s, a);
         if (tps == 7 && tc == 64) return launch_k(conv_bf16_nhwc<KS, S, 7, 4, 1, 4, false, true>, grid, dim3(256), lds, s, a);
@@ -1210,7 +1210,7 @@ __global__ __launch_bounds__(256) void conv_bf16_pw_stream(const ConvArgs a, int
 
 bool pw_stream_eligible(const ConvArgs& a) {
     if (!(a.ks == 1 && a.stride == 1 && a.Cout <= a.CoutPad && a.relu_from == 0 && a.H == a.Ho && a.W == a.Wo)) return false;
-    static const int small_env = getenv("GRNET_BF16_PW_STREAM_SMALL") ? atoi(getenv("GRNET_BF16_PW_STREAM_SMALL")) : 3;     // bit 0: 64 / 32 output channels on 56x56 maps, bit 1: on smaller maps
+    static const int small_env = GRNET_AB(BF16_PW_STREAM_SMALL, 3);     // bit 0: 64 / 32 output channels on 56x56 maps, bit 1: on smaller maps
     if (!(a.CoutPad == 256 || ((a.CoutPad == 64 || a.CoutPad == 32) && (small_env & (a.W >= 56 ? 1 : 2))))) return false;
     if (a.in2 ? !(a.Cin == 128 && a.CinPad == 128 && a.cin_split == 64 && a.in2_ctot % 8 == 0 && a.in2_coff % 8 == 0 && a.in2_ctot - a.in2_coff >= 64 && a.in_ctot - a.in_coff >= 64)
               : !((a.Cin == 64 && a.CinPad == 64) || (a.Cin == 128 && a.CinPad == 128)) || a.in_ctot - a.in_coff < a.CinPad) return false;
@@ -1220,12 +1220,11 @@ bool pw_stream_eligible(const ConvArgs& a) {
     // instantiated: 64 -> 256 {residual, none} x {pair, none}; [t ; x] -> 256 + pair; 64 / 128 -> 64 / 32 without addend
     if (a.CoutPad == 256 ? (a.in2 ? !(a.w2 && a.n_add == 0) : a.Cin != 64) : (a.in2 || a.n_add != 0 || a.w2)) return false;
     const long px = (long)a.N * a.H * a.W;
-    static const int stream_env = getenv("GRNET_BF16_PW_STREAM") ? atoi(getenv("GRNET_BF16_PW_STREAM")) : 1;     // 2: whatever the call size (tests)
-    return px % 32 == 0 && (stream_env == 2 || px / 32 >= 512L * 8);      // persistent workgroups: at least eight tiles each, or their fixed cost (the weights) does not pay
+    return px % 32 == 0 && (a.pw_stream == 2 || px / 32 >= 512L * 8);      // persistent workgroups: at least eight tiles each, or their fixed cost (the weights) does not pay
 }
 hipError_t launch_pw_stream(const ConvArgs& a, hipStream_t s) {
     const int ntiles = (int)((long)a.N * a.H * a.W / 32);
-    static const int wgs_env = getenv("GRNET_BF16_PW_STREAM_WGS") ? atoi(getenv("GRNET_BF16_PW_STREAM_WGS")) : 2;      // workgroups per CU
+    static const int wgs_env = GRNET_AB(BF16_PW_STREAM_WGS, 2);      // workgroups per CU
     int cus = 0;
     GRK_TRY(device_cu_count(&cus));
     const dim3 grid(std::min(ntiles, cus * wgs_env));
@@ -1259,9 +1258,8 @@ hipError_t launch_conv_bf16(ConvArgs a, hipStream_t s, int tile_hint) {
     if (!((a.ks == 1 && a.stride == 1) || (a.ks == 3 && (a.stride == 1 || a.stride == 2)))) return hipErrorInvalidValue;
     if (a.CinPad % kCK != 0 || a.CoutPad % 32 != 0 || a.in_ctot % 8 != 0 || a.in_coff % 8 != 0 || a.out_ctot % 8 != 0 || a.out_coff % 8 != 0)
         return hipErrorInvalidValue;
-    static const int stream_env = getenv("GRNET_BF16_PW_STREAM") ? atoi(getenv("GRNET_BF16_PW_STREAM")) : 1;     // 0: layer1's 64 -> 256 1x1 layers on conv_bf16_nhwc
-    if (stream_env && tile_hint == 0 && pw_stream_eligible(a)) return launch_pw_stream(a, s);
-    static const int direct_env = getenv("GRNET_BF16_DIRECT") ? atoi(getenv("GRNET_BF16_DIRECT")) : 1;
+    if (a.pw_stream && tile_hint == 0 && pw_stream_eligible(a)) return launch_pw_stream(a, s);      // a.pw_stream 0: these layers on conv_bf16_nhwc (GRNET_OPT_BF16_CHAIN bit 7)
+    static const int direct_env = GRNET_AB(BF16_DIRECT, 1);
     if (direct_env && tile_hint == 0 && bf16_direct_eligible(a)) {
         // rows per strip: enough strips to give every SIMD about two waves, at most 8 rows (weights and the first rows are a strip's fixed cost)
         const int halves = a.Cin / 32, cols = a.W / 28;       // a strip is R rows x 28 pixels (2 tiles) x 32 output channels
@@ -1275,7 +1273,7 @@ hipError_t launch_conv_bf16(ConvArgs a, hipStream_t s, int tile_hint) {
     int tc = a.CoutPad % 64 == 0 ? 64 : 32;                // measured at 256 frames: 32 everywhere is 1.5x slower
     // 224-pixel tiles for the 56-wide maps, 112 otherwise (measured: 224 everywhere ties at 256 frames and loses 13 % at 16; 112 everywhere loses 28 %)
     int tps = (tile_hint == 7 || tile_hint == 14) ? tile_hint : (a.Wo >= 56 ? 14 : 7);
-    static const int pw256_env = getenv("GRNET_BF16_PW256") ? atoi(getenv("GRNET_BF16_PW256")) : 0;      // measured: 263 vs 237 us for 64 -> 256 with its residual at 256 frames -- off
+    static const int pw256_env = GRNET_AB(BF16_PW256, 0);      // measured: 263 vs 237 us for 64 -> 256 with its residual at 256 frames -- off
     if ((pw256_env || a.w2) && tile_hint == 0 && a.ks == 1 && a.CoutPad == 256 && a.Wo == 56 && (long)a.N * a.Ho * a.Wo >= 256L * 112 * 2) { tc = 256; tps = 7; }
     if (a.w2 && tc != 256) return hipErrorInvalidValue;    // a pair needs the 256-channel tile
     if (!plan_bf16(a, tps, tc)) {
@@ -1283,11 +1281,11 @@ hipError_t launch_conv_bf16(ConvArgs a, hipStream_t s, int tile_hint) {
         if (!plan_bf16(a, tps, tc)) return hipErrorInvalidValue;
     }
 #ifdef GRNET_ABLATION
-    if (getenv("GRNET_BF16_PHASES")) a.dbg |= 8;
+    if (GRNET_AB_SET(BF16_PHASES)) a.dbg |= 8;
 #endif
     hipError_t e = a.ks == 1 ? dispatch_bf16<1, 1>(a, tps, tc, s) : (a.stride == 1 ? dispatch_bf16<3, 1>(a, tps, tc, s) : dispatch_bf16<3, 2>(a, tps, tc, s));
 #ifdef GRNET_ABLATION
-    static const bool phases = getenv("GRNET_BF16_PHASES") != nullptr;
+    static const bool phases = GRNET_AB_SET(BF16_PHASES);
     if (phases && e == hipSuccess) {
         unsigned long long h[8] = {}, z[8] = {};
         hipStreamSynchronize(s);
@@ -1331,7 +1329,7 @@ hipError_t launch_nhwc_bf16_to_nchw_f32(const void* in, float* out, int N, int C
 }
 hipError_t launch_bilinear2x_bf16(const void* in, void* out, int N, int C, int H, int W, hipStream_t s) {
     if (C % 8 != 0) return hipErrorInvalidValue;
-    static const int rows_env = getenv("GRNET_BF16_BILINEAR_ROWS") ? atoi(getenv("GRNET_BF16_BILINEAR_ROWS")) : 1;     // 0: four taps per output unit through the vector L1
+    static const int rows_env = GRNET_AB(BF16_BILINEAR_ROWS, 1);     // 0: four taps per output unit through the vector L1
     const size_t lds = (size_t)2 * W * C * 2;
     if (rows_env && lds <= 48 * 1024)
         return launch_k(bilinear2x_bf16_rows_kernel, dim3(N * H), dim3(256), lds, s, reinterpret_cast<const u16*>(in), reinterpret_cast<u16*>(out), N, C, H, W);
@@ -1347,10 +1345,10 @@ hipError_t launch_softmax_pool_bf16(const void* heat, int hc, const void* featA,
                                     int P, hipStream_t s) {
     if (CA != 128 || CB != 64 || P != kPoolChunkB * kPoolSplit || hc < 32 || hc % 8 != 0 || ctA % 8 != 0 || ctB % 8 != 0) return hipErrorInvalidValue;
     float* part = pool_ws + (size_t)N * kPoolStatsFloats;
-    const int x16 = getenv("GRNET_BF16_POOL_X16") ? atoi(getenv("GRNET_BF16_POOL_X16")) : 1;     // 0: the fp32-MFMA form (A/B; read per launch)
+    const int x16 = GRNET_AB(BF16_POOL_X16, 1);     // 0: the fp32-MFMA form (A/B; read per launch)
     if (x16)
         {
-            static const int nw_env = getenv("GRNET_BF16_POOL_WAVES") ? atoi(getenv("GRNET_BF16_POOL_WAVES")) : 12;      // 12 (default): one workgroup for all 192 channels; 6: two of 96
+            static const int nw_env = GRNET_AB(BF16_POOL_WAVES, 12);      // 12 (default): one workgroup for all 192 channels; 6: two of 96
             if (nw_env == 12) return launch_k(attn_pool_bf16x_kernel<12>, dim3(N, 1, kPoolSplit), dim3(768), (size_t)24 * kPoolStrideB * 4 + 2 * kPoolPB * (12 * 16 + 8) * 2, s, reinterpret_cast<const u16*>(heat), hc, reinterpret_cast<const u16*>(featA),
                         CA, ctA, reinterpret_cast<const u16*>(featB), CB, ctB, pool_ws, part, P);
             return launch_k(attn_pool_bf16x_kernel<6>, dim3(N, (CA + CB) / 96, kPoolSplit), dim3(384), (size_t)24 * kPoolStrideB * 4 + 2 * kPoolPB * (6 * 16 + 8) * 2, s, reinterpret_cast<const u16*>(heat), hc, reinterpret_cast<const u16*>(featA),

@@ -559,7 +559,11 @@ __global__ __launch_bounds__(512) void conv_bf16_block_frame(const ChainArgs a) 
             lds_barrier();
             chain_kloop_ldsw<P, SB, CS, PS2>(acc2, bread2, wl1);
             // the block's output rows leave straight from the accumulators (round 5: was in place through the plane, a barrier, then 16-byte stores): 8 bytes per lane, the
-            // four k-groups of a pixel make 32 contiguous bytes, the two channel blocks its 64-byte row; nothing of this band's output is needed in LDS again
+            // four k-groups of a pixel make 32 contiguous bytes, the two channel blocks its 64-byte row; nothing of this band's output is needed in LDS again.
+            // The next band's DMAs (issued a whole band ago) and the previous band's stores are the only vector-memory operations in flight: waited for HERE, in front of
+            // this band's stores (round-5 advice: a counted wait behind them assumed CS x PS2 stores per wave, but the stores are predicated -- the wave that owns the
+            // column tiles past the band issues fewer, and its DMAs could then still be in flight when deposit() reads the staging area)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int ps = 0; ps < PS2; ++ps) {
                 int of = o2_first;
@@ -572,9 +576,6 @@ __global__ __launch_bounds__(512) void conv_bf16_block_frame(const ChainArgs a) 
                     if (v2 & (1u << ps)) *reinterpret_cast<u32x2*>(op + cs * 16) = u32x2{pack2_c(relu_c(v[0]), relu_c(v[1])), pack2_c(relu_c(v[2]), relu_c(v[3]))};
                 }
             }
-            // in order: everything older than this band's CS x PS2 stores -- the next band's DMAs, issued a whole band ago -- has landed (stores in the queue can only make
-            // the count stricter)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CS * PS2) : "memory");
         } else {
         lds_barrier();
 #pragma unroll
@@ -1241,9 +1242,9 @@ hipError_t launch_conv_bf16_chain(const ChainArgs& a, int c, int w, hipStream_t 
                 b.out = a.mid[k]; b.out_ctot = a.mid_ctot[k]; b.out_coff = a.mid_coff[k];
             } else { b.out = a.out; b.out_ctot = a.out_ctot; b.out_coff = a.out_coff; }
             // 0 (default): workgroup = frame, seven bands of 8 rows, the next band by LDS-DMA under the current band's MFMAs; 19: workgroup = band, one per CU; 8: two per CU
-            static const int frame_direct = getenv("GRNET_BF16_FRAME_DIRECT") ? atoi(getenv("GRNET_BF16_FRAME_DIRECT")) : 1;
+            static const int frame_direct = GRNET_AB(BF16_FRAME_DIRECT, 1);
             b.flags = frame_direct ? 0 : 1;
-            static const int band_rows = getenv("GRNET_BF16_BAND") ? atoi(getenv("GRNET_BF16_BAND")) : 0;
+            static const int band_rows = GRNET_AB(BF16_BAND, 0);
             if (band_rows == 0) GRK_TRY(launch_k(conv_bf16_block_frame<56, 8>, dim3(a.N), dim3(512), FrameGeom<56, 8>::LDS, s, b));
             else if (band_rows == 19) GRK_TRY(launch_k(conv_bf16_block_band<32, 56, 19, 2>, dim3(a.N * BandGeom<32, 56, 19>::NB), dim3(512), BandGeom<32, 56, 19>::LDS, s, b));
             else GRK_TRY(launch_k(conv_bf16_block_band<32, 56, 8, 4>, dim3(a.N * BandGeom<32, 56, 8>::NB), dim3(512), BandGeom<32, 56, 8>::LDS, s, b));
@@ -1263,30 +1264,30 @@ bool conv_bf16_wide_eligible(const ConvArgs& a) {
     if (a.in_ctot % 8 != 0 || a.in_coff % 8 != 0 || a.out_ctot % 8 != 0 || a.out_coff % 8 != 0 || a.Cout % 8 != 0) return false;
     if (a.W == 56 && a.CinPad == 64 && a.CoutPad == 64) return true;
     // transition1's 256 -> 32 (hrnet.py:348-387): the ring kernel with ONE 32-channel block, every wave a column group (conv_bf16_nhwc ran it at 0.18 of the peak, 2.0 TB/s)
-    static const int ct32_env = getenv("GRNET_BF16_WIDE_CT32") ? atoi(getenv("GRNET_BF16_WIDE_CT32")) : 1;
+    static const int ct32_env = GRNET_AB(BF16_WIDE_CT32, 1);
     if (ct32_env && a.W == 56 && a.CinPad >= 128 && a.CoutPad == 32) return true;
     return (a.W == 56 || a.W == 28) && a.CinPad >= 128 && a.CoutPad % 128 == 0;
 }
 hipError_t launch_conv_bf16_wide(const ConvArgs& a0, hipStream_t s) {
     if (!conv_bf16_wide_eligible(a0) || a0.N < 1) return hipErrorInvalidValue;
-    static const int xcd_env = getenv("GRNET_BF16_XCD") ? atoi(getenv("GRNET_BF16_XCD")) : 1;
+    static const int xcd_env = GRNET_AB(BF16_XCD, 1);
     ConvArgs a = a0;
     a.xcd = xcd_env;
 #ifdef GRNET_ABLATION
-    a.dbg = getenv("GRNET_WIDE_DBG") ? atoi(getenv("GRNET_WIDE_DBG")) : 0;
+    a.dbg = GRNET_AB(WIDE_DBG, 0);
 #endif
     // (64 -> 64 on the ring kernel -- 7-row bands, two chunks: the second streams under the first -- measured 93 us against the band kernel's 79: stays here)
     if (a.CinPad == 64) return launch_k(conv_bf16_wide_band<64, 64, 56, 14>, dim3(a.N * WideGeom<64, 64, 56, 14>::NB), dim3(512), WideGeom<64, 64, 56, 14>::LDS, s, a);
     if (a.CoutPad == 32) return launch_k(conv_bf16_wide_ring<32, 56, 8>, dim3(a.N * RingGeom<32, 56, 8>::NB), dim3(512), RingGeom<32, 56, 8>::LDS, s, a);
     const int ncb = a.CoutPad / 128;
     // 1 (default): the ring of one-chunk planes; 0: the 128-channel plane refilled between passes (A/B)
-    static const int ring_env = getenv("GRNET_BF16_WIDE_RING") ? atoi(getenv("GRNET_BF16_WIDE_RING")) : 1;
+    static const int ring_env = GRNET_AB(BF16_WIDE_RING, 1);
     if (ring_env && a.CinPad >= 64) {
         // 256 output channels at 56x56: ONE workgroup for all channels of a 4-row band (eight channel waves, 15 column tiles each) -- the band is fetched once, not once per
         // 128-channel tile: 6 input rows per 4 output rows instead of 2 x 10 per 8, 5 plane pieces per chunk and wave instead of 7; the tile leaves from the accumulators.
         // Alone it ties the 128-channel tiles (1 222 / 1 221 us for 480 -> 256, 644 / 647 for 256 -> 256 at 256 frames); in the step 10.49 against 10.51-10.53 ms (two pairs).
         // GRNET_BF16_WIDE_CT256=0: 128-channel tiles
-        static const int ct256_env = getenv("GRNET_BF16_WIDE_CT256") ? atoi(getenv("GRNET_BF16_WIDE_CT256")) : 1;
+        static const int ct256_env = GRNET_AB(BF16_WIDE_CT256, 1);
         if (ct256_env && a.W == 56 && a.CoutPad == 256)
             return launch_k(conv_bf16_wide_ring<256, 56, 4, true>, dim3(a.N * RingGeom<256, 56, 4, true>::NB), dim3(512), RingGeom<256, 56, 4, true>::LDS, s, a);
         // 56x56: 8-row bands (7 per frame, 15 column tiles per wave, 244 registers) measured against 7-row ones (8 per frame): 480 -> 256 1 240 / 1 240 us,

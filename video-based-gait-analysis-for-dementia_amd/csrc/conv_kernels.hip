@@ -815,7 +815,7 @@ struct Cfg { int family, tps, tcs; int nw = 4; };   // nw: split-K waves per wor
 
 // The image width the split-K kernel is compiled for (edge-pointer variants: splitk_body), 0 = the generic kernel.
 int splitk_width_variant(const ConvArgs& a, const Cfg& c) {
-    static const int on = getenv("GRNET_EDGEPTR") ? atoi(getenv("GRNET_EDGEPTR")) : 1;
+    static const int on = GRNET_AB(EDGEPTR, 1);
     if (!on || c.family != 1 || a.rows != 1 || a.ks != 3 || c.tcs != 1) return 0;
     if (!((c.tps == 7 && (c.nw == 8 || c.nw == 4)) || (c.tps == 4 && c.nw == 8))) return 0;
     return (a.W == 56 || a.W == 28 || a.W == 14) ? a.W : 0;
@@ -901,7 +901,7 @@ hipError_t dispatch(const ConvArgs& a_in, const Cfg& c, size_t lds, hipStream_t 
     ConvArgs a = a_in;
     a.gx = a.tiles_y * a.groups;
     a.gy = a.CoutPad / (c.tcs * 16);
-    static const int xcd_env = getenv("GRNET_XCD_ORDER") ? atoi(getenv("GRNET_XCD_ORDER")) : 3;   // A/B runs: 0 plain (tile, block) order, 1 tile-major only
+    static const int xcd_env = GRNET_AB(XCD_ORDER, 3);   // A/B runs: 0 plain (tile, block) order, 1 tile-major only
     const double in_bytes = 4.0 * a.N * a.Cin * a.H * a.W, w_bytes = 4.0 * a.ks * a.ks * a.Cin * a.Cout;
     a.gx8 = (a.gx + 7) / 8;
     a.xcd = 0;
@@ -995,7 +995,7 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s, int tile_hint) {
         // a split-K launch of at most ~2 workgroups per CU leaves each SIMD one or two waves: eight waves per workgroup
         // (half the channels each) give the MFMA pipe a second wave to switch to (measured: 7x7 25.0 -> 21.3 us,
         // 14x14 17.9 -> 15.7, 28x28 16.0 -> 15.4; the 896-block 56x56 launches lose)
-        static const int nw8_env = getenv("GRNET_NW8") ? atoi(getenv("GRNET_NW8")) : 1;
+        static const int nw8_env = GRNET_AB(NW8, 1);
         if (found && nw8_env && best.family == 1 && best.tcs == 1) {
             ConvArgs t = a;
             plan_tile(t, best.tps, 1);
@@ -1013,7 +1013,7 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s, int tile_hint) {
     const size_t lds = lds_bytes(a, best);
     const hipError_t e = a.rows == 1 ? dispatch_ks<true>(a, best, lds, s) : dispatch_ks<false>(a, best, lds, s);
 #ifdef GRNET_ABLATION
-    static const bool phases = getenv("GRNET_F32_PHASES") != nullptr;
+    static const bool phases = GRNET_AB_SET(F32_PHASES);
     if (phases && e == hipSuccess && best.family == 0) {
         unsigned long long h[8] = {}, z[8] = {};
         hipStreamSynchronize(s);

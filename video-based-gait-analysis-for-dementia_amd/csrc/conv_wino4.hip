@@ -608,7 +608,7 @@ __global__ __launch_bounds__(512) void conv_wino4w_f32(const ConvArgs a) { conv_
 // the branch chains need the short launches), bit 2 the 28x28 layers with output channels in 128s (half the CUs: 95 / 51 us against 74 / 39,
 // step unchanged), bit 3 the 64-channel layers on 56x56 maps (21.6 us alone against 24.2, but 3.530 -> 3.549 ms in the step).
 int conv_wino4_wide(int cout, int w) {
-    static const int wide_env = getenv("GRNET_WINO_WIDE") ? atoi(getenv("GRNET_WINO_WIDE")) : 1;
+    static const int wide_env = GRNET_AB(WINO_WIDE, 1);
     if (w == 56) return cout % 128 == 0 ? ((wide_env & 1) ? 4 : 0) : cout == 64 ? ((wide_env & 8) ? 2 : 0) : 0;
     if (w == 28) return cout % 128 == 0 ? ((wide_env & 4) ? 4 : 0) : cout == 64 ? ((wide_env & 2) ? 2 : 0) : 0;
     return 0;
@@ -621,7 +621,7 @@ bool conv_wino4_eligible(int cin, int cout, int ks, int stride, int h, int w, in
 
 // GRNET_WINO_LDS_PAD (diagnostic): extra bytes of LDS the 4-wave launches ask for -- how sensitive the step is to the workgroups per CU
 static size_t wino4_lds() {
-    static const size_t pad = getenv("GRNET_WINO_LDS_PAD") ? (size_t)atoi(getenv("GRNET_WINO_LDS_PAD")) : 0;
+    static const size_t pad = (size_t)GRNET_AB(WINO_LDS_PAD, 0);
     return kLdsB + pad;
 }
 
@@ -648,7 +648,7 @@ static hipError_t launch_wino4_w(ConvArgs a, hipStream_t s, int nb, int* n_launc
 #endif
     if (nb == 2) return launch_k(conv_wino4_f32<2, WD>, dim3(total), dim3(256), kLdsB, s, a);
     // a last round of workgroups that is at most half full runs as twice as many half-size workgroups
-    static const int split_env = getenv("GRNET_WINO_SPLIT") ? atoi(getenv("GRNET_WINO_SPLIT")) : 1;
+    static const int split_env = GRNET_AB(WINO_SPLIT, 1);
     int kCUs = 0;                                        // workgroups per round = CUs of this device (one workgroup fits a CU)
     if (hipError_t e = device_cu_count(&kCUs); e != hipSuccess) return e;
     const int full = total / kCUs * kCUs, rest = total - full;
@@ -695,7 +695,7 @@ hipError_t launch_conv_wino4(ConvArgs a, hipStream_t s, int* n_launches) {
         return npw == 4 ? launch_k(conv_wino4w_f32<28, 4>, grid, dim3(512), kLdsW, s, a) : launch_k(conv_wino4w_f32<28, 2>, grid, dim3(512), kLdsW, s, a);
     }
 #ifdef GRNET_ABLATION
-    if (getenv("GRNET_W4_PHASES")) {
+    if (GRNET_AB_SET(W4_PHASES)) {
         a.dbg |= 8;
         const hipError_t e = a.W == 56 ? launch_wino4_w<56>(a, s, nb, n_launches) : launch_wino4_w<28>(a, s, nb, n_launches);
         unsigned long long h[8] = {}, z[8] = {};

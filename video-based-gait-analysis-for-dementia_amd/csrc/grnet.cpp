@@ -203,6 +203,33 @@ struct grnet {
         return code;
     }
 
+    // GRNET_OPT_GRU_MODE (gru_kernels.hip): 3 = rows-per-wave split recurrence with v_exp / v_rcp gates (default), 2 = the same with expf / tanhf,
+    // 1 = round 3's column slices, 0 = one workgroup per (sequence, direction); + 16: agent-scope granule stores whatever the placement.
+    // gru_fault: one host-mapped word the split kernels set when a hand-off poll hits its bound (an XCD-placement or memory-scope assumption broke:
+    // round-5 advice).  The next temporal call sees it WITHOUT a synchronisation, reports GRNET_ESTATE once and moves the handle to agent-scope stores.
+    int gru_mode = 3;
+    unsigned* gru_fault = nullptr;        // host pointer (hipHostMalloc, mapped)
+    unsigned* gru_fault_dev = nullptr;    // the same word as the device sees it
+    int gru_fault_check() {
+        if (!gru_fault) {
+            void* q = nullptr;
+            if (hipHostMalloc(&q, 64, hipHostMallocMapped) != hipSuccess) return fail(GRNET_ENOMEM, "hipHostMalloc of the GRU fault word failed");
+            gru_fault = static_cast<unsigned*>(q);
+            *gru_fault = 0u;
+            void* d = nullptr;
+            if (hipHostGetDevicePointer(&d, q, 0) != hipSuccess) return fail(GRNET_EHIP, "hipHostGetDevicePointer failed");
+            gru_fault_dev = static_cast<unsigned*>(d);
+        }
+        if (*reinterpret_cast<volatile unsigned*>(gru_fault)) {
+            *gru_fault = 0u;
+            const bool was_agent = (gru_mode & 16) != 0;
+            gru_mode = was_agent ? 0 : (gru_mode | 16);
+            return fail(GRNET_ESTATE, std::string("a hand-off poll of the split GRU recurrence timed out in an earlier call on this handle: the outputs of that call are NaN-poisoned. ") +
+                        (was_agent ? "The handle now runs the unsplit recurrence (GRNET_OPT_GRU_MODE 0)." : "The handle now publishes with agent-scope stores (GRNET_OPT_GRU_MODE + 16).") + " Repeat the call.");
+        }
+        return 0;
+    }
+
     // Scratch of the temporal modules (GRU, attention block, feature corrector): owned by the handle and grown on demand, so a call
     // with a size seen before allocates nothing (graph-capturable, no allocator traffic per call).  Growing synchronises the device.
     float* temporal_ws = nullptr;
@@ -232,6 +259,7 @@ struct grnet {
         for (hipEvent_t e : op_events_flat) if (e) (void)hipEventDestroy(e);
         for (void* p : dev_allocs) (void)hipFree(p);
         if (temporal_ws) (void)hipFree(temporal_ws);
+        if (gru_fault) (void)hipHostFree(gru_fault);
         if (arena) (void)hipFree(arena);
     }
     void drop_graphs() {
@@ -345,8 +373,8 @@ struct grnet {
         for (int b = 0; b < nb; ++b) name_view(tag + "x" + std::to_string(b), xs[b]);
         // GRNET_FUSE_UP=0: the round-3 fuse layer (one 1x1 launch per up term, an elementwise launch for output 0)
         // (GRNET_BF16_FUSE_UP=0 does the same for the bf16 path, which has the grouped launch since round 5)
-        static const int fuse_up_env = getenv("GRNET_FUSE_UP") ? atoi(getenv("GRNET_FUSE_UP")) : 1;
-        const int fuse_up_bf_env = getenv("GRNET_BF16_FUSE_UP") ? atoi(getenv("GRNET_BF16_FUSE_UP")) : 0;    // read per handle: the tests build all three.  0 is the default: at 256 frames the lane-overlapped step is 10.68 / 10.91 / 10.67 ms for 0 / 1 / 2 (one lane: 11.69 / 11.39) -- the small launches hide behind the other lanes, the stored D_ij of layout 1 do not
+        static const int fuse_up_env = GRNET_AB(FUSE_UP, 1);
+        const int fuse_up_bf_env = GRNET_AB(BF16_FUSE_UP, 0);    // read per handle: the tests build all three.  0 is the default: at 256 frames the lane-overlapped step is 10.68 / 10.91 / 10.67 ms for 0 / 1 / 2 (one lane: 11.69 / 11.39) -- the small launches hide behind the other lanes, the stored D_ij of layout 1 do not
         std::vector<View> outs = (dtype == 0 ? fuse_up_env : fuse_up_bf_env == 1) ? hr_fuse_grouped(xs, p, out0, branch_tail)
                                                                                   : hr_fuse_separate(xs, p, out0, dtype == 1 && fuse_up_bf_env == 2, branch_tail);
         for (int i = 0; i < nb; ++i) name_view(tag + "y" + std::to_string(i), outs[i]);
@@ -385,7 +413,7 @@ struct grnet {
                     if (level < i - j && !(i == nb - 1 && j == nb - 2)) members.push_back(i);
                 // GRNET_FUSE_MERGE (A/B switch): 2 = all first convolutions of a branch in one launch, 1 = only the ReLU'd ones, 0 = none
                 // (the bf16 kernels have no per-segment ReLU: every first convolution is its own launch there)
-                static const int merge_env_f32 = getenv("GRNET_FUSE_MERGE") ? atoi(getenv("GRNET_FUSE_MERGE")) : 2;
+                static const int merge_env_f32 = GRNET_AB(FUSE_MERGE, 2);
                 const int merge_env = dtype == 1 ? 0 : merge_env_f32;
                 std::vector<int> solo;
                 if (level == 0 && merge_env < 2) {
@@ -466,7 +494,7 @@ struct grnet {
         std::vector<std::vector<View>> t(nb, std::vector<View>(nb));
         // the up terms W_ij x_j of ONE source branch j (linear 1x1 convolutions at the source's resolution) share their input: one launch, output channels side by side
         // (round 5; 31 -> 18 launches of the 1x1 terms per forward, 10.28 against 10.34 ms at 256 frames bf16; GRNET_FUSE_MERGE_UP=0: one launch per term)
-        static const int merge_up_env = getenv("GRNET_FUSE_MERGE_UP") ? atoi(getenv("GRNET_FUSE_MERGE_UP")) : 1;
+        static const int merge_up_env = GRNET_AB(FUSE_MERGE_UP, 1);
         std::vector<std::vector<char>> tdone(nb, std::vector<char>(nb, 0));
         if (merge_up_env)
             for (int j = 1; j < nb; ++j) {
@@ -531,7 +559,7 @@ struct grnet {
         for (int level = 0; level < nb; ++level) {
             // the ReLU'd first links of the chains that start at ONE branch share their input: one launch with their output channels side by side (round 5, bf16 as well:
             // stage 4's chains (2,0) and (3,0) read the 56x56 branch once instead of twice).  GRNET_FUSE_MERGE_FIRST=0: one launch per chain
-            static const int merge_first_env = getenv("GRNET_FUSE_MERGE_FIRST") ? atoi(getenv("GRNET_FUSE_MERGE_FIRST")) : 1;
+            static const int merge_first_env = GRNET_AB(FUSE_MERGE_FIRST, 1);
             std::vector<std::vector<char>> merged(nb, std::vector<char>(nb, 0));
             if (level == 0 && merge_first_env)
                 for (int j = 0; j < nb - 2; ++j) {
@@ -583,7 +611,7 @@ struct grnet {
         in.p = reinterpret_cast<float*>(~(uintptr_t)0);   // tag: caller's frames pointer
         // bf16: the stem's first convolution reads the caller's fp32 frames itself (conv_bf16_stem, round 4); GRNET_BF16_STEM=0 restores the
         // conversion launch -- frames (N,3,224,224) f32 -> NHWC bf16, 8 channels per pixel -- in front of the generic kernel
-        static const int bf16_stem_env = getenv("GRNET_BF16_STEM") ? atoi(getenv("GRNET_BF16_STEM")) : 1;
+        static const int bf16_stem_env = GRNET_AB(BF16_STEM, 1);
         bf16_stem = dtype == 1 && bf16_stem_env;
         if (dtype == 1 && !bf16_stem) {
             v_in8 = new_buffer(8, 224, 224);
@@ -601,13 +629,19 @@ struct grnet {
         for (int k = 0; k < 4; ++k) {                       // layer1: 4 Bottlenecks (hrnet.py:80-100)
             const std::string q = b + "layer1." + std::to_string(k) + ".";
             // bf16: Bottleneck k-1's expansion and this one's reduction are a PAIR (one launch in large calls): the reduction is the first convolution added below
-            const int first_new = (int)convs.size() + ((k == 0 && !(dtype == 1 && (getenv("GRNET_BF16_MERGE_DS") ? atoi(getenv("GRNET_BF16_MERGE_DS")) : 1))) ? 1 : 0);
+            const int first_new = (int)convs.size() + ((k == 0 && !(dtype == 1 && (GRNET_AB(BF16_MERGE_DS, 1)))) ? 1 : 0);
             struct PairAtExit {
                 grnet* g; int& prev; int first_new;
                 ~PairAtExit() {
                     if (g->dtype == 1 && prev >= 0 && first_new < (int)g->convs.size() && g->convs[first_new].ks == 1 && g->convs[first_new].in.c == 256 && g->convs[first_new].cout == 64) {
                         g->convs[prev].pair_next = first_new;
                         g->convs[first_new].pair_of = prev;
+                        int op_prev = -1, op_new = -1;                 // the member launches nothing in large calls: it shares the expansion's stream, so that a graph
+                        for (int i = 0; i < (int)g->ops.size(); ++i) {  // recorded from this plan hangs the member's consumers on the expansion's node (round-5 advice)
+                            if (g->ops[i].kind == Op::CONV && g->ops[i].conv_idx == prev) op_prev = i;
+                            if (g->ops[i].kind == Op::CONV && g->ops[i].conv_idx == first_new) op_new = i;
+                        }
+                        if (op_prev >= 0 && op_new >= 0) g->ops[op_new].follow = op_prev;
                     }
                     prev = (int)g->convs.size() - 1;         // this Bottleneck's conv3 is the last convolution added
                 }
@@ -615,7 +649,7 @@ struct grnet {
             // bf16, first Bottleneck: relu(BN3(conv3(t)) + BNd(downsample(x))) is ONE 1x1 GEMM over the concatenated inputs [t ; x] (K = 64 + 64, the two
             // BatchNorms folded into their halves of the weights, the shifts summed): the 411 MB downsample tensor (at 256 frames) is neither written nor read
             // back, and a launch goes away.  GRNET_BF16_MERGE_DS=0: the two launches of the reference's graph (hrnet.py:80-100, 389-406).
-            static const int merge_ds = getenv("GRNET_BF16_MERGE_DS") ? atoi(getenv("GRNET_BF16_MERGE_DS")) : 1;
+            static const int merge_ds = GRNET_AB(BF16_MERGE_DS, 1);
             if (k == 0 && dtype == 1 && merge_ds) {
                 View y = conv_bn(x, q + "conv1.weight", q + "bn1", 64, 1, 1, true);
                 y = conv_bn(y, q + "conv2.weight", q + "bn2", 64, 3, 1, true);
@@ -820,7 +854,7 @@ struct grnet {
         for (hipEvent_t e : op_events_flat) if (e) (void)hipEventDestroy(e);
         op_events_flat.clear();
         ops_flat = ops;
-        static const int sched_env = getenv("GRNET_LANE_SCHED") ? atoi(getenv("GRNET_LANE_SCHED")) : 1;   // 0: lanes as written in the plan
+        static const int sched_env = GRNET_AB(LANE_SCHED, 1);   // 0: lanes as written in the plan
         if (sched_env) schedule_lanes(ops_flat, n);
         analyze_dependencies(ops_flat, op_events_flat);
         int used = 1;                                          // only the streams the schedule really uses are forked / joined
@@ -843,8 +877,8 @@ struct grnet {
         std::map<const float*, std::vector<int>> writers;
         std::vector<const float*> r, wr;
         int prev_tail = -1;
-        static const double fix_us = getenv("GRNET_SCHED_FIX") ? atof(getenv("GRNET_SCHED_FIX")) : 6.0;
-        static const double hop_us = getenv("GRNET_SCHED_HOP") ? atof(getenv("GRNET_SCHED_HOP")) : 4.0;
+        static const double fix_us = GRNET_AB_F(SCHED_FIX, 6.0);
+        static const double hop_us = GRNET_AB_F(SCHED_HOP, 4.0);
         for (int i = 0; i < m; ++i) {
             const Op& op = list[i];
             switch (op.kind) {
@@ -893,7 +927,7 @@ struct grnet {
         std::vector<char> done(m, 0);
         for (int i = 0; i < m; ++i) pending[i] = (int)deps[i].size();
         double lane_free[kLanes] = {};
-        static const int n_lanes = std::min(kLanes, std::max(1, getenv("GRNET_LANES") ? atoi(getenv("GRNET_LANES")) : 4));
+        static const int n_lanes = std::min(kLanes, std::max(1, GRNET_AB(LANES, 4)));
         order.reserve(m);
         for (int step = 0; step < m; ++step) {
             int best = -1, best_lane = 0;
@@ -999,13 +1033,13 @@ struct grnet {
         // 256 -> 32 and the 32 -> 32 convolutions of the HR branch; on 28x28 maps the upsample-head layers and the 64 -> 64 convolutions of
         // the HR branch (conv_wino4.hip); on 14x14 / 7x7 maps the 128- / 256-channel HR branches and the 256 -> 256 upsample-head layer
         // (conv_wino4s.hip).  GRNET_WINO4=0 leaves every layer on the direct kernels (as GRNET_OPT_WINOGRAD = 0 does at run time).
-        static const int wino4_env = getenv("GRNET_WINO4") ? atoi(getenv("GRNET_WINO4")) : 2;
+        static const int wino4_env = GRNET_AB(WINO4, 2);
         const bool wino4 = !bf && wino4_env && conv_wino4_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size()) && L.cin_pad % 8 == 0 &&
                            L.cout_pad % (L.cout % 64 == 0 ? 64 : 32) == 0 && (L.adds.empty() || L.adds[0].shift == 0) &&
                            (L.in.w == 56 || (L.in.c >= 64 && L.cout % 64 == 0));
         const bool wino4s = !bf && wino4_env && cin == L.in.c && conv_wino4s_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size()) &&
                             (L.adds.empty() || L.adds[0].shift == 0);          // the small maps: conv_wino4s.hip
-        static const int stem_env = getenv("GRNET_STEM") ? atoi(getenv("GRNET_STEM")) : 1;
+        static const int stem_env = GRNET_AB(STEM, 1);
         const bool stem_shape = cin == L.in.c && L.segs.size() == 1 && conv_stem_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size());
         // GRNET_STEM is the fp32 A/B switch only: a bf16 plan built for conv_bf16_stem (GRNET_BF16_STEM) has no NHWC copy of the frames, so its first
         // convolution MUST get the stem kernel's weights whatever GRNET_STEM says (round-4 advice: the generic kernel then read fp32 NCHW frames as NHWC bf16)
@@ -1301,7 +1335,7 @@ struct grnet {
     // conv_pw.hip (fp32 handles; GRNET_PW: bit 0 64 -> 256, bit 1 128 -> 25, bit 2 the rest of the eligible shapes -- 64 -> 64 and
     // 128 -> 64 measure within 1 us of the generic kernel either way and stay on it; 0: the generic kernel everywhere)
     bool pw_on(const ConvLayer& L) const {
-        static const int pw_env = getenv("GRNET_PW") ? atoi(getenv("GRNET_PW")) : 3;
+        static const int pw_env = GRNET_AB(PW, 3);
         return dtype == 0 && L.in.w == 56 && L.segs.size() == 1 && L.cin_w == L.in.c && (L.adds.empty() || L.adds[0].shift == 0) &&
                conv_pw_eligible(L.in.c, L.cout, L.ks, L.stride, L.in.h, L.in.w, (int)L.adds.size()) && L.cout_pad >= (L.cout > 32 ? (L.cout + 63) / 64 * 64 : 32) &&
                (pw_env & (L.in.c == 64 && L.cout >= 128 ? 1 : L.in.c == 128 && L.cout <= 32 ? 2 : 4));
@@ -1465,6 +1499,7 @@ struct grnet {
             a.add_shift[k] = L.adds[k].shift;
         }
         a.zeros = zeros;
+        a.pw_stream = !(chain_mode & 128) ? 0 : bf16_min_frames ? 2 : 1;
         if (L.in2.c) { a.in2 = L.in2.p; a.in2_ctot = L.in2.ctot; a.in2_coff = L.in2.coff; a.cin_split = L.in.c; a.Cin = L.in.c + L.in2.c; }
         if (L.pair_next >= 0 && pair_active(n)) {
             const ConvLayer& F = convs[L.pair_next];
@@ -1474,7 +1509,8 @@ struct grnet {
     }
     // bf16 layer1: expansion + next reduction as one launch from 19 frames per call on (the 256-channel tile needs >= 512 workgroups of 112 pixels); bit 6 of the
     // GRNET_OPT_BF16_CHAIN mask.  A forced tile switches it off.
-    bool pair_active(int n) const { return dtype == 1 && (chain_mode & 64) && !conv_tile_hint && (long)n * 56 * 56 >= 256L * 112 * 2; }
+    bool pair_active(int n) const { return dtype == 1 && (chain_mode & 64) && !conv_tile_hint && (bf16_min_frames ? n >= bf16_min_frames : (long)n * 56 * 56 >= 256L * 112 * 2); }
+    int bf16_min_frames = 0;                         // GRNET_OPT_BF16_MIN_FRAMES: 0 = every kernel group of chain_mode from its own smallest call (64 / 32 / 64 / 19 / 42 frames), else from this many
 
     // Which kernel runs convolution L in a call of n frames: ONE place, used by the launcher, by the executed-FLOP report and by the
     // per-kernel table of bench.py (round-3 review: the report read a hidden "latest n" and ignored the environment masks).
@@ -1484,27 +1520,28 @@ struct grnet {
     // there a launch per BasicBlock with 19-row bands resident;
     // GRNET_BF16_CHAIN_MIN: smallest call that takes it).  A forced tile (tests / tuning) switches it off like every special kernel.
     bool chain_active(const ChainPlan& c, int n) const {
-        static const int chain_min = getenv("GRNET_BF16_CHAIN_MIN") ? atoi(getenv("GRNET_BF16_CHAIN_MIN")) : 64;
+        const int chain_min = bf16_min_frames ? bf16_min_frames : 64;
         return dtype == 1 && !conv_tile_hint && n >= chain_min && (chain_mode & (c.w == 28 ? 1 : c.w == 14 ? 2 : c.w == 7 ? 4 : 8));
     }
     // bf16: the wide 3x3 stride-1 layers (upsample heads, PARE head, layer1's 3x3) on conv_bf16_wide_band.  A workgroup is a band of 7 / 14 rows of one
     // frame x 128 (64) output channels: from 32 frames per call on a launch has at least one workgroup per CU (bit 4 of the GRNET_OPT_BF16_CHAIN mask;
     // GRNET_BF16_WIDE_MIN: smallest call).  A forced tile switches it off like every special kernel.
     bool wide_runs(const ConvLayer& L, int n) const {
-        static const int wide_min = getenv("GRNET_BF16_WIDE_MIN") ? atoi(getenv("GRNET_BF16_WIDE_MIN")) : 32;
+        const int wide_min = bf16_min_frames ? bf16_min_frames : 32;
         if (dtype != 1 || !(chain_mode & 16) || conv_tile_hint || n < wide_min || L.stem_dev || !L.w_dev) return false;
         return conv_bf16_wide_eligible(conv_args(L, nullptr, n));
     }
     // bf16: the 3x3 stride-2 layers (fuse-layer down paths, transitions, the stem's second convolution) on conv_bf16_s2_band, from 64 frames per call on
     // (a workgroup is a band of one frame; GRNET_BF16_S2_MIN).  Bit 5 of the GRNET_OPT_BF16_CHAIN mask.
     bool s2_runs(const ConvLayer& L, int n) const {
-        static const int s2_min = getenv("GRNET_BF16_S2_MIN") ? atoi(getenv("GRNET_BF16_S2_MIN")) : 64;
+        const int s2_min = bf16_min_frames ? bf16_min_frames : 64;
         if (dtype != 1 || !(chain_mode & 32) || conv_tile_hint || n < s2_min || L.stem_dev || !L.w_dev || L.in2.c) return false;
         return conv_bf16_s2_eligible(conv_args(L, nullptr, n));
     }
-    int chain_mode = getenv("GRNET_BF16_CHAIN") ? atoi(getenv("GRNET_BF16_CHAIN")) : 127;     // bits 0-3: BasicBlock chains by branch, bit 4: wide-band kernel, bit 5: stride-2 band kernel, bit 6: layer1 1x1 pairs      // GRNET_OPT_BF16_CHAIN
+    static constexpr int kChainModeAll = 255;
+    int chain_mode = (getenv("GRNET_BF16_CHAIN") ? atoi(getenv("GRNET_BF16_CHAIN")) : kChainModeAll) & kChainModeAll;     // GRNET_OPT_BF16_CHAIN: bits 0-3 BasicBlock chains by branch, 4 wide bands, 5 stride-2 bands, 6 layer1 1x1 pairs, 7 1x1 stream kernel
     ConvKernel kernel_for(const ConvLayer& L, int n) const {
-        static const int w4s_env = getenv("GRNET_WINO4S") ? atoi(getenv("GRNET_WINO4S")) : 7;      // bit 0: 128 @14x14, bit 1: 256 @7x7, bit 2: 256 @14x14
+        static const int w4s_env = GRNET_AB(WINO4S, 7);      // bit 0: 128 @14x14, bit 1: 256 @7x7, bit 2: 256 @14x14
         if (dtype == 1 && L.chain >= 0 && chain_active(chains[L.chain], n)) return L.chain_pos == 0 ? K_BF16_CHAIN : K_BF16_CHAIN_MEMBER;
         if (dtype == 1 && L.pair_next >= 0 && pair_active(n)) return K_BF16_PAIR;
         if (dtype == 1 && L.pair_of >= 0 && pair_active(n)) return K_BF16_PAIR_MEMBER;
@@ -1551,7 +1588,7 @@ struct grnet {
         }
     }
     int launch_conv_op(const ConvLayer& L, const float* frames, int n, hipStream_t s, int* n_launches) {
-        static const int w4s_ks = getenv("GRNET_WINO4S_KS") ? atoi(getenv("GRNET_WINO4S_KS")) : 0;
+        static const int w4s_ks = GRNET_AB(WINO4S_KS, 0);
         *n_launches = 1;
         switch (kernel_for(L, n)) {
             case K_BF16: HIP_TRY(launch_conv_bf16(conv_args(L, frames, n), s, hint_for(L, n))); break;
@@ -1580,7 +1617,7 @@ struct grnet {
             case K_WINO4S: {
                 ConvArgs wa = conv_args(L, frames, n);
                 wa.w = L.wino4s_dev;
-                static const int w4s_prio = getenv("GRNET_WINO4S_PRIO") ? atoi(getenv("GRNET_WINO4S_PRIO")) : 3;   // bit 0: 14x14 layers, bit 1: 7x7 layers at wave priority 1
+                static const int w4s_prio = GRNET_AB(WINO4S_PRIO, 3);   // bit 0: 14x14 layers, bit 1: 7x7 layers at wave priority 1
                 wa.prio = (w4s_prio & (L.in.w == 7 ? 2 : 1)) ? 1 : 0;
                 HIP_TRY(launch_conv_wino4s(wa, s, w4s_ks));
                 break;
@@ -1595,7 +1632,7 @@ struct grnet {
             case K_WINO4: {
                 ConvArgs wa = conv_args(L, frames, n);
                 wa.w = L.wino4_dev;
-                static const int chain_prio4 = getenv("GRNET_WINO_PRIO") ? atoi(getenv("GRNET_WINO_PRIO")) : 1;
+                static const int chain_prio4 = GRNET_AB(WINO_PRIO, 1);
                 // the BasicBlock chains of the 56x56 and 28x28 HR branches (32-channel workgroups): wave priority 1.  Worth +1 % when
                 // only the 56x56 chain ran on a Winograd kernel; with both on F(4x4,3x3) every combination is within 0.5 %
                 wa.prio = (L.in.c == L.cout && L.cout <= 64 && !L.solo) ? chain_prio4 : 0;
@@ -1668,11 +1705,7 @@ struct grnet {
             }
             // timing-only ablation (results are garbage): GRNET_ABL_SKIP=<substring of a weight key>[,<substring>...] drops the matching
             // convolution launches and "fuse_up" the grouped fuse launches, events and dependencies stay -- what is a group of launches worth?
-#ifdef GRNET_ABLATION                                                  // diagnostic builds only (make ABLATION=1): a stray variable must not make the product drop launches
-            static const char* abl_skip = getenv("GRNET_ABL_SKIP");
-#else
-            static const char* abl_skip = nullptr;
-#endif
+            static const char* abl_skip = GRNET_AB_STR(ABL_SKIP);          // diagnostic builds only (make ABLATION=1): a stray variable must not make the product drop launches
             if (abl_skip && (op.kind == Op::CONV || op.kind == Op::FUSEUP)) {
                 const std::string lbl = op_label(op);
                 bool skip = false;
@@ -1836,7 +1869,8 @@ struct grnet {
         a.ks = ks; a.stride = stride; a.relu = relu;
         if (add_dev) { a.n_add = 1; a.add[0] = static_cast<const float*>(xadd); a.add_ctot[0] = cout8; a.add_coff[0] = 0; a.add_shift[0] = 0; }
         a.zeros = zeros;
-        if (const char* d = getenv("GRNET_CONV_DBG")) a.dbg = atoi(d);
+        a.pw_stream = 1;
+        if (const char* d = GRNET_AB_STR(CONV_DBG)) a.dbg = atoi(d);
         const bool wide = tile_hint == 3003, s2 = tile_hint == 3004;      // conv_bf16_wide_band / conv_bf16_s2_band on this one convolution
         if ((wide && !conv_bf16_wide_eligible(a)) || (s2 && !conv_bf16_s2_eligible(a))) {
             hipFree(wd); hipFree(bd); hipFree(xin); hipFree(xout);
@@ -1845,7 +1879,7 @@ struct grnet {
         }
         auto launch_one = [&]() { return wide ? launch_conv_bf16_wide(a, s) : s2 ? launch_conv_bf16_s2(a, s) : launch_conv_bf16(a, s, tile_hint); };
         if (e == hipSuccess) e = launch_one();
-        if (const char* r = getenv("GRNET_CONV_REPS")) {       // timing loop for tools/bf16_micro.py
+        if (const char* r = GRNET_AB_STR(CONV_REPS)) {       // timing loop for tools/bf16_micro.py
             const int reps = atoi(r);
             hipEvent_t e0, e1;
             hipEventCreate(&e0); hipEventCreate(&e1);
@@ -1942,6 +1976,7 @@ struct grnet {
     // pass's results for the WHOLE clip(s); the second head pass runs in chunks of max_frames.
     int gait_correct(const float* plf, const float* csf, const float* cam, int cam_ld, const float* bbox, const float* cimg, int b, int T,
                      const grnet_outputs_t& o, const grnet_gait_outputs_t& g, hipStream_t s) {
+        if (int rc = gru_fault_check()) return rc;
         const size_t M = (size_t)b * T;
         const size_t gru_need = M * 3072 * 2 + 2 * M * 900 + 2 * M * 600 + (size_t)b * 1200 + (size_t)b * 2 * kGruXbufU64PerSeq + 1024;
         auto al = [](size_t f) { return (f + 63) & ~(size_t)63; };         // every sub-buffer starts 256-byte aligned (16-byte vector loads, 8-byte granules)
@@ -1962,6 +1997,7 @@ struct grnet {
         w.l1 = w.l0 + M * 600;
         w.hfin = w.l1 + M * 600;
         w.xbuf = reinterpret_cast<unsigned long long*>(w.hfin + (((size_t)b * 1200 + 63) & ~(size_t)63));
+        w.mode = gru_mode; w.fault = gru_fault_dev;
         float* fws = p + gru_need;
         HIP_TRY(launch_gait_cparams(cam, cam_ld, bbox, cimg, cparams, (int)M, s));
         HIP_TRY(launch_gru(plf, cparams, gruw, w, avg, phase, xc_buf, b, T, s));
@@ -2076,7 +2112,7 @@ struct grnet {
             // GRNET_GRAPH_EDGES (diagnostic): 0 = dependencies given at node creation (edges in plan order; default), 1 = lane-chain edges first, 2 = cross-lane
             // edges first.  The order changes how ROCm 7.2's executor deals the nodes over its queues (108 / 26 / 142 / 16, 105 / 20 / 159 / 8, 116 / 90 / 70 / 16)
             // but none of them replays faster than 4.16 ms against 3.5 ms for the eager lane streams (profiles/r04_graph_vs_eager_timeline.txt)
-            static const int edges_env = getenv("GRNET_GRAPH_EDGES") ? atoi(getenv("GRNET_GRAPH_EDGES")) : 0;
+            static const int edges_env = GRNET_AB(GRAPH_EDGES, 0);
             recorder.edge_order = edges_env;
             g_recorder = &recorder;
             int rc = enqueue(frames, n, o, s);
@@ -2253,6 +2289,7 @@ int grnet_gru_forward(grnet_t* h, const float* x, const float* cp, int b, int T,
     if (!h || !x || !cp || !y || !phase || b < 1 || T < 1) return GRNET_EINVAL;
     if (!h->gru_ready) return h->fail(GRNET_ESTATE, "GRU weights were not loaded (keys gru.* or pfeat_corrector.featnet.*)");
     DeviceGuard guard(h->device);
+    if (int rc = h->gru_fault_check()) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t rows = (size_t)b * T;
     float* ws = nullptr;                                   // handle-owned scratch: no allocation once a size has been seen
@@ -2268,6 +2305,7 @@ int grnet_gru_forward(grnet_t* h, const float* x, const float* cp, int b, int T,
     w.l1 = w.l0 + rows * 600;
     w.hfin = w.l1 + rows * 600;
     w.xbuf = reinterpret_cast<unsigned long long*>(w.hfin + (((size_t)b * 1200 + 63) & ~(size_t)63));
+    w.mode = h->gru_mode; w.fault = h->gru_fault_dev;
     hipError_t e = launch_gru(x, cp, h->gruw, w, y, phase, xc_buf, b, T, s);
     if (e != hipSuccess) return h->fail(GRNET_EHIP, std::string("launch_gru: ") + hipGetErrorString(e));
     return 0;
@@ -2300,7 +2338,18 @@ int grnet_set_option(grnet_t* h, int option, int value) {
         return 0;
     }
     if (option == GRNET_OPT_WINOGRAD) { h->wino_mode = value != 0; h->drop_graphs(); return 0; }
-    if (option == GRNET_OPT_BF16_CHAIN) { h->chain_mode = value & 127; h->drop_graphs(); return 0; }
+    if (option == GRNET_OPT_BF16_CHAIN) { h->chain_mode = value & grnet::kChainModeAll; h->drop_graphs(); return 0; }
+    if (option == GRNET_OPT_GRU_MODE) {
+        if (value < 0 || (value & 15) > 3 || (value & ~31)) return h->fail(GRNET_EINVAL, "GRU mode is 0 .. 3, + 16 for agent-scope stores");
+        h->gru_mode = value;
+        return 0;
+    }
+    if (option == GRNET_OPT_BF16_MIN_FRAMES) {
+        if (value < 0) return h->fail(GRNET_EINVAL, "the smallest call of the bf16 kernel groups is >= 1 frame (0: each group's own default)");
+        h->bf16_min_frames = value;
+        h->drop_graphs();
+        return 0;
+    }
     if (option == GRNET_OPT_MULTI_LANE) {
         h->multi_lane = value != 0;
         h->drop_graphs();
@@ -2514,7 +2563,7 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
     a.w = wd; a.bias = bd; a.CinPad = cin_pad; a.CoutPad = cout_pad; a.ks = ks; a.stride = stride; a.relu = relu;
     if (add_dev) { a.n_add = 1; a.add[0] = add_dev; a.add_ctot[0] = cout; a.add_coff[0] = 0; a.add_shift[0] = 0; }
     a.zeros = h->zeros;
-    if (const char* d = getenv("GRNET_CONV_DBG")) a.dbg = atoi(d);
+    if (const char* d = GRNET_AB_STR(CONV_DBG)) a.dbg = atoi(d);
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* ud = nullptr;
     if (tile_hint == 2003) { tile_hint = 2001; a.dbg |= 32; }   // 2003: the 4-wave F(4x4,3x3) kernel also where the 8-wave one would run
@@ -2573,7 +2622,7 @@ int grnet_op_conv2d(grnet_t* h, const float* in_dev, int n, int cin, int hgt, in
         return w4s_on ? launch_conv_wino4s(a, s, w4s_ks) : tile_hint == 2001 ? launch_conv_wino4(a, s) : tile_hint == 3001 ? launch_conv_stem(a, s) : tile_hint == 3002 ? launch_conv_pw(a, s) : launch_conv(a, s, tile_hint);
     };
     hipError_t e = launch_one();
-    if (const char* r = getenv("GRNET_CONV_REPS")) {           // timing loop for tools/conv_micro.py
+    if (const char* r = GRNET_AB_STR(CONV_REPS)) {           // timing loop for tools/conv_micro.py
         const int reps = atoi(r);
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);

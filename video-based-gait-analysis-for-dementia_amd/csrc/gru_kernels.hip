@@ -203,7 +203,7 @@ __global__ __launch_bounds__(512) void gru_recurrent_split_kernel(const float* _
                                                                     const float* __restrict__ w_hhT_b, const float* __restrict__ b_hh_f,
                                                                     const float* __restrict__ b_hh_b, float* __restrict__ out,
                                                                     float* __restrict__ hfin, int hfin_off, int b, int T,
-                                                                    unsigned long long* __restrict__ xbuf) {
+                                                                    unsigned long long* __restrict__ xbuf, unsigned* __restrict__ fault) {
     __shared__ float h[kGruSlices * kGruCols];                 // 304: columns >= 300 stay 0
     __shared__ float part[kGruSlices][128];
     // block id = slice*8 + (group % 8) + 64*(group / 8): the 8 slices of a group have ids congruent mod 8 -> one XCD (speed only)
@@ -253,7 +253,9 @@ __global__ __launch_bounds__(512) void gru_recurrent_split_kernel(const float* _
             } while ((unsigned)(v >> 32) != (unsigned)step && ++polls < (1u << 26));   // tag of step-1's result = (step-1)+1
             // the bound (tens of seconds) is never reached while the launcher's residency check holds; if it ever is, the result is
             // poisoned with NaN instead of hanging the GPU
-            h[tid] = (unsigned)(v >> 32) == (unsigned)step ? __uint_as_float((unsigned)v) : __builtin_nanf("");
+            const bool arrived = (unsigned)(v >> 32) == (unsigned)step;
+            if (!arrived && fault) *fault = 1u;                   // host-visible: the next temporal call reports it and falls back (grnet.cpp)
+            h[tid] = arrived ? __uint_as_float((unsigned)v) : __builtin_nanf("");
         }
         __syncthreads();
         const float hv = (lane < kGruCols) ? h[c0 + lane] : 0.f;
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(512) void gru_recurrent_rows_kernel(const float* __
                                                                    const float* __restrict__ w_hhT_b, const float* __restrict__ b_hh_f,
                                                                    const float* __restrict__ b_hh_b, float* __restrict__ out,
                                                                    float* __restrict__ hfin, int hfin_off, int b, int T,
-                                                                   unsigned long long* __restrict__ xbuf, int force_agent) {
+                                                                   unsigned long long* __restrict__ xbuf, int force_agent, unsigned* __restrict__ fault) {
     __shared__ __align__(16) float h[2][4 * kGruQuadCols];       // [parity][304]: columns >= 300 stay 0
     __shared__ int same_xcd;
     const int slot = blockIdx.x & 7, slice = (blockIdx.x >> 3) & 7, group = (blockIdx.x >> 6) * 8 + slot;
@@ -393,7 +395,9 @@ __global__ __launch_bounds__(512) void gru_recurrent_rows_kernel(const float* __
             } while ((unsigned)(v >> 32) != (unsigned)step && ++polls < (1u << 26));   // tag of step-1's result = (step-1)+1
             // the bound (tens of seconds) is never reached while the launcher's residency check holds; if it ever is, the result is
             // poisoned with NaN instead of hanging the GPU
-            h[step & 1][tid] = (unsigned)(v >> 32) == (unsigned)step ? __uint_as_float((unsigned)v) : __builtin_nanf("");
+            const bool arrived = (unsigned)(v >> 32) == (unsigned)step;
+            if (!arrived && fault) *fault = 1u;                   // host-visible: the next temporal call reports it and falls back to agent-scope stores (grnet.cpp)
+            h[step & 1][tid] = arrived ? __uint_as_float((unsigned)v) : __builtin_nanf("");
         }
         __syncthreads();
         f32x2v acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
@@ -467,7 +471,7 @@ hipError_t launch_gru(const float* x, const float* cparams, GruWeights w, GruWor
             e = launch_gemm_nt_bias(layer_in, w.w_ih[layer][d], w.b_ih[layer][d], ws.gi + (size_t)d * rows * 900, (int)rows, 900, in_size, 900, s);
             if (e != hipSuccess) return e;
         }
-        static const int split_env = getenv("GRNET_GRU_SPLIT") ? atoi(getenv("GRNET_GRU_SPLIT")) : 3;     // A/B: 0 = one workgroup per (sequence, direction)
+        const int split_env = ws.mode & 15;                  // GRNET_OPT_GRU_MODE; 0 = one workgroup per (sequence, direction)
         // the 8 slices of a (sequence, direction) spin on each other: every workgroup of the grid must be resident at once, i.e. the
         // grid may not exceed one 512-thread workgroup per CU of THIS device (256 on MI355X; fewer on a partitioned or smaller part)
         const int split_grid = 64 * ((2 * b + 7) / 8);
@@ -476,16 +480,16 @@ hipError_t launch_gru(const float* x, const float* cparams, GruWeights w, GruWor
         if (split_env && ws.xbuf && b <= 16 && T >= 8 && split_grid <= cus) {
             // W_hh resident in registers, split over 8 workgroups per (sequence, direction); the exchange buffer (granules + placement table) starts zeroed
             // 3 (default): rows per wave, one barrier per step, hand-off inside the XCD's L2 where the group's placement allows, v_exp / v_rcp gate functions;
-            // 2: the same with expf / tanhf; 1: round 3's column slices, two barriers per step, agent-scope hand-off.  GRNET_GRU_AGENT=1: agent-scope
+            // 2: the same with expf / tanhf; 1: round 3's column slices, two barriers per step, agent-scope hand-off.  GRNET_OPT_GRU_MODE + 16: agent-scope
             // granule stores whatever the placement (the path a group spanning XCDs takes)
-            static const int force_agent = getenv("GRNET_GRU_AGENT") ? atoi(getenv("GRNET_GRU_AGENT")) : 0;
+            const int force_agent = (ws.mode >> 4) & 1;
             GRK_TRY(hipMemsetAsync(ws.xbuf, 0, (size_t)b * kGruXbufU64PerSeq * sizeof(unsigned long long), s));
             if (split_env == 1)
                 GRK_TRY(launch_k(gru_recurrent_split_kernel, dim3(split_grid), dim3(512), 0, s, (const float*)ws.gi, w.w_hh[layer][0], w.w_hh[layer][1],
-                                 w.b_hh[layer][0], w.b_hh[layer][1], layer_out[layer], ws.hfin, layer * 600, b, T, ws.xbuf));
+                                 w.b_hh[layer][0], w.b_hh[layer][1], layer_out[layer], ws.hfin, layer * 600, b, T, ws.xbuf, ws.fault));
             else
                 GRK_TRY(launch_k(split_env == 2 ? gru_recurrent_rows_kernel<false> : gru_recurrent_rows_kernel<true>, dim3(split_grid), dim3(512), 0, s, (const float*)ws.gi,
-                                 w.w_hh[layer][0], w.w_hh[layer][1], w.b_hh[layer][0], w.b_hh[layer][1], layer_out[layer], ws.hfin, layer * 600, b, T, ws.xbuf, force_agent));
+                                 w.w_hh[layer][0], w.w_hh[layer][1], w.b_hh[layer][0], w.b_hh[layer][1], layer_out[layer], ws.hfin, layer * 600, b, T, ws.xbuf, force_agent, ws.fault));
         } else {
             GRK_TRY(launch_k(gru_recurrent_kernel, dim3(b, 2), dim3(1024), 0, s, ws.gi, w.w_hh[layer][0], w.w_hh[layer][1],
                              w.b_hh[layer][0], w.b_hh[layer][1], layer_out[layer], ws.hfin, layer * 600, b, T));

@@ -11,6 +11,26 @@
 #include <utility>
 #include <vector>
 
+// ---- environment switches ------------------------------------------------------------------------------------------------------------
+// The product library reads FIVE environment variables, all documented in include/grnet_hip.h ("Environment"): GRNET_TRACE, GRNET_RCCL_LIB,
+// GRNET_MULTI_LANE, GRNET_WINO, GRNET_BF16_CHAIN (the last three are the process-wide defaults of grnet_set_option values).  Every other
+// A/B switch of the kernels and of the plan is a GRNET_AB(NAME, default): the default as a compile-time constant in the product build -- a
+// stray GRNET_* variable cannot change kernels, numerics or the schedule there (tests/test_host_cpu.py greps for getenv, tests/
+// test_gpu_options.py sets retired variables and compares bits) -- and read from the environment variable GRNET_<NAME> only in diagnostic
+// builds (`make ABLATION=1 BUILD=build_abl LIB=../libgrnet_hip_abl.so`, loaded by tools/ through GRNET_LIB_PATH).
+#ifdef GRNET_ABLATION
+#include <cstdlib>
+#define GRNET_AB(name, dflt) (getenv("GRNET_" #name) ? atoi(getenv("GRNET_" #name)) : (dflt))
+#define GRNET_AB_F(name, dflt) (getenv("GRNET_" #name) ? atof(getenv("GRNET_" #name)) : (dflt))
+#define GRNET_AB_SET(name) (getenv("GRNET_" #name) != nullptr)
+#define GRNET_AB_STR(name) getenv("GRNET_" #name)
+#else
+#define GRNET_AB(name, dflt) (dflt)
+#define GRNET_AB_F(name, dflt) (dflt)
+#define GRNET_AB_SET(name) false
+#define GRNET_AB_STR(name) (static_cast<const char*>(nullptr))
+#endif
+
 namespace grk {
 
 // One-time work per device (kernel attributes, device queries) that launchers used to cache in plain function-local statics: two host
@@ -137,6 +157,7 @@ struct ConvArgs {
     float inv_RW, inv_Wo, inv_upc;   // 1 / (R*Wo), 1 / Wo, 1 / (PSTR/4) for the kernels' reciprocal-multiply divisions
     int nbuf;                  // bf16 kernel: patch buffers in LDS (2 = chunks double-buffered)
     int gx, gy, gx8, xcd;           // pixel tiles x output-channel blocks of the 1-D grid; xcd: XCD-aware block order (see xcd_block)
+    int pw_stream;             // bf16 1x1 layers: 0 = never the stream kernel (conv_bf16_pw_stream), 1 = from the call size it pays at, 2 = whatever the call size
     int dbg;                   // timing-only ablation bits (tools/conv_micro.py); 0 in the product path
     int prio;                  // Winograd kernel: 0 = default wave priority, 1 / 2 = s_setprio 1 / 3 (critical-chain layers)
     int blk0, wsplit;          // Winograd kernel: first tile id of this launch; 1 = the 32-channel kernel on HALF a 64-channel block
@@ -267,6 +288,8 @@ struct GruWorkspace {
     float* l0;       // (b*T, 600)
     float* l1;       // (b*T, 600)
     float* hfin;     // (b, 1200)
+    int mode = 3;                         // GRNET_OPT_GRU_MODE: recurrence form 0 .. 3 (+ 16: agent-scope granule stores whatever the placement)
+    unsigned* fault = nullptr;            // host-visible word the split kernels set when a hand-off poll ran into its bound (the results of that call are NaN-poisoned)
     unsigned long long* xbuf = nullptr;   // b * kGruXbufU64PerSeq 8-byte words: (b, 2 dirs, 2 parities, 300) {h value, step tag} granules of the split recurrence, then
                                           // (b, 2 dirs, 8 slices) {XCC id, 1} placement words (may be null: the unsplit kernel runs)
 };

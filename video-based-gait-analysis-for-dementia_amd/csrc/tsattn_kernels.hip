@@ -355,21 +355,30 @@ static hipError_t device_lds_per_block(int* bytes) {
     if (e != hipSuccess) return e;
     return once_per_device(c, dev, [&](int* v) { return hipDeviceGetAttribute(v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev); }, bytes);
 }
-int tsattn_max_frames() {
+// Smallest clip on the blocked kernel (450 frames: 0.98 ms against 0.87 for the per-query kernel -- 32 workgroups; 10 000: 6 against 107); 0: never.
+static int tsattn_flash_min() { return GRNET_AB(TSATTN_FLASH, 1024); }
+static int per_query_max_frames() {                                          // what the per-query kernel's softmax row leaves of THIS device's LDS per workgroup
     int lds = 0;
     if (device_lds_per_block(&lds) != hipSuccess || lds <= 0) return 0;
     const long fit = (long)lds / (long)sizeof(float) - 512;
     return (int)std::min<long>(kTsAttnMaxFrames, fit > 0 ? fit : 0);
 }
+// The per-query kernel holds a softmax row over the clip in LDS; the blocked kernel's LDS use is fixed (85 KB), so with it on, the per-query limit binds
+// only the clips that still run the per-query kernel (round-5 advice: the entry check turned away clips the blocked kernel could serve)
+int tsattn_max_frames() {
+    const int pq = per_query_max_frames(), fm = tsattn_flash_min();
+    return (fm > 0 && fm - 1 <= pq) ? kTsAttnMaxFrames : pq;
+}
 
 hipError_t launch_tsattn(const float* x, const float* xs, const TsAttnWeights& w, float* ws, float* y, int b, int n, hipStream_t s) {
     if (b < 1 || n < 1 || n > tsattn_max_frames()) return hipErrorInvalidValue;
-    const size_t attn_lds = (size_t)(256 + n + 256) * sizeof(float);       // query row + one softmax row over the n frames of the clip
-    if (attn_lds > 64 * 1024) {                                             // clips beyond ~15 800 frames: raise the kernel's dynamic LDS limit once per device
+    const bool flash = tsattn_flash_min() > 0 && n >= tsattn_flash_min();
+    const size_t attn_lds = (size_t)(256 + n + 256) * sizeof(float);       // per-query kernel: query row + one softmax row over the n frames of the clip
+    if (!flash && attn_lds > 64 * 1024) {                                   // only when THAT kernel is the one launched: raise its dynamic LDS limit once per device
         static PerDeviceOnce attr;
         int dev = 0;
         GRK_TRY(current_device(&dev));
-        const int max_n = tsattn_max_frames();
+        const int max_n = per_query_max_frames();
         GRK_TRY(once_per_device(attr, dev, [max_n](int*) {
             return hipFuncSetAttribute(reinterpret_cast<const void*>(temporal_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)((256 + max_n + 256) * sizeof(float)));
@@ -388,8 +397,7 @@ hipError_t launch_tsattn(const float* x, const float* xs, const TsAttnWeights& w
     GRK_TRY(launch_gemm_nt_bias(x, w.qkv_t_w, w.qkv_t_b, qkv_t, (int)R, 3 * kE, kD, 3 * kE, s));
     GRK_TRY(launch_gemm_nt_bias(xs, w.qkv_s_w, w.qkv_s_b, qkv_s, (int)R, 3 * kE, kD + kF, 3 * kE, s));
     // clips of >= 1024 frames: the blocked kernel (keys / values read once per 64 queries, fp32 matrix cores); shorter clips: one workgroup per query
-    static const int flash_env = getenv("GRNET_TSATTN_FLASH") ? atoi(getenv("GRNET_TSATTN_FLASH")) : 1024;     // smallest clip that takes it (450 frames: 0.98 ms against 0.87 -- 32 workgroups; 10 000: 29 against 117); 0: never
-    if (flash_env > 0 && n >= flash_env) {
+    if (flash) {
         static PerDeviceOnce fattr;
         int dev = 0;
         GRK_TRY(current_device(&dev));
