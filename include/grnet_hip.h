@@ -129,7 +129,9 @@ int grnet_tsattn_forward(grnet_t* h, const float* x_dev, const float* xs_dev, in
                                    * down paths, transitions, the stem's second convolution) with the band de-interleaved by row / column parity, >= 64 frames.
                                    * Bit 6: layer1's 64 -> 256 expansions (hrnet.py:80-100) also run the NEXT Bottleneck's 256 -> 64 reduction from the tile they
                                    * hold in LDS, >= 19 frames.  Bit 7: the 1x1 layers of layer1 and of the PARE head on the persistent stream kernel
-                                   * (conv_bf16_pw_stream, bit-identical to the generic kernel), >= 42 frames. */
+                                   * (conv_bf16_pw_stream, bit-identical to the generic kernel), >= 42 frames.  Bit 8: each layer1 Bottleneck (hrnet.py:62-100: 1x1
+                                   * reduce, 3x3, 1x1 expand + residual) and bit 9: the stem pair (hrnet.py:470-476) as ONE launch whose workgroups walk a frame row
+                                   * by row with every intermediate in LDS (csrc/conv_bf16_roll.hip), >= 64 frames; they take precedence over bits 4-7 on those layers. */
 #define GRNET_OPT_GRU_MODE 9      /* form of the bi-GRU recurrence (csrc/gru_kernels.hip; gait_feat_encoder.py:79-104).  3 (default): W_hh resident in registers, split over 8
                                    * workgroups per (sequence, direction), rows per wave, v_exp / v_rcp gate functions, h_t handed over inside the XCD's L2
                                    * (workgroup-scope granule stores + L1-bypassing polls) where the 8 workgroups verifiably share an XCD; 2: the same with

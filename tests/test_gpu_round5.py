@@ -116,7 +116,7 @@ def test_bf16_forward_with_chains_equals_forward_without(bmodel, pkg):
     finally:
         bmodel.set_option(pkg._lib.OPT_BF16_CHAIN, -1)
     torch.cuda.synchronize()
-    assert n_without - n_with == 7 * (8 + 7 + 3) + 4 * 8 + 3, (n_with, n_without)    # + 3 layer1 reductions run inside their expansions' launches; 18 chains of 8 convolutions became 18 launches, 8 chains of the 56x56 branch 4 launches each
+    assert n_without - n_with == 7 * (8 + 7 + 3) + 4 * 8 + 8 + 1, (n_with, n_without)    # 18 chains of 8 convolutions became 18 launches, 8 chains of the 56x56 branch 4 launches each; layer1's 12 convolutions 4 Bottleneck launches, the stem's two one (round 6)
     # (the wide-band and stride-2 band kernels -- bits 4, 5 of the mask -- replace launches one for one: 45 stride-2 layers with up to three shifted addends run here)
     for k in keys + ("theta", "kp_3d", "verts"):
         a, b = with_chain[k].float().cpu().numpy(), without[k].float().cpu().numpy()
@@ -345,18 +345,19 @@ def _forward_digest(m, frames):
 def test_bf16_layer1_stream_kernel_is_bit_identical_to_the_generic_one(pkg, bmodel, n):
     """conv_bf16_pw_stream (persistent workgroups, register prefetch; all three forms: [t ; x] two-input + pair, residual + pair, residual alone) against
     conv_bf16_nhwc on the same layers: same operands, same k order, same (acc + residual) + bias -> ReLU -> bf16 -- the whole forward may not change by a
-    bit.  GRNET_OPT_BF16_CHAIN bit 7 switches the stream kernel, bit 8 the Bottleneck launches that replace both in large calls (off here).  8 frames: forced
+    bit.  GRNET_OPT_BF16_CHAIN bit 7 switches the stream kernel; bits 8 / 9 -- the Bottleneck and stem-pair launches that replace these layers in large calls -- are off here.  8 frames: forced
     on with GRNET_OPT_BF16_MIN_FRAMES = 1 (fewer tiles than workgroups, the clamped re-request of the last tile); 64 frames: the size it is picked at."""
     lib = pkg._lib
     frames = torch.from_numpy(np.tile(pkg.synth.make_frames(8), (n // 8, 1, 1, 1))).cuda()
     try:
+        base = 1023 - 256 - 512                                   # the Bottleneck / stem-pair launches off: layer1's 1x1 layers run as launches of their own
         bmodel.set_option(lib.OPT_BF16_MIN_FRAMES, 1)
-        bmodel.set_option(lib.OPT_BF16_CHAIN, 255 - 128)
+        bmodel.set_option(lib.OPT_BF16_CHAIN, base - 128)
         ref = _forward_digest(bmodel, frames)
-        bmodel.set_option(lib.OPT_BF16_CHAIN, 255)
+        bmodel.set_option(lib.OPT_BF16_CHAIN, base)
         got = _forward_digest(bmodel, frames)
         assert ref == got                                         # same number of launches, same bits
-        bmodel.set_option(lib.OPT_BF16_CHAIN, 255 - 64)
+        bmodel.set_option(lib.OPT_BF16_CHAIN, base - 64)
         unpaired = _forward_digest(bmodel, frames)
         assert unpaired[1:] == ref[1:]
     finally:

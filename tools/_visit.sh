@@ -1,0 +1,4 @@
+D=gpurun_out/v5; mkdir -p $D; export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_bf16_roll.py -m gpu -q -x --timeout 900 2>&1 | tail -12
+export GRNET_LIB_PATH=$PWD/video-based-gait-analysis-for-dementia_amd/libgrnet_hip_abl.so
+for d in 0 7 31; do GRNET_ROLL_DBG=$d timeout 120 python tools/roll_micro.py 256 2>&1 | grep "^n="; done | tee $D/roll_abl.txt

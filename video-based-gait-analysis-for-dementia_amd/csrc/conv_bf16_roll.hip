@@ -1,0 +1,465 @@
+// bf16 path, round 6: the stem pair (hrnet.py:470-476: conv1-BN-ReLU 3 -> 64 s2, conv2-BN-ReLU 64 -> 64 s2) and each layer1 Bottleneck
+// (hrnet.py:62-100: 1x1 reduce -> 3x3 -> 1x1 expand + residual, ReLU) as ONE launch, a workgroup walking a frame ROW BY ROW.
+//
+// Why: at 256 frames stem + layer1 were 1.46 ms of the 9.5 ms step and nothing but HBM round trips (profiles/r05_bf16_n256_layer_table.md): the
+// 411 MB stem intermediate (64 ch @112x112) crossed HBM twice, and per Bottleneck the 64-channel tensors t and u were written and read back
+// (4 x 103 MB) beside the 256-channel tensor's one read and one write (2 x 411 MB).  The MFMA work of these layers is 0.18 ms at peak.
+// Here every intermediate lives in LDS: a launch reads its input once and writes its output once (stem: 154 MB of fp32 frames in, 103 MB out;
+// Bottleneck: 411 MB in, 411 MB out; the first one 103 MB in).
+//
+// Shape of both kernels: workgroup = one frame (or one of S row segments of it, for calls with fewer frames than CUs), 8 waves, persistent over the
+// rows.  The only spatial operator is the 3x3 convolution on a 64-channel tensor, so three rows of that tensor form a ring in LDS and one row
+// step is: make the ring's newest row (Bottleneck: 1x1 reduce of x row y; stem: conv1 rows 2Y, 2Y + 1 gathered from the fp32 frame), run the 3x3
+// for the output row whose lower neighbour has just arrived, finish it (Bottleneck: 1x1 expand + residual) and store it as whole NHWC rows.
+// Nothing is recomputed inside a segment; a segment boundary costs one extra ring row.  The 3x3's weights (73.7 KB) stay in LDS for the whole
+// launch (XOR-swizzled 64-byte rows as in conv_bf16_block_frame), the 1x1 weights in registers; the next input row is requested into registers
+// two steps (Bottleneck) / one step (stem) ahead -- ordinary loads, so the counted vmcnt waits of hipcc apply -- and barriers are
+// s_waitcnt lgkmcnt(0) + s_barrier (a __syncthreads() would drain that prefetch).
+//
+// Roles as everywhere on the bf16 path: A[cout l&15][k = 8(l>>4)+j] = weights, B[k][pixel l&15] = activations, D[cout 4(l>>4)+r][pixel l&15];
+// k order = input-channel chunk (32) outer, tap inner -- the order of the launch-per-convolution kernels, so a fused launch differs from them by
+// fp32 summation order inside a k-step at most (tests: equal to the fp32 oracle on bf16-rounded operands with bf16-rounded intermediates).
+#include "kernels.h"
+
+namespace grk {
+
+#define GRK_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return _e; } while (0)
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_r __attribute__((ext_vector_type(2)));
+typedef float f32x2_r __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack2_r(float lo, float hi) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_r{lo, hi}, bf16x2_r)); }
+__device__ __forceinline__ float relu_r(float x) { const int i = __float_as_int(x); return __int_as_float(i > 0 ? i : 0); }
+__device__ __forceinline__ float bflo(unsigned v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float bfhi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
+__device__ __forceinline__ u32x2 pack4_relu(const f32x4 v) { return u32x2{pack2_r(relu_r(v[0]), relu_r(v[1])), pack2_r(relu_r(v[2]), relu_r(v[3]))}; }
+__device__ __forceinline__ void lds_sync() {                  // every wave's LDS operations so far are done; global loads and stores stay in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+constexpr int kW2Bytes = 2 * 9 * 64 * 64;                     // the 64 -> 64 3x3 weights: [chunk 2][tap 9][cout 64][32 k] bf16, 64-byte rows
+constexpr int kTSB = 160;                                     // slot stride of a 64-channel pixel in LDS: 128 + 32 bytes = 32 x odd (conflict-free b128 reads of 16 consecutive slots)
+
+// the 3x3's weights global -> LDS, part p of row r at p ^ 2 (r >> 3 & 1) (bank groups of the 16 lanes of a ds_read_b128 group all different)
+__device__ __forceinline__ void stage_w2(unsigned char* w2l, const void* w2g, int tid) {
+    constexpr int NU = kW2Bytes / 16 / 512;
+    u32x4 v[NU];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) v[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(w2g) + (size_t)(i * 512 + tid) * 16);
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        const int u = i * 512 + tid, row = u >> 2, part = u & 3;
+        *reinterpret_cast<u32x4*>(w2l + row * 64 + ((part ^ (((row >> 3) & 1) << 1)) * 16)) = v[i];
+    }
+}
+
+// One output row of the 64 -> 64 3x3 (both strides): wave (blk, tp) owns output channels 16 blk .. + 15 of column tiles 2 tp, 2 tp + 1 (X = 16 T + l15).
+// rb[dy]: this lane's B operand of tap row dy at X = l15 of tile 0, chunk 0, column tap 0; XS(dx): byte offset of column tap dx; a tile is TS bytes on.
+template <typename XS>
+__device__ __forceinline__ void conv3x3_row(f32x4 (&acc)[2], const unsigned char* (&rb)[3], const unsigned char* wl, int tp, XS xs, int ts) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            bf16x8 af[3], bfr[3][2];
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                af[dx] = *reinterpret_cast<const bf16x8*>(wl + ((c * 9 + dy * 3 + dx) * 64) * 64);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) bfr[dx][i] = *reinterpret_cast<const bf16x8*>(rb[dy] + (2 * tp + i) * ts + xs(dx) + c * 64);
+            }
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dx], bfr[dx][i], acc[i], 0, 0, 0);
+        }
+}
+
+}  // namespace
+
+struct RollArgs {
+    const void* in; int in_ctot, in_coff;                      // Bottleneck: x, NHWC bf16 (256 channels; the first one: the stem's 64)
+    const float* frames;                                        // stem: the caller's fp32 NCHW frames (N, 3, 224, 224)
+    void* out; int out_ctot, out_coff;
+    int N, S;                                                   // frames; row segments per frame (1, 2 or 4)
+    const void *w1, *w2, *w3;                                   // packed as the layers' own launches take them (grnet.cpp pack_conv); stem: w1 = pack_stem_weights_bf16
+    const float *b1, *b2, *b3;
+    int dbg;                                                    // diagnostic builds (make ABLATION=1, GRNET_ROLL_DBG): timing-only ablation bits, results garbage; 0 in the product
+};
+
+namespace {
+
+// ---- layer1 Bottleneck.  FIRST: layer1.0 -- x has 64 channels, and relu(BN3(conv3(u)) + BNd(downsample(x))) is ONE GEMM over [u ; x] (K = 64 + 64: the plan's
+// two-input 1x1, weights [4][1][256][32]) instead of expand + identity.
+// Row step y (ring slot of a row = (row + 3) % 3; row -1 and row 56 are the 3x3's zero padding):
+//   1. x row y: registers -> LDS (requested two steps ago); request x row y + 2                                                    | barrier
+//   2. reduce: t[y] = relu(W1 x[y] + b1) -> ring; the lanes that will hold row y's outputs keep their residual values of x[y]      | barrier
+//   3. 3x3: u[y-1] = relu(W2 * t[y-2 .. y] + b2) -> ubuf                                                                            | barrier
+//   4. expand: relu((W3 u[y-1] + b3) + x[y-1]) -> staging (the x row's buffer: x[y] is dead by now)                                 | barrier
+//   5. every thread moves the SAME 16-byte units it refills in the next step's phase 1 from the staging to HBM (whole rows of 512 bytes): no barrier between the two
+// (A form with TWO rows per step -- half the barriers per row -- needs the LDS of the 3x3's weights for its rows; with those weights streamed from L2 every step
+// instead it measured 306 us per Bottleneck against this form's 249: profiles/r06_roll_ablation.txt.)
+template <bool FIRST>
+__global__ __launch_bounds__(512) void conv_bf16_bneck(const RollArgs a) {
+    constexpr int W = 56, CI = FIRST ? 64 : 256, KC1 = CI / 32, XSB = CI * 2 + 32, OSB = 544, TSLOTS = 66;
+    constexpr int XROW = W * XSB, UPR = W * (CI / 8), NXU = (UPR + 511) / 512;       // bytes of a staged x row; its 16-byte units; units per thread
+    constexpr int KC3 = FIRST ? 4 : 2, OUR = W * 32, NOU = (OUR + 511) / 512;        // k chunks of the expansion; 16-byte units of an output row
+    extern __shared__ __align__(16) unsigned char lds[];
+    unsigned char* w2l = lds;
+    unsigned char* tring = w2l + kW2Bytes;                      // 3 rows x 66 slots: pixel x at slot x + 1, slots 0 and 57 .. 65 stay zero
+    unsigned char* ubuf = tring + 3 * TSLOTS * kTSB;            // 56 slots
+    unsigned char* xrow = ubuf + W * kTSB;                      // FIRST: two rows (by row parity: the expansion of row y - 1 reads x[y-1] while x[y] is staged)
+    unsigned char* ostage = FIRST ? xrow + 2 * XROW : xrow;
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = blockIdx.x / a.S, seg = blockIdx.x - n * a.S;
+    if (n >= a.N) return;
+    const int rs = W / a.S, s0 = seg * rs, s1 = s0 + rs;
+    const int yb = s0 > 0 ? s0 - 1 : 0;
+    const u16* inb = reinterpret_cast<const u16*>(a.in) + (size_t)n * W * W * a.in_ctot + a.in_coff;
+    u16* outb = reinterpret_cast<u16*>(a.out) + (size_t)n * W * W * a.out_ctot + a.out_coff;
+
+    // unit i of this thread (16 bytes of a row): its place in the staged row and in a row of HBM -- the same for every row, kept as two 32-bit offsets each
+    int xl[NXU], xg[NXU], ol[NOU], og[NOU];
+#pragma unroll
+    for (int i = 0; i < NXU; ++i) {
+        const int u = i * 512 + tid, px = u / (CI / 8), part = u - px * (CI / 8);
+        xl[i] = px * XSB + part * 16;
+        xg[i] = px * a.in_ctot + part * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < NOU; ++i) {
+        const int u = i * 512 + tid;
+        ol[i] = (u >> 5) * OSB + (u & 31) * 16;
+        og[i] = (u >> 5) * a.out_ctot + (u & 31) * 8;
+    }
+    u32x4 nxa[NXU], nxb[NXU];
+    auto request = [&](int y, u32x4 (&nx)[NXU]) {               // x row y -> registers (rows past the segment's last ring row: not requested)
+        if (y > s1 || y >= W) return;
+#ifdef GRNET_ABLATION
+        if (a.dbg & 16) return;
+#endif
+        const u16* rowp = inb + (size_t)y * W * a.in_ctot;
+#pragma unroll
+        for (int i = 0; i < NXU; ++i)
+            if (i * 512 + tid < UPR) nx[i] = *reinterpret_cast<const u32x4*>(rowp + xg[i]);
+    };
+    request(yb, nxa);
+    request(yb + 1, nxb);
+    stage_w2(w2l, a.w2, tid);
+    for (int u = tid; u < (3 * TSLOTS * kTSB) / 16; u += 512) reinterpret_cast<u32x4*>(tring)[u] = u32x4{0u, 0u, 0u, 0u};
+
+    // ---- per-wave constants: reduce / 3x3 = (channel block blk, tile pair tp); expand = (channel blocks 2 wave, 2 wave + 1) x 4 tiles
+    const int blk = wave & 3, tp = wave >> 2;
+    bf16x8 w1f[KC1];
+#pragma unroll
+    for (int c = 0; c < KC1; ++c) w1f[c] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const u16*>(a.w1) + ((size_t)c * 64 + blk * 16 + l15) * 32 + lq * 8);
+    bf16x8 w3f[KC3][2];
+#pragma unroll
+    for (int c = 0; c < KC3; ++c)
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi) w3f[c][bi] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const u16*>(a.w3) + ((size_t)c * 256 + (2 * wave + bi) * 16 + l15) * 32 + lq * 8);
+    const f32x4 b1v = *reinterpret_cast<const f32x4*>(a.b1 + blk * 16 + lq * 4), b2v = *reinterpret_cast<const f32x4*>(a.b2 + blk * 16 + lq * 4);
+    f32x4 b3v[2];
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi) b3v[bi] = *reinterpret_cast<const f32x4*>(a.b3 + (2 * wave + bi) * 16 + lq * 4);
+    const unsigned char* wl = w2l + (blk * 16 + l15) * 64 + ((lq ^ (((l15 >> 3) & 1) << 1)) * 16);
+    int pxc[4];                                                 // this lane's pixel of tile T, clamped into the row (lanes past pixel 55 compute copies nobody stores)
+#pragma unroll
+    for (int T = 0; T < 4; ++T) pxc[T] = (16 * T + l15) < W ? 16 * T + l15 : W - 1;
+    const int pxr[2] = {32 * tp + l15, (32 * tp + 16 + l15) < W ? 32 * tp + 16 + l15 : W - 1};      // ... of this wave's two tiles of the reduce / 3x3 mapping
+    u32x2 res_cur[2][4], res_nxt[2][4];
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int T = 0; T < 4; ++T) res_cur[bi][T] = res_nxt[bi][T] = u32x2{0u, 0u};
+    lds_sync();
+
+    auto step = [&](int y, u32x4 (&nx)[NXU]) {
+        const bool has_x = y < W;
+        unsigned char* xr = FIRST ? xrow + (y & 1) * XROW : xrow;
+        // ---- 1. x row y -> LDS
+        if (has_x) {
+#pragma unroll
+            for (int i = 0; i < NXU; ++i)
+                if (i * 512 + tid < UPR) *reinterpret_cast<u32x4*>(xr + xl[i]) = nx[i];
+        }
+        request(y + 2, nx);
+        lds_sync();
+        // ---- 2. reduce -> ring row y (a zero row for y = 56), residual capture
+        unsigned char* trow = tring + ((y + 3) % 3) * (TSLOTS * kTSB);
+        if (has_x) {
+            f32x4 acc[2] = {b1v, b1v};
+#ifdef GRNET_ABLATION
+            if (!(a.dbg & 1))
+#endif
+#pragma unroll
+            for (int c = 0; c < KC1; ++c)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bf16x8 bt = *reinterpret_cast<const bf16x8*>(xr + pxr[i] * XSB + c * 64 + lq * 16);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[c], bt, acc[i], 0, 0, 0);
+                }
+            if (!FIRST) {
+#pragma unroll
+                for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                    for (int T = 0; T < 4; ++T) res_nxt[bi][T] = *reinterpret_cast<const u32x2*>(xr + pxc[T] * XSB + ((2 * wave + bi) * 16 + lq * 4) * 2);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int px = 16 * (2 * tp + i) + l15;
+                if (px < W) *reinterpret_cast<u32x2*>(trow + (px + 1) * kTSB + (blk * 16 + lq * 4) * 2) = pack4_relu(acc[i]);
+            }
+        } else if (tid < W * 8) {
+            *reinterpret_cast<u32x4*>(trow + ((tid >> 3) + 1) * kTSB + (tid & 7) * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+        lds_sync();
+        if (y > s0) {                                           // output row y - 1 belongs to this segment
+            const int yo = y - 1;
+            // ---- 3. 3x3 -> u
+            {
+                const unsigned char* rb[3];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) rb[dy] = tring + ((yo - 1 + dy + 3) % 3) * (TSLOTS * kTSB) + l15 * kTSB + lq * 16;
+                f32x4 acc[2] = {b2v, b2v};
+#ifdef GRNET_ABLATION
+                if (!(a.dbg & 2))
+#endif
+                conv3x3_row(acc, rb, wl, tp, [](int dx) { return dx * kTSB; }, 16 * kTSB);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int px = 16 * (2 * tp + i) + l15;
+                    if (px < W) *reinterpret_cast<u32x2*>(ubuf + px * kTSB + (blk * 16 + lq * 4) * 2) = pack4_relu(acc[i]);
+                }
+            }
+            lds_sync();
+            // ---- 4. expand (+ residual) -> staging
+            {
+                f32x4 acc[2][4];
+#pragma unroll
+                for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                    for (int T = 0; T < 4; ++T) acc[bi][T] = b3v[bi];
+                const unsigned char* xo = xrow + (yo & 1) * XROW;     // FIRST: x row yo
+#ifdef GRNET_ABLATION
+                if (!(a.dbg & 4))
+#endif
+#pragma unroll
+                for (int c = 0; c < KC3; ++c)
+#pragma unroll
+                    for (int T = 0; T < 4; ++T) {
+                        const bf16x8 bt = c < 2 ? *reinterpret_cast<const bf16x8*>(ubuf + pxc[T] * kTSB + c * 64 + lq * 16)
+                                                : *reinterpret_cast<const bf16x8*>(xo + pxc[T] * XSB + (c - 2) * 64 + lq * 16);
+#pragma unroll
+                        for (int bi = 0; bi < 2; ++bi) acc[bi][T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[c][bi], bt, acc[bi][T], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                    for (int T = 0; T < 4; ++T) {
+                        f32x4 v = acc[bi][T];
+                        if (!FIRST) {
+                            const u32x2 r = res_cur[bi][T];
+                            v[0] += bflo(r[0]); v[1] += bfhi(r[0]); v[2] += bflo(r[1]); v[3] += bfhi(r[1]);
+                        }
+                        if (16 * T + l15 < W) *reinterpret_cast<u32x2*>(ostage + (16 * T + l15) * OSB + ((2 * wave + bi) * 16 + lq * 4) * 2) = pack4_relu(v);
+                    }
+            }
+            lds_sync();
+            // ---- 5. staging -> HBM: unit i of the staging is unit i of the x row this thread writes in the next step's phase 1 (FIRST: a buffer of its own, next
+            // written three barriers on) -- no barrier in between
+#ifdef GRNET_ABLATION
+            if (!(a.dbg & 8))
+#endif
+            {
+                u16* rowp = outb + (size_t)yo * W * a.out_ctot;
+#pragma unroll
+                for (int i = 0; i < NOU; ++i)
+                    if (i * 512 + tid < OUR) *reinterpret_cast<u32x4*>(rowp + og[i]) = *reinterpret_cast<const u32x4*>(ostage + ol[i]);
+            }
+        }
+        if (!FIRST) {
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                for (int T = 0; T < 4; ++T) res_cur[bi][T] = res_nxt[bi][T];
+        }
+    };
+#pragma unroll 1
+    for (int y = yb; y <= s1; y += 2) {
+        step(y, nxa);
+        if (y + 1 <= s1) step(y + 1, nxb);
+    }
+}
+
+// ---- the stem pair.  conv1 as conv_bf16_stem computes it (K = (channel, tap) flattened to ONE 32-wide k-step, B gathered from the fp32 frame and rounded
+// to bf16), a wave owning two column tiles of one of the two new conv1 rows of a step; its rows go to LDS de-interleaved by column parity -- the stride-2
+// 3x3 then reads constant offsets: tap column 1 = even plane at X, tap columns 0 / 2 = odd plane at X / X + 1 (the odd plane's slot 0 is column -1: zero).
+// Row step Y (output row of conv2): conv1 rows 2Y, 2Y + 1 -> ring (row 2Y - 1 is the previous step's second row; row -1: zeros) | barrier | gathers of the
+// next step requested; conv2 row Y -> staging | barrier | staging -> 16-byte stores of whole rows (the next step's barrier orders them before the staging is rewritten).
+constexpr int kStemPlane = 65, kStemRowSlots = 2 * kStemPlane;      // even plane: slots 0 .. 64 (columns 0, 2, .. 110 at 0 .. 55), odd plane: 65 .. 129 (column 2X - 1 at 65 + X)
+__global__ __launch_bounds__(512) void conv_bf16_stem_pair(const RollArgs a) {
+    constexpr int H = 224, W = 224, WO = 56;
+    extern __shared__ __align__(16) unsigned char lds[];
+    unsigned char* w2l = lds;
+    unsigned char* ring = w2l + kW2Bytes;                       // 3 conv1 rows
+    unsigned char* ostage = ring + 3 * kStemRowSlots * kTSB;    // 56 x 160
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = blockIdx.x / a.S, seg = blockIdx.x - n * a.S;
+    if (n >= a.N) return;
+    const int rs = WO / a.S, s0 = seg * rs, s1 = s0 + rs;
+    const float* fb = a.frames + (size_t)n * 3 * H * W;
+    u16* outb = reinterpret_cast<u16*>(a.out) + (size_t)n * WO * WO * a.out_ctot + a.out_coff;
+
+    // conv1: this wave's row of a step (0: 2Y, 1: 2Y + 1) and its column tiles (2 of the row's 7; the last wave of a row has one)
+    const int crow = wave >> 2, ct0 = (wave & 3) * 2, nct = ct0 + 1 < 7 ? 2 : 1;
+    bf16x8 wq[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) wq[mt] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const u16*>(a.w1) + ((size_t)mt * 64 + lane) * 8);
+    f32x4 b1v[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) b1v[mt] = *reinterpret_cast<const f32x4*>(a.b1 + mt * 16 + lq * 4);
+    int koff[8];                                                 // this lane's 8 K elements: k = 8 lq + j = channel * 9 + ky * 3 + kx (k >= 27: zero)
+    int kky[8];
+    bool kreal[8], kleft[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * lq + j, c = k / 9, tap = k - 9 * c, ky = tap / 3, kx = tap - 3 * ky;
+        kreal[j] = k < 27;
+        kleft[j] = kx == 0;
+        kky[j] = ky - 1;
+        koff[j] = (c * H + (ky - 1)) * W + (kx - 1);
+    }
+    float g[2][8];
+    auto gather = [&](int y1) {                                  // conv1 row y1 (0 .. 111), this wave's tiles -> registers (fp32, as they lie in the frame)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int x = 16 * (ct0 + i) + l15;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bool ok = i < nct && kreal[j] && (2 * y1 + kky[j] >= 0) && !(kleft[j] && x == 0);
+#ifdef GRNET_ABLATION
+                if (a.dbg & 16) ok = false;
+#endif
+                g[i][j] = ok ? fb[koff[j] + 2 * y1 * W + 2 * x] : 0.f;
+            }
+        }
+    };
+    // a segment's first step also needs conv1 row 2 s0 - 1: computed in a step of its own in front (rows 2 s0 - 2, 2 s0 - 1; the first is not used)
+    const int Yb = s0 > 0 ? s0 - 1 : 0;
+    gather(2 * Yb + crow);
+    stage_w2(w2l, a.w2, tid);
+    for (int u = tid; u < (3 * kStemRowSlots * kTSB) / 16; u += 512) reinterpret_cast<u32x4*>(ring)[u] = u32x4{0u, 0u, 0u, 0u};
+    const int blk = wave & 3, tp = wave >> 2;
+    const f32x4 b2v = *reinterpret_cast<const f32x4*>(a.b2 + blk * 16 + lq * 4);
+    const unsigned char* wl = w2l + (blk * 16 + l15) * 64 + ((lq ^ (((l15 >> 3) & 1) << 1)) * 16);
+    lds_sync();
+
+#pragma unroll 1
+    for (int Y = Yb; Y < s1; ++Y) {
+        // ---- conv1 rows 2Y, 2Y + 1 -> ring slots (row + 3) % 3
+        {
+            const int y1 = 2 * Y + crow;
+            unsigned char* row = ring + ((y1 + 3) % 3) * (kStemRowSlots * kTSB);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (i >= nct) break;
+                const u32x4 bp = {pack2_r(g[i][0], g[i][1]), pack2_r(g[i][2], g[i][3]), pack2_r(g[i][4], g[i][5]), pack2_r(g[i][6], g[i][7])};
+                const bf16x8 b = __builtin_bit_cast(bf16x8, bp);
+                const int x1 = 16 * (ct0 + i) + l15;                 // conv1 column: even -> even plane at x1 / 2, odd -> odd plane at (x1 + 1) / 2
+                unsigned char* dst = row + (((x1 & 1) ? kStemPlane + (x1 + 1) / 2 : x1 / 2)) * kTSB + lq * 8;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const f32x4 v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[mt], b, b1v[mt], 0, 0, 0);
+                    *reinterpret_cast<u32x2*>(dst + mt * 32) = pack4_relu(v);
+                }
+            }
+        }
+        lds_sync();
+        if (Y + 1 < s1) gather(2 * (Y + 1) + crow);              // in flight under the 3x3
+        if (Y >= s0) {
+            // ---- conv2 row Y: tap row dy = conv1 row 2Y + dy - 1
+            const unsigned char* rb[3];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) rb[dy] = ring + ((2 * Y + dy - 1 + 3) % 3) * (kStemRowSlots * kTSB) + l15 * kTSB + lq * 16;
+            f32x4 acc[2] = {b2v, b2v};
+#ifdef GRNET_ABLATION
+            if (!(a.dbg & 2))
+#endif
+            conv3x3_row(acc, rb, wl, tp, [](int dx) { return dx == 1 ? 0 : (kStemPlane + (dx >> 1)) * kTSB; }, 16 * kTSB);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int px = 16 * (2 * tp + i) + l15;
+                if (px < WO) *reinterpret_cast<u32x2*>(ostage + px * kTSB + (blk * 16 + lq * 4) * 2) = pack4_relu(acc[i]);
+            }
+        }
+        lds_sync();
+#ifdef GRNET_ABLATION
+        if (!(a.dbg & 8))
+#endif
+        if (Y >= s0 && tid < WO * 8)
+            *reinterpret_cast<u32x4*>(outb + (size_t)(Y * WO + (tid >> 3)) * a.out_ctot + (tid & 7) * 8) = *reinterpret_cast<const u32x4*>(ostage + (tid >> 3) * kTSB + (tid & 7) * 16);
+    }
+}
+
+template <typename K>
+hipError_t set_lds_roll(K kern, int bytes) { return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); }
+
+constexpr int kBneckLds = kW2Bytes + 3 * 66 * kTSB + 56 * kTSB + 56 * 544;                       // 144 832
+constexpr int kBneckFirstLds = kW2Bytes + 3 * 66 * kTSB + 56 * kTSB + 2 * 56 * 160 + 56 * 544;  // 162 752
+constexpr int kStemPairLds = kW2Bytes + 3 * kStemRowSlots * kTSB + 56 * kTSB;                   // 145 088
+static_assert(kBneckFirstLds <= 160 * 1024 && kStemPairLds <= 160 * 1024, "LDS");
+
+}  // namespace
+
+hipError_t conv_bf16_roll_init() {
+    GRK_TRY(set_lds_roll(conv_bf16_bneck<false>, kBneckLds));
+    GRK_TRY(set_lds_roll(conv_bf16_bneck<true>, kBneckFirstLds));
+    GRK_TRY(set_lds_roll(conv_bf16_stem_pair, kStemPairLds));
+    return hipSuccess;
+}
+
+// row segments per frame: one workgroup per CU wants frames x segments >= CUs; a segment boundary costs one ring row (2 / 14 at four segments)
+int conv_bf16_roll_segments(int n_frames) {
+    int cus = 0;
+    if (device_cu_count(&cus) != hipSuccess || cus <= 0) cus = 256;
+    return n_frames >= cus ? 1 : 2 * n_frames >= cus ? 2 : 4;
+}
+
+// first: layer1.0 (64-channel input, expansion over [u ; x] with the downsample folded in: w3 packed [4][1][256][32])
+hipError_t launch_conv_bf16_bneck(const void* in, int in_ctot, int in_coff, void* out, int out_ctot, int out_coff, int N, bool first, const void* w1, const float* b1,
+                                  const void* w2, const float* b2, const void* w3, const float* b3, hipStream_t s) {
+    const int cin = first ? 64 : 256;
+    if (N < 1 || in_ctot % 8 != 0 || in_coff % 8 != 0 || out_ctot % 8 != 0 || out_coff % 8 != 0 || in_ctot - in_coff < cin || out_ctot - out_coff < 256) return hipErrorInvalidValue;
+    RollArgs a{};
+    a.in = in; a.in_ctot = in_ctot; a.in_coff = in_coff; a.out = out; a.out_ctot = out_ctot; a.out_coff = out_coff;
+    a.N = N; a.S = conv_bf16_roll_segments(N);
+    a.w1 = w1; a.w2 = w2; a.w3 = w3; a.b1 = b1; a.b2 = b2; a.b3 = b3;
+    a.dbg = GRNET_AB(ROLL_DBG, 0);
+    if (first) return launch_k(conv_bf16_bneck<true>, dim3(N * a.S), dim3(512), (size_t)kBneckFirstLds, s, a);
+    return launch_k(conv_bf16_bneck<false>, dim3(N * a.S), dim3(512), (size_t)kBneckLds, s, a);
+}
+
+hipError_t launch_conv_bf16_stem_pair(const float* frames, void* out, int out_ctot, int out_coff, int N, const void* w1pk, const float* b1, const void* w2, const float* b2,
+                                      hipStream_t s) {
+    if (N < 1 || out_ctot % 8 != 0 || out_coff % 8 != 0 || out_ctot - out_coff < 64) return hipErrorInvalidValue;
+    RollArgs a{};
+    a.frames = frames; a.out = out; a.out_ctot = out_ctot; a.out_coff = out_coff;
+    a.N = N; a.S = conv_bf16_roll_segments(N);
+    a.w1 = w1pk; a.w2 = w2; a.b1 = b1; a.b2 = b2;
+    a.dbg = GRNET_AB(ROLL_DBG, 0);
+    return launch_k(conv_bf16_stem_pair, dim3(N * a.S), dim3(512), (size_t)kStemPairLds, s, a);
+}
+
+}  // namespace grk

@@ -74,6 +74,7 @@ struct ConvLayer {
     int pair_next = -1, pair_of = -1;   // bf16 layer1: this 64 -> 256 expansion also runs convolution pair_next (the next Bottleneck's 256 -> 64 reduction) from its tile / this
                                         // reduction runs inside the launch of convolution pair_of (large calls: pair_active())
     int chain = -1, chain_pos = 0;   // bf16: member chain_pos of BasicBlock chain `chain` (conv_bf16_chain.hip); position 0 launches the whole chain in large calls
+    int roll = -1, roll_pos = 0;     // bf16: member roll_pos of the row-walking launch `roll` (conv_bf16_roll.hip: the stem pair, a layer1 Bottleneck); position 0 launches it in large calls
     std::map<int, int> tuned;   // n_frames -> launch configuration (tile hint) measured fastest by grnet_tune
 };
 
@@ -94,6 +95,12 @@ struct FuseUpPlan {
 struct ChainPlan {
     std::vector<int> convs;              // indices into grnet::convs, in execution order
     int c = 0, w = 0;
+};
+
+// Layers that run as ONE row-walking launch on the bf16 path in large calls (conv_bf16_roll.hip)
+struct RollPlan {
+    int kind = 0;                        // 0: stem pair (conv1, conv2); 1: layer1.0 (conv1, conv2, conv3 over [u ; x]); 2: layer1.1-3 (conv1, conv2, conv3 + residual)
+    std::vector<int> convs;              // indices into grnet::convs, in execution order
 };
 
 struct Op {
@@ -483,6 +490,26 @@ struct grnet {
     }
     std::vector<FuseUpPlan> fuse_ups;
     std::vector<ChainPlan> chains;
+    std::vector<RollPlan> rolls;
+    // the convolutions added last (in order) become ONE row-walking launch in large bf16 calls; the members keep their own ops (small calls launch them one by
+    // one), pinned to the launcher's stream in order -- the mechanism of the BasicBlock chains
+    void add_roll(int kind, int n_convs) {
+        RollPlan rp;
+        rp.kind = kind;
+        const int first = (int)convs.size() - n_convs;
+        for (int i = 0; i < n_convs; ++i) {
+            convs[first + i].roll = (int)rolls.size();
+            convs[first + i].roll_pos = i;
+            rp.convs.push_back(first + i);
+        }
+        int prev_op = -1;
+        for (int i = 0; i < (int)ops.size(); ++i)
+            if (ops[i].kind == Op::CONV && ops[i].conv_idx >= first) {
+                if (prev_op >= 0) ops[i].follow = prev_op;
+                prev_op = i;
+            }
+        rolls.push_back(rp);
+    }
 
     // Fuse layer as launched until round 3 (kept for the bf16 path and for A/B runs)
     // up0 (bf16, round 5): output 0 -- the full-resolution one, 4 of the layer's launches -- is finished by ONE hr_fuse_up_bf16 launch instead (only = 0);
@@ -625,6 +652,7 @@ struct grnet {
         name_view("stem_conv1", x);
         x = conv_bn(x, b + "conv2.weight", b + "bn2", 64, 3, 2, true);
         name_view("stem_conv2", x);
+        if (bf16_stem) add_roll(0, 2);
         int prev_conv3 = -1;
         for (int k = 0; k < 4; ++k) {                       // layer1: 4 Bottlenecks (hrnet.py:80-100)
             const std::string q = b + "layer1." + std::to_string(k) + ".";
@@ -658,12 +686,16 @@ struct grnet {
                 convs.back().in2 = xin;
                 convs.back().seg2 = ConvSeg{q + "downsample.0.weight", q + "downsample.1", "", 256};
                 convs.back().macs_per_frame *= 2;                  // K = 64 (t) + 64 (x)
+                add_roll(1, 3);
+                name_view("layer1.0", x);
                 continue;
             }
             View res = k == 0 ? conv_bn(x, q + "downsample.0.weight", q + "downsample.1", 256, 1, 1, false) : x;
             View y = conv_bn(x, q + "conv1.weight", q + "bn1", 64, 1, 1, true);
             y = conv_bn(y, q + "conv2.weight", q + "bn2", 64, 3, 1, true);
             x = conv_bn(y, q + "conv3.weight", q + "bn3", 256, 1, 1, true, {AddRef{res, 0}});
+            if (dtype == 1 && k > 0) add_roll(2, 3);
+            name_view("layer1." + std::to_string(k), x);
         }
         name_view("layer1", x);
         solo_region = false;
@@ -1509,12 +1541,12 @@ struct grnet {
     }
     // bf16 layer1: expansion + next reduction as one launch from 19 frames per call on (the 256-channel tile needs >= 512 workgroups of 112 pixels); bit 6 of the
     // GRNET_OPT_BF16_CHAIN mask.  A forced tile switches it off.
-    bool pair_active(int n) const { return dtype == 1 && (chain_mode & 64) && !conv_tile_hint && (bf16_min_frames ? n >= bf16_min_frames : (long)n * 56 * 56 >= 256L * 112 * 2); }
+    bool pair_active(int n) const { return dtype == 1 && (chain_mode & 64) && !conv_tile_hint && (long)n * 56 * 56 >= 256L * 112 * 2; }      // (geometric: GRNET_OPT_BF16_MIN_FRAMES does not lower it)
     int bf16_min_frames = 0;                         // GRNET_OPT_BF16_MIN_FRAMES: 0 = every kernel group of chain_mode from its own smallest call (64 / 32 / 64 / 19 / 42 frames), else from this many
 
     // Which kernel runs convolution L in a call of n frames: ONE place, used by the launcher, by the executed-FLOP report and by the
     // per-kernel table of bench.py (round-3 review: the report read a hidden "latest n" and ignored the environment masks).
-    enum ConvKernel { K_BF16, K_BF16_STEM, K_BF16_CHAIN, K_BF16_CHAIN_MEMBER, K_BF16_PAIR, K_BF16_PAIR_MEMBER, K_BF16_WIDE, K_BF16_S2, K_WINO4S, K_PW, K_STEM, K_WINO4, K_DIRECT };
+    enum ConvKernel { K_BF16, K_BF16_STEM, K_BF16_ROLL, K_BF16_ROLL_MEMBER, K_BF16_CHAIN, K_BF16_CHAIN_MEMBER, K_BF16_PAIR, K_BF16_PAIR_MEMBER, K_BF16_WIDE, K_BF16_S2, K_WINO4S, K_PW, K_STEM, K_WINO4, K_DIRECT };
     // bf16: does chain `c` run as ONE conv_bf16_chain launch in a call of n frames?  A chain workgroup is one frame on one CU: from about a
     // quarter of the chip's CUs on it beats eight launches (GRNET_BF16_CHAIN: bit 0 64 ch @28x28, bit 1 128 ch @14x14, bit 2 256 ch @7x7, bit 3 32 ch @56x56 --
     // there a launch per BasicBlock with 19-row bands resident;
@@ -1538,10 +1570,16 @@ struct grnet {
         if (dtype != 1 || !(chain_mode & 32) || conv_tile_hint || n < s2_min || L.stem_dev || !L.w_dev || L.in2.c) return false;
         return conv_bf16_s2_eligible(conv_args(L, nullptr, n));
     }
-    static constexpr int kChainModeAll = 255;
+    static constexpr int kChainModeAll = 1023;
+    // bf16: the stem pair (bit 9 of the mask) / a layer1 Bottleneck (bit 8) as ONE row-walking launch (conv_bf16_roll.hip), from 64 frames per call on (a workgroup is a
+    // frame, or a quarter of one): HBM sees the launch's input and output once.  A forced tile switches it off like every special kernel.
+    bool roll_active(const RollPlan& r, int n) const {
+        return dtype == 1 && !conv_tile_hint && n >= (bf16_min_frames ? bf16_min_frames : 64) && (chain_mode & (r.kind == 0 ? 512 : 256));
+    }
     int chain_mode = (getenv("GRNET_BF16_CHAIN") ? atoi(getenv("GRNET_BF16_CHAIN")) : kChainModeAll) & kChainModeAll;     // GRNET_OPT_BF16_CHAIN: bits 0-3 BasicBlock chains by branch, 4 wide bands, 5 stride-2 bands, 6 layer1 1x1 pairs, 7 1x1 stream kernel
     ConvKernel kernel_for(const ConvLayer& L, int n) const {
         static const int w4s_env = GRNET_AB(WINO4S, 7);      // bit 0: 128 @14x14, bit 1: 256 @7x7, bit 2: 256 @14x14
+        if (dtype == 1 && L.roll >= 0 && roll_active(rolls[L.roll], n)) return L.roll_pos == 0 ? K_BF16_ROLL : K_BF16_ROLL_MEMBER;
         if (dtype == 1 && L.chain >= 0 && chain_active(chains[L.chain], n)) return L.chain_pos == 0 ? K_BF16_CHAIN : K_BF16_CHAIN_MEMBER;
         if (dtype == 1 && L.pair_next >= 0 && pair_active(n)) return K_BF16_PAIR;
         if (dtype == 1 && L.pair_of >= 0 && pair_active(n)) return K_BF16_PAIR_MEMBER;
@@ -1569,6 +1607,8 @@ struct grnet {
         switch (kernel_for(L, n)) {
             case K_BF16: return "conv_bf16";
             case K_BF16_STEM: return "conv_bf16_stem";
+            case K_BF16_ROLL: return rolls[L.roll].kind == 0 ? "conv_bf16_stem_pair" : "conv_bf16_bneck";
+            case K_BF16_ROLL_MEMBER: return rolls[L.roll].kind == 0 ? "conv_bf16_stem_pair+" : "conv_bf16_bneck+";      // runs inside the launch of the group's first member
             case K_BF16_PAIR: return "conv_bf16_pair";
             case K_BF16_PAIR_MEMBER: return "conv_bf16_pair+";     // runs inside the pair's launch
             case K_BF16_WIDE: snprintf(b, sizeof b, "conv_bf16_wide<%d,%d>", L.in.c >= 128 ? 128 : 64, L.in.w); return b;
@@ -1610,6 +1650,20 @@ struct grnet {
                 break;
             }
             case K_BF16_CHAIN_MEMBER: *n_launches = 0; break;       // its work is in the launch of the chain's first member
+            case K_BF16_ROLL: {
+                const RollPlan& rp = rolls[L.roll];
+                const ConvLayer& last = convs[rp.convs.back()];
+                if (rp.kind == 0) {
+                    const ConvLayer& c2 = convs[rp.convs[1]];
+                    HIP_TRY(launch_conv_bf16_stem_pair(frames, last.out.p, last.out.ctot, last.out.coff, n, L.stem_dev, L.b_dev, c2.w_dev, c2.b_dev, s));
+                } else {
+                    const ConvLayer &c2 = convs[rp.convs[1]], &c3 = convs[rp.convs[2]];
+                    HIP_TRY(launch_conv_bf16_bneck(L.in.p, L.in.ctot, L.in.coff, last.out.p, last.out.ctot, last.out.coff, n, rp.kind == 1, L.w_dev, L.b_dev, c2.w_dev, c2.b_dev,
+                                                   c3.w_dev, c3.b_dev, s));
+                }
+                break;
+            }
+            case K_BF16_ROLL_MEMBER: *n_launches = 0; break;        // its work is in the launch of the group's first member
             case K_BF16_PAIR: HIP_TRY(launch_conv_bf16(conv_args(L, frames, n), s, 0)); break;
             case K_BF16_PAIR_MEMBER: *n_launches = 0; break;        // its work is the second stage of the expansion's launch
             case K_BF16_WIDE: HIP_TRY(launch_conv_bf16_wide(conv_args(L, frames, n), s)); break;
@@ -2159,7 +2213,7 @@ int grnet_create(grnet_t** out_handle, int device_id, int dtype, int max_frames)
     h->build_plan();
     int rc = h->allocate();
     if (rc) { fprintf(stderr, "grnet_create: %s\n", h->err.c_str()); return rc; }
-    if (conv_init() != hipSuccess || conv_bf16_init() != hipSuccess || conv_bf16_chain_init() != hipSuccess) { fprintf(stderr, "grnet_create: conv_init failed\n"); return GRNET_EHIP; }
+    if (conv_init() != hipSuccess || conv_bf16_init() != hipSuccess || conv_bf16_chain_init() != hipSuccess || conv_bf16_roll_init() != hipSuccess) { fprintf(stderr, "grnet_create: conv_init failed\n"); return GRNET_EHIP; }
     *out_handle = h.release();
     return 0;
 }

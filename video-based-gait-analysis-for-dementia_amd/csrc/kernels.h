@@ -294,6 +294,13 @@ struct GruWorkspace {
                                           // (b, 2 dirs, 8 slices) {XCC id, 1} placement words (may be null: the unsplit kernel runs)
 };
 constexpr int kGruXbufU64PerSeq = 2 * 2 * 300 + 2 * 8;
+// bf16 path, round 6 (conv_bf16_roll.hip): the stem pair and a whole layer1 Bottleneck as ONE launch, a workgroup walking a frame row by row
+hipError_t conv_bf16_roll_init();
+int conv_bf16_roll_segments(int n_frames);          // row segments per frame of those launches (1, 2 or 4: frames x segments >= CUs)
+hipError_t launch_conv_bf16_bneck(const void* in, int in_ctot, int in_coff, void* out, int out_ctot, int out_coff, int N, bool first, const void* w1, const float* b1,
+                                  const void* w2, const float* b2, const void* w3, const float* b3, hipStream_t s);
+hipError_t launch_conv_bf16_stem_pair(const float* frames, void* out, int out_ctot, int out_coff, int N, const void* w1pk, const float* b1, const void* w2, const float* b2,
+                                      hipStream_t s);
 // bf16 path (conv_bf16.hip): NHWC bf16 activations, fp32 accumulation on the bf16 matrix cores ----------------------
 hipError_t conv_bf16_init();
 hipError_t launch_conv_bf16(ConvArgs a, hipStream_t s, int tile_hint = 0);     // pointers in `a` address bf16 data (bias fp32)
