@@ -231,10 +231,12 @@ def test_bf16_layer1_pairs_are_bit_identical(bmodel, pkg):
     the stand-alone launch would read from HBM, in the same k order -- the whole forward must not change by a bit (compared with the 256-channel tile
     of the expansion forced either way, so that the only difference is where the reduction runs)."""
     frames = torch.from_numpy(np.tile(pkg.synth.make_frames(8), (8, 1, 1, 1))).cuda()
-    a = bmodel(frames, extras=("features",))[-1]
-    n_a = bmodel.num_kernel_launches()
-    bmodel.set_option(pkg._lib.OPT_BF16_CHAIN, 255 - 64)
+    base = 1023 - 256 - 512                                       # (round 6: the Bottleneck launches, bits 8 / 9, replace the pairs at this call size: off here)
     try:
+        bmodel.set_option(pkg._lib.OPT_BF16_CHAIN, base)
+        a = bmodel(frames, extras=("features",))[-1]
+        n_a = bmodel.num_kernel_launches()
+        bmodel.set_option(pkg._lib.OPT_BF16_CHAIN, base - 64)
         b = bmodel(frames, extras=("features",))[-1]
         n_b = bmodel.num_kernel_launches()
     finally:

@@ -21,6 +21,8 @@
 // fp32 summation order inside a k-step at most (tests: equal to the fp32 oracle on bf16-rounded operands with bf16-rounded intermediates).
 #include "kernels.h"
 
+#include <type_traits>
+
 namespace grk {
 
 #define GRK_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return _e; } while (0)
@@ -124,37 +126,45 @@ __global__ __launch_bounds__(512) void conv_bf16_bneck(const RollArgs a) {
     const int n = blockIdx.x / a.S, seg = blockIdx.x - n * a.S;
     if (n >= a.N) return;
     const int rs = W / a.S, s0 = seg * rs, s1 = s0 + rs;
-    const int yb = s0 > 0 ? s0 - 1 : 0;
     const u16* inb = reinterpret_cast<const u16*>(a.in) + (size_t)n * W * W * a.in_ctot + a.in_coff;
     u16* outb = reinterpret_cast<u16*>(a.out) + (size_t)n * W * W * a.out_ctot + a.out_coff;
 
-    // unit i of this thread (16 bytes of a row): its place in the staged row and in a row of HBM -- the same for every row, kept as two 32-bit offsets each
+    // unit i of this thread (16 bytes of a row): its place in the staged row and in a row of HBM -- the same for every row, kept as two 32-bit offsets each.
+    // A row is not a whole number of units per thread: the threads past its end LOAD a unit of the row's tail a second time (and drop it), so that every thread issues
+    // the same number of loads per step.
+    constexpr int XDUP = UPR % 512 ? 512 - UPR % 512 : 0, ODUP = OUR % 512 ? 512 - OUR % 512 : 0;
     int xl[NXU], xg[NXU], ol[NOU], og[NOU];
 #pragma unroll
     for (int i = 0; i < NXU; ++i) {
-        const int u = i * 512 + tid, px = u / (CI / 8), part = u - px * (CI / 8);
+        int u = i * 512 + tid;
+        if (u >= UPR) u -= XDUP;
+        const int px = u / (CI / 8), part = u - px * (CI / 8);
         xl[i] = px * XSB + part * 16;
         xg[i] = px * a.in_ctot + part * 8;
     }
 #pragma unroll
     for (int i = 0; i < NOU; ++i) {
-        const int u = i * 512 + tid;
+        int u = i * 512 + tid;
+        if (u >= OUR) u -= ODUP;
         ol[i] = (u >> 5) * OSB + (u & 31) * 16;
         og[i] = (u >> 5) * a.out_ctot + (u & 31) * 8;
     }
+    // hipcc counts the vector-memory queue in order, and its wait in front of the x row's first use came out as vmcnt(0) while loads or stores sat under branches of
+    // the row loop ("anything may be pending" at the joins): every step then drained the two-step prefetch AND the previous step's stores -- compute, loads and stores
+    // added up exactly (tools/roll_micro.py).  So the steps that store (rows s0 + 1 .. s1) are a loop whose body issues its NXU loads and NOU stores unconditionally --
+    // rows the segment does not need are requested all the same (clamped, never used) -- and the two steps in front of it (ring rows s0 - 1, s0) are a copy without
+    // the output phases.  (Loads hipcc does not count -- inline asm with a hand-counted wait -- are not an option for registers: it may copy them before the wait.)
     u32x4 nxa[NXU], nxb[NXU];
-    auto request = [&](int y, u32x4 (&nx)[NXU]) {               // x row y -> registers (rows past the segment's last ring row: not requested)
-        if (y > s1 || y >= W) return;
+    auto request = [&](int y, u32x4 (&nx)[NXU]) {               // x row y -> registers
+        const u16* rowp = inb + (size_t)(y < 0 ? 0 : y < W ? y : W - 1) * W * a.in_ctot;
 #ifdef GRNET_ABLATION
         if (a.dbg & 16) return;
 #endif
-        const u16* rowp = inb + (size_t)y * W * a.in_ctot;
 #pragma unroll
-        for (int i = 0; i < NXU; ++i)
-            if (i * 512 + tid < UPR) nx[i] = *reinterpret_cast<const u32x4*>(rowp + xg[i]);
+        for (int i = 0; i < NXU; ++i) nx[i] = *reinterpret_cast<const u32x4*>(rowp + xg[i]);
     };
-    request(yb, nxa);
-    request(yb + 1, nxb);
+    request(s0 - 1, nxa);
+    request(s0, nxb);
     stage_w2(w2l, a.w2, tid);
     for (int u = tid; u < (3 * TSLOTS * kTSB) / 16; u += 512) reinterpret_cast<u32x4*>(tring)[u] = u32x4{0u, 0u, 0u, 0u};
 
@@ -184,14 +194,15 @@ __global__ __launch_bounds__(512) void conv_bf16_bneck(const RollArgs a) {
         for (int T = 0; T < 4; ++T) res_cur[bi][T] = res_nxt[bi][T] = u32x2{0u, 0u};
     lds_sync();
 
-    auto step = [&](int y, u32x4 (&nx)[NXU]) {
-        const bool has_x = y < W;
+    auto step = [&](auto out_tag, int y, u32x4 (&nx)[NXU]) {
+        constexpr bool OUT = decltype(out_tag)::value;          // the step finishes output row y - 1
+        const bool has_x = y >= 0 && y < W;
         unsigned char* xr = FIRST ? xrow + (y & 1) * XROW : xrow;
         // ---- 1. x row y -> LDS
         if (has_x) {
 #pragma unroll
             for (int i = 0; i < NXU; ++i)
-                if (i * 512 + tid < UPR) *reinterpret_cast<u32x4*>(xr + xl[i]) = nx[i];
+                if (i * 512 + tid < UPR) *reinterpret_cast<u32x4*>(xr + xl[i]) = nx[i];      // (a thread past the row's end holds a second copy of a tail unit: loaded, not written)
         }
         request(y + 2, nx);
         lds_sync();
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(512) void conv_bf16_bneck(const RollArgs a) {
             *reinterpret_cast<u32x4*>(trow + ((tid >> 3) + 1) * kTSB + (tid & 7) * 16) = u32x4{0u, 0u, 0u, 0u};
         }
         lds_sync();
-        if (y > s0) {                                           // output row y - 1 belongs to this segment
+        if constexpr (OUT) {                                    // output row y - 1 (rows s0 .. s1 - 1)
             const int yo = y - 1;
             // ---- 3. 3x3 -> u
             {
@@ -285,7 +296,7 @@ __global__ __launch_bounds__(512) void conv_bf16_bneck(const RollArgs a) {
                 u16* rowp = outb + (size_t)yo * W * a.out_ctot;
 #pragma unroll
                 for (int i = 0; i < NOU; ++i)
-                    if (i * 512 + tid < OUR) *reinterpret_cast<u32x4*>(rowp + og[i]) = *reinterpret_cast<const u32x4*>(ostage + ol[i]);
+                    if (i * 512 + tid < OUR) *reinterpret_cast<u32x4*>(rowp + og[i]) = *reinterpret_cast<const u32x4*>(ostage + ol[i]);      // (only a unit's owner may move it: the owner refills it without a barrier)
             }
         }
         if (!FIRST) {
@@ -295,10 +306,12 @@ __global__ __launch_bounds__(512) void conv_bf16_bneck(const RollArgs a) {
                 for (int T = 0; T < 4; ++T) res_cur[bi][T] = res_nxt[bi][T];
         }
     };
+    step(std::false_type{}, s0 - 1, nxa);                       // ring rows s0 - 1 (row -1: zeros) and s0
+    step(std::false_type{}, s0, nxb);
 #pragma unroll 1
-    for (int y = yb; y <= s1; y += 2) {
-        step(y, nxa);
-        if (y + 1 <= s1) step(y + 1, nxb);
+    for (int y = s0 + 1; y <= s1; y += 2) {                     // an even number of steps: rows per segment are 56, 28 or 14
+        step(std::true_type{}, y, nxa);
+        step(std::true_type{}, y + 1, nxb);
     }
 }
 
