@@ -355,23 +355,28 @@ __global__ __launch_bounds__(512) void conv_bf16_stem_pair(const RollArgs a) {
         koff[j] = (c * H + (ky - 1)) * W + (kx - 1);
     }
     float g[2][8];
-    auto gather = [&](int y1) {                                  // conv1 row y1 (0 .. 111), this wave's tiles -> registers (fp32, as they lie in the frame)
+    // conv1 row y1 (0 .. 111; clamped: rows past the frame are requested and never used), this wave's tiles -> registers (fp32, as they lie in the frame).  Every
+    // load is issued by every lane -- padding elements read a clamped address and are replaced by zeros -- and the storing loop below has no branch around its loads
+    // and stores: hipcc then counts its vmcnt waits (with the predicated gathers of the first form every use waited for vmcnt(0), i.e. also for the output row stored
+    // just before: gathers, stores and MFMA phases added up exactly, tools/roll_micro.py).
+    auto gather = [&](int y1r) {
+        const int y1 = y1r < 0 ? 0 : y1r > 111 ? 111 : y1r;
+#ifdef GRNET_ABLATION
+        if (a.dbg & 16) return;
+#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int x = 16 * (ct0 + i) + l15;
+            const int x = 16 * (ct0 + (i < nct ? i : 0)) + l15;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                bool ok = i < nct && kreal[j] && (2 * y1 + kky[j] >= 0) && !(kleft[j] && x == 0);
-#ifdef GRNET_ABLATION
-                if (a.dbg & 16) ok = false;
-#endif
-                g[i][j] = ok ? fb[koff[j] + 2 * y1 * W + 2 * x] : 0.f;
+                const bool ok = kreal[j] && (2 * y1 + kky[j] >= 0) && !(kleft[j] && x == 0);
+                const float v = fb[ok ? koff[j] + 2 * y1 * W + 2 * x : 0];
+                g[i][j] = ok ? v : 0.f;
             }
         }
     };
-    // a segment's first step also needs conv1 row 2 s0 - 1: computed in a step of its own in front (rows 2 s0 - 2, 2 s0 - 1; the first is not used)
-    const int Yb = s0 > 0 ? s0 - 1 : 0;
-    gather(2 * Yb + crow);
+    // a segment's first step also needs conv1 row 2 s0 - 1: a step of its own in front computes rows 2 s0 - 2, 2 s0 - 1 (for s0 = 0: two rows of nothing, kept zero)
+    gather(2 * (s0 - 1) + crow);
     stage_w2(w2l, a.w2, tid);
     for (int u = tid; u < (3 * kStemRowSlots * kTSB) / 16; u += 512) reinterpret_cast<u32x4*>(ring)[u] = u32x4{0u, 0u, 0u, 0u};
     const int blk = wave & 3, tp = wave >> 2;
@@ -379,29 +384,35 @@ __global__ __launch_bounds__(512) void conv_bf16_stem_pair(const RollArgs a) {
     const unsigned char* wl = w2l + (blk * 16 + l15) * 64 + ((lq ^ (((l15 >> 3) & 1) << 1)) * 16);
     lds_sync();
 
-#pragma unroll 1
-    for (int Y = Yb; Y < s1; ++Y) {
-        // ---- conv1 rows 2Y, 2Y + 1 -> ring slots (row + 3) % 3
-        {
-            const int y1 = 2 * Y + crow;
-            unsigned char* row = ring + ((y1 + 3) % 3) * (kStemRowSlots * kTSB);
+    auto conv1_rows = [&](int Y) {                               // conv1 rows 2Y, 2Y + 1 -> ring slots (row + 3) % 3 (rows above the frame: nothing is written, the slot keeps its zeros)
+        const int y1 = 2 * Y + crow;
+        if (y1 < 0) return;
+        unsigned char* row = ring + ((y1 + 3) % 3) * (kStemRowSlots * kTSB);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (i >= nct) break;
-                const u32x4 bp = {pack2_r(g[i][0], g[i][1]), pack2_r(g[i][2], g[i][3]), pack2_r(g[i][4], g[i][5]), pack2_r(g[i][6], g[i][7])};
-                const bf16x8 b = __builtin_bit_cast(bf16x8, bp);
-                const int x1 = 16 * (ct0 + i) + l15;                 // conv1 column: even -> even plane at x1 / 2, odd -> odd plane at (x1 + 1) / 2
-                unsigned char* dst = row + (((x1 & 1) ? kStemPlane + (x1 + 1) / 2 : x1 / 2)) * kTSB + lq * 8;
+        for (int i = 0; i < 2; ++i) {
+            if (i >= nct) break;
+            const u32x4 bp = {pack2_r(g[i][0], g[i][1]), pack2_r(g[i][2], g[i][3]), pack2_r(g[i][4], g[i][5]), pack2_r(g[i][6], g[i][7])};
+            const bf16x8 b = __builtin_bit_cast(bf16x8, bp);
+            const int x1 = 16 * (ct0 + i) + l15;                 // conv1 column: even -> even plane at x1 / 2, odd -> odd plane at (x1 + 1) / 2
+            unsigned char* dst = row + (((x1 & 1) ? kStemPlane + (x1 + 1) / 2 : x1 / 2)) * kTSB + lq * 8;
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    const f32x4 v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[mt], b, b1v[mt], 0, 0, 0);
-                    *reinterpret_cast<u32x2*>(dst + mt * 32) = pack4_relu(v);
-                }
+            for (int mt = 0; mt < 4; ++mt) {
+                const f32x4 v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[mt], b, b1v[mt], 0, 0, 0);
+                *reinterpret_cast<u32x2*>(dst + mt * 32) = pack4_relu(v);
             }
         }
+    };
+    conv1_rows(s0 - 1);
+    lds_sync();
+    gather(2 * s0 + crow);
+    lds_sync();
+    const int sl = tid >> 3, sp = tid & 7;                        // the thread's unit of an output row (56 pixels x 8 units of 16 bytes: threads 0 .. 447)
+#pragma unroll 1
+    for (int Y = s0; Y < s1; ++Y) {
+        conv1_rows(Y);
         lds_sync();
-        if (Y + 1 < s1) gather(2 * (Y + 1) + crow);              // in flight under the 3x3
-        if (Y >= s0) {
+        gather(2 * (Y + 1) + crow);                              // in flight under the 3x3 and the next barrier
+        {
             // ---- conv2 row Y: tap row dy = conv1 row 2Y + dy - 1
             const unsigned char* rb[3];
 #pragma unroll
@@ -421,8 +432,8 @@ __global__ __launch_bounds__(512) void conv_bf16_stem_pair(const RollArgs a) {
 #ifdef GRNET_ABLATION
         if (!(a.dbg & 8))
 #endif
-        if (Y >= s0 && tid < WO * 8)
-            *reinterpret_cast<u32x4*>(outb + (size_t)(Y * WO + (tid >> 3)) * a.out_ctot + (tid & 7) * 8) = *reinterpret_cast<const u32x4*>(ostage + (tid >> 3) * kTSB + (tid & 7) * 16);
+        if (wave < 7)                                             // (wave-uniform: 448 threads move the row; the next step's barrier orders these reads before the staging is rewritten)
+            *reinterpret_cast<u32x4*>(outb + (size_t)(Y * WO + sl) * a.out_ctot + sp * 8) = *reinterpret_cast<const u32x4*>(ostage + sl * kTSB + sp * 16);
     }
 }
 
