@@ -21,6 +21,7 @@
 // fp32 summation order inside a k-step at most (tests: equal to the fp32 oracle on bf16-rounded operands with bf16-rounded intermediates).
 #include "kernels.h"
 
+#include <cstdio>
 #include <type_traits>
 
 namespace grk {
@@ -68,22 +69,28 @@ __device__ __forceinline__ void stage_w2(unsigned char* w2l, const void* w2g, in
 // rb[dy]: this lane's B operand of tap row dy at X = l15 of tile 0, chunk 0, column tap 0; XS(dx): byte offset of column tap dx; a tile is TS bytes on.
 template <typename XS>
 __device__ __forceinline__ void conv3x3_row(f32x4 (&acc)[2], const unsigned char* (&rb)[3], const unsigned char* wl, int tp, XS xs, int ts) {
+    // six groups (chunk, tap row) of 3 tap columns x 2 tiles: the next group's nine fragments are requested in front of this group's six MFMAs (left to itself hipcc
+    // waits for a group's reads right in front of its MFMAs: six exposed LDS latencies per row)
+    bf16x8 af[2][3], bfr[2][3][2];
+    auto fetch = [&](int g, int slot) {
+        const int c = g / 3, dy = g % 3;
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+        for (int dx = 0; dx < 3; ++dx) {
+            af[slot][dx] = *reinterpret_cast<const bf16x8*>(wl + ((c * 9 + dy * 3 + dx) * 64) * 64);
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            bf16x8 af[3], bfr[3][2];
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                af[dx] = *reinterpret_cast<const bf16x8*>(wl + ((c * 9 + dy * 3 + dx) * 64) * 64);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) bfr[dx][i] = *reinterpret_cast<const bf16x8*>(rb[dy] + (2 * tp + i) * ts + xs(dx) + c * 64);
-            }
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dx], bfr[dx][i], acc[i], 0, 0, 0);
+            for (int i = 0; i < 2; ++i) bfr[slot][dx][i] = *reinterpret_cast<const bf16x8*>(rb[dy] + (2 * tp + i) * ts + xs(dx) + c * 64);
         }
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+        if (g + 1 < 6) fetch(g + 1, (g + 1) & 1);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g & 1][dx], bfr[g & 1][dx][i], acc[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 }  // namespace
@@ -315,6 +322,270 @@ __global__ __launch_bounds__(512) void conv_bf16_bneck(const RollArgs a) {
     }
 }
 
+// ---- layer1.1 - layer1.3 with the x rows prefetched by LDS-DMA.  In the kernel above the next rows travel through registers and hipcc's counted waits: its wait
+// at the head of the row loop still asks for the one-step-old row, so a step has about one row of loads and one of stores in flight (57 KB per CU, 3.4 TB/s: the
+// loads, the stores and the MFMA phases added up instead of overlapping, profiles/r06_roll_ablation.txt).  Here:
+//   * x rows arrive by LDS-DMA into TWO row buffers (row y in buffer y & 1), requested right behind the barrier that ends the reduce of the row the buffer held --
+//     1.7 steps ahead; no registers, no staging instructions.  The pieces are inline asm hipcc does not count, and the wait is counted by hand: the queue is in
+//     order and a wave's step is [DMA pieces of row y + 2][stores of row y - 1], so in front of the reduce of row y a wave has its pieces of row y when at most
+//     (stores + pieces + stores) = 3 ND operations are outstanding (ND = 4 for waves 0-3, 3 for waves 4-7, for pieces and stores alike); the first three steps
+//     of a segment, whose queue is shorter, wait for everything;
+//   * the LDS for the second row buffer and a staging row of its own: half of the 3x3's weights (input channels 32-63, 9 fragments = 36 registers per wave) live
+//     in registers -- the registers the register prefetch held -- and the 256-channel rows are unpadded (512 bytes per pixel), the 16-byte part p of pixel x at
+//     p ^ (x & 15): the 16 lanes of a fragment read (16 pixels, one part) hit 16 different bank groups, and the DMA (lane-linear in LDS) applies the permutation
+//     in its source addresses; the staging row leaves in the same permuted order (each pixel's 512 bytes by 32 lanes: whole lines all the same).
+// Steps, barriers and arithmetic are those of the kernel above.
+#ifdef GRNET_ABLATION
+__device__ unsigned long long g_roll_phase[8];                 // diagnostic builds, GRNET_ROLL_PHASES: clock ticks of wave 0 of every workgroup per phase of conv_bf16_bneck_dma
+#define ROLL_TICK(k) do { if (a.dbg & 32) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc_[k] += t_ - tick_; tick_ = t_; } } while (0)
+#else
+#define ROLL_TICK(k) do { } while (0)
+#endif
+constexpr int kXRowB = 56 * 512;
+constexpr int kBneckDmaLds = 9 * 64 * 64 + 3 * 58 * kTSB + 56 * kTSB + 3 * kXRowB + 384 * 4;      // 161 216
+static_assert(kBneckDmaLds <= 160 * 1024, "LDS");
+__device__ __forceinline__ void dma16_row(unsigned off, const void* base, unsigned lds) {      // lane l's 16 bytes at base + off land at lds + 16 l; one wait state between the M0 write and the DMA
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds) : "memory");
+}
+
+__global__ __launch_bounds__(512) void conv_bf16_bneck_dma(const RollArgs a) {
+    constexpr int W = 56, TSLOTS = 58, TROW = TSLOTS * kTSB;
+    extern __shared__ __align__(16) unsigned char lds[];
+    unsigned char* w2l = lds;                                   // chunk 0 of the 3x3's weights: [9][64][32] bf16
+    unsigned char* tring = w2l + 9 * 64 * 64;                   // 3 rows x 58 slots (a lane past pixel 55 reads up to 8 slots past its row: inside the allocation, dropped)
+    unsigned char* ubuf = tring + 3 * TROW;
+    unsigned char* xb = ubuf + W * kTSB;                        // two x rows
+    unsigned char* ost = xb + 2 * kXRowB;                       // the staging row
+    float* bl = reinterpret_cast<float*>(ost + kXRowB);         // the three biases (64 + 64 + 256 floats): 16 registers the reduce's read batches need
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = blockIdx.x / a.S, seg = blockIdx.x - n * a.S;
+    if (n >= a.N) return;
+    const int rs = W / a.S, s0 = seg * rs, s1 = s0 + rs;
+    const u16* inb = reinterpret_cast<const u16*>(a.in) + (size_t)n * W * W * a.in_ctot + a.in_coff;
+    u16* outb = reinterpret_cast<u16*>(a.out) + (size_t)n * W * W * a.out_ctot + a.out_coff;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;      // LDS byte address of the allocation
+
+    // a row is 28 pieces of 1 KiB (two pixels each): wave w moves pieces w, w + 8, w + 16 (and w + 24 for w < 4); unit (lane) of a piece = pixel 2q + (l >> 5), slot l & 31
+    const int ND = wave < 4 ? 4 : 3;
+    // (piece w + 8 j starts 16 j pixels on: the permutation (x & 15) is the same for all four, so one lane offset + a uniform stride)
+    const unsigned doff0 = (unsigned)((2 * wave + (lane >> 5)) * a.in_ctot + ((lane & 31) ^ ((2 * wave + (lane >> 5)) & 15)) * 8) * 2u, dstep = (unsigned)(16 * a.in_ctot) * 2u;
+    auto request = [&](int y) {                                 // x row y -> buffer (y + 2) & 1 (rows outside the frame: clamped, landed and never used -- the counts stay the same)
+        const u16* rowp = inb + (size_t)(y < 0 ? 0 : y < W ? y : W - 1) * W * a.in_ctot;
+        const unsigned dst = lds0 + (unsigned)(xb - lds) + ((y + 2) & 1) * kXRowB + wave * 1024;
+#ifdef GRNET_ABLATION
+        if (a.dbg & 16) return;
+#endif
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < ND) dma16_row(doff0 + j * dstep, rowp, dst + j * 8192);
+    };
+    request(s0 - 1);
+    request(s0);
+    {   // chunk 0 of the 3x3's weights -> LDS (swizzled 64-byte rows), the rings' zeros
+        constexpr int NU = 9 * 64 * 4;
+        for (int u = tid; u < NU; u += 512) {
+            const int row = u >> 2, part = u & 3;
+            *reinterpret_cast<u32x4*>(w2l + row * 64 + ((part ^ (((row >> 3) & 1) << 1)) * 16)) = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(a.w2) + (size_t)u * 16);
+        }
+        for (int u = tid; u < (3 * TROW) / 16; u += 512) reinterpret_cast<u32x4*>(tring)[u] = u32x4{0u, 0u, 0u, 0u};
+        if (tid < 64) { bl[tid] = a.b1[tid]; bl[64 + tid] = a.b2[tid]; }
+        if (tid < 256) bl[128 + tid] = a.b3[tid];
+    }
+    const int blk = wave & 3, tp = wave >> 2;
+    bf16x8 w1f[8], w2r[9], w3f[2][2];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) w1f[c] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const u16*>(a.w1) + ((size_t)c * 64 + blk * 16 + l15) * 32 + lq * 8);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w2r[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const u16*>(a.w2) + ((size_t)(9 + t) * 64 + blk * 16 + l15) * 32 + lq * 8);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi) w3f[c][bi] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const u16*>(a.w3) + ((size_t)c * 256 + (2 * wave + bi) * 16 + l15) * 32 + lq * 8);
+    const float* b1p = bl + blk * 16 + lq * 4;
+    const float* b3p = bl + 128 + 2 * wave * 16 + lq * 4;
+    const unsigned char* wl = w2l + (blk * 16 + l15) * 64 + ((lq ^ (((l15 >> 3) & 1) << 1)) * 16);
+    int pxc[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) pxc[T] = (16 * T + l15) < W ? 16 * T + l15 : W - 1;
+    const int pxr[2] = {32 * tp + l15, (32 * tp + 16 + l15) < W ? 32 * tp + 16 + l15 : W - 1};
+    // byte offset of (pixel px, 16-byte part p) in an unpadded row
+    auto xat = [](int px, int p) { return px * 512 + ((p ^ (px & 15)) * 16); };
+    // this thread's units of the staging row (linear in LDS: unit i * 512 + tid) and where they go in a row of HBM (16 i pixels on: same permutation)
+    const int sg0 = (tid >> 5) * a.out_ctot + ((tid & 31) ^ ((tid >> 5) & 15)) * 8, sgstep = 16 * a.out_ctot;
+    // the residuals of the current and of the next output row: x[y] as the lanes that will finish row y hold its outputs, taken while the reduce has the row.
+    // (ONE set, refilled behind its use in the expansion, frees 32 registers but moves the request of row y + 2 behind that phase, next to the stores: measured
+    // 244 us per launch against 227 -- the pieces issue slowly there and arrive late.)
+    u32x2 res_cur[2][4], res_nxt[2][4];
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int T = 0; T < 4; ++T) res_cur[bi][T] = res_nxt[bi][T] = u32x2{0u, 0u};
+
+#ifdef GRNET_ABLATION
+    unsigned long long tick_ = __builtin_readcyclecounter(), tacc_[8] = {};
+#endif
+    auto step = [&](auto out_tag, auto steady_tag, int y) {
+        constexpr bool OUT = decltype(out_tag)::value, STEADY = decltype(steady_tag)::value;
+        const bool has_x = y >= 0 && y < W;
+        const unsigned char* xr = xb + ((y + 2) & 1) * kXRowB;
+        ROLL_TICK(7);
+        // ---- 1. this wave's pieces of row y have landed; everybody's
+        if (STEADY) {
+            if (wave < 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        ROLL_TICK(0);
+        lds_sync();
+        ROLL_TICK(1);
+        // ---- 2. reduce -> ring row y (a zero row outside the frame), residual capture
+        unsigned char* trow = tring + ((y + 3) % 3) * TROW;
+        if (has_x) {
+            const f32x4 b1v = *reinterpret_cast<const f32x4*>(b1p);
+            f32x4 acc[2] = {b1v, b1v};
+#ifdef GRNET_ABLATION
+            if (!(a.dbg & 1))
+#endif
+            {   // the row's fragments in two batches of eight reads, the second requested in front of the first one's MFMAs (left to itself hipcc keeps one or two reads
+                // in flight: 16 LDS latencies in a row were 1 500 of the phase's 2 400 cycles, GRNET_ROLL_PHASES)
+                bf16x8 bt[2][4][2];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) bt[0][c][i] = *reinterpret_cast<const bf16x8*>(xr + xat(pxr[i], 4 * c + lq));
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) bt[1][c][i] = *reinterpret_cast<const bf16x8*>(xr + xat(pxr[i], 4 * (c + 4) + lq));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[4 * h + c], bt[h][c][i], acc[i], 0, 0, 0);
+            }
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                for (int T = 0; T < 4; ++T) res_nxt[bi][T] = *reinterpret_cast<const u32x2*>(xr + xat(pxc[T], (2 * wave + bi) * 2 + (lq >> 1)) + (lq & 1) * 8);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int px = 16 * (2 * tp + i) + l15;
+                if (px < W) *reinterpret_cast<u32x2*>(trow + (px + 1) * kTSB + (blk * 16 + lq * 4) * 2) = pack4_relu(acc[i]);
+            }
+        } else if (tid < W * 8) {
+            *reinterpret_cast<u32x4*>(trow + ((tid >> 3) + 1) * kTSB + (tid & 7) * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+        lds_sync();
+        ROLL_TICK(2);
+        request(y + 2);                                         // the buffer of row y is free
+        ROLL_TICK(3);
+        if constexpr (OUT) {
+            const int yo = y - 1;
+            // ---- 3. 3x3 -> u: chunk 0's weights from LDS, chunk 1's from registers
+            {
+                const unsigned char* rb[3];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) rb[dy] = tring + ((yo - 1 + dy + 3) % 3) * TROW + l15 * kTSB + lq * 16;
+                const f32x4 b2v = *reinterpret_cast<const f32x4*>(b1p + 64);
+                f32x4 acc[2] = {b2v, b2v};
+#ifdef GRNET_ABLATION
+                if (!(a.dbg & 2))
+#endif
+                {   // six groups (chunk, tap row) of 3 tap columns x 2 tiles; the next group's fragments are requested in front of this group's MFMAs
+                    bf16x8 bfr[2][3][2], afl[2][3];
+                    auto fetch = [&](int g, int slot) {
+                        const int c = g / 3, dy = g % 3;
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            if (c == 0) afl[slot][dx] = *reinterpret_cast<const bf16x8*>(wl + ((dy * 3 + dx) * 64) * 64);
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) bfr[slot][dx][i] = *reinterpret_cast<const bf16x8*>(rb[dy] + (16 * (2 * tp + i) + dx) * kTSB + c * 64);
+                        }
+                    };
+                    fetch(0, 0);
+#pragma unroll
+                    for (int g = 0; g < 6; ++g) {
+                        if (g + 1 < 6) fetch(g + 1, (g + 1) & 1);
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                            for (int i = 0; i < 2; ++i)
+                                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g < 3 ? afl[g & 1][dx] : w2r[(g - 3) * 3 + dx], bfr[g & 1][dx][i], acc[i], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int px = 16 * (2 * tp + i) + l15;
+                    if (px < W) *reinterpret_cast<u32x2*>(ubuf + px * kTSB + (blk * 16 + lq * 4) * 2) = pack4_relu(acc[i]);
+                }
+            }
+            lds_sync();
+            ROLL_TICK(4);
+            // ---- 4. expand + residual -> staging row
+            {
+                f32x4 acc[2][4];
+#pragma unroll
+                for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                    for (int T = 0; T < 4; ++T) acc[bi][T] = *reinterpret_cast<const f32x4*>(b3p + bi * 16);
+#ifdef GRNET_ABLATION
+                if (!(a.dbg & 4))
+#endif
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int T = 0; T < 4; ++T) {
+                        const bf16x8 bt = *reinterpret_cast<const bf16x8*>(ubuf + pxc[T] * kTSB + c * 64 + lq * 16);
+#pragma unroll
+                        for (int bi = 0; bi < 2; ++bi) acc[bi][T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[c][bi], bt, acc[bi][T], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                    for (int T = 0; T < 4; ++T) {
+                        f32x4 v = acc[bi][T];
+                        const u32x2 r = res_cur[bi][T];
+                        v[0] += bflo(r[0]); v[1] += bfhi(r[0]); v[2] += bflo(r[1]); v[3] += bfhi(r[1]);
+                        if (16 * T + l15 < W) *reinterpret_cast<u32x2*>(ost + xat(16 * T + l15, (2 * wave + bi) * 2 + (lq >> 1)) + (lq & 1) * 8) = pack4_relu(v);
+                    }
+            }
+            lds_sync();
+            ROLL_TICK(5);
+            // ---- 5. staging row -> HBM (the staging is next written three barriers on)
+#ifdef GRNET_ABLATION
+            if (!(a.dbg & 8))
+#endif
+            {
+                u16* rowp = outb + (size_t)yo * W * a.out_ctot;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < ND) *reinterpret_cast<u32x4*>(rowp + sg0 + i * sgstep) = *reinterpret_cast<const u32x4*>(ost + (i * 512 + tid) * 16);
+            }
+            ROLL_TICK(6);
+        }
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int T = 0; T < 4; ++T) res_cur[bi][T] = res_nxt[bi][T];
+    };
+    step(std::false_type{}, std::false_type{}, s0 - 1);         // ring rows s0 - 1 (row -1: zeros) and s0
+    step(std::false_type{}, std::false_type{}, s0);
+    step(std::true_type{}, std::false_type{}, s0 + 1);          // the queue in front of these two is shorter than the steady one: they wait for everything
+    step(std::true_type{}, std::false_type{}, s0 + 2);
+#pragma unroll 1
+    for (int y = s0 + 3; y <= s1; ++y) step(std::true_type{}, std::true_type{}, y);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the clamped pieces of the rows past the segment)
+#ifdef GRNET_ABLATION
+    if ((a.dbg & 32) && tid == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_roll_phase[k], tacc_[k]);
+#endif
+}
+
 // ---- the stem pair.  conv1 as conv_bf16_stem computes it (K = (channel, tap) flattened to ONE 32-wide k-step, B gathered from the fp32 frame and rounded
 // to bf16), a wave owning two column tiles of one of the two new conv1 rows of a step; its rows go to LDS de-interleaved by column parity -- the stride-2
 // 3x3 then reads constant offsets: tap column 1 = even plane at X, tap columns 0 / 2 = odd plane at X / X + 1 (the odd plane's slot 0 is column -1: zero).
@@ -450,6 +721,7 @@ static_assert(kBneckFirstLds <= 160 * 1024 && kStemPairLds <= 160 * 1024, "LDS")
 hipError_t conv_bf16_roll_init() {
     GRK_TRY(set_lds_roll(conv_bf16_bneck<false>, kBneckLds));
     GRK_TRY(set_lds_roll(conv_bf16_bneck<true>, kBneckFirstLds));
+    GRK_TRY(set_lds_roll(conv_bf16_bneck_dma, kBneckDmaLds));
     GRK_TRY(set_lds_roll(conv_bf16_stem_pair, kStemPairLds));
     return hipSuccess;
 }
@@ -472,6 +744,24 @@ hipError_t launch_conv_bf16_bneck(const void* in, int in_ctot, int in_coff, void
     a.w1 = w1; a.w2 = w2; a.w3 = w3; a.b1 = b1; a.b2 = b2; a.b3 = b3;
     a.dbg = GRNET_AB(ROLL_DBG, 0);
     if (first) return launch_k(conv_bf16_bneck<true>, dim3(N * a.S), dim3(512), (size_t)kBneckFirstLds, s, a);
+    if (GRNET_AB(ROLL_DMA, 1) && in_ctot * 2 * 56 * 56 < (1 << 30)) {     // (the pieces' lane offsets are 32-bit)
+#ifdef GRNET_ABLATION
+        if (GRNET_AB_SET(ROLL_PHASES)) {
+            a.dbg |= 32;
+            unsigned long long z[8] = {};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_roll_phase), z, sizeof(z));
+            hipError_t e = launch_k(conv_bf16_bneck_dma, dim3(N * a.S), dim3(512), (size_t)kBneckDmaLds, s, a);
+            (void)hipStreamSynchronize(s);
+            unsigned long long h[8] = {};
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_roll_phase), sizeof(h));
+            const double wg = (double)N * a.S * 57.0 / a.S;      // per workgroup and row step (approximately: the warm-up steps have no output phases)
+            fprintf(stderr, "[roll phases] ticks per step: wait-dma %.0f  barrier1 %.0f  reduce+barrier %.0f  request %.0f  3x3+barrier %.0f  expand+barrier %.0f  store %.0f  tail %.0f\n",
+                    h[0] / wg, h[1] / wg, h[2] / wg, h[3] / wg, h[4] / wg, h[5] / wg, h[6] / wg, h[7] / wg);
+            return e;
+        }
+#endif
+        return launch_k(conv_bf16_bneck_dma, dim3(N * a.S), dim3(512), (size_t)kBneckDmaLds, s, a);
+    }
     return launch_k(conv_bf16_bneck<false>, dim3(N * a.S), dim3(512), (size_t)kBneckLds, s, a);
 }
 
