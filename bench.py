@@ -249,7 +249,8 @@ def roofline_object(fps_per_gpu, dtype, conv_flops_per_frame, conv_ms, conv_ms_s
          "kernel": ("conv_wino4_f32 (Winograd F(4x4,3x3) on the fp32 matrix cores: the 3x3 stride-1 layers on 56x56 and 28x28 maps) + conv_wino4s_f32 "
                     "(the same on 14x14 / 7x7 maps, register-resident) + conv_mfma_f32 / conv_splitk_f32 (fp32 MFMA implicit-GEMM convolution: "
                     "1x1, stride-2 and stem layers) + hr_fuse_up_f32 (the 1x1 fuse terms of an HR module, grouped), all launches of a step" if dtype == "f32"
-                    else "conv_bf16_nhwc (bf16 MFMA implicit-GEMM convolution on NHWC activations) + conv_bf16_direct (register-resident kernel of the 32 ch @56x56 / 64 ch @28x28 layers), all launches of a step"),
+                    else "bf16 MFMA convolutions on NHWC activations: conv_bf16_wide_ring / _wide_band (wide 3x3), conv_bf16_chain / _block_frame (HR branches, frame or band resident in LDS), "
+                         "conv_bf16_bneck / _bneck_dma / _stem_pair (layer1 Bottlenecks and the stem pair as row-walking launches), conv_bf16_nhwc / _s2_band / _pw_stream (stride-2, 1x1), all launches of a step"),
          "conv_launches_per_step": n_conv, "conv_gflop_per_step": round(conv_flops / 1e9, 3),
          "gflop_per_launch": round(conv_flops / 1e9 / max(n_conv, 1), 4)}
     if conv_ms:
@@ -266,7 +267,7 @@ def roofline_object(fps_per_gpu, dtype, conv_flops_per_frame, conv_ms, conv_ms_s
     return r
 
 
-LAYER_TABLE_FILES = {"f32": "r05_layer_traffic.json", "bf16": "r05_bf16_n256_layer_traffic.json"}   # per-kernel counter / algorithmic bytes of this round (tools/layer_table.py), optional
+LAYER_TABLE_FILES = {"f32": "r06_layer_traffic.json", "bf16": "r06_bf16_n256_layer_traffic.json"}   # per-kernel counter / algorithmic bytes of this round (tools/layer_table.py), optional
 
 
 def kernel_objects(table, dtype):
@@ -294,7 +295,7 @@ def kernel_objects(table, dtype):
     return dom, top
 
 
-ROUND = "r05"
+ROUND = "r06"
 TRAFFIC_FILES = {("f32", 16): f"{ROUND}_pmc_traffic.json",            # THIS round's counter passes (tools/gpu_profile.sh [f32|bf16] -> tools/summarize_profiles.py)
                  ("bf16", 256): f"{ROUND}_bf16_n256_pmc_traffic.json"}
 

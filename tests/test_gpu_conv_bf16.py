@@ -1,22 +1,23 @@
-"""Round 5: the bf16 BasicBlock chain kernel (csrc/conv_bf16_chain.hip) -- the four BasicBlocks of an HR branch (lib/models/hrnet.py:30-59,
-141-187) as ONE launch with the frame resident in LDS.
-
-Bar (bf16 has no reference mode; stated as in test_gpu_bf16.py): every intermediate is rounded to bf16 exactly where the launch-per-
-convolution path stores it, so the chain must equal (i) the fp32 oracle evaluated block by block on bf16-rounded operands with the
-intermediates rounded to bf16, and (ii) the launch-per-convolution kernels, both up to fp32 summation order: a different order flips an
-output rounding on ties, i.e. single elements differ by ONE bf16 ulp (2^-8 .. 2^-7 relative)."""
+"""bf16 convolution kernels of csrc/conv_bf16_chain.hip and csrc/conv_bf16.hip (round 5): BasicBlock chains with the frame resident in LDS (hrnet.py:30-59,
+141-187), wide-band / ring kernels, stride-2 band kernel, layer1's 1x1 pairs and stream kernel, the bf16 fuse layer, bilinear x2 on NHWC bf16.
+Bar (bf16 has no reference mode; stated as in test_gpu_bf16.py): every intermediate is rounded to bf16 exactly where the launch-per-convolution path stores it, so a
+fused launch must equal (i) the fp32 oracle on bf16-rounded operands with the intermediates rounded to bf16 and (ii) the launch-per-convolution kernels, both up
+to fp32 summation order: single elements differ by ONE bf16 ulp on rounding ties.  (The row-walking launches of round 6: tests/test_gpu_bf16_roll.py.)
+Regrouped by component in round 6; the tests themselves are unchanged."""
+import importlib
 import os
+import sys
 
 import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+from .conftest import CALL_SIZE_NOISE, ROOT, elem_ratio, rel_err
 
+pytestmark = pytest.mark.gpu
 
 def _rb(a):
     return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
-
 
 @pytest.fixture(scope="module")
 def bmodel(pkg):
@@ -24,12 +25,10 @@ def bmodel(pkg):
     yield m
     m.close()
 
-
 def _chain_weights(g, c, nconv):
     ws = [_rb(g.standard_normal((c, c, 3, 3)) * np.sqrt(2.0 / (c * 9))) for _ in range(nconv)]
     bs = [(g.standard_normal((c,)) * 0.1).astype(np.float32) for _ in range(nconv)]
     return ws, bs
-
 
 def _oracle_chain(oracle, x, ws, bs):
     """BasicBlock by BasicBlock on the CPU: t = rb(relu(conv1(x) + b1)); x = rb(relu(conv2(t) + b2 + x))."""
@@ -38,7 +37,6 @@ def _oracle_chain(oracle, x, ws, bs):
         t = torch.from_numpy(_rb(torch.relu(oracle.conv2d(x.numpy(), ws[k], bias=bs[k])).numpy()))
         x = torch.from_numpy(_rb(torch.relu(oracle.conv2d(t.numpy(), ws[k + 1], bias=bs[k + 1]) + x).numpy()))
     return x.numpy()
-
 
 def _close_up_to_rounding_ties(got, ref, max_mismatch, blocks=1):
     """One BasicBlock: an element is off by at most ONE bf16 ulp of itself (plus a floor for sums that cancel).  Behind several blocks an
@@ -52,7 +50,6 @@ def _close_up_to_rounding_ties(got, ref, max_mismatch, blocks=1):
     assert frac <= max_mismatch, frac                                                                                # only on a few elements
     assert float(err.mean()) <= 2e-3 * rms * blocks ** 0.5, float(err.mean() / rms)
     return frac
-
 
 @pytest.mark.parametrize("shape", [(64, 28), (128, 14), (256, 7), (32, 56)], ids=lambda s: f"{s[0]}ch{s[1]}")
 @pytest.mark.parametrize("nconv", [2, 8])
@@ -71,7 +68,6 @@ def test_bf16_chain_equals_oracle_blocks(bmodel, oracle, shape, nconv):
     for sl in (np.s_[:, :, 0], np.s_[:, :, -1], np.s_[:, :, :, 0], np.s_[:, :, :, -1]):
         _close_up_to_rounding_ties(got[sl], ref[sl], 0.06 * nconv, blocks=nconv // 2)
 
-
 @pytest.mark.parametrize("shape", [(64, 28), (128, 14), (256, 7), (32, 56)], ids=lambda s: f"{s[0]}ch{s[1]}")
 def test_bf16_chain_equals_launch_per_convolution(bmodel, shape):
     """One BasicBlock: the chain launch against two launches of the per-convolution kernels on the same handle."""
@@ -87,7 +83,6 @@ def test_bf16_chain_equals_launch_per_convolution(bmodel, shape):
     again = bmodel.op_conv_chain(xd, ws, bs).cpu().numpy()
     assert np.array_equal(got, again)                                    # deterministic
 
-
 def test_bf16_chain_frames_are_independent(bmodel):
     """A workgroup is a frame: the same frame gives the same bits wherever it sits in the call, and a 70-frame call (more workgroups than a
     test usually launches) equals its frames one by one."""
@@ -100,7 +95,6 @@ def test_bf16_chain_frames_are_independent(bmodel):
     one = bmodel.op_conv_chain(x[:5].contiguous(), ws, bs)
     for k in range(14):
         assert torch.equal(out[5 * k:5 * k + 5], one)
-
 
 def test_bf16_forward_with_chains_equals_forward_without(bmodel, pkg):
     """The whole bf16 forward at 64 frames (the chain launches are taken from 64 frames per call on) against the same forward with one
@@ -134,7 +128,6 @@ def test_bf16_forward_with_chains_equals_forward_without(bmodel, pkg):
     th = with_chain["theta"].reshape(8, 8, 85)
     assert torch.equal(th[0], th[5])                                     # the 8 distinct frames repeat exactly
 
-
 @pytest.mark.parametrize("shape", [(64, 28), (128, 14), (256, 7), (32, 56)], ids=lambda s: f"{s[0]}ch{s[1]}")
 def test_bf16_chain_time_at_256_frames(pkg, shape):
     """Not a parity test: prints the duration of the 8-convolution chain launch at 256 frames (one frame per CU) next to eight launches of the
@@ -150,9 +143,7 @@ def test_bf16_chain_time_at_256_frames(pkg, shape):
     assert torch.isfinite(out).all() and us > 0
     m.close()
 
-
 WIDE = [(128, 128, 56), (256, 256, 56), (480, 256, 56), (64, 64, 56), (256, 256, 28), (128, 128, 28), (160, 128, 56), (256, 32, 56)]
-
 
 @pytest.mark.parametrize("case", WIDE, ids=lambda c: "x".join(map(str, c)))
 def test_bf16_wide_band_kernel(bmodel, oracle, case):
@@ -174,14 +165,12 @@ def test_bf16_wide_band_kernel(bmodel, oracle, case):
         for sl in (np.s_[:, :, 0], np.s_[:, :, -1], np.s_[:, :, :, 0], np.s_[:, :, :, -1], np.s_[:, :, 6:8], np.s_[:, :, 13:15]):      # borders, band seams
             assert np.all(np.abs(got[sl] - ref[sl]) <= np.abs(ref[sl]) * 2.0 ** -8 + 1e-5)
 
-
 def test_bf16_wide_band_refuses_other_shapes(bmodel, pkg):
     x = torch.zeros(1, 128, 14, 14).cuda()
     with pytest.raises(pkg._lib.GrnetError, match="not eligible"):
         bmodel.op_conv2d(x, np.zeros((128, 128, 3, 3), np.float32), None, tile_hint=3003)
     with pytest.raises(pkg._lib.GrnetError, match="not eligible"):
         bmodel.op_conv2d(torch.zeros(1, 256, 56, 56).cuda(), np.zeros((96, 256, 3, 3), np.float32), None, tile_hint=3003)
-
 
 @pytest.mark.parametrize("with_add", [True, False])
 def test_bf16_pointwise_256_channel_tile(bmodel, oracle, with_add):
@@ -199,9 +188,7 @@ def test_bf16_pointwise_256_channel_tile(bmodel, oracle, with_add):
     assert np.array_equal(got, _rb(got))
     assert np.all(np.abs(got - ref) <= np.abs(ref) * 2.0 ** -8 + 1e-5), float(np.abs(got - ref).max())
 
-
 S2 = [(64, 64, 112), (64, 128, 28), (32, 128, 28), (32, 32, 28)]
-
 
 @pytest.mark.parametrize("case", S2, ids=lambda c: "x".join(map(str, c)))
 def test_bf16_stride2_band_kernel(bmodel, oracle, case):
@@ -225,7 +212,6 @@ def test_bf16_stride2_band_kernel(bmodel, oracle, case):
         for sl in (np.s_[:, :, 0], np.s_[:, :, -1], np.s_[:, :, :, 0], np.s_[:, :, :, -1]):
             assert np.all(np.abs(got[sl] - ref[sl]) <= np.abs(ref[sl]) * 2.0 ** -8 + 1e-5)
 
-
 def test_bf16_layer1_pairs_are_bit_identical(bmodel, pkg):
     """layer1's 64 -> 256 expansion + the next Bottleneck's 256 -> 64 reduction as one launch (bit 6 of the mask): the reduction reads the very bf16 tile
     the stand-alone launch would read from HBM, in the same k order -- the whole forward must not change by a bit (compared with the 256-channel tile
@@ -246,10 +232,8 @@ def test_bf16_layer1_pairs_are_bit_identical(bmodel, pkg):
     for k in ("features", "theta", "verts"):
         assert torch.equal(a[k], b[k]), k
 
-
 # ----------------------------------------------------------------------------- the grouped fuse launch on the bf16 path (csrc/hr_fuse.hip: hr_fuse_up_bf16)
 FUSE_MODULES = [("stage2", 0, 2)] + [("stage3", m, 3) for m in range(4)] + [("stage4", m, 4) for m in range(3)]
-
 
 @pytest.fixture(scope="module")
 def fmodel(pkg):
@@ -259,7 +243,6 @@ def fmodel(pkg):
     m = pkg.build_synthetic_model(max_frames=16, with_gru=False, dtype="bf16")
     yield m
     m.close()
-
 
 @pytest.mark.parametrize("n", [1, 3, 16])
 def test_bf16_fuse_layer_of_every_hr_module_matches_oracle(fmodel, pkg, oracle, synth_weights, n):
@@ -281,7 +264,6 @@ def test_bf16_fuse_layer_of_every_hr_module_matches_oracle(fmodel, pkg, oracle, 
             assert err.max() <= 1.5e-2 * np.abs(r).max(), (tag, i, float(err.max() / np.abs(r).max()))
             assert err.mean() <= 2e-3 * np.sqrt(np.mean(r * r)), (tag, i, float(err.mean() / np.sqrt(np.mean(r * r))))
 
-
 def test_bf16_fuse_layer_launch_count_and_macs(fmodel):
     """The default bf16 layout has no grouped launch; the 31 1x1 up terms are 18 launches (the terms of ONE source branch merged, output channels side by side);
     the MACs still add up to SURVEY 8(d)'s 15 441 563 648 per frame."""
@@ -291,57 +273,12 @@ def test_bf16_fuse_layer_launch_count_and_macs(fmodel):
     left = [c for c in convs if c["ks"] == 1 and "fuse_layers" in c["name"] and c["cin"]]
     assert len(left) == 18, len(left)
 
-
-def test_blocked_temporal_attention_two_clips_ragged_blocks(pkg, oracle):
-    """temporal_attn_flash_kernel (clips >= 1 024 frames: 128 queries per workgroup, keys / values in blocks of 32, Q fragment in registers, next block in
-    flight) on TWO clips of 1 100 frames -- a last query block of 76 rows (4.75 waves) and a last key block of 12 -- and the two-stage frame mean of the gate
-    (9 partial blocks of 128 frames): the whole attention block against the oracle, each clip also alone (clips must not see each other)."""
-    from .conftest import rel_err
-    m = pkg.build_synthetic_model(max_frames=2, with_gru=True, with_tsattn=True, use_gait_feat=False)
-    tsd = pkg.synth.make_tsattn_state_dict()
-    x, xs = pkg.synth.make_tsattn_inputs(2, 1100)
-    xd, xsd = torch.from_numpy(x).cuda(), torch.from_numpy(xs).cuda()
-    y = m.tsattn_forward(xd, xsd).cpu().numpy()
-    ref = oracle.ts_attn_block(x, xs, tsd)
-    assert y.shape == ref.shape and rel_err(y, ref) < 5e-5, rel_err(y, ref)
-    y1 = m.tsattn_forward(xd[1:2], xsd[1:2]).cpu().numpy()
-    assert np.array_equal(y1[0], y[1])
-    m.close()
-
-
-# ---- GRU recurrence, round 5: rows-per-wave kernel, hand-off inside the XCD's L2 (gru_kernels.hip) --------------------------------------
-@pytest.mark.parametrize("mode", [3, 3 + 16, 2, 1, 0], ids=["default", "agent_scope_stores", "libm_gates", "column_slices", "unsplit"])
-def test_gru_recurrence_variants_long_sequences(pkg, oracle, mode):
-    """Every form of the recurrence (GRNET_OPT_GRU_MODE) against the oracle (gait_feat_encoder.py:79-104) on sequences long enough for an error of the gate
-    functions or a missed hand-off to show: 1 x 2000 steps (each direction 2 layers x 2000 dependent steps), 3 x 257 (six groups of eight
-    workgroups), 16 x 9 (the largest batch the split form takes).  The default takes the v_exp / v_rcp gate functions and, where the eight
-    slices of a group share an XCD, workgroup-scope granule stores; + 16 is the path of a group that spans XCDs (and the handle's own fall-back
-    after a hand-off timeout)."""
-    m = pkg.build_synthetic_model(max_frames=4, with_gru=True)
-    try:
-        m.set_option(pkg._lib.OPT_GRU_MODE, mode)
-        sd = pkg.synth.make_gru_state_dict()
-        for (b, t) in [(1, 2000), (3, 257), (16, 9)]:
-            x, cp = pkg.synth.make_gru_inputs(b, t)
-            y, ph, _ = m.gru_forward(torch.from_numpy(x).cuda(), torch.from_numpy(cp).cuda())
-            torch.cuda.synchronize()
-            ry, rph, _ = oracle.gru_forward(x, cp, sd)
-            e = lambda a, r: float(np.abs(a.cpu().numpy().astype(np.float64) - r).max() / np.abs(r).max())
-            assert bool(torch.isfinite(y).all() and torch.isfinite(ph).all()), (b, t, mode)
-            assert e(y, ry) < 1e-4 and e(ph, rph) < 1e-4, (b, t, mode, e(y, ry), e(ph, rph))
-        with pytest.raises(pkg._lib.GrnetError):
-            m.set_option(pkg._lib.OPT_GRU_MODE, 7)
-    finally:
-        m.close()
-
-
 # ---- layer1's 64 -> 256 1x1 layers as a stream (csrc/conv_bf16.hip: conv_bf16_pw_stream) -------------------------------------------------
 def _forward_digest(m, frames):
     import hashlib
     out = m(frames, extras=("features",))[-1]
     torch.cuda.synchronize()
     return [m.num_kernel_launches()] + [hashlib.sha256(out[k].cpu().numpy().tobytes()).hexdigest() for k in ("features", "theta", "verts")]
-
 
 @pytest.mark.parametrize("n", [8, 64])
 def test_bf16_layer1_stream_kernel_is_bit_identical_to_the_generic_one(pkg, bmodel, n):
@@ -365,7 +302,6 @@ def test_bf16_layer1_stream_kernel_is_bit_identical_to_the_generic_one(pkg, bmod
     finally:
         bmodel.set_option(lib.OPT_BF16_CHAIN, -1)
         bmodel.set_option(lib.OPT_BF16_MIN_FRAMES, 0)
-
 
 @pytest.mark.parametrize("shape", [(2, 64, 28, 28), (3, 128, 14, 14), (2, 256, 7, 7), (1, 128, 28, 28), (2, 256, 28, 28), (16, 256, 14, 14)])
 def test_bf16_bilinear2x_rows_kernel(bmodel, oracle, shape):
