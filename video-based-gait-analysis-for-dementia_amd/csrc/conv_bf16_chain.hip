@@ -531,6 +531,9 @@ __global__ __launch_bounds__(512) void conv_bf16_block_frame(const ChainArgs a) 
         for (int cs = 0; cs < CS; ++cs)
 #pragma unroll
             for (int ps = 0; ps < PS; ++ps) acc[cs][ps] = b1[cs];
+#ifdef GRNET_ABLATION
+        if (!(a.flags & 16))
+#endif
         chain_kloop_ldsw<P, SB, CS, PS>(acc, bread, wl0);
         if (direct_store) {
             // conv2's accumulators start from x + bias2, read at conv2's OWN columns while the plane still holds x (nobody has written yet)
@@ -557,6 +560,9 @@ __global__ __launch_bounds__(512) void conv_bf16_block_frame(const ChainArgs a) 
                     if (valid1 & (1u << ps)) *reinterpret_cast<u32x2*>(owrite + ps * 16 * SB + cs * 32) = u32x2{pack2_c(relu_c(v[0]), relu_c(v[1])), pack2_c(relu_c(v[2]), relu_c(v[3]))};
                 }
             lds_barrier();
+#ifdef GRNET_ABLATION
+            if (!(a.flags & 32))
+#endif
             chain_kloop_ldsw<P, SB, CS, PS2>(acc2, bread2, wl1);
             // the block's output rows leave straight from the accumulators (round 5: was in place through the plane, a barrier, then 16-byte stores): 8 bytes per lane, the
             // four k-groups of a pixel make 32 contiguous bytes, the two channel blocks its 64-byte row; nothing of this band's output is needed in LDS again.
@@ -614,6 +620,9 @@ __global__ __launch_bounds__(512) void conv_bf16_block_frame(const ChainArgs a) 
         }
         if (band + 1 < NB) {
             lds_barrier();                                     // the band's rows have been read out of the plane
+#ifdef GRNET_ABLATION
+            if (!(a.flags & 64))
+#endif
             deposit(y0 + R);
             lds_barrier();                                     // staging is free, the plane holds the next band
             if (band + 2 < NB) request(y0 + 2 * R);
@@ -1243,7 +1252,7 @@ hipError_t launch_conv_bf16_chain(const ChainArgs& a, int c, int w, hipStream_t 
             } else { b.out = a.out; b.out_ctot = a.out_ctot; b.out_coff = a.out_coff; }
             // 0 (default): workgroup = frame, seven bands of 8 rows, the next band by LDS-DMA under the current band's MFMAs; 19: workgroup = band, one per CU; 8: two per CU
             static const int frame_direct = GRNET_AB(BF16_FRAME_DIRECT, 1);
-            b.flags = frame_direct ? 0 : 1;
+            b.flags = (frame_direct ? 0 : 1) | (GRNET_AB(BF16_FRAME_DBG, 0) << 4);      // (diagnostic builds: timing-only ablation bits 16 / 32 / 64 = no conv1 k-loop / no conv2 k-loop / no deposit)
             static const int band_rows = GRNET_AB(BF16_BAND, 0);
             if (band_rows == 0) GRK_TRY(launch_k(conv_bf16_block_frame<56, 8>, dim3(a.N), dim3(512), FrameGeom<56, 8>::LDS, s, b));
             else if (band_rows == 19) GRK_TRY(launch_k(conv_bf16_block_band<32, 56, 19, 2>, dim3(a.N * BandGeom<32, 56, 19>::NB), dim3(512), BandGeom<32, 56, 19>::LDS, s, b));
