@@ -485,10 +485,16 @@ __global__ __launch_bounds__(512) void conv_bf16_block_frame(const ChainArgs a) 
             if (v < WU) wv[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(a.w[cv]) + vv * 16);
         }
         for (int u = tid; u < F::PLANE / 16; u += 512) reinterpret_cast<u32x4*>(plane)[u] = u32x4{0u, 0u, 0u, 0u};
+        // (round 6) the 32 output-channel rows of a tap are PERMUTED on the way in: channel c = 8 q + 4 s + r goes to row s * 16 + 4 q + r, so that lane (pixel, lq) of the
+        // two MFMA blocks s = 0, 1 ends up with channels 8 lq .. 8 lq + 3 and 8 lq + 4 .. 8 lq + 7 -- EIGHT consecutive channels: the in-place epilogue, the conv2 seeds and
+        // the output stores move 16 bytes per lane and tile instead of two times 8 (the stores were 8.7 of a launch's 50 us as 32-byte pieces: profiles/r06_block_frame_ablation.txt).
+        // Every output's dot product is unchanged: bit-identical results.  (The same assignment in the frame-resident chain kernels, whose epilogues are a smaller share of
+        // their launches, measured no change: 103.4 / 107.2 / 174 us per chain against 103.4 / 107.7 / 168.5 -- not kept there.)
 #pragma unroll
         for (int i = 0; i < NWU; ++i) {
-            const int v = i * 512 + tid, row = (v >> 2) & 31, part = v & 3;
-            if (v < WU) *reinterpret_cast<u32x4*>(wlds + (v >> 2) * 64 + ((part ^ (((row >> 3) & 1) << 1)) * 16)) = wv[i];
+            const int v = i * 512 + tid, c = (v >> 2) & 31, part = v & 3;
+            const int row = ((c >> 2) & 1) * 16 + 4 * (c >> 3) + (c & 3);
+            if (v < WU) *reinterpret_cast<u32x4*>(wlds + ((v >> 7) * 32 + row) * 64 + ((part ^ (((row >> 3) & 1) << 1)) * 16)) = wv[i];
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's DMAs of band 0 have landed
@@ -497,10 +503,10 @@ __global__ __launch_bounds__(512) void conv_bf16_block_frame(const ChainArgs a) 
     lds_barrier();                                             // staging is free, the plane holds band 0
     const int o_first = G::O0 + wave * PS * 16 + l15;
     const unsigned char* bread = plane + (o_first - P - 1) * SB + lq * 16;
-    unsigned char* owrite = plane + o_first * SB + lq * 8;
+    unsigned char* owrite = plane + o_first * SB + lq * 16;       // this lane's 8 channels (8 lq ..) of column tile 0
     const unsigned char* wl0 = wlds + l15 * 64 + ((lq ^ (((l15 >> 3) & 1) << 1)) * 16);
     const unsigned char* wl1 = wl0 + 9 * C * 64;
-    const int co = lq * 4;
+    const int co = lq * 8;                                        // MFMA block cs holds channels co + 4 cs .. + 3 of this lane's pixel
     // conv2 needs rows 2 .. R + 1 of the plane only (conv1: rows 1 .. R + 2): its own, shorter tile run -- PS2 = 4 column tiles per wave from slot 2 P + 1 on
     // instead of conv1's PS = 5 from P + 1 on (a fifth of conv2's MFMAs and fragment reads computed rows nobody stores)
     constexpr int NOUT2 = R * P - 1, PS2 = ((NOUT2 + 15) / 16 + 7) / 8;
@@ -509,8 +515,8 @@ __global__ __launch_bounds__(512) void conv_bf16_block_frame(const ChainArgs a) 
     f32x4 b1[CS], b2[CS];
 #pragma unroll
     for (int cs = 0; cs < CS; ++cs) {
-        b1[cs] = *reinterpret_cast<const f32x4*>(a.bias[0] + co + cs * 16);
-        b2[cs] = *reinterpret_cast<const f32x4*>(a.bias[1] + co + cs * 16);
+        b1[cs] = *reinterpret_cast<const f32x4*>(a.bias[0] + co + cs * 4);
+        b2[cs] = *reinterpret_cast<const f32x4*>(a.bias[1] + co + cs * 4);
     }
     if (NB > 1) request(R);                                    // behind the bias loads: waiting for those must not mean waiting for these
     const bool direct_store = !(a.flags & 1);
@@ -543,22 +549,20 @@ __global__ __launch_bounds__(512) void conv_bf16_block_frame(const ChainArgs a) 
             for (int ps = 0; ps < PS2; ++ps) {
                 const int o = o2_first + ps * 16, r = o / P, y = y0 - 2 + r;
                 if (o - r * P != 0 && r >= 2 && r <= R + 1 && y >= 0 && y < W) v2 |= 1u << ps;
+                const u32x4 rr = *reinterpret_cast<const u32x4*>(plane + (o2_first + ps * 16) * SB + lq * 16);
 #pragma unroll
                 for (int cs = 0; cs < CS; ++cs) {
-                    const u32x2 rr = *reinterpret_cast<const u32x2*>(plane + (o2_first + ps * 16) * SB + lq * 8 + cs * 32);
                     f32x4 nx = b2[cs];
-                    nx[0] += bf_lo(rr[0]); nx[1] += bf_hi(rr[0]); nx[2] += bf_lo(rr[1]); nx[3] += bf_hi(rr[1]);
+                    nx[0] += bf_lo(rr[2 * cs]); nx[1] += bf_hi(rr[2 * cs]); nx[2] += bf_lo(rr[2 * cs + 1]); nx[3] += bf_hi(rr[2 * cs + 1]);
                     acc2[cs][ps] = nx;
                 }
             }
             lds_barrier();                                     // every wave has read what it needs of x
 #pragma unroll
-            for (int ps = 0; ps < PS; ++ps)
-#pragma unroll
-                for (int cs = 0; cs < CS; ++cs) {
-                    const f32x4 v = acc[cs][ps];
-                    if (valid1 & (1u << ps)) *reinterpret_cast<u32x2*>(owrite + ps * 16 * SB + cs * 32) = u32x2{pack2_c(relu_c(v[0]), relu_c(v[1])), pack2_c(relu_c(v[2]), relu_c(v[3]))};
-                }
+            for (int ps = 0; ps < PS; ++ps) {
+                const f32x4 A = acc[0][ps], B = acc[1][ps];
+                if (valid1 & (1u << ps)) *reinterpret_cast<u32x4*>(owrite + ps * 16 * SB) = u32x4{pack2_c(relu_c(A[0]), relu_c(A[1])), pack2_c(relu_c(A[2]), relu_c(A[3])), pack2_c(relu_c(B[0]), relu_c(B[1])), pack2_c(relu_c(B[2]), relu_c(B[3]))};
+            }
             lds_barrier();
 #ifdef GRNET_ABLATION
             if (!(a.flags & 32))
@@ -575,12 +579,9 @@ __global__ __launch_bounds__(512) void conv_bf16_block_frame(const ChainArgs a) 
                 int of = o2_first;
                 asm volatile("" : "+v"(of));                   // (tile-independent pixel offsets: not to be hoisted out of the band loop into 2 x PS registers)
                 const int o = of + ps * 16, r = o / P, x = o - r * P - 1;
-                u16* op = outb + ((size_t)(y0 + r - 2) * W + x) * a.out_ctot + lq * 4;
-#pragma unroll
-                for (int cs = 0; cs < CS; ++cs) {
-                    const f32x4 v = acc2[cs][ps];
-                    if (v2 & (1u << ps)) *reinterpret_cast<u32x2*>(op + cs * 16) = u32x2{pack2_c(relu_c(v[0]), relu_c(v[1])), pack2_c(relu_c(v[2]), relu_c(v[3]))};
-                }
+                u16* op = outb + ((size_t)(y0 + r - 2) * W + x) * a.out_ctot + lq * 8;
+                const f32x4 A = acc2[0][ps], B = acc2[1][ps];
+                if (v2 & (1u << ps)) *reinterpret_cast<u32x4*>(op) = u32x4{pack2_c(relu_c(A[0]), relu_c(A[1])), pack2_c(relu_c(A[2]), relu_c(A[3])), pack2_c(relu_c(B[0]), relu_c(B[1])), pack2_c(relu_c(B[2]), relu_c(B[3]))};       // 16 bytes per lane: a pixel's 64-byte row by four lanes
             }
         } else {
         lds_barrier();
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(512) void conv_bf16_block_frame(const ChainArgs a) 
         for (int ps = 0; ps < PS; ++ps)
 #pragma unroll
             for (int cs = 0; cs < CS; ++cs) {
-                unsigned char* pos = owrite + ps * 16 * SB + cs * 32;
+                unsigned char* pos = owrite + ps * 16 * SB + cs * 8;
                 const u32x2 r = *reinterpret_cast<const u32x2*>(pos);
                 const f32x4 v = acc[cs][ps];
                 if (valid1 & (1u << ps)) *reinterpret_cast<u32x2*>(pos) = u32x2{pack2_c(relu_c(v[0]), relu_c(v[1])), pack2_c(relu_c(v[2]), relu_c(v[3]))};
@@ -605,7 +606,7 @@ __global__ __launch_bounds__(512) void conv_bf16_block_frame(const ChainArgs a) 
             for (int cs = 0; cs < CS; ++cs) {
                 const f32x4 v = acc[cs][ps];
                 if (valid2 & (1u << ps))
-                    *reinterpret_cast<u32x2*>(owrite + ps * 16 * SB + cs * 32) = u32x2{pack2_c(relu_c(v[0]), relu_c(v[1])), pack2_c(relu_c(v[2]), relu_c(v[3]))};
+                    *reinterpret_cast<u32x2*>(owrite + ps * 16 * SB + cs * 8) = u32x2{pack2_c(relu_c(v[0]), relu_c(v[1])), pack2_c(relu_c(v[2]), relu_c(v[3]))};
             }
         // the next band's DMAs (issued a whole band ago) and the previous band's stores are the only vector-memory operations in flight: wait for
         // them HERE, in front of this band's stores, so that the wait does not include those stores' round trip
