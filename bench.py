@@ -217,6 +217,9 @@ def prove_exchange(state, world, rank, dist, comm=None):
         nxt = rhi
         got = bits(gathered[r])
         assert got == rsum, f"slot {r} of the gathered block does not hold rank {r}'s send block (checksum {got} != {rsum})"
+    if comm is not None:                                       # the C ABI's communicator also says how many ranks RCCL itself counts (ncclCommCount)
+        nr, rk = comm.info()
+        assert nr == len(ranks) and rk == rank, f"grnet_comm_info reports {nr} ranks / rank {rk}, the gathered records {len(ranks)} ranks / rank {rank}"
     return {"exchange_ranks": len(ranks), "frames_total": nxt,
             "exchange_check": f"slot r of the gathered block == rank r's send block for r = 0..{world - 1} (int64 bit-pattern checksums exchanged through the same collective, "
                               "checked on every rank after the timed region); frame ranges contiguous in rank order"}

@@ -476,6 +476,7 @@ def test_c_abi_exchange_world1(pkg):
     comm = harness.RcclComm(1, 0, dev)
     w, r = C.c_int(), C.c_int()
     assert comm._lib.grnet_comm_info(comm._h, C.byref(w), C.byref(r)) == 0 and (w.value, r.value) == (1, 0)
+    assert comm.info() == (1, 0)                                   # what bench.py's exchange proof cross-checks config.exchange_ranks against
     _, block = harness.pack_layout(16, harness.POSE_RECORD_GAIT)
     g = torch.Generator(device="cpu").manual_seed(5)
     send = torch.randn(block, generator=g).to(dev)

@@ -145,6 +145,12 @@ class RcclComm:
         _lib.check_comm(self._lib, rc, "grnet_allgather")
         return recv
 
+    def info(self):
+        """(ranks, rank) as RCCL's communicator itself reports them (grnet_comm_info -> ncclCommCount / ncclCommUserRank)."""
+        nr, rk = C.c_int(), C.c_int()
+        _lib.check_comm(self._lib, self._lib.grnet_comm_info(self._h, C.byref(nr), C.byref(rk)), "grnet_comm_info")
+        return nr.value, rk.value
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.grnet_comm_destroy(self._h)
