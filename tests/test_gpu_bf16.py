@@ -174,3 +174,29 @@ def test_bf16_stem_kernel_reads_fp32_frames(bmodel, oracle, n):
     assert np.all(np.abs(got - lin) <= np.abs(lin) * 2.0 ** -8 + 1e-5)
     gen = bmodel.op_conv2d(torch.from_numpy(_rb(x32)).cuda(), w, None, stride=2, relu=False, tile_hint=0).cpu().numpy()
     assert np.mean(got != gen) < 0.02                                      # the same sums in another order: they differ on output-rounding ties only
+
+
+def test_bf16_forward_is_bit_stable_under_hbm_contention(pkg):
+    """The band- and row-walking kernels overlap their own loads (LDS-DMA, register prefetch) with compute behind hand-counted or compiler-counted vmcnt
+    waits (conv_bf16_block_frame: round-5 advice on a wait that assumed a store count; conv_bf16_bneck_dma: 3 x ND outstanding operations).  A wait that is one
+    operation short shows only when memory is slow: here a copy kernel on a second stream keeps HBM busy while 64-frame forwards (every kernel group on) run, and
+    every forward must reproduce the undisturbed one bit for bit."""
+    n = 64
+    m = pkg.build_synthetic_model(max_frames=n, with_gru=False, dtype="bf16")
+    try:
+        frames = torch.from_numpy(np.tile(pkg.synth.make_frames(8), (n // 8, 1, 1, 1))).cuda()
+        ref = {k: v.clone() for k, v in m(frames)[-1].items()}
+        torch.cuda.synchronize()
+        big = torch.empty(1 << 27, dtype=torch.float32, device="cuda")
+        big2 = torch.empty_like(big)
+        side = torch.cuda.Stream()
+        for it in range(24):
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    big2.copy_(big)
+            out = m(frames)[-1]
+            torch.cuda.synchronize()
+            for k in ("theta", "verts", "kp_3d", "rotmat"):
+                assert torch.equal(out[k], ref[k]), (it, k)
+    finally:
+        m.close()
