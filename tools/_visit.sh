@@ -1,26 +1,25 @@
 export TMPDIR=/tmp
-for i in 1 2 3 4 5 6; do timeout 600 python -m pytest tests/test_gpu_bf16_roll.py tests/test_gpu_bf16.py -m gpu -q -x --timeout 900 -k "roll or production" 2>&1 | tail -1; done
-python - <<'PY'
-# stress: the Bottleneck / stem launches under memory contention from a copy kernel on another stream, bits compared with an undisturbed run
-import importlib, sys, numpy as np, torch
+mkdir -p gpurun_out
+timeout 1200 python -m pytest tests/test_gpu_temporal.py -m gpu -q -x --timeout 900 2>&1 | tail -3
+cat > /tmp/ov.py <<'PY'
+import importlib, sys, os, time, numpy as np, torch, hashlib
 sys.path.insert(0, '.')
 pkg = importlib.import_module("video-based-gait-analysis-for-dementia_amd")
-n = 256
-m = pkg.build_synthetic_model(max_frames=n, with_gru=False, dtype="bf16")
-frames = torch.from_numpy(np.tile(pkg.synth.make_frames(8), (n // 8, 1, 1, 1))).cuda()
-ref = m(frames)[-1]
-torch.cuda.synchronize()
-ref = {k: v.clone() for k, v in ref.items()}
-big = torch.empty(1 << 28, dtype=torch.float32, device="cuda"); big2 = torch.empty_like(big)
-side = torch.cuda.Stream()
-bad = 0
-for it in range(40):
-    with torch.cuda.stream(side):
-        for _ in range(6): big2.copy_(big)
-    out = m(frames)[-1]
-    torch.cuda.synchronize()
-    for k in ("theta", "verts", "kp_3d"):
-        if not torch.equal(out[k], ref[k]): bad += 1
-print("stress under HBM contention: mismatching outputs in 40 forwards:", bad)
+m = pkg.build_synthetic_model(max_frames=256, use_gait_feat=True)
+for (b, n) in ((1, 10000), (1, 1100), (2, 3000)):
+    x, cp = pkg.synth.make_featcorr_inputs(b, n)
+    bb = np.zeros((b, n, 4), np.float32); bb[..., 2:] = 224.0
+    args = (torch.from_numpy(x).reshape(b * n, 128, 24).cuda(), torch.zeros(b * n, 64, 24).cuda(), torch.from_numpy(cp).reshape(b * n, 3).cuda(),
+            torch.from_numpy(bb).cuda(), torch.zeros(b, n, 2).cuda(), b, n)
+    r = m.gait_correct(*args); torch.cuda.synchronize()
+    ts = []
+    for _ in range(4):
+        t = time.perf_counter(); r = m.gait_correct(*args); torch.cuda.synchronize(); ts.append((time.perf_counter() - t) * 1e3)
+    print("gait_correct", (b, n), "ms", [round(t, 2) for t in ts])
 m.close()
 PY
+python3 /tmp/ov.py
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ovtrace -- python3 /tmp/ov.py > /dev/null 2>&1
+f=$(find gpurun_out/ovtrace -name "*kernel_stats.csv" | head -1)
+head -12 "$f" | cut -c1-200
+rm -rf gpurun_out/ovtrace

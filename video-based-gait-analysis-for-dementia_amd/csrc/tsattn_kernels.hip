@@ -73,135 +73,197 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restr
     }
 }
 
-// The same attention for LONG clips, blocked (round 5).  The kernel above reads every key and value of the clip once per QUERY: at 10 000 frames that is
-// 10 000 x 4 x 2 x 10 MB = 800 GB through L2 and 107 ms -- two thirds of the temporal branch that every rank of a BASELINE configs[3] job repeats after the
-// all-gather (profiles/r05_temporal_phases.txt).  Here a workgroup owns 128 queries of one head (8 waves x 16); keys and values stream through LDS in blocks
-// of 32 (read once per 128 queries), S = Q K^T and O += P V run on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products and sums), the softmax
-// is the running-maximum form: per query row m <- max(m, max_j s_j), O <- O exp(m_old - m) + sum_j exp(s_j - m) v_j, l likewise, out = O / l.  Same
-// arithmetic as softmax(QK^T / sqrt(d)) V in fp32 up to the order of the sums; deterministic (no atomics, fixed order).
-// A first version (4 waves, Q in LDS, K / V block loaded between two barriers: 19.4 ms at 10 000 frames) ran the matrix cores a fifth of the time -- one wave
-// per SIMD, and nothing under the block load.  Now: the wave's Q fragment (its A operand of every S tile: 63 values per lane, 1 / sqrt(d) folded in) lives in
-// REGISTERS, which frees 66 KB of LDS for eight waves per workgroup (two per SIMD: one wave's softmax and staging under the other's MFMAs); the NEXT block of
-// K and V is requested into registers before the current block is computed and stored to LDS behind it.
-// Row strides: 258 floats for K (258 = 2 mod 32: the 16 rows x 4 columns of an MFMA operand read fall on 64 different banks), 272 for V (16 mod 32: 4 rows x
-// 16 columns likewise), 34 for the wave's own P tile (written in the accumulator layout, read back as the A operand of P V).
-constexpr int kFW = 8, kFQ = 16 * kFW, kFK = 32, kFLd = 258, kFLdV = 272, kFLdP = 34;
-constexpr int kFlashLdsFloats = kFK * kFLd + kFK * kFLdV + kFW * 16 * kFLdP;
+// The same attention for LONG clips, blocked.  The kernel above reads every key and value of the clip once per QUERY: at 10 000 frames that is
+// 10 000 x 4 x 2 x 10 MB = 800 GB through L2 and 107 ms.  Here a workgroup owns 128 queries of one head (8 waves x 16); keys and values stream through LDS
+// in blocks of 32 (read once per 128 queries), and both products run on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products and sums).
+// The softmax is the running-maximum form, per query: m <- max(m, max_j s_j), O <- O 2^(m_old - m) + sum_j 2^(s_j - m) v_j, l likewise, out = O / l, with
+// log2(e) / sqrt(d) folded into Q (v_exp_f32) -- the arithmetic of softmax(QK^T / sqrt(d)) V in fp32 up to the order of the sums and the last bit of the
+// exponential; deterministic (no atomics, fixed order).
+// Round 6: everything TRANSPOSED.  S^T = K Q^T (A operand: a K tile from LDS, B operand: the wave's Q fragment, 63 registers per lane), so a lane holds eight
+// scores of ONE query (keys 4 lq + r and 16 + 4 lq + r of the block, query l15): the row maximum is 7 in-lane maxima and two cross-lane steps (round 5: 32
+// ds_bpermute per block), the rescale factor is one scalar per lane, the row sum stays lane-partial until the end.  The accumulator layout of S^T IS the B
+// operand layout of O^T += V^T P^T (k index = lq, column = query l15), so P never leaves the registers (round 5: written to LDS and read back), and the O^T
+// tile (rows = feature 16 dt + 4 lq + r, column = query l15) keeps every lane on its own query: the rescale is in-lane and skipped while no maximum of
+// the wave moved.  Without the P tiles the K / V blocks fit twice: the next block is requested into registers before the current one is computed and stored
+// into the OTHER buffer behind it -- one barrier per block.  Round 5's form ran 9.54 ms at 10 000 frames (profiles/r06_tail_overlap.txt).
+// Row strides: 258 floats for K (2 mod 32: the 16 keys x 2 columns of a 32-lane ds_read_b32 group fall on 32 different banks), 260 for V (4 x 260 = 16 mod
+// 32: 2 key groups x 16 columns likewise).
+// Keys are split over `kparts` workgroups per (query tile, head) where one round of workgroups would leave CUs idle or a second round nearly empty (10 000
+// frames: 79 x 4 = 316 workgroups on 256 CUs); each part leaves (O^T unnormalised, m, l) and temporal_attn_combine_kernel merges them in part order.
+constexpr int kFW = 8, kFQ = 16 * kFW, kFK = 32, kFLd = 258, kFLdV = 260;
+constexpr int kFBufFloats = kFK * kFLd + kFK * kFLdV;
+constexpr int kFlashLdsFloats = 2 * kFBufFloats;
 constexpr int kFU = kFK * (kDh / 2), kFLoads = (kFU + 64 * kFW - 1) / (64 * kFW);       // float2 units of a K (or V) block; per thread
+constexpr int kFlashMaxParts = 8, kFlashMinPartKeys = 256;
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float group16_max(float v) {
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ float group16_sum(float v) {
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__global__ __launch_bounds__(64 * kFW) void temporal_attn_flash_kernel(const float* __restrict__ qkv, float* __restrict__ xt, int n) {
+__global__ __launch_bounds__(64 * kFW) void temporal_attn_flash_kernel(const float* __restrict__ qkv, float* __restrict__ xt, int n, int kparts,
+                                                                         float* __restrict__ part_o, float* __restrict__ part_ml) {
     extern __shared__ float sm[];
-    float* Ks = sm;
-    float* Vs = Ks + kFK * kFLd;
-    float* Ps = Vs + kFK * kFLdV + (threadIdx.x >> 6) * 16 * kFLdP;
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4, wave = tid >> 6;
-    const int q0 = blockIdx.x * kFQ, h = blockIdx.y, bi = blockIdx.z;
+    const int q0 = blockIdx.x * kFQ, h = blockIdx.y, bi = blockIdx.z / kparts, part = blockIdx.z - bi * kparts;
     const float* base = qkv + (size_t)bi * n * 3 * kE;
-    const float scale = 1.0f / sqrtf((float)kDh);
+    const int nblk = (n + kFK - 1) / kFK;
+    const int kbeg = (int)((long)nblk * part / kparts) * kFK, kend = min(n, (int)((long)nblk * (part + 1) / kparts) * kFK);
     typedef float f2 __attribute__((ext_vector_type(2)));
     // this lane's part of the wave's Q fragment: query 16 wave + l15, columns 4 j + lq (columns 250, 251: zero; queries past the clip: zero rows, never stored)
     float qf[63];
     {
+        const float scale = 1.4426950408889634f / sqrtf((float)kDh);
         const int q = q0 + wave * 16 + l15;
         const float* qrow = base + (size_t)(q < n ? q : 0) * 3 * kE + (0 * kH + h) * kDh + lq;
 #pragma unroll
         for (int j = 0; j < 63; ++j) qf[j] = (q < n && 4 * j + lq < kDh) ? qrow[4 * j] * scale : 0.f;
     }
+    // K columns 250 .. 257 and V columns 250 .. 259 of both buffers: zero for good (the staging below never writes them)
+    for (int u = tid; u < 2 * kFK * (kFLd - kDh); u += 64 * kFW) {
+        const int bf = u / (kFK * (kFLd - kDh)), v = u - bf * kFK * (kFLd - kDh);
+        sm[bf * kFBufFloats + (v / (kFLd - kDh)) * kFLd + kDh + v % (kFLd - kDh)] = 0.f;
+    }
+    for (int u = tid; u < 2 * kFK * (kFLdV - kDh); u += 64 * kFW) {
+        const int bf = u / (kFK * (kFLdV - kDh)), v = u - bf * kFK * (kFLdV - kDh);
+        sm[bf * kFBufFloats + kFK * kFLd + (v / (kFLdV - kDh)) * kFLdV + kDh + v % (kFLdV - kDh)] = 0.f;
+    }
     // staging map of a K / V block: unit u = (row, float2 column); rows are 8-byte aligned (a head starts 1000 bytes into its row)
-    for (int u = tid; u < kFK * (kFLd - kDh); u += 64 * kFW) Ks[(u / (kFLd - kDh)) * kFLd + kDh + u % (kFLd - kDh)] = 0.f;      // K columns 250 .. 257: zero for good
-    for (int u = tid; u < kFK * (kFLdV - kDh); u += 64 * kFW) Vs[(u / (kFLdV - kDh)) * kFLdV + kDh + u % (kFLdV - kDh)] = 0.f;
-    f2 kreg[kFLoads], vreg[kFLoads];
-    auto request = [&](int k0) {                               // keys past the clip's end: zero rows (their scores are masked below)
-        const float* kb = base + (size_t)k0 * 3 * kE + (1 * kH + h) * kDh;
-        const float* vb = base + (size_t)k0 * 3 * kE + (2 * kH + h) * kDh;
+    // a block's K half is requested before the S^T phase and stored behind it, its V half before / behind the O^T phase: eight staging registers, not sixteen
+    f2 reg[kFLoads];
+    auto request = [&](int k0, int which) {                    // which: 1 keys, 2 values; keys past the clip's end: zero rows (their scores are masked below)
+        const float* gb = base + (size_t)k0 * 3 * kE + (which * kH + h) * kDh;
 #pragma unroll
         for (int i = 0; i < kFLoads; ++i) {
             const int u = i * 64 * kFW + tid, r = u / (kDh / 2), c2 = u - r * (kDh / 2);      // (recomputed per block: eight registers matter here)
             const bool ok = u < kFU && k0 + r < n;
-            kreg[i] = ok ? *reinterpret_cast<const f2*>(kb + r * 3 * kE + 2 * c2) : f2{0.f, 0.f};
-            vreg[i] = ok ? *reinterpret_cast<const f2*>(vb + r * 3 * kE + 2 * c2) : f2{0.f, 0.f};
+            reg[i] = ok ? *reinterpret_cast<const f2*>(gb + r * 3 * kE + 2 * c2) : f2{0.f, 0.f};
         }
     };
-    auto deposit = [&]() {
+    auto deposit = [&](float* buf, int ld) {
 #pragma unroll
         for (int i = 0; i < kFLoads; ++i)
             if (i * 64 * kFW + tid < kFU) {
                 const int u = i * 64 * kFW + tid, r = u / (kDh / 2), c2 = u - r * (kDh / 2);
-                *reinterpret_cast<f2*>(Ks + r * kFLd + 2 * c2) = kreg[i];
-                *reinterpret_cast<f2*>(Vs + r * kFLdV + 2 * c2) = vreg[i];
+                *reinterpret_cast<f2*>(buf + r * ld + 2 * c2) = reg[i];
             }
     };
-    float m_run[4], l_run[4];
-    f32x4_t O[16];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { m_run[r] = -INFINITY; l_run[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;                      // of query l15, over this lane's keys (4 lq + r, 16 + 4 lq + r of every block) for l
+    f32x4_t O[16];                                             // O^T: rows = features 16 dt + 4 lq + r, column = query l15
 #pragma unroll
     for (int dt = 0; dt < 16; ++dt) O[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    request(0);
-    deposit();
-    for (int k0 = 0; k0 < n; k0 += kFK) {
-        __syncthreads();                                       // block k0 is in LDS
-        if (k0 + kFK < n) request(k0 + kFK);                   // the next block: in flight under this block's MFMAs
-        // S (16 queries x 32 keys) = Q K^T: 63 k-steps of 4 (columns 250, 251 are zeros)
+    request(kbeg, 1);
+    deposit(sm, kFLd);
+    request(kbeg, 2);
+    deposit(sm + kFK * kFLd, kFLdV);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += kFK, cur ^= 1) {
+        const float* Ks = sm + cur * kFBufFloats;
+        const float* Vs = Ks + kFK * kFLd;
+        const bool more = k0 + kFK < kend;
+        float* nxt = sm + (cur ^ 1) * kFBufFloats;              // free since the barrier that ended the previous block
+        if (more) request(k0 + kFK, 1);                        // the next block's keys: in flight under this block's S^T MFMAs
+        // S^T (32 keys x 16 queries) = K Q^T: 63 k-steps of 4 (columns 250, 251 are zeros)
         f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
         const float* k0row = Ks + l15 * kFLd + lq;
         const float* k1row = Ks + (16 + l15) * kFLd + lq;
 #pragma unroll
         for (int j = 0; j < 63; ++j) {
-            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j], k0row[4 * j], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j], k1row[4 * j], s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(k0row[4 * j], qf[j], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(k1row[4 * j], qf[j], s1, 0, 0, 0);
             if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);   // operand reads are hoisted at most 4 steps (8 registers) ahead, not 63
         }
-        // lane: rows (queries) 4 lq + r, column (key) l15 of each tile; keys past the clip's end are -inf
-        const bool in0 = k0 + l15 < n, in1 = k0 + 16 + l15 < n;
-        float alpha[4];
+        if (more) { deposit(nxt, kFLd); request(k0 + kFK, 2); } // ... and its values under the O^T MFMAs
+        if (k0 + kFK > n) {                                    // keys past the clip's end are -inf (only the clip's last block)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (k0 + 4 * lq + r >= n) s0[r] = -INFINITY;
+                if (k0 + 16 + 4 * lq + r >= n) s1[r] = -INFINITY;
+            }
+        }
+        float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);                  // finite: key k0 exists
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float a0 = in0 ? s0[r] : -INFINITY, a1 = in1 ? s1[r] : -INFINITY;
-            const float mx = group16_max(fmaxf(a0, a1));
-            const float m_new = fmaxf(m_run[r], mx);          // finite: key k0 exists
-            alpha[r] = expf(m_run[r] - m_new);
-            const float p0 = expf(a0 - m_new), p1 = expf(a1 - m_new);
-            l_run[r] = l_run[r] * alpha[r] + group16_sum(p0 + p1);
-            m_run[r] = m_new;
-            Ps[(4 * lq + r) * kFLdP + l15] = p0;
-            Ps[(4 * lq + r) * kFLdP + 16 + l15] = p1;
+            s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
+            s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
+            psum += s0[r] + s1[r];
         }
+        l_run = l_run * alpha + psum;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {
 #pragma unroll
-        for (int dt = 0; dt < 16; ++dt) { O[dt][0] *= alpha[0]; O[dt][1] *= alpha[1]; O[dt][2] *= alpha[2]; O[dt][3] *= alpha[3]; }
-        // O (16 queries x 256 columns) += P V: 8 k-steps of 4 keys; the P tile is this wave's own (LDS operations of a wave complete in order)
-        const float* prow = Ps + l15 * kFLdP + lq;
-#pragma unroll
-        for (int kk = 0; kk < kFK / 4; ++kk) {
-            const float a = prow[kk * 4];
-            const float* vrow = Vs + (kk * 4 + lq) * kFLdV + l15;
-#pragma unroll
-            for (int dt = 0; dt < 16; ++dt) O[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vrow[dt * 16], O[dt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);                 // (one k-step's 16 V reads in flight, not all eight)
+            for (int dt = 0; dt < 16; ++dt) O[dt] *= alpha;
         }
-        __syncthreads();                                       // every wave has read block k0
-        if (k0 + kFK < n) deposit();
-    }
+        // O^T (256 features x 16 queries) += V^T P^T: 8 k-steps; k index lq of step (t, r) is key 16 t + 4 lq + r -- the lane's own s_t[r]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int q = q0 + wave * 16 + 4 * lq + r;
-        if (q >= n) continue;
-        const float inv = 1.0f / l_run[r];
-        float* orow = xt + ((size_t)bi * n + q) * kE + h * kDh + l15;
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int dt = 0; dt < 16; ++dt)
-            if (dt * 16 + l15 < kDh) orow[dt * 16] = O[dt][r] * inv;
+            for (int r = 0; r < 4; ++r) {
+                const float pv = t ? s1[r] : s0[r];
+                const float* vrow = Vs + (16 * t + 4 * lq + r) * kFLdV + l15;
+#pragma unroll
+                for (int dt = 0; dt < 16; ++dt) O[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[dt * 16], pv, O[dt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);             // (one k-step's 16 V reads in flight, not all eight)
+            }
+        if (more) deposit(nxt + kFK * kFLd, kFLdV);
+        __syncthreads();                                       // every wave has read block k0 and stored its share of block k0 + 32
     }
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    const int q = q0 + wave * 16 + l15;
+    if (q >= n) return;
+    if (kparts == 1) {
+        const float inv = 1.0f / l_run;
+        float* orow = xt + ((size_t)bi * n + q) * kE + h * kDh + 4 * lq;
+#pragma unroll
+        for (int dt = 0; dt < 16; ++dt) {
+            if (dt * 16 + 4 * lq < kDh) *reinterpret_cast<f2*>(orow + dt * 16) = f2{O[dt][0] * inv, O[dt][1] * inv};
+            if (dt * 16 + 4 * lq + 2 < kDh) *reinterpret_cast<f2*>(orow + dt * 16 + 2) = f2{O[dt][2] * inv, O[dt][3] * inv};
+        }
+    } else {                                                   // this part's share: part_o (part, row, 1000) unnormalised, part_ml (part, row, head, {m, l})
+        const size_t rows = (size_t)gridDim.z / kparts * n, row = (size_t)bi * n + q;
+        float* orow = part_o + ((size_t)part * rows + row) * kE + h * kDh + 4 * lq;
+#pragma unroll
+        for (int dt = 0; dt < 16; ++dt) {
+            if (dt * 16 + 4 * lq < kDh) *reinterpret_cast<f2*>(orow + dt * 16) = f2{O[dt][0], O[dt][1]};
+            if (dt * 16 + 4 * lq + 2 < kDh) *reinterpret_cast<f2*>(orow + dt * 16 + 2) = f2{O[dt][2], O[dt][3]};
+        }
+        if (lq == 0) *reinterpret_cast<f2*>(part_ml + (((size_t)part * rows + row) * kH + h) * 2) = f2{m_run, l_run};
+    }
+}
+
+// out[row, h, :] = sum_p O_p 2^(m_p - M) / sum_p l_p 2^(m_p - M), M = max_p m_p: the parts of one (row, head) merged in part order.  grid (rows), 256 threads.
+__global__ __launch_bounds__(256) void temporal_attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml, float* __restrict__ xt,
+                                                                      size_t rows, int kparts) {
+    const size_t row = blockIdx.x;
+    for (int e = threadIdx.x; e < kE; e += 256) {
+        const int h = e / kDh;
+        float M = -INFINITY;
+        for (int p = 0; p < kparts; ++p) M = fmaxf(M, part_ml[(((size_t)p * rows + row) * kH + h) * 2]);
+        float acc = 0.f, l = 0.f;
+        for (int p = 0; p < kparts; ++p) {
+            const float* ml = part_ml + (((size_t)p * rows + row) * kH + h) * 2;
+            const float w = __builtin_amdgcn_exp2f(ml[0] - M);
+            l += ml[1] * w;
+            acc += part_o[((size_t)p * rows + row) * kE + e] * w;
+        }
+        xt[row * kE + e] = acc / l;
+    }
+}
+
+// Key parts per (query tile, head) of a clip of n frames: the count that minimises rounds of workgroups per part on `cus` CUs (one workgroup per CU: 133 KB of
+// LDS), from n alone -- a clip's result does not depend on what else is in the batch.
+static int flash_key_parts(int n, int cus) {
+    const long wgs = (long)((n + kFQ - 1) / kFQ) * kH;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int p = 1; p <= kFlashMaxParts; ++p) {
+        if (p > 1 && n / p < kFlashMinPartKeys) break;
+        const double cost = (double)((wgs * p + cus - 1) / cus) / p + 0.01 * p;          // rounds x part length (+ a little per part for the merge)
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = p; }
+    }
+    return best;
 }
 
 // grid (R, H): the 25 tokens of one frame, one head.  attention_utils.py:207-217.
@@ -363,7 +425,7 @@ static int per_query_max_frames() {                                          // 
     const long fit = (long)lds / (long)sizeof(float) - 512;
     return (int)std::min<long>(kTsAttnMaxFrames, fit > 0 ? fit : 0);
 }
-// The per-query kernel holds a softmax row over the clip in LDS; the blocked kernel's LDS use is fixed (85 KB), so with it on, the per-query limit binds
+// The per-query kernel holds a softmax row over the clip in LDS; the blocked kernel's LDS use is fixed (133 KB), so with it on, the per-query limit binds
 // only the clips that still run the per-query kernel (round-5 advice: the entry check turned away clips the blocked kernel could serve)
 int tsattn_max_frames() {
     const int pq = per_query_max_frames(), fm = tsattn_flash_min();
@@ -404,7 +466,14 @@ hipError_t launch_tsattn(const float* x, const float* xs, const TsAttnWeights& w
         GRK_TRY(once_per_device(fattr, dev, [](int*) {
             return hipFuncSetAttribute(reinterpret_cast<const void*>(temporal_attn_flash_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kFlashLdsFloats * sizeof(float)));
         }));
-        GRK_TRY(launch_k(temporal_attn_flash_kernel, dim3((n + kFQ - 1) / kFQ, kH, b), dim3(64 * kFW), kFlashLdsFloats * sizeof(float), s, (const float*)qkv_t, xt, n));
+        int cus = 0;
+        GRK_TRY(device_cu_count(&cus));
+        const int kparts = flash_key_parts(n, cus);
+        float* part_o = yt;                                     // yt | ys | x1 (3 R x 3072 floats, all written later) hold the parts: kparts <= 8 need 8 064 R
+        float* part_ml = part_o + (size_t)kparts * R * kE;
+        GRK_TRY(launch_k(temporal_attn_flash_kernel, dim3((n + kFQ - 1) / kFQ, kH, b * kparts), dim3(64 * kFW), kFlashLdsFloats * sizeof(float), s, (const float*)qkv_t, xt, n,
+                         kparts, part_o, part_ml));
+        if (kparts > 1) GRK_TRY(launch_k(temporal_attn_combine_kernel, dim3((unsigned)R), dim3(256), 0, s, (const float*)part_o, (const float*)part_ml, xt, R, kparts));
     } else {
         GRK_TRY(launch_k(temporal_attn_kernel, dim3(n, kH, b), dim3(256), attn_lds, s, qkv_t, xt, n));
     }
