@@ -132,20 +132,22 @@ def test_attention_block_large_lds_branch_17000_frames(pkg, oracle):
     assert rel_err(y.reshape(reps, 50, -1), np.broadcast_to(ref.reshape(1, 50, -1), (reps, 50, ref[0, 0].size))) < 5e-5
     m.close()
 
-def test_blocked_temporal_attention_two_clips_ragged_blocks(pkg, oracle):
-    """temporal_attn_flash_kernel (clips >= 1 024 frames: 128 queries per workgroup, keys / values in blocks of 32, Q fragment in registers, next block in
-    flight) on TWO clips of 1 100 frames -- a last query block of 76 rows (4.75 waves) and a last key block of 12 -- and the two-stage frame mean of the gate
-    (9 partial blocks of 128 frames): the whole attention block against the oracle, each clip also alone (clips must not see each other)."""
+@pytest.mark.parametrize("b,n", [(2, 1100), (3, 500), (1, 385)], ids=["2x1100", "3x500", "1x385"])
+def test_blocked_temporal_attention_ragged_blocks_and_key_parts(pkg, oracle, b, n):
+    """temporal_attn_flash_kernel (clips >= 384 frames: 128 queries per workgroup as S^T = K Q^T / O^T += V^T P^T, keys / values in blocks of 32 through two LDS
+    stages, keys split over up to 8 workgroups whose shares temporal_attn_combine_kernel merges) against the oracle: 1 100 frames -- a last query tile of 76 rows
+    (4.75 waves), a last key block of 12, 35 key blocks over 7 parts -- 500 frames (3 parts, last block of 20 keys) and 385 (one key block beyond 12 full
+    ones, 3 parts); the two-stage frame mean of the gate; each clip also alone (clips must not see each other, and the part count follows from n alone)."""
     from .conftest import rel_err
     m = pkg.build_synthetic_model(max_frames=2, with_gru=True, with_tsattn=True, use_gait_feat=False)
     tsd = pkg.synth.make_tsattn_state_dict()
-    x, xs = pkg.synth.make_tsattn_inputs(2, 1100)
+    x, xs = pkg.synth.make_tsattn_inputs(b, n)
     xd, xsd = torch.from_numpy(x).cuda(), torch.from_numpy(xs).cuda()
     y = m.tsattn_forward(xd, xsd).cpu().numpy()
     ref = oracle.ts_attn_block(x, xs, tsd)
     assert y.shape == ref.shape and rel_err(y, ref) < 5e-5, rel_err(y, ref)
-    y1 = m.tsattn_forward(xd[1:2], xsd[1:2]).cpu().numpy()
-    assert np.array_equal(y1[0], y[1])
+    y1 = m.tsattn_forward(xd[b - 1:b], xsd[b - 1:b]).cpu().numpy()
+    assert np.array_equal(y1[0], y[b - 1])
     m.close()
 
 # ---- GRU recurrence, round 5: rows-per-wave kernel, hand-off inside the XCD's L2 (gru_kernels.hip) --------------------------------------

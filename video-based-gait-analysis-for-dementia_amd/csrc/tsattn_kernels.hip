@@ -94,7 +94,7 @@ constexpr int kFW = 8, kFQ = 16 * kFW, kFK = 32, kFLd = 258, kFLdV = 260;
 constexpr int kFBufFloats = kFK * kFLd + kFK * kFLdV;
 constexpr int kFlashLdsFloats = 2 * kFBufFloats;
 constexpr int kFU = kFK * (kDh / 2), kFLoads = (kFU + 64 * kFW - 1) / (64 * kFW);       // float2 units of a K (or V) block; per thread
-constexpr int kFlashMaxParts = 8, kFlashMinPartKeys = 256;
+constexpr int kFlashMaxParts = 8, kFlashMinPartKeys = 128;
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(64 * kFW) void temporal_attn_flash_kernel(const float* __restrict__ qkv, float* __restrict__ xt, int n, int kparts,
                                                                          float* __restrict__ part_o, float* __restrict__ part_ml) {
@@ -259,7 +259,7 @@ static int flash_key_parts(int n, int cus) {
     int best = 1;
     double best_cost = 1e30;
     for (int p = 1; p <= kFlashMaxParts; ++p) {
-        if (p > 1 && n / p < kFlashMinPartKeys) break;
+        if (p > 1 && n / p < GRNET_AB(TSATTN_PART_KEYS, kFlashMinPartKeys)) break;
         const double cost = (double)((wgs * p + cus - 1) / cus) / p + 0.01 * p;          // rounds x part length (+ a little per part for the merge)
         if (cost < best_cost - 1e-9) { best_cost = cost; best = p; }
     }
@@ -417,8 +417,10 @@ static hipError_t device_lds_per_block(int* bytes) {
     if (e != hipSuccess) return e;
     return once_per_device(c, dev, [&](int* v) { return hipDeviceGetAttribute(v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev); }, bytes);
 }
-// Smallest clip on the blocked kernel (450 frames: 0.98 ms against 0.87 for the per-query kernel -- 32 workgroups; 10 000: 6 against 107); 0: never.
-static int tsattn_flash_min() { return GRNET_AB(TSATTN_FLASH, 1024); }
+// Smallest clip on the blocked kernel; 0: never.  Whole attention block, ms, per-query against blocked (keys split down to 128 per part): 1 x 256 frames 0.537 / 0.534,
+// 1 x 400 0.717 / 0.653, 4 x 400 1.556 / 1.160, 1 x 1000 1.49 / 0.84, 1 x 2000 4.20 / 1.47 (the temporal attention alone at 10 000: 107 / 4.1); below 256 the per-query
+// kernel's n workgroups per head fill the device better than one or two query tiles.
+static int tsattn_flash_min() { return GRNET_AB(TSATTN_FLASH, 384); }
 static int per_query_max_frames() {                                          // what the per-query kernel's softmax row leaves of THIS device's LDS per workgroup
     int lds = 0;
     if (device_lds_per_block(&lds) != hipSuccess || lds <= 0) return 0;
@@ -458,7 +460,7 @@ hipError_t launch_tsattn(const float* x, const float* xs, const TsAttnWeights& w
     float* x1 = ys + R * kD;
     GRK_TRY(launch_gemm_nt_bias(x, w.qkv_t_w, w.qkv_t_b, qkv_t, (int)R, 3 * kE, kD, 3 * kE, s));
     GRK_TRY(launch_gemm_nt_bias(xs, w.qkv_s_w, w.qkv_s_b, qkv_s, (int)R, 3 * kE, kD + kF, 3 * kE, s));
-    // clips of >= 1024 frames: the blocked kernel (keys / values read once per 64 queries, fp32 matrix cores); shorter clips: one workgroup per query
+    // clips of >= 384 frames: the blocked kernel (keys / values read once per 128 queries, fp32 matrix cores); shorter clips: one workgroup per query
     if (flash) {
         static PerDeviceOnce fattr;
         int dev = 0;
