@@ -29,6 +29,7 @@
 // path up to fp32 summation order (output-rounding ties); tests/test_gpu_round5.py compares both and the fp32 oracle on bf16-rounded operands.
 #include "kernels.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 namespace grk {
@@ -50,6 +51,11 @@ typedef float f32x2_c __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack2_c(float lo, float hi) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_c{lo, hi}, bf16x2_c)); }
 // relu on the bits: negative floats (and -0) are negative integers; one v_max_i32, where fmaxf(x, 0) costs a canonicalising v_max first
 __device__ __forceinline__ float relu_c(float x) { const int i = __float_as_int(x); return __int_as_float(i > 0 ? i : 0); }
+typedef short s16x2_c __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned relu_pk(unsigned v) {      // max(x, 0) on two packed bf16: v_pk_max_i16
+    const s16x2_c a = __builtin_bit_cast(s16x2_c, v);
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(a, s16x2_c{0, 0}));
+}
 __device__ __forceinline__ float bf_lo(unsigned v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float bf_hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
 
@@ -629,6 +635,217 @@ __global__ __launch_bounds__(512) void conv_bf16_block_frame(const ChainArgs a) 
             if (band + 2 < NB) request(y0 + 2 * R);
         }
     }
+}
+
+// ---- The whole 32-channel 56x56 chain (HR branch 0 of a module: 4 BasicBlocks = 8 convolutions, hrnet.py:141-187) as ONE launch: a PIPELINE OF ROWS.
+// conv_bf16_block_frame above is bound by its per-band skeleton (57 % of a launch is not the k-loops: profiles/r06_block_frame_ablation.txt) and pays it once per
+// BasicBlock.  Here a workgroup owns a frame and each of its 8 waves owns ONE convolution of the chain for the whole launch:
+//   * the wave's weights (9 taps x 32 x 32 bf16 = 18 KB) live in its REGISTERS (72 per lane: the A fragments of all 18 (tap, channel block) MFMAs), loaded once;
+//   * in step t wave s computes output row t - 2 s of its convolution (4 column tiles x 2 channel blocks x 9 taps = 72 MFMAs) from three rows of its input ring in LDS
+//     and leaves the row -- ReLU, bf16 -- in the input ring of wave s + 1 (the last wave stores to HBM); conv2 of a block seeds its accumulators with bias + x from
+//     the ring its conv1 reads (the block's input row).  A lag of two rows per stage keeps producer and consumers of a ring on different rows within a step, so ONE
+//     barrier per step is all the synchronisation there is; no wave ever waits for weights, addresses are one base + immediates;
+//   * rings: 6 rows for the chain's input (arrives by LDS-DMA three steps ahead, one wave-instruction per step from each of waves 0 .. 3), 5 for a block's input
+//     (its conv1 reads rows r - 1 .. r + 1 while conv2, two steps behind, still takes row r - 2 as the residual), 4 between conv1 and conv2: 37 rows of 4 KB = 148 KB;
+//   * a ring row is 64 slots of 64 bytes (pixel x in slot x + 1, slots 0 and 57 .. 63 zero): no padding between pixels, the 16-byte part p of slot q sits at
+//     p ^ 2 (q >> 2 & 1), which puts the 16 lanes of every ds_read_b128 group on 16 different bank groups for every tile start and tap.
+// 74 steps per frame (56 rows + 14 of pipeline + 4 of input lead); results bit-identical to the launch-per-block kernels (same seeds, same tap order, same rounding
+// points).  HBM sees the chain's input once and its output once (the three intermediates between blocks no longer exist).
+struct PipeGeom {
+    static constexpr int W = 56, C = 32, NS = 8, ROWB = 4096, TILES = 4;
+    static constexpr int ROWS = 6 + 4 * 4 + 3 * 5;             // ring 0: 6 rows; rings 1, 3, 5, 7: 4; rings 2, 4, 6: 5
+    static constexpr int LDS = ROWS * ROWB + 512;             // + the two slots a tile's right-most taps reach past the last row
+    static_assert(ROWS == 37 && LDS <= 160 * 1024, "ring layout");
+};
+
+#ifdef GRNET_ABLATION
+__device__ unsigned long long g_pipe_phase[8][4];             // diagnostic builds, GRNET_PIPE_PHASES: clock ticks per wave: request / compute + store / DMA wait / barrier
+#define PIPE_TICK(k) do { if (a.flags & 128) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc_[k] += t_ - tick_; tick_ = t_; } } while (0)
+#else
+#define PIPE_TICK(k) do { } while (0)
+#endif
+__global__ __launch_bounds__(512) void conv_bf16_chain_pipe(const ChainArgs a) {
+    typedef PipeGeom G;
+    constexpr int W = G::W;
+    extern __shared__ __align__(16) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // waves w and w + 4 share a SIMD: they get conv1 and conv2 of the same block, whose steps are COMPLEMENTARY (below)
+    const int s = wv < 4 ? 2 * wv : 2 * (wv - 4) + 1;         // this wave's convolution
+    const int n = blockIdx.x;
+    if (n >= a.N) return;
+    const u16* inb = reinterpret_cast<const u16*>(a.in) + (size_t)n * W * W * a.in_ctot + a.in_coff;
+    u16* outb = reinterpret_cast<u16*>(a.out) + (size_t)n * W * W * a.out_ctot + a.out_coff;
+    const bool last = s == G::NS - 1, second = (s & 1) != 0;
+
+    // A fragments of this wave's convolution: lane (row i = l15, k group lq) of channel block cs holds W[tap][channel 8 (i >> 2) + 4 cs + (i & 3)][8 lq .. 8 lq + 7]
+    // (the row permutation of conv_bf16_block_frame: a lane's two accumulator blocks are the pixel's channels 8 lq .. 8 lq + 7)
+    bf16x8 wf[9][2];
+    f32x4 bias[2];
+    {
+        const u16* wsrc = reinterpret_cast<const u16*>(a.w[s]);
+        const float* bsrc = a.bias[s];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int cs = 0; cs < 2; ++cs) wf[tap][cs] = *reinterpret_cast<const bf16x8*>(wsrc + ((size_t)tap * 32 + 8 * (l15 >> 2) + 4 * cs + (l15 & 3)) * 32 + 8 * lq);
+#pragma unroll
+        for (int cs = 0; cs < 2; ++cs) bias[cs] = *reinterpret_cast<const f32x4*>(bsrc + 8 * lq + 4 * cs);
+    }
+    for (int u = tid; u < G::LDS / 16; u += 512) reinterpret_cast<u32x4*>(lds)[u] = u32x4{0u, 0u, 0u, 0u};
+    // ring k = the input of convolution k; this wave reads ring s (+ ring s - 1, the block's input, for the residual of a second convolution), writes ring s + 1
+    auto first_of = [](int k) { return k == 0 ? 0 : 6 + ((k - 1) >> 1) * 9 + (((k - 1) & 1) ? 4 : 0); };      // rings 1, 2, 3, ... = 4, 5, 4, 5, ... rows behind ring 0's 6
+    auto rows_of = [](int k) { return k == 0 ? 6 : (k & 1) ? 4 : 5; };
+    const int f_in = first_of(s), n_in = rows_of(s), f_res = first_of(s > 0 ? s - 1 : 0), n_res = rows_of(s > 0 ? s - 1 : 0), f_out = first_of(s + 1), n_out = rows_of(s + 1);
+    // lane offsets inside a ring row for tap column dx: slot 16 j + l15 + dx, part lq swizzled by the slot's bit 2 (16 j leaves that bit alone)
+    unsigned off[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) off[dx] = (unsigned)((l15 + dx) * 64 + ((lq ^ ((((l15 + dx) >> 2) & 1) << 1)) * 16));
+    // the chain's input, one wave-instruction of a row per step from waves 0 .. 3: unit d = 64 wv + lane of the row = (slot d >> 2, swizzled part d & 3)
+    const int dslot = (64 * wv + lane) >> 2, dpart = ((64 * wv + lane) & 3) ^ (((dslot >> 2) & 1) << 1);
+    const bool dma_lane = wv < 4 && dslot >= 1 && dslot <= W;
+    const u16* dsrc = inb + (size_t)(dslot - 1) * a.in_ctot + dpart * 8;
+    auto request = [&](int y, int i_row) {                     // row y of the input -> ring 0 (rows outside the image stay zero: the ring starts zeroed, row 56's slot is zeroed below)
+        unsigned char* dst = lds + i_row * G::ROWB + wv * 1024;
+        if (dma_lane) dma16_c(dsrc + (size_t)y * W * a.in_ctot, dst);
+    };
+    f32x4 acc[2][4];
+    // row r of this wave's convolution into acc: bias (+ the block's input row r for a second convolution), 9 taps x 4 column tiles x 2 channel blocks
+    // ring rows of this step's image rows, kept as counters that wrap (a modulo by a per-wave ring size costs ~40 scalar instructions, six times a step):
+    // i_in: row r - 1 in the input ring, i_res: row r in the residual ring, i_out: row r in the output ring, i_dma: row t + 3 in ring 0
+    int i_in = 0, i_res = 0, i_out = 0, i_dma = 0;
+    auto wrap = [](int i, int nrows) { return i >= nrows ? i - nrows : i; };
+    auto compute_row = [&](int r) {
+        (void)r;
+#ifdef GRNET_ABLATION
+        if (a.flags & 64) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[0][j] = bias[0]; acc[1][j] = bias[1]; }
+        } else
+#endif
+        if (second) {
+            const unsigned char* xr = lds + (f_res + i_res) * G::ROWB + off[1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32x4 rr = *reinterpret_cast<const u32x4*>(xr + j * 1024);
+#pragma unroll
+                for (int cs = 0; cs < 2; ++cs) {
+                    f32x4 nx = bias[cs];
+                    nx[0] += bf_lo(rr[2 * cs]); nx[1] += bf_hi(rr[2 * cs]); nx[2] += bf_lo(rr[2 * cs + 1]); nx[3] += bf_hi(rr[2 * cs + 1]);
+                    acc[cs][j] = nx;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[0][j] = bias[0]; acc[1][j] = bias[1]; }
+        }
+#ifdef GRNET_ABLATION
+        if (a.flags & 16) return;
+#endif
+        const unsigned char* rb[3];
+        rb[0] = lds + (f_in + i_in) * G::ROWB;
+        rb[1] = lds + (f_in + wrap(i_in + 1, n_in)) * G::ROWB;
+        rb[2] = lds + (f_in + wrap(i_in + 2, n_in)) * G::ROWB;
+        // pixel fragments two taps ahead of their MFMAs (three register sets): a tap's 8 MFMAs are 128 cycles, an LDS round trip is more
+        bf16x8 px[3][4];
+#pragma unroll
+        for (int pre = 0; pre < 2; ++pre)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) px[pre][j] = *reinterpret_cast<const bf16x8*>(rb[pre / 3] + off[pre % 3] + j * 1024);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 2 < 9) {
+                const unsigned char* src = rb[(tap + 2) / 3] + off[(tap + 2) % 3];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) px[(tap + 2) % 3][j] = *reinterpret_cast<const bf16x8*>(src + j * 1024);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tap][0], px[tap % 3][j], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tap][1], px[tap % 3][j], acc[1][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // acc (row r) -> ReLU, bf16 -> ring s + 1 (the last convolution: HBM); zero: the padding rows -1 and 56 of the next convolution's input
+    auto store_row = [&](int r, int i_row, bool zero) {            // i_row: ring row of image row r in the output ring
+#ifdef GRNET_ABLATION
+        if (a.flags & 32) return;
+#endif
+        unsigned char* orow = lds + (f_out + i_row) * G::ROWB + off[1];
+        if (zero) {
+            if (!last) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(orow + j * 1024) = u32x4{0u, 0u, 0u, 0u};
+            }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // round to bf16, THEN clamp at zero on the packed halves (v_pk_max_i16: a negative bf16 is a negative 16-bit integer, -0 included) -- the bits of
+            // relu-then-round (rounding keeps the sign) in 8 vector instructions per tile instead of 12
+            const f32x4 A = acc[0][j], B = acc[1][j];
+            u32x4 v = u32x4{relu_pk(pack2_c(A[0], A[1])), relu_pk(pack2_c(A[2], A[3])), relu_pk(pack2_c(B[0], B[1])), relu_pk(pack2_c(B[2], B[3]))};
+            const int x = 16 * j + l15;
+            if (last) {
+                if (j < 3 || x < W) *reinterpret_cast<u32x4*>(outb + ((size_t)r * W + x) * a.out_ctot + lq * 8) = v;
+            } else {
+                if (j == 3 && x >= W) v = u32x4{0u, 0u, 0u, 0u};     // slots 57 .. 64 (the right halo, the spare slots, the next row's left halo) stay zero
+                *reinterpret_cast<u32x4*>(orow + j * 1024) = v;
+            }
+        }
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // weights and bias are in registers (nothing else of this wave's is in flight from here on but DMAs and stores)
+    lds_barrier();                                             // the rings are zero
+    // Schedule.  Convolution s works on row t - c(s) in step t, c = 0, 2, 5, 7, 10, 12, 15, 17: a first convolution computes its row and stores it in the same step
+    // (matrix pipe, then vector ALU); a second convolution stores the row of the PREVIOUS step first, then seeds and computes the next (vector ALU, then matrix
+    // pipe) -- the two waves of a SIMD are in opposite phases.  A second convolution's row therefore appears one step later, and the next block's first
+    // convolution follows it by three steps instead of two; within a step no wave reads a row another one writes (ring sizes above), so one barrier per step.
+    const int c_s = 5 * (s >> 1) + 2 * (s & 1);
+    const int t_end = W + 17 + 2;                              // the last convolution computes row 55 in step 72 and stores it in step 73
+    int pending = 0;                                           // second convolutions: 1 = acc holds the previous step's row, 2 = a padding row is due
+    {   // the counters at t = -4 (rows below -1 are never touched: only the phase matters; 120 = a multiple of every ring size)
+        const int r0 = -4 - c_s;
+        i_in = (r0 - 1 + 120) % n_in; i_res = (r0 + 120) % n_res; i_out = (r0 + 120) % n_out; i_dma = (-4 + 3 + 120) % 6;
+    }
+
+#ifdef GRNET_ABLATION
+    unsigned long long tacc_[4] = {0, 0, 0, 0}, tick_ = __builtin_readcyclecounter();
+#endif
+#pragma unroll 1
+    for (int t = -4; t < t_end; ++t) {
+        if (t + 3 == W && wv == 0) {                           // ring 0's row for image row 56 (the bottom padding) held row 50: zero it (slots 0 .. 63)
+            unsigned char* z = lds + i_dma * G::ROWB;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(z + (i * 64 + lane) * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+        const bool asks = wv < 4 && t + 3 >= 0 && t + 3 < W;
+        if (asks) request(t + 3, i_dma);
+        const int r = t - c_s;
+        PIPE_TICK(0);
+        if (second) {
+            if (pending) store_row(r - 1, i_out == 0 ? n_out - 1 : i_out - 1, pending == 2);
+            pending = 0;
+            if (r >= 0 && r < W) { compute_row(r); pending = 1; }
+            else if (r == -1 || r == W) pending = 2;
+        } else if (r >= -1 && r <= W) {
+            const bool pad = r < 0 || r == W;
+            if (!pad) compute_row(r);
+            store_row(r, i_out, pad);
+        }
+        i_in = wrap(i_in + 1, n_in); i_res = wrap(i_res + 1, n_res); i_out = wrap(i_out + 1, n_out); i_dma = wrap(i_dma + 1, 6);
+        PIPE_TICK(1);
+        // the row this wave requested one step ago has landed (this step's may still fly; a step without a request leaves nothing in flight)
+        if (asks) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if (wv < 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PIPE_TICK(2);
+        lds_barrier();
+        PIPE_TICK(3);
+    }
+#ifdef GRNET_ABLATION
+    if ((a.flags & 128) && lane == 0)
+        for (int k = 0; k < 4; ++k) atomicAdd(&g_pipe_phase[wv][k], tacc_[k]);
+#endif
 }
 
 // ---- ONE wide 3x3 stride-1 convolution (upsample heads hrnet.py:440-453, PARE head pare.py:377-400, layer1's 3x3 hrnet.py:80-100) with a band of
@@ -1224,6 +1441,7 @@ hipError_t conv_bf16_chain_init() {
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_band<128, 128, 28, 14>), hipFuncAttributeMaxDynamicSharedMemorySize, WideGeom<128, 128, 28, 14>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_band<64, 64, 56, 14>), hipFuncAttributeMaxDynamicSharedMemorySize, WideGeom<64, 64, 56, 14>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_block_frame<56, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, FrameGeom<56, 8>::LDS));
+    GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_chain_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, PipeGeom::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_ring<128, 56, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<128, 56, 8>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_ring<256, 56, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<256, 56, 4, true>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wide_ring<32, 56, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, RingGeom<32, 56, 8>::LDS));
@@ -1241,6 +1459,28 @@ int conv_bf16_chain_launches(int c, int w, int nconv) { return c == 32 && w == 5
 hipError_t launch_conv_bf16_chain(const ChainArgs& a, int c, int w, hipStream_t s) {
     if (!conv_bf16_chain_eligible(c, w) || a.nconv < 2 || a.nconv > kMaxChain || (a.nconv & 1) || a.N < 1) return hipErrorInvalidValue;
     if (a.in_ctot % 8 != 0 || a.in_coff % 8 != 0 || a.out_ctot % 8 != 0 || a.out_coff % 8 != 0) return hipErrorInvalidValue;
+    if (c == 32 && a.nconv == 8 && GRNET_AB(BF16_PIPE, 1)) {   // the whole chain as one pipeline of rows, a wave per convolution (a.mid is not used)
+        ChainArgs b = a;
+        b.flags = (GRNET_AB(BF16_FRAME_DBG, 0) << 4) | (GRNET_AB(BF16_PIPE_VSEED, 0) ? 2 : 0);              // (diagnostic builds: timing-only ablation bits 16 / 32 / 64 = no k-loop / no epilogue / no seeds)
+#ifdef GRNET_ABLATION
+        if (GRNET_AB_SET(PIPE_PHASES)) {
+            b.flags |= 128;
+            unsigned long long z[32] = {};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pipe_phase), z, sizeof(z));
+            GRK_TRY(launch_k(conv_bf16_chain_pipe, dim3(a.N), dim3(512), PipeGeom::LDS, s, b));
+            (void)hipStreamSynchronize(s);
+            unsigned long long h[32] = {};
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pipe_phase), sizeof(h));
+            const double d = (double)a.N * 79.0;                 // per workgroup and step
+            for (int w = 0; w < 8; ++w)
+                fprintf(stderr, "[pipe phases] wave %d (conv %d): ticks per step  request %.0f  compute+store %.0f  dma wait %.0f  barrier %.0f\n", w, w < 4 ? 2 * w : 2 * (w - 4) + 1,
+                        h[w * 4] / d, h[w * 4 + 1] / d, h[w * 4 + 2] / d, h[w * 4 + 3] / d);
+            return hipSuccess;
+        }
+#endif
+        GRK_TRY(launch_k(conv_bf16_chain_pipe, dim3(a.N), dim3(512), PipeGeom::LDS, s, b));
+        return hipSuccess;
+    }
     if (c == 32) {                                           // one launch per BasicBlock; block k > 0 reads what block k - 1 wrote: a.mid holds the intermediates
         ChainArgs b = a;
         for (int k = 0; k < a.nconv / 2; ++k) {
