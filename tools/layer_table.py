@@ -36,7 +36,7 @@ def dump(path, dtype="f32"):
         name = C.create_string_buffer(96)
         m._lib.grnet_conv_kernel_info(m._h, pos, n, name, 96, None)
         c["kernel_family"] = name.value.decode()
-        c["dispatches"] = 0 if c["kernel_family"].endswith("+") else 4 if c["kernel_family"].startswith("conv_bf16_chain<32,") else 1
+        c["dispatches"] = 0 if c["kernel_family"].endswith("+") else 1      # (rounds 5: 4 for the 56x56 branch's chain, one launch per BasicBlock; round 6: conv_bf16_chain_pipe, one launch)
     json.dump(convs, open(path, "w"))
     m.close()
 
@@ -104,6 +104,8 @@ def main(rnd, dtype="f32"):
     esz, peak = (2.0, 2500.0) if bf else (4.0, 157.3)
     src = os.path.join(ROOT, "gpurun_out", "bf16") if bf else os.path.join(ROOT, "gpurun_out")
     convs = json.load(open(os.path.join(src, "layers", "convs.json")))
+    for c in convs:
+        if c.get("dispatches", 1) > 1: c["dispatches"] = 1
     n_conv = len(convs)
     dur = per_position(conv_dispatches(os.path.join(src, "prof_serial", "bench_kernel_trace.csv"), lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3), convs)
     fetch = per_position(conv_dispatches(os.path.join(src, "pmc", "FETCH_SIZE_counter_collection.csv"), lambda r: float(r["Counter_Value"]) * 1024.0), convs)

@@ -839,6 +839,9 @@ __global__ __launch_bounds__(512) void conv_bf16_chain_pipe(const ChainArgs a) {
         if (asks) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else if (wv < 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PIPE_TICK(2);
+#ifdef GRNET_ABLATION
+        if (!(a.flags & 256))
+#endif
         lds_barrier();
         PIPE_TICK(3);
     }
@@ -1451,7 +1454,8 @@ hipError_t conv_bf16_chain_init() {
 }
 
 bool conv_bf16_chain_eligible(int c, int w) { return (c == 64 && w == 28) || (c == 128 && w == 14) || (c == 256 && w == 7) || (c == 32 && w == 56); }
-int conv_bf16_chain_launches(int c, int w, int nconv) { return c == 32 && w == 56 ? nconv / 2 : 1; }     // the 56x56 branch: one band-resident launch per BasicBlock
+// the 56x56 branch: ONE launch for a whole module's chain (conv_bf16_chain_pipe, 8 convolutions), otherwise one band-resident launch per BasicBlock
+int conv_bf16_chain_launches(int c, int w, int nconv) { return c == 32 && w == 56 && !(nconv == 8 && GRNET_AB(BF16_PIPE, 1)) ? nconv / 2 : 1; }
 
 // a.in / a.out: NHWC bf16 views of (N, W, W, C) tensors (channel strides in_ctot / out_ctot, first channels in_coff / out_coff, multiples of 8);
 // a.w[i]: [C/32][9][C][32] bf16 (pack_conv's bf16 layout with CoutPad = C), a.bias[i]: fp32 [C]; nconv even, <= kMaxChain:
