@@ -110,7 +110,7 @@ def test_bf16_forward_with_chains_equals_forward_without(bmodel, pkg):
     finally:
         bmodel.set_option(pkg._lib.OPT_BF16_CHAIN, -1)
     torch.cuda.synchronize()
-    assert n_without - n_with == 7 * (8 + 7 + 3) + 4 * 8 + 8 + 1, (n_with, n_without)    # 18 chains of 8 convolutions became 18 launches, 8 chains of the 56x56 branch 4 launches each; layer1's 12 convolutions 4 Bottleneck launches, the stem's two one (round 6)
+    assert n_without - n_with == 7 * (8 + 7 + 3) + 7 * 8 + 8 + 1, (n_with, n_without)    # 26 chains of 8 convolutions became 26 launches (round 6: the 56x56 branch's too -- conv_bf16_chain_pipe); layer1's 12 convolutions 4 Bottleneck launches, the stem's two one
     # (the wide-band and stride-2 band kernels -- bits 4, 5 of the mask -- replace launches one for one: 45 stride-2 layers with up to three shifted addends run here)
     for k in keys + ("theta", "kp_3d", "verts"):
         a, b = with_chain[k].float().cpu().numpy(), without[k].float().cpu().numpy()
@@ -188,13 +188,15 @@ def test_bf16_pointwise_256_channel_tile(bmodel, oracle, with_add):
     assert np.array_equal(got, _rb(got))
     assert np.all(np.abs(got - ref) <= np.abs(ref) * 2.0 ** -8 + 1e-5), float(np.abs(got - ref).max())
 
-S2 = [(64, 64, 112), (64, 128, 28), (32, 128, 28), (32, 32, 28)]
+S2 = [(64, 64, 112), (64, 128, 28), (32, 128, 28), (32, 32, 28), (32, 64, 56), (32, 32, 56), (64, 64, 28)]
 
 @pytest.mark.parametrize("case", S2, ids=lambda c: "x".join(map(str, c)))
 def test_bf16_stride2_band_kernel(bmodel, oracle, case):
     """conv_bf16_s2_band (one 3x3 stride-2 convolution; the input band de-interleaved by row and column parity into four LDS sub-planes so that every tap
-    is a constant offset): every shape it is used for, with and without a fused addend and ReLU, against the fp32 oracle on the same bf16-rounded operands
-    up to the one rounding of the bf16 output.  5 frames of 56 / 28 / 14 / 7 output rows: first, middle and last (partial) bands."""
+    is a constant offset) and, round 6, conv_bf16_s2_rows (32 -> 64 / 32 -> 32 @56 -> 28, 64 -> 64 @28 -> 14: a walk over output rows, two new input rows per step
+    by LDS-DMA de-interleaved by column parity, a wave per (tile, channel block) with its weights in registers; 2 or 5 frames run as 2 or 4 row segments each):
+    every shape they are used for, with and without a fused addend and ReLU, against the fp32 oracle on the same bf16-rounded operands up to the one rounding
+    of the bf16 output.  Frames of 56 / 28 / 14 / 7 output rows: first, middle and last (partial) bands."""
     cin, cout, h = case
     g = np.random.Generator(np.random.Philox(key=[91, cin * 1000 + cout + h]))
     n = 2 if h >= 56 else 5

@@ -1,3 +1,4 @@
 export TMPDIR=/tmp
-export GRNET_LIB_PATH=$PWD/video-based-gait-analysis-for-dementia_amd/libgrnet_hip_abl.so
-for d in 0 16 17 18 20 22 23; do echo "dbg bits $d (1 no k-loop, 2 no epilogue, 4 no seeds, 16 no barrier)"; GRNET_BF16_FRAME_DBG=$d python3 tools/chain_micro.py 20 2>&1 | grep "chain<32"; done
+mkdir -p gpurun_out
+timeout 2400 python -m pytest tests/test_gpu_conv_bf16.py tests/test_gpu_bf16.py tests/test_gpu_bf16_roll.py tests/test_gpu_options.py tests/test_gpu_harness.py -m gpu -q --timeout 1200 > gpurun_out/pytest_bf16.log 2>&1
+grep -E "passed|failed" gpurun_out/pytest_bf16.log | tail -2

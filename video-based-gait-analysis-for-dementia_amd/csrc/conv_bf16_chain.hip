@@ -1408,6 +1408,160 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(S2Geom<CP, 
     }
 }
 
+// ---- The narrow 3x3 stride-2 layers of the fuse down paths (32 / 64 input channels) as a WALK OVER OUTPUT ROWS.  These launches are neither compute- nor
+// byte-bound in the band kernel above or in conv_bf16_nhwc (0.05-0.15 of the matrix peak at 1.9 TB/s: fill -> barrier -> k-loop -> epilogue -> store, one after
+// another per workgroup).  Here a workgroup owns a segment of a frame's output rows; per output row Y it needs input rows 2Y - 1 .. 2Y + 1, of which two are new:
+// they arrive by LDS-DMA one step ahead, DE-INTERLEAVED by column parity (odd columns with a leading zero slot, then even columns: tap dx reads odd index x, even
+// index x, odd index x + 1 -- 16 consecutive slots for 16 output pixels), 16-byte parts XOR-swizzled by slot bits so that every fragment read is conflict-free.  A
+// wave owns one (16-pixel tile, 16-channel block) of the row with that block's weights in its registers for the whole launch (9 x Cin/32 A fragments), so a step is
+// 9 or 18 MFMAs per wave, an epilogue straight from the accumulators (bias, fused addends, ReLU, 8-byte stores) and ONE barrier; the ring is 6 input rows (25 KB), so
+// four workgroups share a CU and cover each other's memory round trips.  Results equal the band kernel's bit for bit (same k order, same epilogue order).
+template <int CIN, int COUT, int WO>
+struct S2RowsGeom {
+    static constexpr int WI = 2 * WO, SB = 2 * CIN, UPS = SB / 16, KS = CIN / 32;
+    static constexpr int MT = (WO + 15) / 16, NBK = COUT / 16, ITEMS = MT * NBK;
+    static constexpr int PO = 16 * MT + 1, PE = 16 * MT, SLOTS = PO + PE;      // odd-column plane (index 0 = column -1), even-column plane
+    static constexpr int ROWB = SLOTS * SB, RING = 6;
+    static constexpr int UNITS = SLOTS * UPS, NDMA = (UNITS + 63) / 64;      // 16-byte units of a row; wave-instructions per row
+    static constexpr int LDS = RING * ROWB + 64 * 16;                         // + what the last instruction of the last row writes past it (masked lanes write nothing)
+    static_assert(ITEMS <= 8 && 2 * NDMA <= 16 && (CIN == 32 || CIN == 64) && COUT % 16 == 0 && LDS <= 64 * 1024, "stride-2 row geometry");
+    static __device__ __forceinline__ int swz(int slot) { return CIN == 32 ? (((slot >> 2) & 1) << 1) : (((slot >> 1) & 3) << 1); }
+};
+
+template <int CIN, int COUT, int WO>
+__global__ __launch_bounds__(512) void conv_bf16_s2_rows(const ConvArgs a, int segs) {
+    typedef S2RowsGeom<CIN, COUT, WO> G;
+    constexpr int WI = G::WI, SB = G::SB, KS = G::KS;
+    extern __shared__ __align__(16) unsigned char ring[];
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = blockIdx.x / segs, seg = blockIdx.x - n * segs;
+    if (n >= a.N) return;
+    const int rows_per = (WO + segs - 1) / segs, y_lo = seg * rows_per, y_hi = min(WO, y_lo + rows_per);
+    const u16* inb = reinterpret_cast<const u16*>(a.in) + (size_t)n * WI * WI * a.in_ctot + a.in_coff;
+    u16* outb = reinterpret_cast<u16*>(a.out) + (size_t)n * WO * WO * a.out_ctot + a.out_coff;
+    const bool works = wave < G::ITEMS;
+    const int nb = wave % G::NBK, mt = wave / G::NBK, co = nb * 16;
+
+    bf16x8 wf[KS][9];
+    f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (works) {
+        const u16* wg = reinterpret_cast<const u16*>(a.w);
+#pragma unroll
+        for (int kc = 0; kc < KS; ++kc)
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) wf[kc][tap] = *reinterpret_cast<const bf16x8*>(wg + (((size_t)kc * 9 + tap) * a.CoutPad + co + l15) * 32 + 8 * lq);
+        bias = *reinterpret_cast<const f32x4*>(a.bias + co + 4 * lq);
+    }
+    for (int u = tid; u < G::LDS / 16; u += 512) reinterpret_cast<u32x4*>(ring)[u] = u32x4{0u, 0u, 0u, 0u};
+    // this wave's share of a step's two new rows: wave-instructions q = wave, wave + 8 of the 2 x NDMA (row q / NDMA, instruction q % NDMA); per lane the unit's
+    // (validity, source offset inside an input row): unit d = (slot, stored part) -> column 2 i - 1 (odd plane, i = slot) or 2 j (even plane), part = stored ^ swz(slot)
+    int dq_row[2], dq_k[2], dq_off[2];
+    bool dq_on[2], dq_lane[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = wave + 8 * i;
+        dq_on[i] = q < 2 * G::NDMA;
+        dq_row[i] = q / G::NDMA; dq_k[i] = q - dq_row[i] * G::NDMA;
+        const int d = dq_k[i] * 64 + lane, slot = d / G::UPS, sp = d - slot * G::UPS;
+        const int col = slot < G::PO ? 2 * slot - 1 : 2 * (slot - G::PO);
+        dq_lane[i] = dq_on[i] && d < G::UNITS && col >= 0 && col < WI && (slot < G::PO ? slot <= WO : slot - G::PO < WO);
+        dq_off[i] = col * a.in_ctot + (sp ^ G::swz(slot)) * 8;
+    }
+    // fragment offsets of this wave's tile inside a ring row: tap dx reads odd index x (dx = 0), even index x (1), odd index x + 1 (2), x = 16 mt + l15
+    unsigned foff[3][KS];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        const int x = 16 * mt + l15, slot = dx == 1 ? G::PO + x : x + (dx >> 1);
+#pragma unroll
+        for (int kc = 0; kc < KS; ++kc) foff[dx][kc] = (unsigned)(slot * SB + (((4 * kc + lq) ^ G::swz(slot)) * 16));
+    }
+    auto request = [&](int y, int rr0) {                       // input rows 2 y, 2 y + 1 -> ring rows rr0, rr0 + 1 (wrapped by the caller)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (dq_on[i]) {
+                const int row = 2 * y + dq_row[i];
+                int rr = rr0 + dq_row[i];
+                rr = rr >= G::RING ? rr - G::RING : rr;
+                if (dq_lane[i] && row < WI) dma16_c(inb + (size_t)row * WI * a.in_ctot + dq_off[i], ring + rr * G::ROWB + dq_k[i] * 1024);
+            }
+    };
+    lds_barrier();                                             // the ring is zero (the halo slots and the row above the image stay zero: no DMA ever writes them ... see below)
+    // ring row of input row r: (r + 2) mod 6 by a wrapping counter; row 2 y_lo - 1 (or the zero row above the image) sits at `cur`
+    int cur = 0;
+    if (y_lo > 0 && wave == 0) {                               // the segment's first output row needs input row 2 y_lo - 1: one extra row, by wave 0
+#pragma unroll
+        for (int k = 0; k < G::NDMA; ++k) {
+            const int d = k * 64 + lane, slot = d / G::UPS, sp = d - slot * G::UPS;
+            const int col = slot < G::PO ? 2 * slot - 1 : 2 * (slot - G::PO);
+            const bool ok = d < G::UNITS && col >= 0 && col < WI && (slot < G::PO ? slot <= WO : slot - G::PO < WO);
+            if (ok) dma16_c(inb + ((size_t)(2 * y_lo - 1) * WI + col) * a.in_ctot + (sp ^ G::swz(slot)) * 8, ring + cur * G::ROWB + k * 1024);
+        }
+    }
+    request(y_lo, cur + 1);
+#pragma unroll 1
+    for (int y = y_lo; y < y_hi; ++y) {
+        // fused addends of this row (nearest-upsampled by 2^shift), requested before the wait below so that it covers them
+        u32x2 av[kMaxAdd];
+        const int x = 16 * mt + l15;
+        const bool px_ok = works && x < WO;
+#pragma unroll
+        for (int k = 0; k < kMaxAdd; ++k) {
+            av[k] = u32x2{0u, 0u};
+            if (k < a.n_add && px_ok) {
+                const int sh = a.add_shift[k], ws = WO >> sh;
+                av[k] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const u16*>(a.add[k]) + ((size_t)n * (WO >> sh) * ws + (size_t)(y >> sh) * ws + (x >> sh)) * a.add_ctot[k] + a.add_coff[k] + co + 4 * lq);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of rows 2 y, 2 y + 1 (requested a step ago) have landed
+        lds_barrier();                                         // ... and everybody's; every wave is done with row 2 y - 2 (the next request overwrites it)
+        f32x4 af[kMaxAdd];                                     // the addends as floats HERE: hipcc's own wait for their loads must not land behind the next request
+#pragma unroll
+        for (int k = 0; k < kMaxAdd; ++k) af[k] = f32x4{bf_lo(av[k][0]), bf_hi(av[k][0]), bf_lo(av[k][1]), bf_hi(av[k][1])};
+        __builtin_amdgcn_sched_barrier(0);
+        int nxt = cur + 3;
+        nxt = nxt >= G::RING ? nxt - G::RING : nxt;
+        if (y + 1 < y_hi) request(y + 1, nxt);
+        if (works) {
+            f32x4 acc = bias;
+            const unsigned char* r0 = ring + cur * G::ROWB;
+            int c1 = cur + 1, c2 = cur + 2;
+            c1 = c1 >= G::RING ? c1 - G::RING : c1; c2 = c2 >= G::RING ? c2 - G::RING : c2;
+            const unsigned char* r1 = ring + c1 * G::ROWB;
+            const unsigned char* r2 = ring + c2 * G::ROWB;
+#pragma unroll
+            for (int kc = 0; kc < KS; ++kc)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const unsigned char* rb = tap < 3 ? r0 : tap < 6 ? r1 : r2;
+                    const bf16x8 px = *reinterpret_cast<const bf16x8*>(rb + foff[tap % 3][kc]);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kc][tap], px, acc, 0, 0, 0);
+                }
+#pragma unroll
+            for (int k = 0; k < kMaxAdd; ++k)
+                if (k < a.n_add) { acc[0] += af[k][0]; acc[1] += af[k][1]; acc[2] += af[k][2]; acc[3] += af[k][3]; }
+            if (a.relu) { acc[0] = relu_c(acc[0]); acc[1] = relu_c(acc[1]); acc[2] = relu_c(acc[2]); acc[3] = relu_c(acc[3]); }
+            if (px_ok) *reinterpret_cast<u32x2*>(outb + ((size_t)y * WO + x) * a.out_ctot + co + 4 * lq) = u32x2{pack2_c(acc[0], acc[1]), pack2_c(acc[2], acc[3])};
+        }
+        cur += 2;
+        cur = cur >= G::RING ? cur - G::RING : cur;
+    }
+}
+// (the three shapes the band kernel lost on; on its own shapes -- 64 -> 128, 32 -> 128, 32 -> 32 @28->14 -- the walk ties with it: 15.1 against 14.5 us, not instantiated)
+#define GRK_S2R_SHAPES(X) X(32, 64, 28) X(32, 32, 28) X(64, 64, 14)
+template <int CIN, int COUT, int WO>
+hipError_t launch_s2_rows(const ConvArgs& a, hipStream_t s) {
+    typedef S2RowsGeom<CIN, COUT, WO> G;
+    int cus = 0;
+    GRK_TRY(device_cu_count(&cus));
+    // segments of output rows per frame: several workgroups per CU where the frame count allows it, but never fewer than 7 rows per workgroup (each one loads
+    // its channel blocks' weights: 18-74 KB from L2)
+    int segs = 1;
+    if (a.N < 4 * cus) segs = 2;
+    if (WO == 28 && a.N * 2 < 4 * cus) segs = 4;
+    return launch_k(conv_bf16_s2_rows<CIN, COUT, WO>, dim3(a.N * segs), dim3(512), G::LDS, s, a, segs);
+}
+
 template <int CP, int CT, int WO, int R>
 hipError_t set_s2_lds() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_s2_band<CP, CT, WO, R>), hipFuncAttributeMaxDynamicSharedMemorySize, S2Geom<CP, CT, WO, R>::LDS);
@@ -1556,11 +1710,19 @@ hipError_t launch_conv_bf16_wide(const ConvArgs& a0, hipStream_t s) {
 // Stride-2 band kernel: 3x3, stride 2, even input size, <= 3 fused addends; (input channels per pass, output-channel tile) by the layer's channel counts.
 static int s2_cp(const ConvArgs& a) { return a.CinPad >= 64 ? 64 : 32; }
 static int s2_ct(const ConvArgs& a) { return a.CoutPad >= 128 ? 128 : a.CoutPad; }
+static bool s2_rows_shape(const ConvArgs& a) {                 // the row-walking kernel's shapes (every add view 4-channel aligned: checked by the caller)
+    if (!GRNET_AB(BF16_S2_ROWS, 1)) return false;
+#define GRK_S2R_HAS(ci_, co_, wo_) if (a.CinPad == ci_ && a.Cin == ci_ && a.Cout == co_ && a.Wo == wo_) return true;
+    GRK_S2R_SHAPES(GRK_S2R_HAS)
+#undef GRK_S2R_HAS
+    return false;
+}
 bool conv_bf16_s2_eligible(const ConvArgs& a) {
     if (a.ks != 3 || a.stride != 2 || a.H != a.W || a.Ho != a.Wo || a.H != 2 * a.Ho || a.CinPad % 32 != 0 || a.n_add > kMaxAdd || a.relu_from != 0) return false;
     if (a.in_ctot % 8 != 0 || a.in_coff % 8 != 0 || a.out_ctot % 8 != 0 || a.out_coff % 8 != 0 || a.Cout % 32 != 0 || a.CoutPad != a.Cout) return false;
     for (int k = 0; k < a.n_add; ++k)
         if (a.add_ctot[k] % 4 != 0 || a.add_coff[k] % 4 != 0) return false;
+    if (s2_rows_shape(a)) return true;
     const int cp = s2_cp(a), ct = s2_ct(a);
     if (a.CinPad != cp) return false;                          // one pass (layers with more input channels lose to the generic kernel: see GRK_S2_SHAPES)
 #define GRK_S2_HAS(cp_, ct_, wo_, r_) if (cp == cp_ && ct == ct_ && a.Wo == wo_) return true;
@@ -1570,6 +1732,11 @@ bool conv_bf16_s2_eligible(const ConvArgs& a) {
 }
 hipError_t launch_conv_bf16_s2(const ConvArgs& a, hipStream_t s) {
     if (!conv_bf16_s2_eligible(a) || a.N < 1) return hipErrorInvalidValue;
+    if (s2_rows_shape(a)) {
+#define GRK_S2R_GO(ci_, co_, wo_) if (a.CinPad == ci_ && a.Cout == co_ && a.Wo == wo_) return launch_s2_rows<ci_, co_, wo_>(a, s);
+        GRK_S2R_SHAPES(GRK_S2R_GO)
+#undef GRK_S2R_GO
+    }
     const int cp = s2_cp(a), ct = s2_ct(a);
 #define GRK_S2_GO(cp_, ct_, wo_, r_) if (cp == cp_ && ct == ct_ && a.Wo == wo_) return launch_s2<cp_, ct_, wo_, r_>(a, s);
     GRK_S2_SHAPES(GRK_S2_GO)
