@@ -214,6 +214,15 @@ def test_bf16_stride2_band_kernel(bmodel, oracle, case):
         for sl in (np.s_[:, :, 0], np.s_[:, :, -1], np.s_[:, :, :, 0], np.s_[:, :, :, -1]):
             assert np.all(np.abs(got[sl] - ref[sl]) <= np.abs(ref[sl]) * 2.0 ** -8 + 1e-5)
 
+def test_bf16_stride2_kernels_refuse_other_shapes(bmodel, pkg):
+    """Forced onto the stride-2 kernels (tile_hint 3004), a shape none of them is built for is refused, not run on something else: a 128-channel input (four
+    passes of the band kernel lose to the generic one, the row walk holds 32 / 64 input channels), a stride-1 layer, an odd map."""
+    for x, w, stride in ((torch.zeros(1, 128, 28, 28), np.zeros((256, 128, 3, 3), np.float32), 2),
+                         (torch.zeros(1, 32, 56, 56), np.zeros((64, 32, 3, 3), np.float32), 1),
+                         (torch.zeros(1, 32, 30, 30), np.zeros((64, 32, 3, 3), np.float32), 2)):
+        with pytest.raises(pkg._lib.GrnetError, match="not eligible"):
+            bmodel.op_conv2d(x.cuda(), w, None, stride=stride, tile_hint=3004)
+
 def test_bf16_layer1_pairs_are_bit_identical(bmodel, pkg):
     """layer1's 64 -> 256 expansion + the next Bottleneck's 256 -> 64 reduction as one launch (bit 6 of the mask): the reduction reads the very bf16 tile
     the stand-alone launch would read from HBM, in the same k order -- the whole forward must not change by a bit (compared with the 256-channel tile
