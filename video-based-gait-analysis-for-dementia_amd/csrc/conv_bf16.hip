@@ -724,26 +724,45 @@ __global__ __launch_bounds__(256) void fuse_sum_bf16_kernel(const SumArgs a) {
     const int n = (bid * rpb) / a.H, yb = bid * rpb - n * a.H;
     u16* out = reinterpret_cast<u16*>(a.out);
     const float inv_c8 = 1.0f / (float)C8, inv_wc = 1.0f / (float)(a.W * C8);
-    for (int i0 = threadIdx.x; i0 < rpb * a.W * C8; i0 += 256) {
-        const int yr = fdiv(i0, inv_wc), i = i0 - yr * a.W * C8, y = yb + yr;
-        const int x = fdiv(i, inv_c8), c8 = i - x * C8;
-        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int total = rpb * a.W * C8;
+    // four units per thread and pass, ALL their loads requested before the first sum (round 6: one unit per iteration left a thread with four 16-byte loads in
+    // flight, the launch at 2.3 TB/s -- 46 us for the 105 MB of the 56x56 output; the sums and their order are unchanged)
+    for (int base = 0; base < total; base += 4 * 256) {
+        u32x4 v[4][4];
+        int yy[4], xx[4], cc[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k >= a.n_add) break;
-            const int sh = a.add_shift[k], hs = a.H >> sh, ws = a.W >> sh;
-            const u16* ap = reinterpret_cast<const u16*>(a.add[k]) + ((size_t)(n * hs + (y >> sh)) * ws + (x >> sh)) * a.add_ctot[k] + a.add_coff[k] + c8 * 8;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(ap);
+        for (int u = 0; u < 4; ++u) {
+            const int i0 = base + u * 256 + (int)threadIdx.x, ic = i0 < total ? i0 : total - 1;      // (past the end: the last unit again, not stored)
+            const int yr = fdiv(ic, inv_wc), i = ic - yr * a.W * C8;
+            yy[u] = yb + yr;
+            xx[u] = fdiv(i, inv_c8);
+            cc[u] = i - xx[u] * C8;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { acc[2 * j] += bf2f((u16)(v[j] & 0xffffu)); acc[2 * j + 1] += bf2f((u16)(v[j] >> 16)); }
+            for (int k = 0; k < 4; ++k) {
+                v[u][k] = u32x4{0u, 0u, 0u, 0u};
+                if (k < a.n_add) {
+                    const int sh = a.add_shift[k], hs = a.H >> sh, ws = a.W >> sh;
+                    v[u][k] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const u16*>(a.add[k]) + ((size_t)(n * hs + (yy[u] >> sh)) * ws + (xx[u] >> sh)) * a.add_ctot[k] + a.add_coff[k] + cc[u] * 8);
+                }
+            }
         }
-        u32x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float lo = a.relu ? fmaxf(acc[2 * j], 0.f) : acc[2 * j], hi = a.relu ? fmaxf(acc[2 * j + 1], 0.f) : acc[2 * j + 1];
-            o[j] = pack2(lo, hi);
+        for (int u = 0; u < 4; ++u) {
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k >= a.n_add) break;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc[2 * j] += bf2f((u16)(v[u][k][j] & 0xffffu)); acc[2 * j + 1] += bf2f((u16)(v[u][k][j] >> 16)); }
+            }
+            u32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float lo = a.relu ? fmaxf(acc[2 * j], 0.f) : acc[2 * j], hi = a.relu ? fmaxf(acc[2 * j + 1], 0.f) : acc[2 * j + 1];
+                o[j] = pack2(lo, hi);
+            }
+            if (base + u * 256 + (int)threadIdx.x < total) *reinterpret_cast<u32x4*>(out + (((size_t)n * a.H + yy[u]) * a.W + xx[u]) * a.out_ctot + a.out_coff + cc[u] * 8) = o;
         }
-        *reinterpret_cast<u32x4*>(out + (((size_t)n * a.H + y) * a.W + x) * a.out_ctot + a.out_coff + c8 * 8) = o;
     }
 }
 
