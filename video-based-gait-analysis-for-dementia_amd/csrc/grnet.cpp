@@ -1446,6 +1446,9 @@ struct grnet {
         int best_mode = -1;
         for (int mode : {0, 1, 4, 5})
             if (t_mode[mode] < 1e30f && (best_mode < 0 || t_mode[mode] < t_mode[best_mode])) best_mode = mode;
+        // three forwards per mode are a noisy clock (+-3 % from run to run on a shared node): a replayed graph has to win by more than that over the eager
+        // launches of the same table to be taken (it never has: ROCm 7.2's executor deals the branches to fewer queues than the four lane streams)
+        if (best_mode >= 0 && !(best_mode & 4) && t_mode[best_mode | 4] < 1e30f && t_mode[best_mode] > 0.97f * t_mode[best_mode | 4]) best_mode |= 4;
         if (best_mode < 0) return fail(GRNET_ESTATE, "no schedule could be timed");
         tuned_mode[n] = best_mode;
         // in-context refinement (level 2): greedy coordinate descent on the time of the whole replayed forward --
