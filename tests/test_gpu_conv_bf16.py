@@ -83,6 +83,19 @@ def test_bf16_chain_equals_launch_per_convolution(bmodel, shape):
     again = bmodel.op_conv_chain(xd, ws, bs).cpu().numpy()
     assert np.array_equal(got, again)                                    # deterministic
 
+def test_bf16_pipeline_chain_equals_the_block_kernels_bit_for_bit(bmodel):
+    """The 56x56 branch's 8-convolution chain is ONE launch (conv_bf16_chain_pipe: a pipeline of rows, a wave per convolution, rings of 4-6 rows in LDS); the same
+    chain as two 4-convolution calls runs conv_bf16_block_frame (one launch per BasicBlock, the frame walked in bands).  Same seeds, tap order and rounding points:
+    the bits must agree -- on 5 frames whose rows differ (a ring row read one step early or late would show), and again on a second call of the same handle."""
+    c, w = 32, 56
+    g = np.random.Generator(np.random.Philox(key=[89, 1]))
+    x = torch.from_numpy(_rb(g.standard_normal((5, c, w, w)))).cuda()
+    ws, bs = _chain_weights(g, c, 8)
+    for _ in range(2):
+        whole = bmodel.op_conv_chain(x, ws, bs)
+        halves = bmodel.op_conv_chain(bmodel.op_conv_chain(x, ws[:4], bs[:4]), ws[4:], bs[4:])
+        assert torch.equal(whole, halves)
+
 def test_bf16_chain_frames_are_independent(bmodel):
     """A workgroup is a frame: the same frame gives the same bits wherever it sits in the call, and a 70-frame call (more workgroups than a
     test usually launches) equals its frames one by one."""
