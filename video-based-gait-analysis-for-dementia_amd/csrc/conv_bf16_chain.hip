@@ -746,25 +746,22 @@ __global__ __launch_bounds__(512) void conv_bf16_chain_pipe(const ChainArgs a) {
         rb[0] = lds + (f_in + i_in) * G::ROWB;
         rb[1] = lds + (f_in + wrap(i_in + 1, n_in)) * G::ROWB;
         rb[2] = lds + (f_in + wrap(i_in + 2, n_in)) * G::ROWB;
-        // pixel fragments two taps ahead of their MFMAs (three register sets): a tap's 8 MFMAs are 128 cycles, an LDS round trip is more
-        bf16x8 px[3][4];
+        // pixel fragments as a ring of two sets: fragment j of tap t + 2 is requested right behind the two MFMAs that consumed fragment j of tap t (16 MFMAs = 256
+        // cycles ahead of its use), so every wait in front of an MFMA pair is for ONE read with seven younger ones in flight
+        bf16x8 px[2][4];
 #pragma unroll
         for (int pre = 0; pre < 2; ++pre)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) px[pre][j] = *reinterpret_cast<const bf16x8*>(rb[pre / 3] + off[pre % 3] + j * 1024);
+            for (int j = 0; j < 4; ++j) px[pre][j] = *reinterpret_cast<const bf16x8*>(rb[0] + off[pre] + j * 1024);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            if (tap + 2 < 9) {
-                const unsigned char* src = rb[(tap + 2) / 3] + off[(tap + 2) % 3];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) px[(tap + 2) % 3][j] = *reinterpret_cast<const bf16x8*>(src + j * 1024);
-            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tap][0], px[tap % 3][j], acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tap][1], px[tap % 3][j], acc[1][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tap][0], px[tap & 1][j], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tap][1], px[tap & 1][j], acc[1][j], 0, 0, 0);
+                if (tap + 2 < 9) px[tap & 1][j] = *reinterpret_cast<const bf16x8*>(rb[(tap + 2) / 3] + off[(tap + 2) % 3] + j * 1024);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
     };
     // acc (row r) -> ReLU, bf16 -> ring s + 1 (the last convolution: HBM); zero: the padding rows -1 and 56 of the next convolution's input
