@@ -385,6 +385,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 __device__ __forceinline__ void dma16_c(const u16* src, unsigned char* lds_wave_base) {      // lane l's 16 bytes land at lds_wave_base + 16 l
     __builtin_amdgcn_global_load_lds((const GRNET_GLOBAL_AS void*)src, (GRNET_LDS_AS void*)lds_wave_base, 16, 0, 0);
 }
+// LDS-DMA pieces the compiler does not know of: lane l's 16 bytes land at lds + 16 l (M0 = LDS byte address of the piece).
+// uniform base + 32-bit lane offset, only the lanes of `mask` (all lanes are on around it: the callers are in uniform control flow)
+__device__ __forceinline__ void dma16_masked(unsigned off, const void* base, unsigned lds, unsigned long long mask) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, %3\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(off), "s"(base), "s"(lds), "s"(mask) : "memory");
+}
+// all lanes (the weights).  One wait state between the M0 write and the DMA that reads it.
+__device__ __forceinline__ void dma16_hidden_s(unsigned off, const void* base, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds) : "memory");
+}
+
 __device__ __forceinline__ void lds_barrier() {               // every wave's LDS operations so far are done; vector-memory operations (DMAs, stores) stay in flight
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -704,10 +714,14 @@ __global__ __launch_bounds__(512) void conv_bf16_chain_pipe(const ChainArgs a) {
     // the chain's input, one wave-instruction of a row per step from waves 0 .. 3: unit d = 64 wv + lane of the row = (slot d >> 2, swizzled part d & 3)
     const int dslot = (64 * wv + lane) >> 2, dpart = ((64 * wv + lane) & 3) ^ (((dslot >> 2) & 1) << 1);
     const bool dma_lane = wv < 4 && dslot >= 1 && dslot <= W;
-    const u16* dsrc = inb + (size_t)(dslot - 1) * a.in_ctot + dpart * 8;
+    // The piece is inline asm hipcc does not know of (dma16_masked: uniform row base + 32-bit lane offset, EXEC = the row's real units): with an LDS-DMA it DOES know
+    // of in the loop, every wait in front of a fragment's MFMAs is lgkmcnt(0) -- the younger reads included; without, the waits are counted (lgkmcnt(7): one read
+    // back of eight).  Its landing is awaited explicitly (vmcnt below, then the step's barrier), as before.
+    const unsigned dlane = dma_lane ? (unsigned)(((dslot - 1) * a.in_ctot + dpart * 8) * 2) : 0u;
+    const unsigned long long dmask = __ballot(dma_lane);
+    const unsigned lds0 = (unsigned)(size_t)lds;
     auto request = [&](int y, int i_row) {                     // row y of the input -> ring 0 (rows outside the image stay zero: the ring starts zeroed, row 56's slot is zeroed below)
-        unsigned char* dst = lds + i_row * G::ROWB + wv * 1024;
-        if (dma_lane) dma16_c(dsrc + (size_t)y * W * a.in_ctot, dst);
+        dma16_masked(dlane, reinterpret_cast<const unsigned char*>(inb) + (size_t)y * W * a.in_ctot * 2, lds0 + (unsigned)(i_row * G::ROWB + wv * 1024), dmask);
     };
     f32x4 acc[2][4];
     // row r of this wave's convolution into acc: bias (+ the block's input row r for a second convolution), 9 taps x 4 column tiles x 2 channel blocks
@@ -1041,16 +1055,6 @@ struct RingGeom {
     static_assert(LDS <= 160 * 1024 && NFILL >= 2 && NFILL <= 7 && PS <= 32 && (DIRECT || (O0 + NT * 16) * OSB <= LDS) && CT % 32 == 0 && 8 % (CT / 32) == 0, "ring geometry");
     static_assert((PS - 1) * 16 * SB + (2 * P + 2) * SB + 64 < 65536 && (O0 + NT * 16 + P + 2) * SB + 64 <= LDS - PB, "ds_read immediates / the farthest dead read stays inside the allocation");
 };
-
-// LDS-DMA pieces the compiler does not know of: lane l's 16 bytes land at lds + 16 l (M0 = LDS byte address of the piece).
-// uniform base + 32-bit lane offset, only the lanes of `mask` (all lanes are on around it: the callers are in uniform control flow)
-__device__ __forceinline__ void dma16_masked(unsigned off, const void* base, unsigned lds, unsigned long long mask) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, %3\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(off), "s"(base), "s"(lds), "s"(mask) : "memory");
-}
-// all lanes (the weights).  One wait state between the M0 write and the DMA that reads it.
-__device__ __forceinline__ void dma16_hidden_s(unsigned off, const void* base, unsigned lds) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds) : "memory");
-}
 
 template <int CT, int W, int R, bool DIRECT = false>
 __global__ __launch_bounds__(512) void conv_bf16_wide_ring(const ConvArgs a) {
