@@ -48,8 +48,12 @@ __device__ __forceinline__ int fdiv(int q, float inv_d) { return (int)(((float)q
 // LDS-DMA: lane l's 16 bytes land at lds_wave_base + 16*l; the source address is per lane.
 #define GRNET_GLOBAL_AS __attribute__((address_space(1)))
 #define GRNET_LDS_AS __attribute__((address_space(3)))
+// (round 6) Inline asm, NOT __builtin_amdgcn_global_load_lds: while an LDS-DMA hipcc knows of is in flight, every wait it puts in front of an LDS operand read is
+// lgkmcnt(0) and the reads are not hoisted -- conv_bf16_nhwc's tap loop was `ds_read, s_waitcnt lgkmcnt(0), v_mfma` 63 times over, one exposed LDS round trip per
+// MFMA.  The kernel waits for its pieces itself (s_waitcnt vmcnt(0) in front of every chunk's barrier), so the compiler does not have to know.  M0 = the wave's LDS
+// byte address (one wait state between its write and the DMA); every lane is on (padding units fetch zeros).
 __device__ __forceinline__ void dma16(const u16* src, u16* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const GRNET_GLOBAL_AS void*)src, (GRNET_LDS_AS void*)lds_wave_base, 16, 0, 0);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(__builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base)) : "memory");
 }
 
 // Diagnostic build only (make ABLATION=1, GRNET_BF16_PHASES=1): where a workgroup of the bf16 kernel spends its life, in shader-clock
