@@ -59,12 +59,16 @@ __device__ __forceinline__ unsigned relu_pk(unsigned v) {      // max(x, 0) on t
 __device__ __forceinline__ float bf_lo(unsigned v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float bf_hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
 
-template <int C, int W>
+// F frames per workgroup (round 6; F = 2 for the 256-channel 7x7 chain): the frames are stacked in ONE flattened plane, a zero row between them (plane rows 1 .. W:
+// frame 0, W + 1: zero, W + 2 .. 2 W + 1: frame 1), so a workgroup's weight stream -- 9.4 MB per chain from L2, the bound of that chain: two single-frame workgroups
+// per CU pulled 46 B/clk of the CU's 64 -- serves two frames.  The separator row is never written (the column mask below), so it stays the zero padding of both.
+template <int C, int W, int F = 1>
 struct ChainGeom {
     static constexpr int P = W + 1;                         // row pitch in slots
     static constexpr int SB = 2 * C + 32;                   // slot stride, bytes
     static constexpr int O0 = P + 1;                        // slot of pixel (0, 0) = first output column
-    static constexpr int NOUT = W * P - 1;                  // output columns o0 .. slot of pixel (W-1, W-1)
+    static constexpr int H = F * W + F - 1;                 // plane rows that carry outputs (the separator rows included)
+    static constexpr int NOUT = H * P - 1;                  // output columns o0 .. slot of pixel (W-1, W-1) of the last frame
     static constexpr int CS = 2;                            // 16-channel blocks per wave
     static constexpr int WCB = C / (16 * CS);               // waves along the output channels
     static constexpr int WPG = 8 / WCB;                     // waves along the pixels
@@ -74,12 +78,12 @@ struct ChainGeom {
     static constexpr int LDS = NSLOT * SB;
     static constexpr int NS = 9 * (C / 32);                 // k-steps per convolution
     static constexpr int UPP = C / 8;                       // 16-byte units per pixel
-    static constexpr int NU = (W * W * UPP + 511) / 512;    // units per thread of the plane
+    static constexpr int NU = (F * W * W * UPP + 511) / 512;    // units per thread of the plane
     static_assert(C % 32 == 0 && WCB >= 1 && WCB <= 8 && 8 % WCB == 0, "wave grid");
     static_assert((SB / 16) % 2 == 0 && ((SB / 32) % 2) == 1, "slot stride must be 32 * odd bytes (conflict-free b128 reads)");
     static_assert(NS % 3 == 0, "the weight ring has three register sets");
     static_assert(LDS <= 160 * 1024, "the plane must fit the LDS");
-    static_assert((PS - 1) * 16 * SB + (2 * P + 2) * SB + (C / 32) * 64 < 65536, "ds_read immediates");
+    static_assert(F > 1 || (PS - 1) * 16 * SB + (2 * P + 2) * SB + (C / 32) * 64 < 65536, "ds_read immediates");      // (F = 2: 70 KB of plane, hipcc keeps a second base register)
 };
 
 // One convolution's k-loop over the LDS plane, shared by the frame-resident chain and the band-resident block kernel.
@@ -133,26 +137,27 @@ __device__ __forceinline__ void chain_kloop(f32x4 (&acc)[CS][PS], bf16x8 (&wr)[R
 // Registers: the 256-channel 7x7 chain (L2-bound on its weight stream, MFMA-busy 0.41) is held to 96 (five waves per SIMD; 32 bytes of scratch): two of its workgroups fit
 // a CU -- 158 -> 147 us per chain alone at 256 frames -- and one fits BESIDE a workgroup of the 128-channel 14x14 chain (2 x 96 + 2 x 160 registers, 45 + 74 KB of LDS), which
 // is launched on another lane at the same time.  The step did not show the latter (10.59-10.68 ms either way, three pairs on one box).
-template <int C, int W>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 256 ? 5 : 2))) void conv_bf16_chain(const ChainArgs a) {
-    typedef ChainGeom<C, W> G;
+template <int C, int W, int F = 1>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 256 && F == 1 ? 5 : 2))) void conv_bf16_chain(const ChainArgs a) {
+    typedef ChainGeom<C, W, F> G;
     constexpr int P = G::P, SB = G::SB, CS = G::CS, PS = G::PS, UPP = G::UPP, NU = G::NU;
     extern __shared__ __align__(16) unsigned char plane[];
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cb = wave % G::WCB, pg = wave / G::WCB;
-    const int n = blockIdx.x;
+    const int n = blockIdx.x * F;                            // first frame of this workgroup; frames n .. n + nf - 1 exist
     if (n >= a.N) return;
+    const int nf = a.N - n < F ? a.N - n : F;
 
-    // ---- the frame: HBM -> registers (all loads in flight), zero the plane meanwhile, then registers -> interior slots
+    // ---- the frames: HBM -> registers (all loads in flight), zero the plane meanwhile, then registers -> interior slots (frame f: plane rows f (W + 1) + 1 ..)
     const u16* inb = reinterpret_cast<const u16*>(a.in) + (size_t)n * W * W * a.in_ctot + a.in_coff;
     u32x4 stage[NU];
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
         const int u = tid + i * 512;
         stage[i] = u32x4{0u, 0u, 0u, 0u};
-        if (u < W * W * UPP) {
-            const int px = u / UPP, part = u - px * UPP;
+        if (u < nf * W * W * UPP) {
+            const int px = u / UPP, part = u - px * UPP;      // px runs over the frames: they are contiguous in memory
             stage[i] = *reinterpret_cast<const u32x4*>(inb + (size_t)px * a.in_ctot + part * 8);
         }
     }
@@ -161,9 +166,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 256 ? 
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
         const int u = tid + i * 512;
-        if (u < W * W * UPP) {
-            const int px = u / UPP, part = u - px * UPP, y = px / W, x = px - y * W;
-            *reinterpret_cast<u32x4*>(plane + ((y + 1) * P + x + 1) * SB + part * 16) = stage[i];
+        if (u < nf * W * W * UPP) {
+            const int px = u / UPP, part = u - px * UPP, f = px / (W * W), pf = px - f * W * W, y = pf / W, x = pf - y * W;
+            *reinterpret_cast<u32x4*>(plane + ((f * (W + 1) + y + 1) * P + x + 1) * SB + part * 16) = stage[i];
         }
     }
 
@@ -174,8 +179,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 256 ? 
     unsigned valid = 0;                                                       // bit ps: column tile ps of this lane is a real pixel
 #pragma unroll
     for (int ps = 0; ps < PS; ++ps) {
-        const int o = o_first + ps * 16;
-        if (o % P != 0 && o <= W * P + W) valid |= 1u << ps;
+        const int o = o_first + ps * 16, row = o / P;      // plane row 1 .. H; rows that are a multiple of W + 1 separate two frames
+        if (o % P != 0 && o <= G::H * P + W && row % (W + 1) != 0 && (row - 1) / (W + 1) < nf) valid |= 1u << ps;
     }
     const unsigned wlb = ((cb * CS * 16 + l15) * 32 + lq * 8) * 2;           // byte offset of this lane in a [C][32] weight row block
     const int co = cb * CS * 16 + lq * 4;                                     // first of this lane's 4 output channels (block 0)
@@ -235,9 +240,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(C == 256 ? 
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
         const int u = tid + i * 512;
-        if (u < W * W * UPP) {
-            const int px = u / UPP, part = u - px * UPP, y = px / W, x = px - y * W;
-            *reinterpret_cast<u32x4*>(outb + (size_t)px * a.out_ctot + part * 8) = *reinterpret_cast<const u32x4*>(plane + ((y + 1) * P + x + 1) * SB + part * 16);
+        if (u < nf * W * W * UPP) {
+            const int px = u / UPP, part = u - px * UPP, f = px / (W * W), pf = px - f * W * W, y = pf / W, x = pf - y * W;
+            *reinterpret_cast<u32x4*>(outb + (size_t)px * a.out_ctot + part * 8) = *reinterpret_cast<const u32x4*>(plane + ((f * (W + 1) + y + 1) * P + x + 1) * SB + part * 16);
         }
     }
 }
@@ -1591,6 +1596,7 @@ hipError_t conv_bf16_chain_init() {
     GRK_TRY((set_chain_lds<64, 28>()));
     GRK_TRY((set_chain_lds<128, 14>()));
     GRK_TRY((set_chain_lds<256, 7>()));
+    GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_chain<256, 7, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ChainGeom<256, 7, 2>::LDS));
     GRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_block_band<32, 56, 19, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, BandGeom<32, 56, 19>::LDS));
 #define GRK_S2_SET(cp, ct, wo, r) GRK_TRY((set_s2_lds<cp, ct, wo, r>()));
     GRK_S2_SHAPES(GRK_S2_SET)
@@ -1662,6 +1668,7 @@ hipError_t launch_conv_bf16_chain(const ChainArgs& a, int c, int w, hipStream_t 
     }
     if (c == 64) return launch_k(conv_bf16_chain<64, 28>, dim3(a.N), dim3(512), ChainGeom<64, 28>::LDS, s, a);
     if (c == 128) return launch_k(conv_bf16_chain<128, 14>, dim3(a.N), dim3(512), ChainGeom<128, 14>::LDS, s, a);
+    if (GRNET_AB(BF16_CHAIN7_PAIR, 1) && a.N >= 2) return launch_k(conv_bf16_chain<256, 7, 2>, dim3((a.N + 1) / 2), dim3(512), ChainGeom<256, 7, 2>::LDS, s, a);
     return launch_k(conv_bf16_chain<256, 7>, dim3(a.N), dim3(512), ChainGeom<256, 7>::LDS, s, a);
 }
 
